@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py -- user+item column samples/sec per Gibbs iteration on MI355X.
+
+One "step" = one full Gibbs iteration of the reference's main loop
+(c++/bpmf.cpp:182-195): movies.sample(users); users.sample(movies);
+movies.predict(users) -- both host hyper-parameter draws, the device->host
+reductions and the RMSE evaluation are inside the timed region, exactly what the
+reference's `items/sec` covers.  value = (N_users + N_movies) * steps / seconds.
+
+N = 1: the ML-1M-shaped synthetic R (6040 x 3706, 1 000 209 ratings, 90/10 split),
+K = 32, fp64 -- BASELINE.json configs[1] (the reference ships only ML-100K).
+N > 1: the same matrix, columns of both sides sharded over the ranks (strong
+scaling), factors exchanged by RCCL between half-iterations.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the per-column
+sampler k_gram<K> [+ k_finish_multi], timed with HIP events on its stream) and
+`cpu_baseline` (the oracle's OpenMP build on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_PEAK_TFLOPS = 78.6    # MI355X datasheet FP64 vector = matrix ([recalled])
+
+
+def algorithmic_bytes(nnz, ncols, K, s=8):
+    """SURVEY 8(d), one half-iteration (= one launch of the sampler): per rating a row index,
+    a value and one K-vector; per column the K-vector written back + its column pointer."""
+    return nnz * (4 + s + K * s) + ncols * (K * s + 8)
+
+
+def algorithmic_flops(nnz, ncols, K):
+    return nnz * (K * (K + 1) + 2 * K) + ncols * (K ** 3 / 3.0 + 4 * K * K + 3 * K)
+
+
+def cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies, budget_s=20.0):
+    """Times the oracle's -O3/OpenMP build (a restatement of c++/sample.cpp; the real
+    reference needs Eigen3 and cannot be built here) on all host cores."""
+    from oracle import oracle as orc
+    try:
+        orc.build(native=True)          # -march=native on the box it is timed on
+    except Exception:
+        pass
+    o = orc.Oracle(fast=True)
+    cores = os.cpu_count() or 1
+    o.gibbs(K, M, Mt, T, Tt, nsims=1, burnin=0, nthreads=cores)            # warm-up
+    t0 = time.perf_counter()
+    r = o.gibbs(K, M, Mt, T, Tt, nsims=2, burnin=0, nthreads=cores)
+    per_iter = (time.perf_counter() - t0) / 2
+    n = int(max(2, min(40, budget_s / max(per_iter, 1e-3))))
+    r = o.gibbs(K, M, Mt, T, Tt, nsims=n, burnin=0, nthreads=cores)
+    secs = float(np.sum(r["secs"][1:])) / (n - 1)
+    return {"value": (nusers + nmovies) / secs, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%d Gibbs iterations of the same ML-1M-shaped matrix, K=%d, OpenMP schedule(guided), "
+                      "%d threads, gcc -O3 -march=native; %.1f ms/iter" % (n, K, cores, secs * 1e3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--K", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import bpmf_amd
+    from bpmf_amd import synth
+    from bpmf_amd.sys import Sys
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (bpmf_amd has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+        from bpmf_amd.dist import TorchComm
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        comm = TorchComm(torch.device("cuda", local_rank))
+
+    K = args.K
+    M, Mt, T, Tt, nusers, nmovies = synth.ml1m_shaped(seed=42)
+    nnz = int(M[0][-1])
+    mean = float(np.sum(M[2])) / nnz
+
+    eng = bpmf_amd.HipEngine(K, device=local_rank)
+    Sys.nsims, Sys.burnin, Sys.alpha = args.steps + args.warmup, 5, 2.0
+    if world == 1:
+        movies = Sys("movs", eng, M, nmovies, nusers, T=T, mean_rating=mean)
+        users = Sys("users", eng, Mt, nusers, nmovies, mean_rating=mean)
+        dom_m, dom_u = (0, nmovies), (0, nusers)
+    else:
+        bm = synth.balanced_ranges(M[0], world); bu = synth.balanced_ranges(Mt[0], world)
+        dom_m, dom_u = (bm[rank], bm[rank + 1]), (bu[rank], bu[rank + 1])
+        movies = Sys("movs", eng, synth.slice_cols(M, *dom_m), nmovies, nusers, T=synth.slice_cols(T, *dom_m),
+                     dom=dom_m, mean_rating=mean, comm=comm)
+        users = Sys("users", eng, synth.slice_cols(Mt, *dom_u), nusers, nmovies, dom=dom_u, mean_rating=mean, comm=comm)
+        comm.register(movies, bm); comm.register(users, bu)
+
+    def step():
+        movies.sample(users)
+        users.sample(movies)
+        movies.predict(users)
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kern_ms = {"movs": 0.0, "users": 0.0}
+    red_ms = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        movies.sample(users)
+        a, b = eng.last_kernel_ms(movies.side); kern_ms["movs"] += a; red_ms += b
+        users.sample(movies)
+        a, b = eng.last_kernel_ms(users.side); kern_ms["users"] += a; red_ms += b
+        movies.predict(users)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # roofline of the dominant kernel (the sampler), per launch, this rank's shard
+    nnz_m = movies.local_nnz; nnz_u = users.local_nnz
+    bytes_launch = 0.5 * (algorithmic_bytes(nnz_m, dom_m[1] - dom_m[0], K) + algorithmic_bytes(nnz_u, dom_u[1] - dom_u[0], K))
+    flops_launch = 0.5 * (algorithmic_flops(nnz_m, dom_m[1] - dom_m[0], K) + algorithmic_flops(nnz_u, dom_u[1] - dom_u[0], K))
+    launch_s = (kern_ms["movs"] + kern_ms["users"]) / (2.0 * args.steps) * 1e-3
+    achieved = bytes_launch / launch_s / 1e9 if launch_s > 0 else 0.0
+
+    movies.predict(users, True)
+    out = {
+        "metric": "user+item column samples/sec per Gibbs iter; test RMSE vs reference",
+        "value": (nusers + nmovies) * args.steps / dt,
+        "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "ML-1M-shaped synthetic R (6040 users x 3706 movies, 1000209 ratings, 90/10 split), "
+                               "K=%d, alpha=2, full Gibbs iteration incl. host Normal-Wishart draws and RMSE" % K,
+                   "nnz_train": nnz, "nnz_test": int(T[0][-1]), "K": K,
+                   "parallelism": "columns of U and V sharded over %d GPU(s)" % world},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "k_gram<%d>+k_finish_multi<%d>" % (K, K),
+                     "launch_ms": launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_launch,
+                     "fp64_tflops": flops_launch / launch_s / 1e12 if launch_s > 0 else 0.0,
+                     "fp64_frac": (flops_launch / launch_s / 1e12) / FP64_PEAK_TFLOPS if launch_s > 0 else 0.0,
+                     "colstats_ms": red_ms / (2.0 * args.steps),
+                     "note": "factors fit in L2/MALL at this size, so achieved may exceed HBM peak (SURVEY 8d)"},
+        "rmse": movies.rmse, "rmse_avg": movies.rmse_avg,
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies)
+            except Exception as e:  # the GPU number must still be reported
+                out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,89 @@
+"""ctypes binding of include/bpmf_hip.h (the C ABI of the hot path)."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_i64p = C.POINTER(C.c_int64)
+c_i32p = C.POINTER(C.c_int32)
+c_f64p = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); mirrors include/bpmf_hip.h one to one
+_SIGNATURES = {
+    "bpmf_hip_last_error": (C.c_char_p, []),
+    "bpmf_hip_abi_version": (C.c_int, []),
+    "bpmf_hip_supports_k": (C.c_int, [C.c_int]),
+    "bpmf_hip_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bpmf_hip_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "bpmf_hip_ctx_sync": (C.c_int, [C.c_void_p]),
+    "bpmf_hip_ctx_stream": (C.c_void_p, [C.c_void_p]),
+    "bpmf_hip_side_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_double, C.POINTER(C.c_void_p)]),
+    "bpmf_hip_side_create_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_double, C.POINTER(C.c_void_p)]),
+    "bpmf_hip_side_destroy": (C.c_int, [C.c_void_p]),
+    "bpmf_hip_side_items_dev": (C.c_void_p, [C.c_void_p]),
+    "bpmf_hip_side_bind_items": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bpmf_hip_side_get_items": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bpmf_hip_side_set_items": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bpmf_hip_sample_side": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bpmf_hip_sample_side_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]),
+    "bpmf_hip_sample_side_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bpmf_hip_failed_column": (C.c_int64, [C.c_void_p]),
+    "bpmf_hip_test_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bpmf_hip_test_destroy": (C.c_int, [C.c_void_p]),
+    "bpmf_hip_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bpmf_hip_test_get": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bpmf_hyper_sample": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bpmf_cov_from_sums": (None, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bpmf_randn_stream": (None, [C.c_uint32, C.c_int, C.c_void_p]),
+    "bpmf_hip_randn_stream": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
+    "bpmf_hip_side_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+}
+
+
+class BpmfHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("bpmf_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def library_path():
+    return os.path.join(_HERE, "libbpmf_hip.so")
+
+
+def build_library():
+    """hipcc --offload-arch=gfx950 build of the in-tree extension (bpmf_amd/csrc/Makefile)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+
+
+def exported_signatures():
+    return dict(_SIGNATURES)
+
+
+def load_library():
+    """Loads libbpmf_hip.so; raises (never falls back) when it is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(bpmf_amd has no CPU fallback)" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.bpmf_hip_abi_version() != 1:
+        raise ImportError("libbpmf_hip.so ABI version mismatch")
+    _LIB = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise BpmfHipError(rc, load_library().bpmf_hip_last_error().decode("utf-8", "replace"))

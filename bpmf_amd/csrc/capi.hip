@@ -1,0 +1,566 @@
+// capi.hip -- implementation of include/bpmf_hip.h on top of kernels.h.
+//
+// Host-side responsibilities: own the device buffers of a `Sys`, build the
+// static work schedule of a side once (columns sorted by cost, heavy columns
+// cut into nnz chunks), upload hp.mu / hp.LambdaF per half-iteration, launch
+// the kernels on one stream and bring the K*K+K+1 reduction words back.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/bpmf_hip.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(e_ == hipErrorOutOfMemory ? BPMF_HIP_ENOMEM : BPMF_HIP_ENODEV,                 \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                            \
+    } while (0)
+
+template <typename T>
+int dev_upload(T **dst, const T *src, size_t n)
+{
+    *dst = nullptr;
+    if (n == 0) n = 1;
+    HIP_TRY(hipMalloc((void **)dst, n * sizeof(T)));
+    if (src) HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int env_int(const char *name, int dflt)
+{
+    const char *s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+}  // namespace
+
+extern "C" void bpmf_hip_set_error_(const char *msg) { g_err = msg; }
+
+struct bpmf_hip_ctx {
+    int device = 0;
+    int K = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cu = 256;
+    // per-call parameter blob: LambdaF[K*K] | Lmu[K] | fail (u64)
+    double *h_in = nullptr, *d_in = nullptr;
+    // result blob: prod[K*K] | sum[K] | norm | fail (u64) ; predict: se | se_avg
+    double *h_out = nullptr, *d_out = nullptr;
+    size_t in_words = 0, out_words = 0;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+};
+
+struct bpmf_hip_side {
+    bpmf_hip_ctx *ctx = nullptr;
+    int64_t ncols = 0, nrows = 0, from = 0, to = 0, nnz = 0;
+    double mean_rating = 0.0;
+    int32_t *d_rowidx = nullptr; double *d_vals = nullptr; bool own_csc = true;
+    double *d_items = nullptr; bool own_items = true;
+    // schedule
+    int nwork = 0, nmulti = 0, nslots = 0;
+    int32_t *d_wi_col = nullptr, *d_wi_len = nullptr, *d_wi_slot = nullptr;
+    int64_t *d_wi_p0 = nullptr;
+    int32_t *d_mc_col = nullptr, *d_mc_slot0 = nullptr, *d_mc_nch = nullptr;
+    double *d_partials = nullptr;
+    int nstat_waves = 0;
+    double *d_stat_partials = nullptr;
+    int64_t failed_column = -1;
+    bool pending = false;
+    float last_sample_ms = 0.f, last_reduce_ms = 0.f;
+};
+
+struct bpmf_hip_test {
+    bpmf_hip_side *side = nullptr;
+    int64_t nnz = 0;
+    int32_t *d_tcol = nullptr, *d_trow = nullptr;
+    double *d_tval = nullptr, *d_pavg = nullptr, *d_pm2 = nullptr, *d_partial = nullptr;
+    int64_t nwaves = 0, per_wave = 0;
+};
+
+namespace {
+
+template <int K>
+size_t part_words() { return (size_t)bpmf::Geo<K>::PART; }
+
+size_t part_words_rt(int K)
+{
+    switch (K) {
+    case 8: return part_words<8>();
+    case 16: return part_words<16>();
+    case 32: return part_words<32>();
+    case 64: return part_words<64>();
+    }
+    return 0;
+}
+
+// Build the static schedule of a side.  Cost model: one MFMA k-step per 4
+// ratings per tile triple, plus a constant for the factorisation.
+int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
+{
+    const int64_t nloc = s->to - s->from;
+    const int K = s->ctx->K;
+    int chunk = env_int("BPMF_HIP_CHUNK", 0);
+    if (chunk <= 0) {
+        // aim at >= 8 work items per SIMD so the tail of the launch stays short
+        const int64_t simds = (int64_t)s->ctx->num_cu * 4;
+        int64_t c = s->nnz / (simds * 8);
+        c = (c + 15) / 16 * 16;
+        chunk = (int)std::min<int64_t>(std::max<int64_t>(c, 128), 4096);
+    }
+    chunk = (chunk + 15) / 16 * 16;
+
+    struct Item { int32_t col; int64_t p0; int32_t len; int32_t slot; int64_t cost; };
+    std::vector<Item> items;
+    items.reserve((size_t)nloc + (size_t)(s->nnz / chunk) + 16);
+    std::vector<int32_t> mc_col, mc_slot0, mc_nch;
+    const int64_t fin_cost = (int64_t)K * K / 4 + 64;     // in units of "ratings"
+    int32_t slots = 0;
+    for (int64_t c = 0; c < nloc; ++c) {
+        const int64_t p0 = colptr[c], n = colptr[c + 1] - colptr[c];
+        if (n < 0) return fail(BPMF_HIP_EINVAL, "colptr is not monotone");
+        if (n <= chunk) {
+            items.push_back({(int32_t)c, p0, (int32_t)n, -1, n + fin_cost});
+        } else {
+            const int nch = (int)((n + chunk - 1) / chunk);
+            // equalise the chunks of one column (multiples of 16 ratings)
+            int64_t per = ((n + nch - 1) / nch + 15) / 16 * 16;
+            mc_col.push_back((int32_t)c); mc_slot0.push_back(slots); mc_nch.push_back(nch);
+            for (int k = 0; k < nch; ++k) {
+                const int64_t b = std::min<int64_t>(k * per, n), e = std::min<int64_t>(b + per, n);
+                items.push_back({(int32_t)c, p0 + b, (int32_t)(e - b), slots++, e - b});
+            }
+        }
+    }
+    std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.cost > b.cost; });
+    // heavy columns' finish pass: most chunks first
+    std::vector<int> order(mc_col.size());
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return mc_nch[a] > mc_nch[b]; });
+
+    const size_t nw = items.size();
+    std::vector<int32_t> wcol(nw), wlen(nw), wslot(nw);
+    std::vector<int64_t> wp0(nw);
+    for (size_t i = 0; i < nw; ++i) { wcol[i] = items[i].col; wlen[i] = items[i].len; wslot[i] = items[i].slot; wp0[i] = items[i].p0; }
+    std::vector<int32_t> mcol(order.size()), mslot(order.size()), mnch(order.size());
+    for (size_t i = 0; i < order.size(); ++i) { mcol[i] = mc_col[order[i]]; mslot[i] = mc_slot0[order[i]]; mnch[i] = mc_nch[order[i]]; }
+
+    s->nwork = (int)nw; s->nmulti = (int)order.size(); s->nslots = slots;
+    int rc;
+    if ((rc = dev_upload(&s->d_wi_col, wcol.data(), nw))) return rc;
+    if ((rc = dev_upload(&s->d_wi_len, wlen.data(), nw))) return rc;
+    if ((rc = dev_upload(&s->d_wi_slot, wslot.data(), nw))) return rc;
+    if ((rc = dev_upload(&s->d_wi_p0, wp0.data(), nw))) return rc;
+    if ((rc = dev_upload(&s->d_mc_col, mcol.data(), mcol.size()))) return rc;
+    if ((rc = dev_upload(&s->d_mc_slot0, mslot.data(), mslot.size()))) return rc;
+    if ((rc = dev_upload(&s->d_mc_nch, mnch.data(), mnch.size()))) return rc;
+    const size_t pw = part_words_rt(K);
+    if ((rc = dev_upload<double>(&s->d_partials, nullptr, (size_t)slots * pw))) return rc;
+    // column statistics: one wave per 64+ columns, at most 2 waves per CU
+    s->nstat_waves = (int)std::max<int64_t>(1, std::min<int64_t>((nloc + 63) / 64, (int64_t)s->ctx->num_cu * 2));
+    if ((rc = dev_upload<double>(&s->d_stat_partials, nullptr, (size_t)s->nstat_waves * pw))) return rc;
+    return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+extern "C" const char *bpmf_hip_last_error(void) { return g_err.c_str(); }
+extern "C" int bpmf_hip_abi_version(void) { return BPMF_HIP_ABI_VERSION; }
+extern "C" int bpmf_hip_supports_k(int K) { return K == 8 || K == 16 || K == 32 || K == 64; }
+
+extern "C" int bpmf_hip_ctx_create(int device, int K, void *stream, bpmf_hip_ctx **out)
+{
+    if (!out) return fail(BPMF_HIP_EINVAL, "ctx_create: out is NULL");
+    *out = nullptr;
+    if (!bpmf_hip_supports_k(K)) return fail(BPMF_HIP_EINVAL, "ctx_create: unsupported num_latent " + std::to_string(K) + " (8, 16, 32, 64)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(BPMF_HIP_ENODEV, "no HIP device available (the BPMF hot path has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(BPMF_HIP_EINVAL, "ctx_create: bad device index");
+    HIP_TRY(hipSetDevice(device));
+    bpmf_hip_ctx *c = new (std::nothrow) bpmf_hip_ctx();
+    if (!c) return fail(BPMF_HIP_ENOMEM, "ctx_create: out of host memory");
+    c->device = device; c->K = K;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    c->in_words = (size_t)K * K + K + 1;
+    c->out_words = (size_t)K * K + K + 1 + 1 + 2;
+    HIP_TRY(hipHostMalloc((void **)&c->h_in, c->in_words * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&c->h_out, c->out_words * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **)&c->d_in, c->in_words * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&c->d_out, c->out_words * sizeof(double)));
+    for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
+    *out = c;
+    return BPMF_HIP_OK;
+}
+
+extern "C" int bpmf_hip_ctx_destroy(bpmf_hip_ctx *c)
+{
+    if (!c) return BPMF_HIP_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->h_in) (void)hipHostFree(c->h_in);
+    if (c->h_out) (void)hipHostFree(c->h_out);
+    if (c->d_in) (void)hipFree(c->d_in);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return BPMF_HIP_OK;
+}
+
+extern "C" int bpmf_hip_ctx_sync(bpmf_hip_ctx *c)
+{
+    if (!c) return fail(BPMF_HIP_EINVAL, "ctx_sync: NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BPMF_HIP_OK;
+}
+
+extern "C" void *bpmf_hip_ctx_stream(bpmf_hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+// ---------------------------------------------------------------------------
+static int side_create_common(bpmf_hip_ctx *ctx, int64_t ncols, int64_t nrows, int64_t from, int64_t to,
+                              const int64_t *colptr, const int32_t *rowidx, const double *vals, bool dev_arrays,
+                              double mean_rating, bpmf_hip_side **out)
+{
+    if (!out) return fail(BPMF_HIP_EINVAL, "side_create: out is NULL");
+    *out = nullptr;
+    if (!ctx || !colptr || ncols <= 0 || nrows <= 0 || from < 0 || to < from || to > ncols)
+        return fail(BPMF_HIP_EINVAL, "side_create: bad argument");
+    const int64_t nloc = to - from;
+    if (nloc >= (int64_t)1 << 31) return fail(BPMF_HIP_EINVAL, "side_create: more than 2^31-1 local columns");
+    if (colptr[0] != 0) return fail(BPMF_HIP_EINVAL, "side_create: colptr[0] must be 0 (pass the local slice)");
+    const int64_t nnz = colptr[nloc];
+    if (nnz > 0 && (!rowidx || !vals)) return fail(BPMF_HIP_EINVAL, "side_create: NULL rowidx/vals");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!dev_arrays) {
+        for (int64_t p = 0; p < nnz; ++p)
+            if (rowidx[p] < 0 || rowidx[p] >= nrows) return fail(BPMF_HIP_EINVAL, "side_create: row index out of range");
+    }
+    bpmf_hip_side *s = new (std::nothrow) bpmf_hip_side();
+    if (!s) return fail(BPMF_HIP_ENOMEM, "side_create: out of host memory");
+    s->ctx = ctx; s->ncols = ncols; s->nrows = nrows; s->from = from; s->to = to; s->nnz = nnz; s->mean_rating = mean_rating;
+    int rc = 0;
+    if (dev_arrays) {
+        s->d_rowidx = const_cast<int32_t *>(rowidx); s->d_vals = const_cast<double *>(vals); s->own_csc = false;
+    } else {
+        if ((rc = dev_upload(&s->d_rowidx, rowidx, (size_t)nnz)) || (rc = dev_upload(&s->d_vals, vals, (size_t)nnz))) { bpmf_hip_side_destroy(s); return rc; }
+    }
+    const size_t words = (size_t)ctx->K * (size_t)ncols;
+    hipError_t e = hipMalloc((void **)&s->d_items, words * sizeof(double));
+    if (e != hipSuccess) { bpmf_hip_side_destroy(s); return fail(BPMF_HIP_ENOMEM, "side_create: factor matrix allocation failed"); }
+    e = hipMemset(s->d_items, 0, words * sizeof(double));           // items().setZero(), c++/sample.cpp:185
+    if (e != hipSuccess) { bpmf_hip_side_destroy(s); return fail(BPMF_HIP_ENODEV, "side_create: memset failed"); }
+    if ((rc = build_schedule(s, colptr))) { bpmf_hip_side_destroy(s); return rc; }
+    *out = s;
+    return BPMF_HIP_OK;
+}
+
+extern "C" int bpmf_hip_side_create(bpmf_hip_ctx *ctx, int64_t ncols, int64_t nrows, int64_t from, int64_t to,
+                                    const int64_t *colptr, const int32_t *rowidx, const double *vals,
+                                    double mean_rating, bpmf_hip_side **out)
+{
+    return side_create_common(ctx, ncols, nrows, from, to, colptr, rowidx, vals, false, mean_rating, out);
+}
+
+extern "C" int bpmf_hip_side_create_dev(bpmf_hip_ctx *ctx, int64_t ncols, int64_t nrows, int64_t from, int64_t to,
+                                        const int64_t *colptr_host, const int32_t *rowidx_dev, const double *vals_dev,
+                                        double mean_rating, bpmf_hip_side **out)
+{
+    return side_create_common(ctx, ncols, nrows, from, to, colptr_host, rowidx_dev, vals_dev, true, mean_rating, out);
+}
+
+extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
+{
+    if (!s) return BPMF_HIP_OK;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipStreamSynchronize(s->ctx->stream);
+    if (s->own_csc) { if (s->d_rowidx) (void)hipFree(s->d_rowidx); if (s->d_vals) (void)hipFree(s->d_vals); }
+    if (s->own_items && s->d_items) (void)hipFree(s->d_items);
+    void *ptrs[] = {s->d_wi_col, s->d_wi_len, s->d_wi_slot, s->d_wi_p0, s->d_mc_col, s->d_mc_slot0, s->d_mc_nch, s->d_partials, s->d_stat_partials};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    delete s;
+    return BPMF_HIP_OK;
+}
+
+extern "C" double *bpmf_hip_side_items_dev(bpmf_hip_side *s) { return s ? s->d_items : nullptr; }
+
+extern "C" int bpmf_hip_side_bind_items(bpmf_hip_side *s, double *items_dev)
+{
+    if (!s || !items_dev) return fail(BPMF_HIP_EINVAL, "bind_items: NULL");
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    if (s->own_items && s->d_items) (void)hipFree(s->d_items);
+    s->d_items = items_dev; s->own_items = false;
+    return BPMF_HIP_OK;
+}
+
+extern "C" int bpmf_hip_side_get_items(bpmf_hip_side *s, double *h)
+{
+    if (!s || !h) return fail(BPMF_HIP_EINVAL, "get_items: NULL");
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    HIP_TRY(hipMemcpy(h, s->d_items, (size_t)s->ctx->K * s->ncols * sizeof(double), hipMemcpyDeviceToHost));
+    return BPMF_HIP_OK;
+}
+
+extern "C" int bpmf_hip_side_set_items(bpmf_hip_side *s, const double *h)
+{
+    if (!s || !h) return fail(BPMF_HIP_EINVAL, "set_items: NULL");
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    HIP_TRY(hipMemcpy(s->d_items, h, (size_t)s->ctx->K * s->ncols * sizeof(double), hipMemcpyHostToDevice));
+    return BPMF_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+namespace {
+
+template <int K>
+int do_launch(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double alpha)
+{
+    using namespace bpmf;
+    bpmf_hip_ctx *c = self->ctx;
+    SampleArgs a;
+    a.rowidx = self->d_rowidx; a.vals = self->d_vals;
+    a.wi_col = self->d_wi_col; a.wi_p0 = self->d_wi_p0; a.wi_len = self->d_wi_len; a.wi_slot = self->d_wi_slot;
+    a.mc_col = self->d_mc_col; a.mc_slot0 = self->d_mc_slot0; a.mc_nchunks = self->d_mc_nch;
+    a.partials = self->d_partials;
+    a.other_items = other->d_items; a.items = self->d_items; a.col_from = self->from;
+    a.LambdaF = c->d_in; a.Lmu = c->d_in + (size_t)K * K;
+    a.fail = (unsigned long long *)(c->d_in + (size_t)K * K + K);
+    a.mean_rating = self->mean_rating; a.alpha = alpha; a.iter_plus_1 = (uint32_t)(iter + 1);
+
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    if (self->nwork > 0) hipLaunchKernelGGL(k_gram<K>, dim3(self->nwork), dim3(64), 0, c->stream, a);
+    if (self->nmulti > 0) hipLaunchKernelGGL(k_finish_multi<K>, dim3(self->nmulti), dim3(64), 0, c->stream, a);
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    hipLaunchKernelGGL(k_colstats<K>, dim3(self->nstat_waves), dim3(64), 0, c->stream,
+                       (const double *)self->d_items, self->from, self->to, self->nstat_waves, self->d_stat_partials);
+    hipLaunchKernelGGL(k_colstats_final<K>, dim3(1), dim3(256), 0, c->stream,
+                       (const double *)self->d_stat_partials, self->nstat_waves, c->d_out);
+    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int bpmf_hip_sample_side_launch(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double alpha,
+                                           const double *mu, const double *LambdaF)
+{
+    if (!self || !other || !mu || !LambdaF) return fail(BPMF_HIP_EINVAL, "sample_side: NULL argument");
+    bpmf_hip_ctx *c = self->ctx;
+    if (other->ctx != c) return fail(BPMF_HIP_EINVAL, "sample_side: sides belong to different contexts");
+    if (other->ncols != self->nrows) return fail(BPMF_HIP_EINVAL, "sample_side: other side has the wrong number of columns");
+    if (iter < 0) return fail(BPMF_HIP_EINVAL, "sample_side: iter < 0");
+    if (self->pending) return fail(BPMF_HIP_EINVAL, "sample_side_launch: previous launch not finished");
+    const int K = c->K;
+    HIP_TRY(hipSetDevice(c->device));
+    // rr = hp_LambdaF * hp.mu is the same for every column (c++/sample.cpp:285)
+    for (int j = 0; j < K; ++j)
+        for (int i = 0; i < K; ++i) c->h_in[(size_t)j * K + i] = LambdaF[(size_t)j * K + i];
+    for (int i = 0; i < K; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < K; ++j) s += LambdaF[(size_t)j * K + i] * mu[j];
+        c->h_in[(size_t)K * K + i] = s;
+    }
+    const unsigned long long nofail = ~0ull;
+    memcpy(&c->h_in[(size_t)K * K + K], &nofail, sizeof(nofail));
+    HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, c->in_words * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int rc = 0;
+    switch (K) {
+    case 8: rc = do_launch<8>(self, other, iter, alpha); break;
+    case 16: rc = do_launch<16>(self, other, iter, alpha); break;
+    case 32: rc = do_launch<32>(self, other, iter, alpha); break;
+    case 64: rc = do_launch<64>(self, other, iter, alpha); break;
+    default: return fail(BPMF_HIP_EINVAL, "sample_side: unsupported K");
+    }
+    if (rc) return rc;
+    // prod | sum | norm already in d_out; append the fail word and bring everything back
+    HIP_TRY(hipMemcpyAsync(c->d_out + (size_t)K * K + K + 1, c->d_in + (size_t)K * K + K, sizeof(double),
+                           hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, ((size_t)K * K + K + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    self->pending = true;
+    return BPMF_HIP_OK;
+}
+
+extern "C" int bpmf_hip_sample_side_finish(bpmf_hip_side *self, double *sum_out, double *prod_out, double *norm_out)
+{
+    if (!self || !sum_out || !prod_out || !norm_out) return fail(BPMF_HIP_EINVAL, "sample_side_finish: NULL argument");
+    if (!self->pending) return fail(BPMF_HIP_EINVAL, "sample_side_finish: nothing launched");
+    bpmf_hip_ctx *c = self->ctx;
+    const int K = c->K;
+    HIP_TRY(hipSetDevice(c->device));
+    self->pending = false;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(prod_out, c->h_out, sizeof(double) * K * K);
+    memcpy(sum_out, c->h_out + (size_t)K * K, sizeof(double) * K);
+    *norm_out = c->h_out[(size_t)K * K + K];
+    unsigned long long f;
+    memcpy(&f, &c->h_out[(size_t)K * K + K + 1], sizeof(f));
+    (void)hipEventElapsedTime(&self->last_sample_ms, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&self->last_reduce_ms, c->ev[1], c->ev[2]);
+    if (f != ~0ull) {
+        self->failed_column = (int64_t)f;
+        return fail(BPMF_HIP_ECHOL, "Cholesky failed in column " + std::to_string((long long)f));
+    }
+    self->failed_column = -1;
+    return BPMF_HIP_OK;
+}
+
+extern "C" int bpmf_hip_sample_side(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double alpha,
+                                    const double *mu, const double *LambdaF,
+                                    double *sum_out, double *prod_out, double *norm_out)
+{
+    int rc = bpmf_hip_sample_side_launch(self, other, iter, alpha, mu, LambdaF);
+    if (rc) return rc;
+    return bpmf_hip_sample_side_finish(self, sum_out, prod_out, norm_out);
+}
+
+extern "C" int64_t bpmf_hip_failed_column(const bpmf_hip_side *s) { return s ? s->failed_column : -1; }
+
+extern "C" int bpmf_hip_side_last_kernel_ms(bpmf_hip_side *s, float *sample_ms, float *reduce_ms)
+{
+    if (!s) return fail(BPMF_HIP_EINVAL, "last_kernel_ms: NULL");
+    if (sample_ms) *sample_ms = s->last_sample_ms;
+    if (reduce_ms) *reduce_ms = s->last_reduce_ms;
+    return BPMF_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int bpmf_hip_test_create(bpmf_hip_side *side, const int64_t *tcolptr, const int32_t *trowidx,
+                                    const double *tvals, bpmf_hip_test **out)
+{
+    if (!out) return fail(BPMF_HIP_EINVAL, "test_create: out is NULL");
+    *out = nullptr;
+    if (!side || !tcolptr) return fail(BPMF_HIP_EINVAL, "test_create: NULL argument");
+    const int64_t nloc = side->to - side->from;
+    if (tcolptr[0] != 0) return fail(BPMF_HIP_EINVAL, "test_create: tcolptr[0] must be 0");
+    const int64_t nnz = tcolptr[nloc];
+    if (nnz > 0 && (!trowidx || !tvals)) return fail(BPMF_HIP_EINVAL, "test_create: NULL rowidx/vals");
+    HIP_TRY(hipSetDevice(side->ctx->device));
+    std::vector<int32_t> tcol((size_t)std::max<int64_t>(nnz, 1));
+    for (int64_t c = 0; c < nloc; ++c) {
+        if (tcolptr[c + 1] < tcolptr[c]) return fail(BPMF_HIP_EINVAL, "test_create: tcolptr is not monotone");
+        for (int64_t p = tcolptr[c]; p < tcolptr[c + 1]; ++p) {
+            if (trowidx[p] < 0 || trowidx[p] >= side->nrows) return fail(BPMF_HIP_EINVAL, "test_create: row index out of range");
+            tcol[p] = (int32_t)c;
+        }
+    }
+    bpmf_hip_test *t = new (std::nothrow) bpmf_hip_test();
+    if (!t) return fail(BPMF_HIP_ENOMEM, "test_create: out of host memory");
+    t->side = side; t->nnz = nnz;
+    // a wave takes a contiguous run of test ratings, 4 at a time
+    const int64_t maxw = (int64_t)side->ctx->num_cu * 8;
+    int64_t nw = std::max<int64_t>(1, std::min<int64_t>((nnz + 63) / 64, maxw));
+    nw = (nw + 3) / 4 * 4;
+    t->per_wave = std::max<int64_t>(4, (((nnz + nw - 1) / nw) + 3) / 4 * 4);
+    t->nwaves = nw;
+    int rc;
+    if ((rc = dev_upload(&t->d_tcol, tcol.data(), (size_t)nnz)) || (rc = dev_upload(&t->d_trow, trowidx, (size_t)nnz)) ||
+        (rc = dev_upload(&t->d_tval, tvals, (size_t)nnz)) || (rc = dev_upload(&t->d_pavg, tvals, (size_t)nnz)) ||
+        (rc = dev_upload(&t->d_pm2, tvals, (size_t)nnz)) || (rc = dev_upload<double>(&t->d_partial, nullptr, (size_t)nw * 2))) {
+        bpmf_hip_test_destroy(t);
+        return rc;
+    }
+    *out = t;
+    return BPMF_HIP_OK;
+}
+
+extern "C" int bpmf_hip_test_destroy(bpmf_hip_test *t)
+{
+    if (!t) return BPMF_HIP_OK;
+    (void)hipSetDevice(t->side->ctx->device);
+    (void)hipStreamSynchronize(t->side->ctx->stream);
+    void *ptrs[] = {t->d_tcol, t->d_trow, t->d_tval, t->d_pavg, t->d_pm2, t->d_partial};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    delete t;
+    return BPMF_HIP_OK;
+}
+
+namespace {
+template <int K>
+void launch_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const bpmf_hip_side *other, int n)
+{
+    bpmf_hip_ctx *c = self->ctx;
+    hipLaunchKernelGGL(bpmf::k_predict<K>, dim3((unsigned)(t->nwaves / 4)), dim3(256), 0, c->stream,
+                       (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz, t->per_wave,
+                       (const double *)self->d_items, (const double *)other->d_items, self->from, self->mean_rating, n,
+                       t->d_pavg, t->d_pm2, t->d_partial);
+    hipLaunchKernelGGL(bpmf::k_predict_final, dim3(1), dim3(64), 0, c->stream, (const double *)t->d_partial, t->nwaves,
+                       c->d_out + c->out_words - 2);
+}
+}  // namespace
+
+extern "C" int bpmf_hip_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const bpmf_hip_side *other, int n,
+                                double *se, double *se_avg, int64_t *count)
+{
+    if (!t || !self || !other || !se || !se_avg || !count) return fail(BPMF_HIP_EINVAL, "predict: NULL argument");
+    if (t->side != self) return fail(BPMF_HIP_EINVAL, "predict: test matrix belongs to another side");
+    if (n < 0) return fail(BPMF_HIP_EINVAL, "predict: n < 0");
+    bpmf_hip_ctx *c = self->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    if (t->nnz == 0) { *se = 0.0; *se_avg = 0.0; *count = 0; return BPMF_HIP_OK; }
+    switch (c->K) {
+    case 8: launch_predict<8>(t, self, other, n); break;
+    case 16: launch_predict<16>(t, self, other, n); break;
+    case 32: launch_predict<32>(t, self, other, n); break;
+    case 64: launch_predict<64>(t, self, other, n); break;
+    default: return fail(BPMF_HIP_EINVAL, "predict: unsupported K");
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->h_out + c->out_words - 2, c->d_out + c->out_words - 2, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *se = c->h_out[c->out_words - 2];
+    *se_avg = c->h_out[c->out_words - 1];
+    *count = t->nnz;
+    return BPMF_HIP_OK;
+}
+
+extern "C" int bpmf_hip_test_get(bpmf_hip_test *t, double *pavg, double *pm2)
+{
+    if (!t) return fail(BPMF_HIP_EINVAL, "test_get: NULL");
+    HIP_TRY(hipSetDevice(t->side->ctx->device));
+    HIP_TRY(hipStreamSynchronize(t->side->ctx->stream));
+    if (pavg) HIP_TRY(hipMemcpy(pavg, t->d_pavg, (size_t)t->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    if (pm2) HIP_TRY(hipMemcpy(pm2, t->d_pm2, (size_t)t->nnz * sizeof(double), hipMemcpyDeviceToHost));
+    return BPMF_HIP_OK;
+}
+
+extern "C" int bpmf_hip_randn_stream(bpmf_hip_ctx *c, uint32_t counter, int n, double *out)
+{
+    if (!c || !out || n < 0 || n > 128) return fail(BPMF_HIP_EINVAL, "randn_stream: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    double *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 128 * sizeof(double)));
+    hipLaunchKernelGGL(bpmf::k_randn_probe, dim3(1), dim3(64), 0, c->stream, counter, n, d);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d, n * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(BPMF_HIP_ENODEV, std::string("randn_stream: ") + hipGetErrorString(e));
+    return BPMF_HIP_OK;
+}

@@ -1,0 +1,171 @@
+// hyper.cpp -- host-side Normal-Wishart hyper-parameter draw.
+//
+// The north-star keeps this step on the host.  It replaces HyperParams::sample
+// (c++/bpmf.h:98-103) and the chain CondNormalWishart -> NormalWishart ->
+// WishartChol -> WishartUnitChol / MvNormalChol_prec (c++/mvnormal.cpp:56-135).
+// Seed-for-seed parity needs the *same* consumption of the Philox stream as the
+// reference, so the draws go through libstdc++'s std::normal_distribution /
+// std::gamma_distribution themselves (c++/mvnormal.cpp:42,68) on a URNG with
+// the MicroURNG word order (philox.h).  Dense algebra is a few small
+// hand-written routines (no Eigen): K is at most 128.
+#include <cmath>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "../../include/bpmf_hip.h"
+#include "philox.h"
+
+namespace {
+
+struct Mat {   // column-major K x K view
+    double *p; int K;
+    double &operator()(int i, int j) const { return p[(size_t)j * K + i]; }
+};
+
+double randn(bpmf::MicroPhilox &rng) { return std::normal_distribution<>()(rng); }   // c++/mvnormal.cpp:41-43
+
+// inverse through LU with row pivoting (role of Eigen's inverse(), c++/mvnormal.cpp:124)
+bool invert(int K, const double *A_in, double *inv)
+{
+    std::vector<double> lu(A_in, A_in + (size_t)K * K);
+    std::vector<int> perm(K);
+    Mat A{lu.data(), K};
+    for (int i = 0; i < K; ++i) perm[i] = i;
+    for (int c = 0; c < K; ++c) {
+        int best = c;
+        for (int r = c + 1; r < K; ++r)
+            if (std::fabs(A(r, c)) > std::fabs(A(best, c))) best = r;
+        if (A(best, c) == 0.0) return false;
+        if (best != c) {
+            for (int j = 0; j < K; ++j) std::swap(A(c, j), A(best, j));
+            std::swap(perm[c], perm[best]);
+        }
+        const double piv = A(c, c);
+        for (int r = c + 1; r < K; ++r) {
+            const double f = (A(r, c) /= piv);
+            for (int j = c + 1; j < K; ++j) A(r, j) -= f * A(c, j);
+        }
+    }
+    Mat X{inv, K};
+    for (int c = 0; c < K; ++c) {
+        for (int r = 0; r < K; ++r) {          // forward: L z = P e_c
+            double s = perm[r] == c ? 1.0 : 0.0;
+            for (int j = 0; j < r; ++j) s -= A(r, j) * X(j, c);
+            X(r, c) = s;
+        }
+        for (int r = K - 1; r >= 0; --r) {     // backward: U x = z
+            double s = X(r, c);
+            for (int j = r + 1; j < K; ++j) s -= A(r, j) * X(j, c);
+            X(r, c) = s / A(r, r);
+        }
+    }
+    return true;
+}
+
+// lower Cholesky factor from the lower triangle (sigma.llt(), c++/mvnormal.cpp:78)
+bool cholesky_lower(int K, const double *S_in, double *L_out)
+{
+    Mat S{const_cast<double *>(S_in), K}, L{L_out, K};
+    std::memset(L_out, 0, sizeof(double) * K * K);
+    for (int c = 0; c < K; ++c) {
+        double d = S(c, c);
+        for (int j = 0; j < c; ++j) d -= L(c, j) * L(c, j);
+        if (!(d > 0.0)) return false;
+        L(c, c) = std::sqrt(d);
+        for (int r = c + 1; r < K; ++r) {
+            double s = S(r, c);
+            for (int j = 0; j < c; ++j) s -= L(r, j) * L(c, j);
+            L(r, c) = s / L(c, c);
+        }
+    }
+    return true;
+}
+
+thread_local char g_hyper_err[256];
+
+}  // namespace
+
+extern "C" void bpmf_hip_set_error_(const char *msg);   // capi.cpp
+
+extern "C" int bpmf_hyper_sample(int K, int64_t N, const double *cov, const double *Um, uint32_t counter,
+                                 double *mu, double *LambdaU, double *LambdaF)
+{
+    if (K <= 0 || K > 1024 || N <= 0 || !cov || !mu || !LambdaU || !LambdaF) {
+        bpmf_hip_set_error_("bpmf_hyper_sample: bad argument");
+        return BPMF_HIP_EINVAL;
+    }
+    const size_t KK = (size_t)K * K;
+    bpmf::MicroPhilox rng(counter);                      // rng_set_pos(iter), c++/sample.cpp:349
+
+    // fixed prior (c++/bpmf.h:80-96): mu0 = 0, kappa = b0 = 2, T = WI = I, nu = df = K
+    const double kappa = 2.0, dN = (double)N;
+    std::vector<double> mu_m(K), mu_c(K), X(KK), Tc(KK), R(KK), au(KK, 0.0), z(K);
+    for (int i = 0; i < K; ++i) {
+        const double um = Um ? Um[i] : 0.0;
+        mu_m[i] = 0.0 - um;
+        mu_c[i] = (kappa * 0.0 + dN * um) / (kappa + dN);
+    }
+    const double kappa_c = kappa + dN;
+    const double kappa_m = (kappa * dN) / (kappa + dN);
+    for (int j = 0; j < K; ++j)
+        for (int i = 0; i < K; ++i)
+            X[(size_t)j * K + i] = ((i == j ? 1.0 : 0.0) + dN * cov[(size_t)j * K + i]) + kappa_m * (mu_m[i] * mu_m[j]);
+    if (!invert(K, X.data(), Tc.data())) {
+        bpmf_hip_set_error_("bpmf_hyper_sample: singular posterior scale matrix");
+        return BPMF_HIP_ENUM;
+    }
+    const double nu_c = (double)((int64_t)K + N);
+
+    // WishartChol (c++/mvnormal.cpp:75-92)
+    if (!cholesky_lower(K, Tc.data(), R.data())) {
+        bpmf_hip_set_error_("bpmf_hyper_sample: posterior scale matrix not positive definite");
+        return BPMF_HIP_ENUM;
+    }
+    Mat AU{au.data(), K}, Rl{R.data(), K}, U{LambdaU, K}, F{LambdaF, K};
+    for (int i = 0; i < K; ++i) {                         // WishartUnitChol (c++/mvnormal.cpp:64-73)
+        std::gamma_distribution<> gam(0.5 * (nu_c - i));
+        AU(i, i) = std::sqrt(2.0 * gam(rng));
+        for (int j = 0; j < K - i - 1; ++j) (void)randn(rng);      // `VectorXd r = nrandn(...)`, drawn and dropped (:70)
+        for (int j = i + 1; j < K; ++j) AU(i, j) = randn(rng);
+    }
+    for (int j = 0; j < K; ++j)                           // U = au * chol.matrixU()
+        for (int i = 0; i < K; ++i) {
+            double s = 0.0;
+            for (int k = i; k <= j; ++k) s += AU(i, k) * Rl(j, k);
+            U(i, j) = s;
+        }
+
+    // MvNormalChol_prec (c++/mvnormal.cpp:56-61)
+    for (int i = 0; i < K; ++i) z[i] = randn(rng);
+    for (int i = K - 1; i >= 0; --i) {
+        double s = z[i];
+        for (int j = i + 1; j < K; ++j) s -= U(i, j) * z[j];
+        z[i] = s / U(i, i);
+    }
+    const double sk = std::sqrt(kappa_c);
+    for (int i = 0; i < K; ++i) mu[i] = z[i] / sk + mu_c[i];
+
+    for (int j = 0; j < K; ++j)                           // LambdaF = LambdaU^T LambdaU (c++/bpmf.h:101)
+        for (int i = 0; i < K; ++i) {
+            double s = 0.0;
+            const int m = i < j ? i : j;
+            for (int k = 0; k <= m; ++k) s += U(k, i) * U(k, j);
+            F(i, j) = s;
+        }
+    (void)g_hyper_err;
+    return BPMF_HIP_OK;
+}
+
+extern "C" void bpmf_cov_from_sums(int K, int64_t N, const double *sum, const double *prod, double *cov)
+{
+    for (int j = 0; j < K; ++j)
+        for (int i = 0; i < K; ++i)
+            cov[(size_t)j * K + i] = (prod[(size_t)j * K + i] - (sum[i] * sum[j] / (double)N)) / (double)(N - 1);
+}
+
+extern "C" void bpmf_randn_stream(uint32_t counter, int n, double *out)
+{
+    bpmf::MicroPhilox rng(counter);
+    for (int i = 0; i < n; ++i) out[i] = randn(rng);
+}

@@ -1,0 +1,181 @@
+"""HipEngine: numpy-facing wrapper of the C ABI (device = one MI355X).
+
+The engine interface (side_create / sample_side / predict / items get/set /
+hyper_sample) is what `Sys` is written against.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class _Side:
+    def __init__(self, handle, K, ncols, nrows, col_from, col_to, keep):
+        self.handle, self.K, self.ncols, self.nrows = handle, K, ncols, nrows
+        self.col_from, self.col_to = col_from, col_to
+        self._keep = keep          # arrays / tensors that must outlive the handle
+
+
+class HipEngine:
+    """One context = one GPU + one stream.  `stream` is an integer hipStream_t or None."""
+
+    name = "hip"
+
+    def __init__(self, K, device=0, stream=None):
+        self.lib = _lib.load_library()
+        self.K = int(K)
+        h = C.c_void_p()
+        _lib.check(self.lib.bpmf_hip_ctx_create(int(device), self.K, C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.ctx = h
+        self.device = device
+        self._sides = []
+
+    # -- lifetime -----------------------------------------------------------
+    def close(self):
+        if getattr(self, "ctx", None):
+            for s in self._sides:
+                if s.handle:
+                    self.lib.bpmf_hip_side_destroy(s.handle)
+                    s.handle = None
+            self.lib.bpmf_hip_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def sync(self):
+        _lib.check(self.lib.bpmf_hip_ctx_sync(self.ctx))
+
+    # -- sides ----------------------------------------------------------------
+    def side_create(self, ncols, nrows, colptr, rowidx, vals, mean_rating, col_from=0, col_to=None):
+        col_to = ncols if col_to is None else col_to
+        colptr = np.ascontiguousarray(colptr, np.int64)
+        rowidx = np.ascontiguousarray(rowidx, np.int32)
+        vals = np.ascontiguousarray(vals, np.float64)
+        assert len(colptr) == col_to - col_from + 1
+        h = C.c_void_p()
+        _lib.check(self.lib.bpmf_hip_side_create(self.ctx, ncols, nrows, col_from, col_to, _ptr(colptr), _ptr(rowidx),
+                                                 _ptr(vals), float(mean_rating), C.byref(h)))
+        s = _Side(h, self.K, ncols, nrows, col_from, col_to, None)
+        self._sides.append(s)
+        return s
+
+    def side_create_dev(self, ncols, nrows, colptr_host, rowidx_dev_ptr, vals_dev_ptr, mean_rating, col_from=0,
+                        col_to=None, keep=None):
+        col_to = ncols if col_to is None else col_to
+        colptr_host = np.ascontiguousarray(colptr_host, np.int64)
+        h = C.c_void_p()
+        _lib.check(self.lib.bpmf_hip_side_create_dev(self.ctx, ncols, nrows, col_from, col_to, _ptr(colptr_host),
+                                                     C.c_void_p(rowidx_dev_ptr), C.c_void_p(vals_dev_ptr),
+                                                     float(mean_rating), C.byref(h)))
+        s = _Side(h, self.K, ncols, nrows, col_from, col_to, keep)
+        self._sides.append(s)
+        return s
+
+    def side_destroy(self, side):
+        if side.handle:
+            _lib.check(self.lib.bpmf_hip_side_destroy(side.handle))
+            side.handle = None
+
+    def items_dev_ptr(self, side):
+        return self.lib.bpmf_hip_side_items_dev(side.handle)
+
+    def bind_items(self, side, dev_ptr, keep=None):
+        _lib.check(self.lib.bpmf_hip_side_bind_items(side.handle, C.c_void_p(dev_ptr)))
+        side._items_keep = keep
+
+    def items_tensor(self, side, device):
+        """Allocates the factor matrix as a torch tensor [ncols, K] on `device`, binds the side to
+        it (bpmf_hip_side_bind_items) and returns it, so RCCL collectives work on it in place."""
+        import torch
+        t = torch.zeros((side.ncols, self.K), dtype=torch.float64, device=device)
+        self.bind_items(side, t.data_ptr(), keep=t)
+        return t
+
+    def get_items(self, side):
+        """[ncols, K] C-order array = the K x ncols column-major factor matrix."""
+        out = np.empty((side.ncols, self.K), np.float64)
+        _lib.check(self.lib.bpmf_hip_side_get_items(side.handle, _ptr(out)))
+        return out
+
+    def set_items(self, side, items):
+        items = np.ascontiguousarray(items, np.float64)
+        assert items.shape == (side.ncols, self.K)
+        _lib.check(self.lib.bpmf_hip_side_set_items(side.handle, _ptr(items)))
+
+    # -- hot path ---------------------------------------------------------------
+    def sample_side_launch(self, side, other, it, alpha, mu, LambdaF):
+        mu = np.ascontiguousarray(mu, np.float64)
+        LF = np.asfortranarray(LambdaF, np.float64)
+        _lib.check(self.lib.bpmf_hip_sample_side_launch(side.handle, other.handle, int(it), float(alpha), _ptr(mu), _ptr(LF)))
+
+    def sample_side_finish(self, side):
+        K = self.K
+        s = np.empty(K); prod = np.empty((K, K), order="F"); nrm = np.empty(1)
+        _lib.check(self.lib.bpmf_hip_sample_side_finish(side.handle, _ptr(s), _ptr(prod), _ptr(nrm)))
+        return s, prod, float(nrm[0])
+
+    def sample_side(self, side, other, it, alpha, mu, LambdaF):
+        """Returns (sum[K], prod[K,K], norm) over the columns [col_from,col_to) of `side`."""
+        self.sample_side_launch(side, other, it, alpha, mu, LambdaF)
+        return self.sample_side_finish(side)
+
+    def last_kernel_ms(self, side):
+        a = C.c_float(); b = C.c_float()
+        _lib.check(self.lib.bpmf_hip_side_last_kernel_ms(side.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    # -- prediction -----------------------------------------------------------
+    def test_create(self, side, tcolptr, trowidx, tvals):
+        tcolptr = np.ascontiguousarray(tcolptr, np.int64)
+        trowidx = np.ascontiguousarray(trowidx, np.int32)
+        tvals = np.ascontiguousarray(tvals, np.float64)
+        h = C.c_void_p()
+        _lib.check(self.lib.bpmf_hip_test_create(side.handle, _ptr(tcolptr), _ptr(trowidx), _ptr(tvals), C.byref(h)))
+        return (h, int(tcolptr[-1]))
+
+    def predict(self, test, side, other, n):
+        se = C.c_double(); sea = C.c_double(); cnt = C.c_int64()
+        _lib.check(self.lib.bpmf_hip_predict(test[0], side.handle, other.handle, int(n), C.byref(se), C.byref(sea), C.byref(cnt)))
+        return se.value, sea.value, cnt.value
+
+    def test_get(self, test):
+        pavg = np.empty(test[1]); pm2 = np.empty(test[1])
+        _lib.check(self.lib.bpmf_hip_test_get(test[0], _ptr(pavg), _ptr(pm2)))
+        return pavg, pm2
+
+    # -- host-side hyper parameters (also in the library, not device code) -------
+    def hyper_sample(self, N, cov, counter, Um=None):
+        return hyper_sample(self.K, N, cov, counter, Um)
+
+    def randn_device(self, counter, n):
+        out = np.empty(n)
+        _lib.check(self.lib.bpmf_hip_randn_stream(self.ctx, int(counter) & 0xFFFFFFFF, int(n), _ptr(out)))
+        return out
+
+
+def hyper_sample(K, N, cov, counter, Um=None):
+    """HyperParams::sample on the host (c++/bpmf.h:98-103): returns mu[K], LambdaU[K,K], LambdaF[K,K]."""
+    lib = _lib.load_library()
+    cov = np.asfortranarray(cov, np.float64)
+    mu = np.empty(K); LU = np.empty((K, K), order="F"); LF = np.empty((K, K), order="F")
+    um = np.ascontiguousarray(Um, np.float64) if Um is not None else None
+    _lib.check(lib.bpmf_hyper_sample(int(K), int(N), _ptr(cov), _ptr(um), int(counter) & 0xFFFFFFFF, _ptr(mu), _ptr(LU), _ptr(LF)))
+    return mu, LU, LF
+
+
+def cov_from_sums(K, N, s, prod):
+    lib = _lib.load_library()
+    s = np.ascontiguousarray(s, np.float64); prod = np.asfortranarray(prod, np.float64)
+    cov = np.empty((K, K), order="F")
+    lib.bpmf_cov_from_sums(int(K), int(N), _ptr(s), _ptr(prod), _ptr(cov))
+    return cov
+
+
+def randn_host(counter, n):
+    lib = _lib.load_library()
+    out = np.empty(n)
+    lib.bpmf_randn_stream(int(counter) & 0xFFFFFFFF, int(n), _ptr(out))
+    return out

@@ -1,0 +1,169 @@
+/*
+ * bpmf_hip.h -- C ABI of the MI355X-native BPMF Gibbs hot path (libbpmf_hip.so).
+ *
+ * This is the drop-in boundary for the per-column sampler of ExaScience/bpmf.
+ * The reference has no FFI: its boundary is the C++ class `struct Sys`
+ * (c++/bpmf.h:112-239) selected at compile time through `#define SYS <Backend>_Sys`
+ * (c++/nocomm.h:6, c++/bpmf.cpp:19-39,131-132).  A new back-end header
+ * (INTEGRATION.md shows `hip_sys.h`) subclasses Sys and forwards the virtuals
+ * below to these entry points; each prototype cites the reference member it
+ * replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative BPMF_HIP_E* code and
+ *     leaves a message for bpmf_hip_last_error() (thread-local);
+ *   - matrices are column-major doubles exactly like Eigen's MatrixNNd / the
+ *     `items()` map (c++/bpmf.h:56,193-194): a factor matrix is K x N with one
+ *     contiguous K-vector per user / item, so `.ddm` dumps stay byte-compatible;
+ *   - sparse matrices are CSC with ascending row indices per column (what
+ *     Eigen::SparseMatrix<double> holds after setFromTriplets, c++/io.cpp:521),
+ *     int64 column pointers (2e9 nnz configs overflow Eigen's int), int32 rows;
+ *   - host pointers unless a name ends in `_dev`; the caller keeps ownership of
+ *     everything it passes in; handles own their device memory;
+ *   - one context per process per GPU, used from one host thread at a time
+ *     (the reference calls Sys::sample from the main thread, c++/bpmf.cpp:184-185).
+ *   - there is NO CPU fallback: without a usable HIP device every entry point
+ *     that touches the device fails with BPMF_HIP_ENODEV.
+ */
+#ifndef BPMF_HIP_H
+#define BPMF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BPMF_HIP_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define BPMF_API __attribute__((visibility("default")))
+#else
+#define BPMF_API
+#endif
+
+enum {
+    BPMF_HIP_OK = 0,
+    BPMF_HIP_EINVAL = -1,   /* bad argument (unsupported K, NULL, range)            */
+    BPMF_HIP_ENODEV = -2,   /* no HIP device / HIP runtime error                     */
+    BPMF_HIP_ENOMEM = -3,   /* device or host allocation failed                      */
+    BPMF_HIP_ECHOL = -4,    /* "Cholesky failed" (c++/sample.cpp:308); see _failed_column */
+    BPMF_HIP_ENUM = -5      /* host-side numerical failure in the hyper-parameter draw */
+};
+
+typedef struct bpmf_hip_ctx bpmf_hip_ctx;     /* one GPU + stream + scratch            */
+typedef struct bpmf_hip_side bpmf_hip_side;   /* one `Sys`: ratings CSC + factor matrix */
+typedef struct bpmf_hip_test bpmf_hip_test;   /* test matrix T with Pavg / Pm2           */
+
+/* message of the last failing call on this thread */
+BPMF_API const char *bpmf_hip_last_error(void);
+BPMF_API int bpmf_hip_abi_version(void);
+/* 1 if K (BPMF_NUMLATENT, c++/bpmf.h:22-24,53) has an instantiated kernel: 8,16,32,64 */
+BPMF_API int bpmf_hip_supports_k(int K);
+
+/* ---- context --------------------------------------------------------------
+ * Replaces Sys::Init / Sys::Finalize (c++/nocomm.h:19-27).  `stream` is a
+ * hipStream_t to launch on (e.g. torch's current stream) or NULL to let the
+ * context create its own non-blocking stream. */
+BPMF_API int bpmf_hip_ctx_create(int device, int K, void *stream, bpmf_hip_ctx **out);
+BPMF_API int bpmf_hip_ctx_destroy(bpmf_hip_ctx *ctx);
+BPMF_API int bpmf_hip_ctx_sync(bpmf_hip_ctx *ctx);
+BPMF_API void *bpmf_hip_ctx_stream(bpmf_hip_ctx *ctx);
+
+/* ---- one side (= one Sys) ---------------------------------------------------
+ * Replaces Sys::Sys + alloc_and_init + Sys::init (c++/sample.cpp:112-137,179-226,
+ * c++/nocomm.h:29-33).  The factor matrix has `ncols` columns (all of them,
+ * replicated on every GPU) and is zero-initialised (items().setZero(), :185).
+ * This rank samples columns [col_from, col_to) -- Sys::from()/to(),
+ * c++/bpmf.h:170-172 -- and passes the CSC slice of exactly those columns:
+ * colptr has col_to-col_from+1 entries starting at 0, rowidx are row ids of the
+ * ratings = column ids of the OTHER side (must be < nrows).  mean_rating is
+ * M.sum()/M.nonZeros() over the whole matrix (c++/sample.cpp:183).
+ * The arrays are copied to the device; the `_dev` variant adopts device arrays
+ * the caller keeps alive (e.g. a synthetic matrix generated on the GPU). */
+BPMF_API int bpmf_hip_side_create(bpmf_hip_ctx *ctx, int64_t ncols, int64_t nrows, int64_t col_from, int64_t col_to,
+                         const int64_t *colptr, const int32_t *rowidx, const double *vals,
+                         double mean_rating, bpmf_hip_side **out);
+BPMF_API int bpmf_hip_side_create_dev(bpmf_hip_ctx *ctx, int64_t ncols, int64_t nrows, int64_t col_from, int64_t col_to,
+                             const int64_t *colptr_host, const int32_t *rowidx_dev, const double *vals_dev,
+                             double mean_rating, bpmf_hip_side **out);
+BPMF_API int bpmf_hip_side_destroy(bpmf_hip_side *side);
+
+/* items(): device address of the K x ncols factor matrix (c++/bpmf.h:193-194);
+ * bind_items makes the side use caller-owned device storage instead (so a
+ * torch tensor / RCCL buffer can be exchanged in place; replaces the
+ * backend's malloc in alloc_and_init, c++/nocomm.h:31). */
+BPMF_API double *bpmf_hip_side_items_dev(bpmf_hip_side *side);
+BPMF_API int bpmf_hip_side_bind_items(bpmf_hip_side *side, double *items_dev);
+/* host <-> device copies of the whole K x ncols matrix (the -v / -o dumps,
+ * c++/bpmf.cpp:206-207,234-239) */
+BPMF_API int bpmf_hip_side_get_items(bpmf_hip_side *side, double *items_host);
+BPMF_API int bpmf_hip_side_set_items(bpmf_hip_side *side, const double *items_host);
+
+/* ---- the hot path ----------------------------------------------------------
+ * Replaces the column loop of Sys::sample(Sys&) (c++/sample.cpp:352-384) with
+ * Sys::sample(long,Sys&) + computeMuLambda (:248-336) and the Philox/polar
+ * draw (c++/mvnormal.cpp:18-47) inside: for every column idx in
+ * [col_from,col_to) of `self`, from the current factor of `other`,
+ *     Lambda* = LambdaF + alpha * sum_j u_j u_j^T,  b = LambdaF*mu + alpha * sum_j (r_ij - mean) u_j,
+ *     x = L^-T (L^-1 b + z),  z ~ N(0,I) from stream (idx+1)*K*(iter+1) mod 2^32,
+ * and writes x into self.items[:, idx].  `iter` is the value of Sys::iter after
+ * the `iter++` at :344 (0 for the first call).  mu / LambdaF are the output of
+ * bpmf_hyper_sample (hp.mu / hp.LambdaF).  On return the three reductions
+ * over this rank's columns are on the host (thread_vector combine, :379-381):
+ *     sum_out[K] = sum x,  prod_out[K*K] = sum x x^T (col-major),  *norm_out = sum |x|^2.
+ * The call blocks until they have arrived.  BPMF_HIP_ECHOL if a pivot is not
+ * positive (THROWERROR("Cholesky failed"), :308). */
+BPMF_API int bpmf_hip_sample_side(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double alpha,
+                         const double *mu, const double *LambdaF,
+                         double *sum_out, double *prod_out, double *norm_out);
+/* the same split in two so that an exchange of the fresh columns can overlap
+ * the reductions: _launch enqueues the kernels, _finish waits for the partials */
+BPMF_API int bpmf_hip_sample_side_launch(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double alpha,
+                                const double *mu, const double *LambdaF);
+BPMF_API int bpmf_hip_sample_side_finish(bpmf_hip_side *self, double *sum_out, double *prod_out, double *norm_out);
+/* global id of the first column whose factorisation failed, or -1 */
+BPMF_API int64_t bpmf_hip_failed_column(const bpmf_hip_side *side);
+
+/* ---- prediction / RMSE -------------------------------------------------------
+ * Replaces Sys::predict (c++/sample.cpp:48-96).  The test matrix slice covers
+ * the same columns [col_from,col_to) as `side`; Pavg = Pm2 = T initially
+ * (c++/sample.cpp:123).  n = iter < burnin ? 0 : iter - burnin (:50).  Returns
+ * the partial sums of this rank: se = sum (r-pred)^2, se_avg = sum (r-avg)^2,
+ * count = number of predictions; rmse = sqrt(se/count) (:93-95). */
+BPMF_API int bpmf_hip_test_create(bpmf_hip_side *side, const int64_t *tcolptr, const int32_t *trowidx,
+                         const double *tvals, bpmf_hip_test **out);
+BPMF_API int bpmf_hip_test_destroy(bpmf_hip_test *test);
+BPMF_API int bpmf_hip_predict(bpmf_hip_test *test, const bpmf_hip_side *self, const bpmf_hip_side *other, int n,
+                     double *se, double *se_avg, int64_t *count);
+/* Pavg / Pm2 in the nnz order of the slice passed to _test_create (Pavg.sdm /
+ * Pm2.sdm outputs, c++/bpmf.cpp:229-230) */
+BPMF_API int bpmf_hip_test_get(bpmf_hip_test *test, double *pavg_host, double *pm2_host);
+
+/* ---- hyper-parameters (host) --------------------------------------------------
+ * Replaces rng_set_pos(iter) + HyperParams::sample (c++/sample.cpp:349-350,
+ * c++/bpmf.h:98-103) = CondNormalWishart/NormalWishart/WishartChol/
+ * WishartUnitChol/MvNormalChol_prec (c++/mvnormal.cpp:56-135) with the fixed
+ * prior mu0=0, b0=2, WI=I, df=K.  Runs on the host with libstdc++'s
+ * normal/gamma distributions on the Philox stream `counter` (= iter).
+ * cov is K x K; Um is sum/N or NULL for the reference's behaviour (its member
+ * `sum` is never updated, so it always passes 0).  Outputs: mu[K], LambdaU
+ * (upper Cholesky factor, K x K), LambdaF = LambdaU^T LambdaU. */
+BPMF_API int bpmf_hyper_sample(int K, int64_t N, const double *cov, const double *Um, uint32_t counter,
+                      double *mu, double *LambdaU, double *LambdaF);
+/* cov = (prod - sum sum^T / N) / (N - 1)  (c++/sample.cpp:383-384) */
+BPMF_API void bpmf_cov_from_sums(int K, int64_t N, const double *sum, const double *prod, double *cov);
+/* the per-column normal stream, for tests: out[i] = i-th randn() after
+ * rng_set_pos(counter) (c++/mvnormal.cpp:34-43) */
+BPMF_API void bpmf_randn_stream(uint32_t counter, int n, double *out);
+/* the same n draws produced by the device sampler (n <= 128) */
+BPMF_API int bpmf_hip_randn_stream(bpmf_hip_ctx *ctx, uint32_t counter, int n, double *out);
+
+/* kernel timing of the last _sample_side on this side, in milliseconds, from
+ * HIP events recorded on the context's stream (for bench.py's roofline line) */
+BPMF_API int bpmf_hip_side_last_kernel_ms(bpmf_hip_side *side, float *sample_ms, float *reduce_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BPMF_HIP_H */

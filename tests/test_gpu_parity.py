@@ -1,0 +1,224 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on identical
+seeds.  fp64 tolerance: the sampled factors must agree to RTOL = 1e-9 of the
+largest factor entry after one half-iteration (differences come from the
+summation order of the Gram, 1/sqrt vs divide, and log/sqrt ulps), and RMSE
+traces of whole runs to 1e-6 (north-star bar: 1e-3)."""
+import math
+
+import numpy as np
+import pytest
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def half_iteration_pair(oracle, eng, K, M, nrows, other_items, it, alpha=2.0, cov=None, chunk_note=""):
+    """Runs one Sys::sample(Sys&) on both sides of the fence; returns (hip, ref) tuples."""
+    ncols = len(M[0]) - 1
+    cov = np.zeros((K, K)) if cov is None else cov
+    mu, LU, LF = oracle.hyper_sample(K, ncols, cov, it)
+    mean = util.mean_rating(M)
+    items_ref = np.zeros((ncols, K))
+    s_ref, p_ref, n_ref = oracle.sample_side(K, M, mean, alpha, other_items, items_ref, it, mu, LF)
+    me = eng.side_create(ncols, nrows, *M, mean)
+    ot = eng.side_create(nrows, ncols, np.zeros(nrows + 1, np.int64), np.zeros(0, np.int32), np.zeros(0), 0.0)
+    eng.set_items(ot, other_items)
+    s, p, n = eng.sample_side(me, ot, it, alpha, mu, LF)
+    items = eng.get_items(me)
+    eng.side_destroy(me); eng.side_destroy(ot)
+    return (items, s, p, n), (items_ref, s_ref, p_ref, n_ref)
+
+
+def check_half_iteration(hip, ref):
+    items, s, p, n = hip
+    items_ref, s_ref, p_ref, n_ref = ref
+    assert np.all(np.isfinite(items))
+    assert rel_err(items, items_ref) < RTOL
+    assert rel_err(s, s_ref) < 1e-8 and rel_err(p, p_ref) < 1e-8 and abs(n - n_ref) <= 1e-8 * abs(n_ref)
+
+
+@pytest.mark.parametrize("counter", [0, 1, 32, 8 * 5 * 9, 2 ** 32 - 1, 1234567])
+def test_device_normal_stream(oracle, hip_engine_factory, counter):
+    """draw_normals (ballot-ranked polar attempts) == the sequential stream of randn()."""
+    eng = hip_engine_factory(32)
+    for n in (1, 8, 32, 64, 128):
+        z = eng.randn_device(counter, n)
+        ref = oracle.randn(counter, n)
+        # identical accept/reject decisions; log/sqrt may differ in the last ulps
+        assert np.allclose(z, ref, rtol=4e-16 * 8, atol=0), (counter, n)
+
+
+@pytest.mark.parametrize("K", [8, 16, 32, 64])
+def test_tiny_first_half_iterations(oracle, hip_engine_factory, K):
+    M, Mt, T, Tt, nu, nm = util.tiny()
+    eng = hip_engine_factory(K)
+    rng = np.random.default_rng(K)
+    # iteration 0: factors are zero (Sys::init); then with random factors
+    for it, U in ((0, np.zeros((nu, K))), (3, rng.standard_normal((nu, K)))):
+        check_half_iteration(*half_iteration_pair(oracle, eng, K, M, nu, U, it))
+    V = rng.standard_normal((nm, K))
+    check_half_iteration(*half_iteration_pair(oracle, eng, K, Mt, nm, V, 2))
+
+
+@pytest.mark.parametrize("K", [16, 32, 64])
+def test_ml100k_half_iterations(oracle, hip_engine_factory, K):
+    M, Mt, T, Tt, nu, nm = util.ml100k()
+    eng = hip_engine_factory(K)
+    rng = np.random.default_rng(100 + K)
+    U = 0.3 * rng.standard_normal((nu, K)); V = 0.3 * rng.standard_normal((nm, K))
+    A = rng.standard_normal((K, 3 * K)); cov = A @ A.T / (3 * K)
+    # movies side: 32 empty columns (sample from the prior), median 21 ratings
+    check_half_iteration(*half_iteration_pair(oracle, eng, K, M, nu, U, 5, cov=cov))
+    check_half_iteration(*half_iteration_pair(oracle, eng, K, Mt, nm, V, 7, cov=cov))
+
+
+def test_heavy_column_is_chunked(oracle, hip_engine_factory):
+    """A column far above the chunk size goes through partial tiles + k_finish_multi."""
+    K = 32
+    M, Mt, T, Tt, nu, nm = util.synthetic(6000, 300, 60000, seed=3, heavy=(7, 5000))
+    assert np.diff(M[0]).max() >= 5000
+    eng = hip_engine_factory(K)
+    rng = np.random.default_rng(5)
+    U = 0.2 * rng.standard_normal((nu, K))
+    check_half_iteration(*half_iteration_pair(oracle, eng, K, M, nu, U, 1))
+
+
+def test_ragged_and_empty(oracle, hip_engine_factory):
+    """Columns with 0, 1, 2, 3, 4, 5, 15, 16, 17 ratings (MFMA k-step and unroll tails)."""
+    K = 32
+    counts = [0, 1, 2, 3, 4, 5, 15, 16, 17, 31, 33, 0, 64, 65]
+    nrows = 80
+    rng = np.random.default_rng(11)
+    colptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    rowidx = np.concatenate([np.sort(rng.choice(nrows, c, replace=False)) for c in counts]).astype(np.int32)
+    vals = rng.integers(1, 6, len(rowidx)).astype(np.float64)
+    M = (colptr, rowidx, vals)
+    U = rng.standard_normal((nrows, K))
+    eng = hip_engine_factory(K)
+    check_half_iteration(*half_iteration_pair(oracle, eng, K, M, nrows, U, 4))
+
+
+def test_counter_wraps_mod_2_32(oracle, hip_engine_factory):
+    """(idx+1)*K*(iter+1) is truncated to uint32: use a huge iteration number."""
+    K = 8
+    M, Mt, T, Tt, nu, nm = util.tiny()
+    eng = hip_engine_factory(K)
+    U = np.random.default_rng(0).standard_normal((nu, K))
+    it = 2 ** 29 + 3
+    check_half_iteration(*half_iteration_pair(oracle, eng, K, M, nu, U, it))
+
+
+def test_predict_matches_oracle(oracle, hip_engine_factory):
+    K = 32
+    M, Mt, T, Tt, nu, nm = util.ml100k()
+    eng = hip_engine_factory(K)
+    rng = np.random.default_rng(9)
+    U = 0.3 * rng.standard_normal((nu, K)); V = 0.3 * rng.standard_normal((nm, K))
+    mean = util.mean_rating(M)
+    movies = eng.side_create(nm, nu, *M, mean)
+    users = eng.side_create(nu, nm, *Mt, mean)
+    eng.set_items(movies, V); eng.set_items(users, U)
+    test = eng.test_create(movies, *T)
+    pavg = T[2].copy(); pm2 = T[2].copy()
+    for n in (0, 0, 1, 2, 5):                       # Q6: n = iter - burnin, avg is overwritten at n = 0 and n = 1
+        se, sea, cnt = eng.predict(test, movies, users, n)
+        se_r, sea_r, cnt_r = oracle.predict(K, T, V, U, mean, n, pavg, pm2)
+        assert cnt == cnt_r == 20000
+        assert abs(se - se_r) < 1e-9 * se_r and abs(sea - sea_r) < 1e-9 * sea_r
+        a, b = eng.test_get(test)
+        assert np.allclose(a, pavg, rtol=1e-12, atol=1e-12) and np.allclose(b, pm2, rtol=1e-10, atol=1e-12)
+        V = V + 0.01 * rng.standard_normal(V.shape); eng.set_items(movies, V)
+    eng.side_destroy(movies); eng.side_destroy(users)
+
+
+def test_full_run_tiny_reference_smoke(oracle, hip_engine_factory):
+    """The reference's own (disabled) test: data/tiny, -i 9 -b 0, Final Avg RMSE < 3 (run_test.sh:14-16)."""
+    import bpmf_amd
+    K = 8
+    M, Mt, T, Tt, nu, nm = util.tiny()
+    eng = hip_engine_factory(K)
+    res = bpmf_amd.gibbs(eng, M, Mt, T, nu, nm, nsims=9, burnin=0)
+    ref = oracle.gibbs(K, M, Mt, T, Tt, nsims=9, burnin=0)
+    assert res["final_rmse_avg"] < 3.0
+    assert abs(res["final_rmse_avg"] - ref["final_rmse_avg"]) < 1e-6
+    assert np.allclose(res["rmse"], ref["rmse"], atol=1e-6)
+    assert rel_err(res["U"], ref["U"]) < 1e-7 and rel_err(res["V"], ref["V"]) < 1e-7
+
+
+def test_full_run_ml100k_matches_oracle(oracle, hip_engine_factory):
+    """Default run (-i 20 -b 5, K = 32) on the shipped MovieLens-100K split: RMSE trace,
+    final averaged RMSE and the sampled factors against the CPU path on identical seeds."""
+    import bpmf_amd
+    K = 32
+    M, Mt, T, Tt, nu, nm = util.ml100k()
+    eng = hip_engine_factory(K)
+    res = bpmf_amd.gibbs(eng, M, Mt, T, nu, nm, nsims=20, burnin=5)
+    ref = oracle.gibbs(K, M, Mt, T, Tt, nsims=20, burnin=5, nthreads=1)
+    assert abs(res["rmse"][0] - 1.153676) < 2e-3          # iteration 0 = mean predictor
+    assert np.allclose(res["rmse"], ref["rmse"], atol=1e-6)
+    assert np.allclose(res["rmse_avg"], ref["rmse_avg"], atol=1e-6)
+    assert abs(res["final_rmse_avg"] - ref["final_rmse_avg"]) < 1e-6
+    assert 0.94 < res["final_rmse_avg"] < 0.97
+    assert np.allclose(res["norm_u"], ref["norm_u"], rtol=1e-7) and np.allclose(res["norm_m"], ref["norm_m"], rtol=1e-7)
+    # after 20 coupled iterations the chains are still on top of each other
+    assert rel_err(res["U"], ref["U"]) < 1e-6 and rel_err(res["V"], ref["V"]) < 1e-6
+
+
+def test_posterior_moments_of_one_column(hip_engine_factory):
+    """Statistical check that does not involve the oracle: many draws of the same column
+    (different iter => different streams) have mean Lambda*^-1 b and covariance Lambda*^-1."""
+    K = 8
+    rng = np.random.default_rng(2)
+    nrows, nd = 40, 4000
+    rows = np.sort(rng.choice(nrows, 12, replace=False)).astype(np.int32)
+    vals = rng.integers(1, 6, 12).astype(np.float64)
+    # nd identical columns -> nd independent draws in one call (stream depends on idx)
+    colptr = (np.arange(nd + 1) * 12).astype(np.int64)
+    M = (colptr, np.tile(rows, nd), np.tile(vals, nd))
+    U = rng.standard_normal((nrows, K))
+    A = rng.standard_normal((K, 2 * K)); LF = A @ A.T / K + np.eye(K); mu = rng.standard_normal(K)
+    eng = hip_engine_factory(K)
+    mean, alpha = 3.0, 2.0
+    me = eng.side_create(nd, nrows, *M, mean)
+    ot = eng.side_create(nrows, nd, np.zeros(nrows + 1, np.int64), np.zeros(0, np.int32), np.zeros(0), 0.0)
+    eng.set_items(ot, U)
+    eng.sample_side(me, ot, 0, alpha, mu, LF)
+    X = eng.get_items(me)
+    Y = U[rows]
+    Lam = LF + alpha * Y.T @ Y
+    b = LF @ mu + alpha * Y.T @ (vals - mean)
+    m_true = np.linalg.solve(Lam, b); C_true = np.linalg.inv(Lam)
+    se = np.sqrt(np.diag(C_true) / nd)
+    assert np.all(np.abs(X.mean(0) - m_true) < 5 * se)
+    assert np.abs(np.cov(X.T) - C_true).max() < 6 * np.abs(C_true).max() / math.sqrt(nd)
+    eng.side_destroy(me); eng.side_destroy(ot)
+
+
+def test_cholesky_failure_is_reported(hip_engine_factory):
+    """THROWERROR("Cholesky failed") (c++/sample.cpp:308) -> BPMF_HIP_ECHOL + column id."""
+    import bpmf_amd
+    K = 8
+    M, Mt, T, Tt, nu, nm = util.tiny()
+    eng = hip_engine_factory(K)
+    me = eng.side_create(nm, nu, *M, 3.0)
+    ot = eng.side_create(nu, nm, np.zeros(nu + 1, np.int64), np.zeros(0, np.int32), np.zeros(0), 0.0)
+    with pytest.raises(bpmf_amd.BpmfHipError) as e:
+        eng.sample_side(me, ot, 0, 2.0, np.zeros(K), -np.eye(K))       # negative definite prior precision
+    assert e.value.code == -4 and "Cholesky failed in column 0" in str(e.value)
+    eng.side_destroy(me); eng.side_destroy(ot)
+
+
+def test_bad_arguments_are_rejected(hip_engine_factory):
+    import bpmf_amd
+    eng = hip_engine_factory(8)
+    with pytest.raises(bpmf_amd.BpmfHipError):
+        eng.side_create(2, 4, np.array([0, 1, 2], np.int64), np.array([0, 9], np.int32), np.ones(2), 1.0)   # row 9 >= nrows
+    with pytest.raises(bpmf_amd.BpmfHipError):
+        bpmf_amd.HipEngine(24)                                                                              # unsupported K
