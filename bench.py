@@ -42,7 +42,7 @@ def algorithmic_flops(nnz, ncols, K):
     return nnz * (K * (K + 1) + 2 * K) + ncols * (K ** 3 / 3.0 + 4 * K * K + 3 * K)
 
 
-def cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies, budget_s=20.0):
+def cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies, budget_s=15.0):
     """Times the oracle's -O3/OpenMP build (a restatement of c++/sample.cpp; the real
     reference needs Eigen3 and cannot be built here) on all host cores."""
     from oracle import oracle as orc
@@ -51,17 +51,26 @@ def cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies, budget_s=20.0):
     except Exception:
         pass
     o = orc.Oracle(fast=True)
-    cores = os.cpu_count() or 1
-    o.gibbs(K, M, Mt, T, Tt, nsims=1, burnin=0, nthreads=cores)            # warm-up
-    t0 = time.perf_counter()
-    r = o.gibbs(K, M, Mt, T, Tt, nsims=2, burnin=0, nthreads=cores)
-    per_iter = (time.perf_counter() - t0) / 2
-    n = int(max(2, min(40, budget_s / max(per_iter, 1e-3))))
+    hw = os.cpu_count() or 1
+    # thread sweep: the container may be limited to fewer CPUs than it can see, and the
+    # column loop stops scaling well before 256 threads; report the best setting
+    best = (None, float("inf"))
+    for nt in sorted({t for t in (8, 16, 32, 64, 128, hw) if t <= hw}):
+        o.gibbs(K, M, Mt, T, Tt, nsims=1, burnin=0, nthreads=nt)
+        r = o.gibbs(K, M, Mt, T, Tt, nsims=3, burnin=0, nthreads=nt)
+        per = float(np.mean(r["secs"][1:]))
+        if per < best[1]:
+            best = (nt, per)
+        if per > 4 * best[1]:
+            break
+    cores, per_iter = best
+    n = int(max(3, min(200, budget_s / max(per_iter, 1e-3))))
     r = o.gibbs(K, M, Mt, T, Tt, nsims=n, burnin=0, nthreads=cores)
     secs = float(np.sum(r["secs"][1:])) / (n - 1)
     return {"value": (nusers + nmovies) / secs, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": "%d Gibbs iterations of the same ML-1M-shaped matrix, K=%d, OpenMP schedule(guided), "
-                      "%d threads, gcc -O3 -march=native; %.1f ms/iter" % (n, K, cores, secs * 1e3)}
+                      "%d threads (best of a sweep up to %d hardware threads), gcc -O3 -march=native; %.2f ms/iter"
+                      % (n, K, cores, hw, secs * 1e3)}
 
 
 def main():

@@ -32,6 +32,9 @@ _SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "bpmf_hip_sample_side_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p]),
     "bpmf_hip_sample_side_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bpmf_hip_sys_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double]),
+    "bpmf_hip_sys_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
     "bpmf_hip_failed_column": (C.c_int64, [C.c_void_p]),
     "bpmf_hip_test_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "bpmf_hip_test_destroy": (C.c_int, [C.c_void_p]),

@@ -62,6 +62,7 @@ struct bpmf_hip_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cu = 256;
+    unsigned ablate = 0;
     // per-call parameter blob: LambdaF[K*K] | Lmu[K] | fail (u64)
     double *h_in = nullptr, *d_in = nullptr;
     // result blob: prod[K*K] | sum[K] | norm | fail (u64) ; predict: se | se_avg
@@ -87,6 +88,12 @@ struct bpmf_hip_side {
     int64_t failed_column = -1;
     bool pending = false;
     float last_sample_ms = 0.f, last_reduce_ms = 0.f;
+    // state of the reference's Sys (c++/bpmf.h:139,221-226) for bpmf_hip_sys_sample
+    int iter = -1;
+    double norm = 0.0;
+    std::vector<double> cov, hp_mu, hp_LambdaU, hp_LambdaF;      // current
+    std::vector<double> nx_mu, nx_LambdaU, nx_LambdaF;           // pre-drawn for iteration nx_iter
+    int nx_iter = -2;
 };
 
 struct bpmf_hip_test {
@@ -94,7 +101,7 @@ struct bpmf_hip_test {
     int64_t nnz = 0;
     int32_t *d_tcol = nullptr, *d_trow = nullptr;
     double *d_tval = nullptr, *d_pavg = nullptr, *d_pm2 = nullptr, *d_partial = nullptr;
-    int64_t nwaves = 0, per_wave = 0;
+    int64_t nblocks = 0;
 };
 
 namespace {
@@ -176,7 +183,7 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     const size_t pw = part_words_rt(K);
     if ((rc = dev_upload<double>(&s->d_partials, nullptr, (size_t)slots * pw))) return rc;
     // column statistics: one wave per 64+ columns, at most 2 waves per CU
-    s->nstat_waves = (int)std::max<int64_t>(1, std::min<int64_t>((nloc + 63) / 64, (int64_t)s->ctx->num_cu * 2));
+    s->nstat_waves = (int)std::max<int64_t>(1, std::min<int64_t>((nloc + 31) / 32, (int64_t)s->ctx->num_cu * 2));
     if ((rc = dev_upload<double>(&s->d_stat_partials, nullptr, (size_t)s->nstat_waves * pw))) return rc;
     return 0;
 }
@@ -204,6 +211,7 @@ extern "C" int bpmf_hip_ctx_create(int device, int K, void *stream, bpmf_hip_ctx
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->ablate = (unsigned)env_int("BPMF_HIP_ABLATE", 0);
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     c->in_words = (size_t)K * K + K + 1;
@@ -353,15 +361,16 @@ int do_launch(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double 
     a.LambdaF = c->d_in; a.Lmu = c->d_in + (size_t)K * K;
     a.fail = (unsigned long long *)(c->d_in + (size_t)K * K + K);
     a.mean_rating = self->mean_rating; a.alpha = alpha; a.iter_plus_1 = (uint32_t)(iter + 1);
+    a.ablate = c->ablate;
 
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (self->nwork > 0) hipLaunchKernelGGL(k_gram<K>, dim3(self->nwork), dim3(64), 0, c->stream, a);
-    if (self->nmulti > 0) hipLaunchKernelGGL(k_finish_multi<K>, dim3(self->nmulti), dim3(64), 0, c->stream, a);
+    if (self->nmulti > 0 && !(c->ablate & 1u)) hipLaunchKernelGGL(k_finish_multi<K>, dim3(self->nmulti), dim3(64), 0, c->stream, a);
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     hipLaunchKernelGGL(k_colstats<K>, dim3(self->nstat_waves), dim3(64), 0, c->stream,
                        (const double *)self->d_items, self->from, self->to, self->nstat_waves, self->d_stat_partials);
-    hipLaunchKernelGGL(k_colstats_final<K>, dim3(1), dim3(256), 0, c->stream,
-                       (const double *)self->d_stat_partials, self->nstat_waves, c->d_out);
+    hipLaunchKernelGGL(k_colstats_final<K>, dim3((K * K + K + 63) / 64), dim3(256), 0, c->stream,
+                       (const double *)self->d_stat_partials, self->nstat_waves, (const unsigned long long *)a.fail, c->d_out);
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -400,9 +409,7 @@ extern "C" int bpmf_hip_sample_side_launch(bpmf_hip_side *self, const bpmf_hip_s
     default: return fail(BPMF_HIP_EINVAL, "sample_side: unsupported K");
     }
     if (rc) return rc;
-    // prod | sum | norm already in d_out; append the fail word and bring everything back
-    HIP_TRY(hipMemcpyAsync(c->d_out + (size_t)K * K + K + 1, c->d_in + (size_t)K * K + K, sizeof(double),
-                           hipMemcpyDeviceToDevice, c->stream));
+    // prod | sum | - | fail word are in d_out: bring them back
     HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, ((size_t)K * K + K + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     self->pending = true;
     return BPMF_HIP_OK;
@@ -419,7 +426,11 @@ extern "C" int bpmf_hip_sample_side_finish(bpmf_hip_side *self, double *sum_out,
     HIP_TRY(hipStreamSynchronize(c->stream));
     memcpy(prod_out, c->h_out, sizeof(double) * K * K);
     memcpy(sum_out, c->h_out + (size_t)K * K, sizeof(double) * K);
-    *norm_out = c->h_out[(size_t)K * K + K];
+    {   // sum |x|^2 = trace(sum x x^T)
+        double nn = 0.0;
+        for (int i = 0; i < K; ++i) nn += c->h_out[(size_t)i * K + i];
+        *norm_out = nn;
+    }
     unsigned long long f;
     memcpy(&f, &c->h_out[(size_t)K * K + K + 1], sizeof(f));
     (void)hipEventElapsedTime(&self->last_sample_ms, c->ev[0], c->ev[1]);
@@ -452,6 +463,71 @@ extern "C" int bpmf_hip_side_last_kernel_ms(bpmf_hip_side *s, float *sample_ms, 
 }
 
 // ---------------------------------------------------------------------------
+// Stateful form = the virtual the reference's back-ends override: Sys::sample(Sys&)
+// (c++/sample.cpp:341-385) including iter++, the host hyper-parameter draw and the cov update.
+namespace {
+void ensure_state(bpmf_hip_side *s)
+{
+    const size_t K = (size_t)s->ctx->K;
+    if (s->cov.size() != K * K) {
+        s->cov.assign(K * K, 0.0);                                   // cov.setZero(), c++/sample.cpp:188
+        s->hp_mu.assign(K, 0.0); s->hp_LambdaU.assign(K * K, 0.0); s->hp_LambdaF.assign(K * K, 0.0);
+        s->nx_mu.assign(K, 0.0); s->nx_LambdaU.assign(K * K, 0.0); s->nx_LambdaF.assign(K * K, 0.0);
+    }
+}
+}  // namespace
+
+extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, double alpha)
+{
+    if (!self || !other) return fail(BPMF_HIP_EINVAL, "sys_sample: NULL argument");
+    if (self->to - self->from != self->ncols)
+        return fail(BPMF_HIP_EINVAL, "sys_sample: the side is a shard; use bpmf_hip_sample_side + an all-reduce");
+    const int K = self->ctx->K;
+    ensure_state(self); ensure_state(other);
+    self->iter++;                                                     // :344
+    int rc;
+    if (self->nx_iter == self->iter) {                                // drawn while the device was busy
+        self->hp_mu.swap(self->nx_mu); self->hp_LambdaU.swap(self->nx_LambdaU); self->hp_LambdaF.swap(self->nx_LambdaF);
+    } else {                                                          // rng_set_pos(iter); hp.sample(num(), sum, cov)  (:349-350)
+        rc = bpmf_hyper_sample(K, self->ncols, self->cov.data(), nullptr, (uint32_t)self->iter,
+                               self->hp_mu.data(), self->hp_LambdaU.data(), self->hp_LambdaF.data());
+        if (rc) { self->iter--; return rc; }
+    }
+    self->nx_iter = -2;
+    rc = bpmf_hip_sample_side_launch(self, other, self->iter, alpha, self->hp_mu.data(), self->hp_LambdaF.data());
+    if (rc) { self->iter--; return rc; }
+    // While the GPU samples this side, draw the OTHER side's next hyper-parameters: they depend
+    // only on its own cov and iteration counter, both final until its next sys_sample.
+    if (other != self && other->nx_iter != other->iter + 1) {
+        const int rc2 = bpmf_hyper_sample(K, other->ncols, other->cov.data(), nullptr, (uint32_t)(other->iter + 1),
+                                          other->nx_mu.data(), other->nx_LambdaU.data(), other->nx_LambdaF.data());
+        other->nx_iter = rc2 ? -2 : other->iter + 1;
+    }
+    std::vector<double> sum(K), prod((size_t)K * K);
+    double norm = 0.0;
+    rc = bpmf_hip_sample_side_finish(self, sum.data(), prod.data(), &norm);
+    if (rc) return rc;
+    self->norm = norm;                                                // :381
+    bpmf_cov_from_sums(K, self->ncols, sum.data(), prod.data(), self->cov.data());   // :383-384
+    return BPMF_HIP_OK;
+}
+
+extern "C" int bpmf_hip_sys_state(const bpmf_hip_side *s, int *iter, double *norm, double *cov, double *mu,
+                                  double *LambdaF, double *LambdaU)
+{
+    if (!s) return fail(BPMF_HIP_EINVAL, "sys_state: NULL");
+    const size_t K = (size_t)s->ctx->K;
+    if (iter) *iter = s->iter;
+    if (norm) *norm = s->norm;
+    const bool have = s->cov.size() == K * K;
+    if (cov) { if (have) memcpy(cov, s->cov.data(), sizeof(double) * K * K); else memset(cov, 0, sizeof(double) * K * K); }
+    if (mu) { if (have) memcpy(mu, s->hp_mu.data(), sizeof(double) * K); else memset(mu, 0, sizeof(double) * K); }
+    if (LambdaF) { if (have) memcpy(LambdaF, s->hp_LambdaF.data(), sizeof(double) * K * K); else memset(LambdaF, 0, sizeof(double) * K * K); }
+    if (LambdaU) { if (have) memcpy(LambdaU, s->hp_LambdaU.data(), sizeof(double) * K * K); else memset(LambdaU, 0, sizeof(double) * K * K); }
+    return BPMF_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
 extern "C" int bpmf_hip_test_create(bpmf_hip_side *side, const int64_t *tcolptr, const int32_t *trowidx,
                                     const double *tvals, bpmf_hip_test **out)
 {
@@ -474,12 +550,8 @@ extern "C" int bpmf_hip_test_create(bpmf_hip_side *side, const int64_t *tcolptr,
     bpmf_hip_test *t = new (std::nothrow) bpmf_hip_test();
     if (!t) return fail(BPMF_HIP_ENOMEM, "test_create: out of host memory");
     t->side = side; t->nnz = nnz;
-    // a wave takes a contiguous run of test ratings, 4 at a time
-    const int64_t maxw = (int64_t)side->ctx->num_cu * 8;
-    int64_t nw = std::max<int64_t>(1, std::min<int64_t>((nnz + 63) / 64, maxw));
-    nw = (nw + 3) / 4 * 4;
-    t->per_wave = std::max<int64_t>(4, (((nnz + nw - 1) / nw) + 3) / 4 * 4);
-    t->nwaves = nw;
+    t->nblocks = std::max<int64_t>(1, (nnz + 255) / 256);       // one lane per test rating
+    const int64_t nw = t->nblocks;
     int rc;
     if ((rc = dev_upload(&t->d_tcol, tcol.data(), (size_t)nnz)) || (rc = dev_upload(&t->d_trow, trowidx, (size_t)nnz)) ||
         (rc = dev_upload(&t->d_tval, tvals, (size_t)nnz)) || (rc = dev_upload(&t->d_pavg, tvals, (size_t)nnz)) ||
@@ -507,11 +579,11 @@ template <int K>
 void launch_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const bpmf_hip_side *other, int n)
 {
     bpmf_hip_ctx *c = self->ctx;
-    hipLaunchKernelGGL(bpmf::k_predict<K>, dim3((unsigned)(t->nwaves / 4)), dim3(256), 0, c->stream,
-                       (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz, t->per_wave,
+    hipLaunchKernelGGL(bpmf::k_predict<K>, dim3((unsigned)t->nblocks), dim3(256), 0, c->stream,
+                       (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz,
                        (const double *)self->d_items, (const double *)other->d_items, self->from, self->mean_rating, n,
                        t->d_pavg, t->d_pm2, t->d_partial);
-    hipLaunchKernelGGL(bpmf::k_predict_final, dim3(1), dim3(64), 0, c->stream, (const double *)t->d_partial, t->nwaves,
+    hipLaunchKernelGGL(bpmf::k_predict_final, dim3(1), dim3(256), 0, c->stream, (const double *)t->d_partial, t->nblocks,
                        c->d_out + c->out_words - 2);
 }
 }  // namespace

@@ -25,7 +25,24 @@ struct Mat {   // column-major K x K view
 
 double randn(bpmf::MicroPhilox &rng) { return std::normal_distribution<>()(rng); }   // c++/mvnormal.cpp:41-43
 
-// inverse through LU with row pivoting (role of Eigen's inverse(), c++/mvnormal.cpp:124)
+// Advances the stream exactly as `n` calls of randn() would, without the log/sqrt of the
+// accepted attempt: the reference draws `nrandn(K-i-1)` into a vector it never reads
+// (c++/mvnormal.cpp:70).  Same acceptance test as libstdc++'s polar loop, evaluated un-fused.
+void skip_randn(bpmf::MicroPhilox &rng, int n)
+{
+    for (int i = 0; i < n; ++i) {
+        double r2;
+        do {
+            const uint32_t a0 = rng(), a1 = rng(), b0 = rng(), b1 = rng();
+            const double x = 2.0 * bpmf::canonical53(a0, a1) - 1.0;
+            const double y = 2.0 * bpmf::canonical53(b0, b1) - 1.0;
+            r2 = x * x + y * y;
+        } while (r2 > 1.0 || r2 == 0.0);
+    }
+}
+
+// inverse through LU with row pivoting (role of Eigen's inverse(), c++/mvnormal.cpp:124);
+// all inner loops run down a column (contiguous)
 bool invert(int K, const double *A_in, double *inv)
 {
     std::vector<double> lu(A_in, A_in + (size_t)K * K);
@@ -42,22 +59,27 @@ bool invert(int K, const double *A_in, double *inv)
             std::swap(perm[c], perm[best]);
         }
         const double piv = A(c, c);
-        for (int r = c + 1; r < K; ++r) {
-            const double f = (A(r, c) /= piv);
-            for (int j = c + 1; j < K; ++j) A(r, j) -= f * A(c, j);
+        double *lc = &A(0, c);
+        for (int r = c + 1; r < K; ++r) lc[r] /= piv;
+        for (int j = c + 1; j < K; ++j) {
+            double *aj = &A(0, j);
+            const double f = aj[c];
+            for (int r = c + 1; r < K; ++r) aj[r] -= lc[r] * f;
         }
     }
-    Mat X{inv, K};
     for (int c = 0; c < K; ++c) {
-        for (int r = 0; r < K; ++r) {          // forward: L z = P e_c
-            double s = perm[r] == c ? 1.0 : 0.0;
-            for (int j = 0; j < r; ++j) s -= A(r, j) * X(j, c);
-            X(r, c) = s;
+        double *x = inv + (size_t)c * K;
+        int first = K;
+        for (int r = 0; r < K; ++r) { x[r] = perm[r] == c ? 1.0 : 0.0; if (perm[r] == c) first = r; }
+        for (int j = first; j < K; ++j) {      // forward, unit lower: x_r -= L(r,j) x_j
+            const double xj = x[j];
+            const double *lj = &A(0, j);
+            for (int r = j + 1; r < K; ++r) x[r] -= lj[r] * xj;
         }
-        for (int r = K - 1; r >= 0; --r) {     // backward: U x = z
-            double s = X(r, c);
-            for (int j = r + 1; j < K; ++j) s -= A(r, j) * X(j, c);
-            X(r, c) = s / A(r, r);
+        for (int j = K - 1; j >= 0; --j) {     // backward, upper
+            const double *uj = &A(0, j);
+            const double xj = (x[j] /= uj[j]);
+            for (int r = 0; r < j; ++r) x[r] -= uj[r] * xj;
         }
     }
     return true;
@@ -126,7 +148,7 @@ extern "C" int bpmf_hyper_sample(int K, int64_t N, const double *cov, const doub
     for (int i = 0; i < K; ++i) {                         // WishartUnitChol (c++/mvnormal.cpp:64-73)
         std::gamma_distribution<> gam(0.5 * (nu_c - i));
         AU(i, i) = std::sqrt(2.0 * gam(rng));
-        for (int j = 0; j < K - i - 1; ++j) (void)randn(rng);      // `VectorXd r = nrandn(...)`, drawn and dropped (:70)
+        skip_randn(rng, K - i - 1);                               // `VectorXd r = nrandn(...)`, drawn and dropped (:70)
         for (int j = i + 1; j < K; ++j) AU(i, j) = randn(rng);
     }
     for (int j = 0; j < K; ++j)                           // U = au * chol.matrixU()

@@ -50,6 +50,20 @@ __device__ __forceinline__ d4 mfma16(double a, double b, d4 c)
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// 1/sqrt(d) to <= 1 ulp: v_rsq_f64 (2^-26 relative) + two Newton steps, 10 dependent
+// instructions instead of the ~25 of sqrt followed by a divide.  d <= 0 or NaN gives NaN/inf,
+// which is what flags the column as "Cholesky failed".
+__device__ __forceinline__ double rsqrt_nr(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    const double hd = 0.5 * d;
+    double e = fma(-hd * y, y, 0.5);      // 0.5 - 0.5*d*y^2
+    y = fma(y, e, y);
+    e = fma(-hd * y, y, 0.5);
+    y = fma(y, e, y);
+    return y;
+}
+
 // value of `v` in lane `src` (wave-uniform src) through v_readlane_b32: no LDS traffic
 __device__ __forceinline__ double bcast(double v, int src)
 {
@@ -82,6 +96,7 @@ struct SampleArgs {
     double mean_rating;
     double alpha;
     uint32_t iter_plus_1;
+    uint32_t ablate;            // profiling only (BPMF_HIP_ABLATE): 1 = skip the factorisation, 2 = skip the Gram
 };
 
 // ---------------------------------------------------------------------------
@@ -129,29 +144,59 @@ __device__ __forceinline__ void gram_chunk(const int32_t *__restrict__ rowidx, c
 {
     constexpr int NT = Geo<K>::NT;
     const int kq = lane >> 4, li = lane & 15;
-    constexpr int UN = 4;                                          // 4 MFMA k-steps (16 ratings) per trip
-    for (int base = 0; base < len; base += 4 * UN) {
-        double y[UN][NT], w[UN];
-#pragma unroll
-        for (int s = 0; s < UN; ++s) {
-            const int q = base + s * 4 + kq;
-            const bool ok = q < len;
-            const int row = ok ? rowidx[q] : 0;
-            w[s] = ok ? (vals[q] - mean) * alpha : 0.0;            // c++/sample.cpp:256
-            const double *col = other + (size_t)row * K + li;
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                y[s][t] = (ok && (t * 16 + li < K)) ? col[t * 16] : 0.0;
+    // The ratings are consumed in blocks of 64: one coalesced load brings 64 row ids and 64
+    // values (lane l holds rating b+l), the 16 MFMA k-steps of the block then fetch their 4
+    // row ids with a cross-lane permute instead of a dependent memory round trip.  Gathers of
+    // the next 16 ratings are in flight while the MFMAs of the current 16 issue.
+    int ri_n = (0 + lane < len) ? rowidx[lane] : -1;
+    double wv_n = (0 + lane < len) ? (vals[lane] - mean) * alpha : 0.0;        // c++/sample.cpp:256
+    for (int b = 0; b < len; b += 64) {
+        const int ri = ri_n;
+        const double wv = wv_n;
+        if (b + 64 < len) {                                                      // wave-uniform
+            const int q = b + 64 + lane;
+            ri_n = (q < len) ? rowidx[q] : -1;
+            wv_n = (q < len) ? (vals[q] - mean) * alpha : 0.0;
         }
+        const int nsteps = (len - b >= 64) ? 16 : (len - b + 3) >> 2;           // k-steps in this block
+        double y[4][NT], w[4];
+        auto gather = [&](int g, double (&yy)[4][NT], double (&ww)[4]) {
 #pragma unroll
-        for (int s = 0; s < UN; ++s) {
+            for (int s = 0; s < 4; ++s) {
+                const int src = (g * 4 + s) * 4 + kq;
+                const int row = __shfl(ri, src);
+                ww[s] = __shfl(wv, src);
+                const bool ok = row >= 0;
+                const double *col = other + (size_t)(ok ? row : 0) * K + li;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) r[t] = fma(y[s][t], w[s], r[t]);
-            int tri = 0;
+                for (int t = 0; t < NT; ++t) yy[s][t] = (ok && (t * 16 + li < K)) ? col[t * 16] : 0.0;
+            }
+        };
+        gather(0, y, w);
 #pragma unroll
-            for (int I = 0; I < NT; ++I)
+        for (int g = 0; g < 4; ++g) {
+            if (g * 4 >= nsteps) break;                                          // wave-uniform
+            double yn[4][NT], wn[4];
+            const bool more = (g + 1) * 4 < nsteps;
+            if (g < 3 && more) gather(g + 1, yn, wn);
 #pragma unroll
-                for (int J = I; J < NT; ++J, ++tri) acc[tri] = mfma16(y[s][I], y[s][J], acc[tri]);
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) r[t] = fma(y[s][t], w[s], r[t]);
+                int tri = 0;
+#pragma unroll
+                for (int I = 0; I < NT; ++I)
+#pragma unroll
+                    for (int J = I; J < NT; ++J, ++tri) acc[tri] = mfma16(y[s][I], y[s][J], acc[tri]);
+            }
+            if (g < 3 && more) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    w[s] = wn[s];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) y[s][t] = yn[s][t];
+                }
+            }
         }
     }
     // the 4 k-groups of lanes hold partial rhs sums for the same latent index
@@ -230,7 +275,7 @@ __device__ __forceinline__ void finish_column(const SampleArgs &a, int col_local
         const int hk = k % S, mk = k / S;
         const double d = bcast(row[mk], hk * K + k);
         dmin = fmin(dmin, d);                                     // Eigen LLT: pivot <= 0 -> info() != Success (:308)
-        const double dinv = 1.0 / sqrt(d);
+        const double dinv = rsqrt_nr(d);
         // owners publish column k (row k: sqrt(d); rows i>k: L(i,k)); the other lanes hit a dummy
         // slot so that the step stays branch-free (branches let LLVM sink whole FMA chains)
         double *dst = (h == hk) ? &sA[i * LD + k] : &sdummy[lane];
@@ -288,8 +333,15 @@ __global__ __launch_bounds__(64, Geo<K>::WPS) void k_gram(SampleArgs a)
 #pragma unroll
     for (int t = 0; t < NT; ++t) r[t] = 0.0;
 
-    gram_chunk<K>(a.rowidx + p0, a.vals + p0, len, a.other_items, a.mean_rating, a.alpha, acc, r, lane);
+    gram_chunk<K>(a.rowidx + p0, a.vals + p0, (a.ablate & 2u) ? 0 : len, a.other_items, a.mean_rating, a.alpha, acc, r, lane);
 
+    if (a.ablate & 1u) {                                           // timing ablation: keep the Gram live, skip the rest
+        double v = r[0];
+#pragma unroll
+        for (int t = 0; t < NTRI; ++t) v += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+        if (slot < 0 && lane < K) a.items[(size_t)(a.col_from + col) * K + lane] = v;
+        return;
+    }
     if (slot >= 0) {                                               // chunk of a heavy column: park the partial
         double *p = a.partials + (size_t)slot * PART;
 #pragma unroll
@@ -395,13 +447,19 @@ __global__ __launch_bounds__(64) void k_colstats(const double *__restrict__ item
     }
 }
 
-// out: prod[K*K] col-major | sum[K] | norm
+// out: prod[K*K] col-major | sum[K] | (unused) | fail word.  64 outputs per block, the
+// partials of the waves are split over 4 thread groups and combined in a fixed order.
 template <int K>
-__global__ __launch_bounds__(256) void k_colstats_final(const double *__restrict__ partials, int nwaves, double *__restrict__ out)
+__global__ __launch_bounds__(256) void k_colstats_final(const double *__restrict__ partials, int nwaves,
+                                                        const unsigned long long *__restrict__ fail_in,
+                                                        double *__restrict__ out)
 {
     constexpr int NT = Geo<K>::NT, NTRI = Geo<K>::NTRI, PART = Geo<K>::PART;
-    __shared__ double diag[K];
-    for (int e = threadIdx.x; e < K * K + K; e += blockDim.x) {
+    __shared__ double red[4][64];
+    const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + o;
+    double s = 0.0;
+    if (e < K * K + K) {
         int off;
         if (e < K * K) {
             int i = e % K, j = e / K;
@@ -413,74 +471,89 @@ __global__ __launch_bounds__(256) void k_colstats_final(const double *__restrict
         } else {
             off = NTRI * 256 + (e - K * K);
         }
-        double s = 0.0;
-        for (int w = 0; w < nwaves; ++w) s += partials[(size_t)w * PART + off];
-        out[e] = s;
-        if (e < K * K && (e % K) == (e / K)) diag[e % K] = s;
+        const int per = (nwaves + 3) >> 2;
+        const int w0 = grp * per, w1 = (w0 + per < nwaves) ? w0 + per : nwaves;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int w = w0;
+        for (; w + 3 < w1; w += 4) {
+            s0 += partials[(size_t)(w + 0) * PART + off];
+            s1 += partials[(size_t)(w + 1) * PART + off];
+            s2 += partials[(size_t)(w + 2) * PART + off];
+            s3 += partials[(size_t)(w + 3) * PART + off];
+        }
+        for (; w < w1; ++w) s0 += partials[(size_t)w * PART + off];
+        s = (s0 + s1) + (s2 + s3);
     }
+    red[grp][o] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double nn = 0.0;
-        for (int i = 0; i < K; ++i) nn += diag[i];
-        out[K * K + K] = nn;
+    if (grp == 0 && e < K * K + K) out[e] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out[K * K + K] = 0.0;
+        reinterpret_cast<unsigned long long *>(out)[K * K + K + 1] = *fail_in;
     }
 }
 
 // ---------------------------------------------------------------------------
-// Sys::predict (c++/sample.cpp:48-96): 16 lanes per test rating.
+// Sys::predict (c++/sample.cpp:48-96): one lane per test rating; each lane walks its two
+// K-vectors with 16-byte loads (a 128-B line is consumed by one lane in 8 consecutive loads).
 // ---------------------------------------------------------------------------
 template <int K>
 __global__ __launch_bounds__(256) void k_predict(const int32_t *__restrict__ tcol, const int32_t *__restrict__ trow,
-                                                 const double *__restrict__ tval, int64_t nnz, int64_t per_wave,
+                                                 const double *__restrict__ tval, int64_t nnz,
                                                  const double *__restrict__ items, const double *__restrict__ other,
                                                  int64_t col_from, double mean, int n, double *__restrict__ pavg,
                                                  double *__restrict__ pm2, double *__restrict__ partial)
 {
-    const int lane = threadIdx.x & 63, kq = lane >> 4, li = lane & 15;
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int64_t b = wave * per_wave;
-    const int64_t e = (b + per_wave < nnz) ? b + per_wave : nnz;
+    __shared__ double red[2][4];
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double se = 0.0, se_avg = 0.0;
-    for (int64_t q0 = b; q0 < e; q0 += 4) {
-        const int64_t q = q0 + kq;
-        const bool ok = q < e;
-        double dot = 0.0;
-        if (ok) {
-            const double *m = items + (size_t)(col_from + tcol[q]) * K;
-            const double *u = other + (size_t)trow[q] * K;
+    if (q < nnz) {
+        const double2 *m = reinterpret_cast<const double2 *>(items + (size_t)(col_from + tcol[q]) * K);
+        const double2 *u = reinterpret_cast<const double2 *>(other + (size_t)trow[q] * K);
+        double d0 = 0.0, d1 = 0.0;
 #pragma unroll
-            for (int t = 0; t < (K + 15) / 16; ++t)
-                if (t * 16 + li < K) dot = fma(m[t * 16 + li], u[t * 16 + li], dot);
+        for (int t = 0; t < K / 2; ++t) {
+            const double2 a = m[t], b = u[t];
+            d0 = fma(a.x, b.x, d0);
+            d1 = fma(a.y, b.y, d1);
         }
-        dot += __shfl_xor(dot, 8);
-        dot += __shfl_xor(dot, 4);
-        dot += __shfl_xor(dot, 2);
-        dot += __shfl_xor(dot, 1);
-        if (ok && li == 0) {
-            const double pred = dot + mean;                         // :78
-            const double v = tval[q];
-            se += (v - pred) * (v - pred);
-            double avg = pavg[q];
-            const double delta = pred - avg;
-            avg = (n == 0) ? pred : (avg + delta / n);              // :84 (n, not n+1: reference quirk)
-            pavg[q] = avg;
-            pm2[q] = (n == 0) ? 0.0 : pm2[q] + delta * (pred - avg);   // :86
-            se_avg += (v - avg) * (v - avg);
-        }
+        const double pred = (d0 + d1) + mean;                       // :78
+        const double v = tval[q];
+        se = (v - pred) * (v - pred);
+        double avg = pavg[q];
+        const double delta = pred - avg;
+        avg = (n == 0) ? pred : (avg + delta / n);                  // :84 (n, not n+1: reference quirk)
+        pavg[q] = avg;
+        pm2[q] = (n == 0) ? 0.0 : pm2[q] + delta * (pred - avg);    // :86
+        se_avg = (v - avg) * (v - avg);
     }
-    // lanes 0,16,32,48 hold this wave's partial sums
-    se += __shfl_xor(se, 16);      se += __shfl_xor(se, 32);
-    se_avg += __shfl_xor(se_avg, 16); se_avg += __shfl_xor(se_avg, 32);
-    if (lane == 0) { partial[2 * wave] = se; partial[2 * wave + 1] = se_avg; }
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        se += __shfl_xor(se, sh);
+        se_avg += __shfl_xor(se_avg, sh);
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wv] = se; red[1][wv] = se_avg; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        partial[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
 }
 
-__global__ void k_predict_final(const double *__restrict__ partial, int64_t nwaves, double *__restrict__ out)
+// fixed-shape tree over the block partials (deterministic)
+__global__ __launch_bounds__(256) void k_predict_final(const double *__restrict__ partial, int64_t nblocks, double *__restrict__ out)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double se = 0.0, sa = 0.0;
-        for (int64_t w = 0; w < nwaves; ++w) { se += partial[2 * w]; sa += partial[2 * w + 1]; }
-        out[0] = se; out[1] = sa;
+    __shared__ double red[2][256];
+    double se = 0.0, sa = 0.0;
+    for (int64_t w = threadIdx.x; w < nblocks; w += 256) { se += partial[2 * w]; sa += partial[2 * w + 1]; }
+    red[0][threadIdx.x] = se; red[1][threadIdx.x] = sa;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) { red[0][threadIdx.x] += red[0][threadIdx.x + st]; red[1][threadIdx.x] += red[1][threadIdx.x + st]; }
+        __syncthreads();
     }
+    if (threadIdx.x == 0) { out[0] = red[0][0]; out[1] = red[1][0]; }
 }
 
 // test probe: the first n normals of stream `counter`

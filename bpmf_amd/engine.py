@@ -122,6 +122,18 @@ class HipEngine:
         self.sample_side_launch(side, other, it, alpha, mu, LambdaF)
         return self.sample_side_finish(side)
 
+    def sys_sample(self, side, other, alpha):
+        """Sys::sample(Sys&) with the state (iter, cov, hp) kept inside the library."""
+        _lib.check(self.lib.bpmf_hip_sys_sample(side.handle, other.handle, float(alpha)))
+
+    def sys_state(self, side):
+        """(iter, norm, cov, mu, LambdaF, LambdaU) of a side driven by sys_sample."""
+        K = self.K
+        it = C.c_int(); nrm = C.c_double()
+        cov = np.empty((K, K), order="F"); mu = np.empty(K); LF = np.empty((K, K), order="F"); LU = np.empty((K, K), order="F")
+        _lib.check(self.lib.bpmf_hip_sys_state(side.handle, C.byref(it), C.byref(nrm), _ptr(cov), _ptr(mu), _ptr(LF), _ptr(LU)))
+        return it.value, nrm.value, cov, mu, LF, LU
+
     def last_kernel_ms(self, side):
         a = C.c_float(); b = C.c_float()
         _lib.check(self.lib.bpmf_hip_side_last_kernel_ms(side.handle, C.byref(a), C.byref(b)))

@@ -80,6 +80,13 @@ class Sys:
         self.num_predict = 0
         self.sample_ms = 0.0
 
+    def refresh(self):
+        """Pulls norm / cov / hp back from the library after sys_sample calls."""
+        if getattr(self, "_stale", False):
+            it, self.norm, self.cov, self.hp.mu, self.hp.LambdaF, self.hp.LambdaU = self.engine.sys_state(self.side)
+            assert it == self.iter
+            self._stale = False
+
     # -- accessors with the reference's names ---------------------------------
     def num(self):
         return self._num
@@ -96,6 +103,13 @@ class Sys:
 
     # -- Sys::sample(Sys&), c++/sample.cpp:341-385 ------------------------------
     def sample(self, other):
+        if self.comm is None and hasattr(self.engine, "sys_sample"):
+            # NO_COMM: the whole of Sys::sample(Sys&) (iter++, hyper draw, column loop, cov) runs
+            # behind one C-ABI call, which also overlaps the host draws with the kernels
+            self.engine.sys_sample(self.side, other.side, Sys.alpha)
+            self.iter += 1
+            self._stale = True
+            return
         self.iter += 1
         self.hp.sample(self.num(), self.sum, self.cov, self.iter)          # :349-350
         t0 = time.perf_counter()
@@ -150,6 +164,7 @@ def gibbs(engine, M, Mt, T, nusers, nmovies, nsims=20, burnin=5, alpha=2.0, out=
         users.sample(movies)
         movies.predict(users)                        # users.predict(movies) has no observable effect: see DESIGN.md
         stop = time.perf_counter()
+        movies.refresh(); users.refresh()
         ips = (users.num() + movies.num()) / (stop - start)
         rps = nnz / (stop - start)
         avg_items += ips

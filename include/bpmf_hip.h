@@ -122,6 +122,19 @@ BPMF_API int bpmf_hip_sample_side(bpmf_hip_side *self, const bpmf_hip_side *othe
 BPMF_API int bpmf_hip_sample_side_launch(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double alpha,
                                 const double *mu, const double *LambdaF);
 BPMF_API int bpmf_hip_sample_side_finish(bpmf_hip_side *self, double *sum_out, double *prod_out, double *norm_out);
+/* Stateful form, the virtual every reference back-end overrides: Sys::sample(Sys&)
+ * (c++/sample.cpp:341-385; e.g. c++/mpi_bcast.h:21-30 wraps it).  Does iter++ (:344),
+ * rng_set_pos(iter) + hp.sample(num(), sum = 0, cov) on the host (:349-350), the column loop
+ * on the device, and cov = (prod - sum sum^T/N)/(N-1), norm (:379-384).  iter starts at -1
+ * (:113), cov at 0 (:188).  Only for a side that owns all its columns (NO_COMM); a shard uses
+ * bpmf_hip_sample_side and all-reduces the sums.  While the device is busy the call pre-draws
+ * `other`'s next hyper-parameters (they depend only on other's own cov and iter), which is
+ * invisible to the caller except in time. */
+BPMF_API int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, double alpha);
+/* Sys::iter, Sys::norm, Sys::cov, hp.mu, hp.LambdaF, hp.LambdaU (c++/bpmf.h:86-89,139,222-223);
+ * any output pointer may be NULL */
+BPMF_API int bpmf_hip_sys_state(const bpmf_hip_side *side, int *iter, double *norm, double *cov, double *mu,
+                                double *LambdaF, double *LambdaU);
 /* global id of the first column whose factorisation failed, or -1 */
 BPMF_API int64_t bpmf_hip_failed_column(const bpmf_hip_side *side);
 
