@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -63,11 +64,13 @@ struct bpmf_hip_ctx {
     bool own_stream = false;
     int num_cu = 256;
     unsigned ablate = 0;
-    // per-call parameter blob: LambdaF[K*K] | Lmu[K] | fail (u64)
-    double *h_in = nullptr, *d_in = nullptr;
-    // result blob: prod[K*K] | sum[K] | norm | fail (u64) ; predict: se | se_avg
-    double *h_out = nullptr, *d_out = nullptr;
+    // per-call parameter blob: LambdaF[K*K] | Lmu[K] | fail (u64); pinned host copy + device copy
+    double *h_in = nullptr, *h_in_dev = nullptr, *d_in = nullptr;
+    // result blob in pinned host memory the kernels write directly (zero-copy):
+    // prod[K*K] | sum[K] | - | fail (u64) | se | se_avg | flag (u32)
+    double *h_out = nullptr, *h_out_dev = nullptr;
     size_t in_words = 0, out_words = 0;
+    unsigned seq = 0;                    // value the next k_signal will publish
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 };
 
@@ -79,15 +82,17 @@ struct bpmf_hip_side {
     double *d_items = nullptr; bool own_items = true;
     // schedule
     int nwork = 0, nmulti = 0, nslots = 0;
-    int32_t *d_wi_col = nullptr, *d_wi_len = nullptr, *d_wi_slot = nullptr;
+    int32_t *d_wi_col = nullptr, *d_wi_len = nullptr, *d_wi_mc = nullptr, *d_wi_chunk = nullptr;
     int64_t *d_wi_p0 = nullptr;
-    int32_t *d_mc_col = nullptr, *d_mc_slot0 = nullptr, *d_mc_nch = nullptr;
+    int32_t *d_mc_slot0 = nullptr, *d_mc_nch = nullptr;
+    unsigned *d_mc_count = nullptr;
     double *d_partials = nullptr;
     int nstat_waves = 0;
     double *d_stat_partials = nullptr;
     int64_t failed_column = -1;
     bool pending = false;
     float last_sample_ms = 0.f, last_reduce_ms = 0.f;
+    bool timing_valid = true;
     // state of the reference's Sys (c++/bpmf.h:139,221-226) for bpmf_hip_sys_sample
     int iter = -1;
     double norm = 0.0;
@@ -120,6 +125,34 @@ size_t part_words_rt(int K)
     return 0;
 }
 
+// The kernels write their few result words straight into pinned host memory; a one-thread
+// kernel then publishes a sequence number and the host thread spins on it.  This replaces
+// hipMemcpyAsync(D2H) + hipStreamSynchronize (a copy-engine hop and a sleeping wait per
+// half-iteration) on a path whose device work is only tens of microseconds.
+void signal_host(bpmf_hip_ctx *c)
+{
+    c->seq++;
+    unsigned *flag = reinterpret_cast<unsigned *>(c->h_out_dev + c->out_words - 1);
+    hipLaunchKernelGGL(bpmf::k_signal, dim3(1), dim3(64), 0, c->stream, flag, c->seq);
+}
+
+int wait_host(bpmf_hip_ctx *c)
+{
+    unsigned *flag = reinterpret_cast<unsigned *>(c->h_out + c->out_words - 1);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == c->seq) return 0;
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFu) == 0xFFFu) {
+            const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (s > 0.05) break;                 // long kernel (big matrix) or an error: fall back to a blocking wait
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != c->seq) return fail(BPMF_HIP_ENODEV, "device did not publish its results");
+    return 0;
+}
+
 // Build the static schedule of a side.  Cost model: one MFMA k-step per 4
 // ratings per tile triple, plus a constant for the factorisation.
 int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
@@ -136,50 +169,51 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     }
     chunk = (chunk + 15) / 16 * 16;
 
-    struct Item { int32_t col; int64_t p0; int32_t len; int32_t slot; int64_t cost; };
+    struct Item { int32_t col; int64_t p0; int32_t len; int32_t mc; int32_t chunk; int64_t cost; };
     std::vector<Item> items;
     items.reserve((size_t)nloc + (size_t)(s->nnz / chunk) + 16);
-    std::vector<int32_t> mc_col, mc_slot0, mc_nch;
-    const int64_t fin_cost = (int64_t)K * K / 4 + 64;     // in units of "ratings"
+    std::vector<int32_t> mc_slot0, mc_nch;
+    const int64_t fin_cost = (int64_t)K * K / 4 + 64;     // factorisation etc., in units of "ratings"
     int32_t slots = 0;
     for (int64_t c = 0; c < nloc; ++c) {
         const int64_t p0 = colptr[c], n = colptr[c + 1] - colptr[c];
         if (n < 0) return fail(BPMF_HIP_EINVAL, "colptr is not monotone");
         if (n <= chunk) {
-            items.push_back({(int32_t)c, p0, (int32_t)n, -1, n + fin_cost});
+            items.push_back({(int32_t)c, p0, (int32_t)n, -1, 0, n + fin_cost});
         } else {
             const int nch = (int)((n + chunk - 1) / chunk);
             // equalise the chunks of one column (multiples of 16 ratings)
-            int64_t per = ((n + nch - 1) / nch + 15) / 16 * 16;
-            mc_col.push_back((int32_t)c); mc_slot0.push_back(slots); mc_nch.push_back(nch);
+            const int64_t per = ((n + nch - 1) / nch + 15) / 16 * 16;
+            const int32_t mc = (int32_t)mc_slot0.size();
+            mc_slot0.push_back(slots); mc_nch.push_back(nch);
             for (int k = 0; k < nch; ++k) {
                 const int64_t b = std::min<int64_t>(k * per, n), e = std::min<int64_t>(b + per, n);
-                items.push_back({(int32_t)c, p0 + b, (int32_t)(e - b), slots++, e - b});
+                // whichever chunk arrives last also factorises: spread that cost over the chunks
+                items.push_back({(int32_t)c, p0 + b, (int32_t)(e - b), mc, k, (e - b) + fin_cost / nch});
             }
+            slots += nch;
         }
     }
     std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.cost > b.cost; });
-    // heavy columns' finish pass: most chunks first
-    std::vector<int> order(mc_col.size());
-    std::iota(order.begin(), order.end(), 0);
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return mc_nch[a] > mc_nch[b]; });
 
     const size_t nw = items.size();
-    std::vector<int32_t> wcol(nw), wlen(nw), wslot(nw);
+    std::vector<int32_t> wcol(nw), wlen(nw), wmc(nw), wchunk(nw);
     std::vector<int64_t> wp0(nw);
-    for (size_t i = 0; i < nw; ++i) { wcol[i] = items[i].col; wlen[i] = items[i].len; wslot[i] = items[i].slot; wp0[i] = items[i].p0; }
-    std::vector<int32_t> mcol(order.size()), mslot(order.size()), mnch(order.size());
-    for (size_t i = 0; i < order.size(); ++i) { mcol[i] = mc_col[order[i]]; mslot[i] = mc_slot0[order[i]]; mnch[i] = mc_nch[order[i]]; }
+    for (size_t i = 0; i < nw; ++i) { wcol[i] = items[i].col; wlen[i] = items[i].len; wmc[i] = items[i].mc; wchunk[i] = items[i].chunk; wp0[i] = items[i].p0; }
 
-    s->nwork = (int)nw; s->nmulti = (int)order.size(); s->nslots = slots;
+    s->nwork = (int)nw; s->nmulti = (int)mc_slot0.size(); s->nslots = slots;
     int rc;
     if ((rc = dev_upload(&s->d_wi_col, wcol.data(), nw))) return rc;
     if ((rc = dev_upload(&s->d_wi_len, wlen.data(), nw))) return rc;
-    if ((rc = dev_upload(&s->d_wi_slot, wslot.data(), nw))) return rc;
+    if ((rc = dev_upload(&s->d_wi_mc, wmc.data(), nw))) return rc;
+    if ((rc = dev_upload(&s->d_wi_chunk, wchunk.data(), nw))) return rc;
     if ((rc = dev_upload(&s->d_wi_p0, wp0.data(), nw))) return rc;
-    if ((rc = dev_upload(&s->d_mc_col, mcol.data(), mcol.size()))) return rc;
-    if ((rc = dev_upload(&s->d_mc_slot0, mslot.data(), mslot.size()))) return rc;
-    if ((rc = dev_upload(&s->d_mc_nch, mnch.data(), mnch.size()))) return rc;
+    if ((rc = dev_upload(&s->d_mc_slot0, mc_slot0.data(), mc_slot0.size()))) return rc;
+    if ((rc = dev_upload(&s->d_mc_nch, mc_nch.data(), mc_nch.size()))) return rc;
+    {
+        std::vector<unsigned> zeros(std::max<size_t>(mc_slot0.size(), 8 * 32), 0u);
+        if ((rc = dev_upload(&s->d_mc_count, zeros.data(), std::max<size_t>(mc_slot0.size(), 1)))) return rc;
+    }
     const size_t pw = part_words_rt(K);
     if ((rc = dev_upload<double>(&s->d_partials, nullptr, (size_t)slots * pw))) return rc;
     // column statistics: one wave per 64+ columns, at most 2 waves per CU
@@ -215,11 +249,13 @@ extern "C" int bpmf_hip_ctx_create(int device, int K, void *stream, bpmf_hip_ctx
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     c->in_words = (size_t)K * K + K + 1;
-    c->out_words = (size_t)K * K + K + 1 + 1 + 2;
-    HIP_TRY(hipHostMalloc((void **)&c->h_in, c->in_words * sizeof(double), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void **)&c->h_out, c->out_words * sizeof(double), hipHostMallocDefault));
+    c->out_words = (size_t)K * K + K + 1 + 1 + 2 + 1;
+    HIP_TRY(hipHostMalloc((void **)&c->h_in, c->in_words * sizeof(double), hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc((void **)&c->h_out, c->out_words * sizeof(double), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void **)&c->h_in_dev, c->h_in, 0));
+    HIP_TRY(hipHostGetDevicePointer((void **)&c->h_out_dev, c->h_out, 0));
+    memset(c->h_out, 0, c->out_words * sizeof(double));
     HIP_TRY(hipMalloc((void **)&c->d_in, c->in_words * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&c->d_out, c->out_words * sizeof(double)));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     *out = c;
     return BPMF_HIP_OK;
@@ -234,7 +270,6 @@ extern "C" int bpmf_hip_ctx_destroy(bpmf_hip_ctx *c)
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->d_in) (void)hipFree(c->d_in);
-    if (c->d_out) (void)hipFree(c->d_out);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return BPMF_HIP_OK;
@@ -308,7 +343,7 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->own_csc) { if (s->d_rowidx) (void)hipFree(s->d_rowidx); if (s->d_vals) (void)hipFree(s->d_vals); }
     if (s->own_items && s->d_items) (void)hipFree(s->d_items);
-    void *ptrs[] = {s->d_wi_col, s->d_wi_len, s->d_wi_slot, s->d_wi_p0, s->d_mc_col, s->d_mc_slot0, s->d_mc_nch, s->d_partials, s->d_stat_partials};
+    void *ptrs[] = {s->d_wi_col, s->d_wi_len, s->d_wi_mc, s->d_wi_chunk, s->d_wi_p0, s->d_mc_slot0, s->d_mc_nch, s->d_mc_count, s->d_partials, s->d_stat_partials};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete s;
     return BPMF_HIP_OK;
@@ -354,9 +389,9 @@ int do_launch(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double 
     bpmf_hip_ctx *c = self->ctx;
     SampleArgs a;
     a.rowidx = self->d_rowidx; a.vals = self->d_vals;
-    a.wi_col = self->d_wi_col; a.wi_p0 = self->d_wi_p0; a.wi_len = self->d_wi_len; a.wi_slot = self->d_wi_slot;
-    a.mc_col = self->d_mc_col; a.mc_slot0 = self->d_mc_slot0; a.mc_nchunks = self->d_mc_nch;
-    a.partials = self->d_partials;
+    a.wi_col = self->d_wi_col; a.wi_p0 = self->d_wi_p0; a.wi_len = self->d_wi_len; a.wi_mc = self->d_wi_mc; a.wi_chunk = self->d_wi_chunk;
+    a.mc_slot0 = self->d_mc_slot0; a.mc_nchunks = self->d_mc_nch; a.mc_count = self->d_mc_count;
+    a.partials = self->d_partials; a.nwork = self->nwork;
     a.other_items = other->d_items; a.items = self->d_items; a.col_from = self->from;
     a.LambdaF = c->d_in; a.Lmu = c->d_in + (size_t)K * K;
     a.fail = (unsigned long long *)(c->d_in + (size_t)K * K + K);
@@ -364,13 +399,17 @@ int do_launch(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double 
     a.ablate = c->ablate;
 
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    if (self->nwork > 0) hipLaunchKernelGGL(k_gram<K>, dim3(self->nwork), dim3(64), 0, c->stream, a);
-    if (self->nmulti > 0 && !(c->ablate & 1u)) hipLaunchKernelGGL(k_finish_multi<K>, dim3(self->nmulti), dim3(64), 0, c->stream, a);
+    if (self->nwork > 0) {
+        // persistent waves: as many single-wave workgroups as the chip holds at this kernel's occupancy
+        const int resident = c->num_cu * 4 * Geo<K>::WPS;
+        const int grid = std::min(self->nwork, env_int("BPMF_HIP_GRID", resident));
+        hipLaunchKernelGGL(k_sample<K>, dim3(grid), dim3(64), 0, c->stream, a);
+    }
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     hipLaunchKernelGGL(k_colstats<K>, dim3(self->nstat_waves), dim3(64), 0, c->stream,
                        (const double *)self->d_items, self->from, self->to, self->nstat_waves, self->d_stat_partials);
     hipLaunchKernelGGL(k_colstats_final<K>, dim3((K * K + K + 63) / 64), dim3(256), 0, c->stream,
-                       (const double *)self->d_stat_partials, self->nstat_waves, (const unsigned long long *)a.fail, c->d_out);
+                       (const double *)self->d_stat_partials, self->nstat_waves, (const unsigned long long *)a.fail, c->h_out_dev);
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -399,7 +438,8 @@ extern "C" int bpmf_hip_sample_side_launch(bpmf_hip_side *self, const bpmf_hip_s
     }
     const unsigned long long nofail = ~0ull;
     memcpy(&c->h_in[(size_t)K * K + K], &nofail, sizeof(nofail));
-    HIP_TRY(hipMemcpyAsync(c->d_in, c->h_in, c->in_words * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(bpmf::k_stage, dim3((unsigned)((c->in_words + 255) / 256)), dim3(256), 0, c->stream,
+                       (const double *)c->h_in_dev, c->d_in, (int)c->in_words);
     int rc = 0;
     switch (K) {
     case 8: rc = do_launch<8>(self, other, iter, alpha); break;
@@ -409,8 +449,9 @@ extern "C" int bpmf_hip_sample_side_launch(bpmf_hip_side *self, const bpmf_hip_s
     default: return fail(BPMF_HIP_EINVAL, "sample_side: unsupported K");
     }
     if (rc) return rc;
-    // prod | sum | - | fail word are in d_out: bring them back
-    HIP_TRY(hipMemcpyAsync(c->h_out, c->d_out, ((size_t)K * K + K + 2) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    // prod | sum | - | fail word land in the pinned result blob; publish the sequence number behind them
+    signal_host(c);
+    HIP_TRY(hipGetLastError());
     self->pending = true;
     return BPMF_HIP_OK;
 }
@@ -423,7 +464,7 @@ extern "C" int bpmf_hip_sample_side_finish(bpmf_hip_side *self, double *sum_out,
     const int K = c->K;
     HIP_TRY(hipSetDevice(c->device));
     self->pending = false;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    { const int rcw = wait_host(c); if (rcw) return rcw; }
     memcpy(prod_out, c->h_out, sizeof(double) * K * K);
     memcpy(sum_out, c->h_out + (size_t)K * K, sizeof(double) * K);
     {   // sum |x|^2 = trace(sum x x^T)
@@ -433,8 +474,7 @@ extern "C" int bpmf_hip_sample_side_finish(bpmf_hip_side *self, double *sum_out,
     }
     unsigned long long f;
     memcpy(&f, &c->h_out[(size_t)K * K + K + 1], sizeof(f));
-    (void)hipEventElapsedTime(&self->last_sample_ms, c->ev[0], c->ev[1]);
-    (void)hipEventElapsedTime(&self->last_reduce_ms, c->ev[1], c->ev[2]);
+    self->timing_valid = false;
     if (f != ~0ull) {
         self->failed_column = (int64_t)f;
         return fail(BPMF_HIP_ECHOL, "Cholesky failed in column " + std::to_string((long long)f));
@@ -457,6 +497,13 @@ extern "C" int64_t bpmf_hip_failed_column(const bpmf_hip_side *s) { return s ? s
 extern "C" int bpmf_hip_side_last_kernel_ms(bpmf_hip_side *s, float *sample_ms, float *reduce_ms)
 {
     if (!s) return fail(BPMF_HIP_EINVAL, "last_kernel_ms: NULL");
+    if (!s->timing_valid) {          // the events of the last launch on this context
+        bpmf_hip_ctx *c = s->ctx;
+        HIP_TRY(hipEventSynchronize(c->ev[2]));
+        (void)hipEventElapsedTime(&s->last_sample_ms, c->ev[0], c->ev[1]);
+        (void)hipEventElapsedTime(&s->last_reduce_ms, c->ev[1], c->ev[2]);
+        s->timing_valid = true;
+    }
     if (sample_ms) *sample_ms = s->last_sample_ms;
     if (reduce_ms) *reduce_ms = s->last_reduce_ms;
     return BPMF_HIP_OK;
@@ -584,7 +631,7 @@ void launch_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const bpmf_hip_
                        (const double *)self->d_items, (const double *)other->d_items, self->from, self->mean_rating, n,
                        t->d_pavg, t->d_pm2, t->d_partial);
     hipLaunchKernelGGL(bpmf::k_predict_final, dim3(1), dim3(256), 0, c->stream, (const double *)t->d_partial, t->nblocks,
-                       c->d_out + c->out_words - 2);
+                       c->h_out_dev + c->out_words - 3);
 }
 }  // namespace
 
@@ -604,11 +651,11 @@ extern "C" int bpmf_hip_predict(bpmf_hip_test *t, const bpmf_hip_side *self, con
     case 64: launch_predict<64>(t, self, other, n); break;
     default: return fail(BPMF_HIP_EINVAL, "predict: unsupported K");
     }
+    signal_host(c);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(c->h_out + c->out_words - 2, c->d_out + c->out_words - 2, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    *se = c->h_out[c->out_words - 2];
-    *se_avg = c->h_out[c->out_words - 1];
+    { const int rcw = wait_host(c); if (rcw) return rcw; }
+    *se = c->h_out[c->out_words - 3];
+    *se_avg = c->h_out[c->out_words - 2];
     *count = t->nnz;
     return BPMF_HIP_OK;
 }

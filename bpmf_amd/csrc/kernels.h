@@ -3,20 +3,19 @@
 // The path (c++/sample.cpp:248-336 + c++/mvnormal.cpp:18-47 of the reference),
 // re-designed for MI355X:
 //
-//   k_gram<K>        one wavefront per (column, nnz-chunk) work item.  The K-vectors
-//                    of the rated rows are gathered straight into MFMA operand
-//                    layout (16 lanes x 8 B = one 128-B line per 16 latent dims per
-//                    rating, 4 ratings per instruction) and the upper-triangular
-//                    16x16 tiles of sum_j u_j u_j^T are accumulated with
-//                    v_mfma_f64_16x16x4_f64; the K-vector sum_j w_j u_j rides along
-//                    on the VALU.  Columns that fit one chunk are finished in the
-//                    same wave; chunks of heavy columns write their partial tiles.
-//   k_finish_multi<K> sums the partial tiles of a heavy column in chunk order and
-//                    finishes it.
-//   finish_column<K> Lambda* = LambdaF + alpha*G into LDS, one row per lane into
-//                    registers, right-looking Cholesky with the pivot column
-//                    broadcast through LDS, fused forward solve, Philox/polar
-//                    normal draw, backward solve, coalesced 8*K-byte store.
+//   k_sample<K>      persistent single-wave workgroups pull (column, rating-chunk) work items
+//                    from per-XCD queues.  The K-vectors of the rated rows are gathered straight
+//                    into MFMA operand layout (16 lanes x 8 B = one 128-B line per 16 latent dims
+//                    per rating, 4 ratings per instruction) and the upper-triangular 16x16 tiles of
+//                    sum_j u_j u_j^T are accumulated with v_mfma_f64_16x16x4_f64; the K-vector
+//                    sum_j w_j u_j rides along on the VALU.  A column that fits one chunk is
+//                    finished by the same wave; chunks of a heavy column park their partial tiles
+//                    (write-through stores) and the wave drawing the last ticket sums them in
+//                    chunk order and finishes the column.
+//   finish_column<K> Lambda* = LambdaF + alpha*G through LDS into registers (S lanes per row),
+//                    right-looking Cholesky two columns per step with the pivot block through
+//                    v_readlane and the scaled columns broadcast through LDS, fused forward
+//                    solve, Philox/polar normal draw, backward solve, coalesced 8*K-byte store.
 //   k_colstats<K>    sum x, sum x x^T of the fresh columns (again an MFMA Gram),
 //                    reduced in a fixed order so results are run-to-run identical.
 //   k_predict<K>     test-set dot products, running mean / M2, squared errors.
@@ -38,9 +37,17 @@ struct Geo {
     static constexpr int NTRI = NT * (NT + 1) / 2;        // upper-triangular tiles incl. diagonal
     static constexpr int LD = K + 1;                      // LDS leading dimension in doubles (odd: column walks hit distinct banks)
     static constexpr int PART = NTRI * 256 + NT * 16;     // doubles in one partial: tiles in accumulator layout + rhs
-    // waves per SIMD the sampler is compiled for (bounds the VGPR budget: 512 / WPS):
-    // a lane keeps one K-double row of Lambda* in registers during the factorisation
+    // waves per SIMD the sampler is compiled for (bounds the VGPR budget: 512 / WPS)
     static constexpr int WPS = K <= 32 ? 4 : 2;
+    // factorisation layout: S lanes per row of Lambda*, each lane owns QN column pairs
+    static constexpr int S = (64 / K < K / 2) ? 64 / K : K / 2;
+    static constexpr int NP = K / 2;                      // column pairs
+    static constexpr int QN = NP / S;                     // pairs per lane
+    static constexpr int M = 2 * QN;                      // matrix entries per lane (+2 for the rhs column)
+    static constexpr int FLD = K + 2;                     // LDS leading dimension: even, so a pair is 16-B aligned
+    static constexpr int LANES = K * S;                   // lanes that carry distinct work (64, or 32 at K=8)
+    // LDS doubles: L (K rows) | rhs (K) | normals (K) | dummy pair slots (2K) | one zero
+    static constexpr int LDS_WORDS = K * FLD + 4 * K + 2;
 };
 
 // v_mfma_f64_16x16x4_f64 operand / result layout (lane l, kq = l>>4, li = l&15):
@@ -76,15 +83,17 @@ struct SampleArgs {
     // ratings of this rank's columns
     const int32_t *rowidx;
     const double *vals;
-    // schedule
-    const int32_t *wi_col;      // local column of work item
-    const int64_t *wi_p0;       // first nnz of the chunk
-    const int32_t *wi_len;      // nnz in the chunk
-    const int32_t *wi_slot;     // partial slot, or -1: single-chunk column, finish in place
-    const int32_t *mc_col;      // heavy columns: local column, first slot, number of chunks
-    const int32_t *mc_slot0;
+    // static schedule of the side: work item = (column, chunk of its ratings)
+    const int32_t *wi_col;      // local column
+    const int64_t *wi_p0;       // first rating of the chunk
+    const int32_t *wi_len;      // ratings in the chunk
+    const int32_t *wi_mc;       // heavy column index the chunk belongs to, or -1 (whole column)
+    const int32_t *wi_chunk;    // ordinal of the chunk inside its column
+    const int32_t *mc_slot0;    // heavy columns: first partial slot, number of chunks
     const int32_t *mc_nchunks;
+    unsigned *mc_count;         // arrival counters of the heavy columns (zero between launches)
     double *partials;
+    int nwork;
     // factors
     const double *other_items;  // K x nrows
     double *items;              // K x ncols
@@ -209,25 +218,29 @@ __device__ __forceinline__ void gram_chunk(const int32_t *__restrict__ rowidx, c
 
 // ---------------------------------------------------------------------------
 // Everything after the Gram for one column (c++/sample.cpp:285,297-324).
-// lds: K*LD + 2*K + 64 doubles.
 //
-// The wave holds Lambda* in registers, S = 64/K lanes per row: lane (h, i) =
-// (lane / K, lane % K) owns the entries (i, j) with j = m*S + h, m = 0..M-1
-// (M = K*K/64: 16 doubles at K=32).  Right-looking Cholesky: at step k the
-// pivot comes from its owner lane through v_readlane, the owners scale column k
-// and publish it to LDS (row-major L, reused by the backward solve), then every
-// lane updates its own entries with L(i,k) * L(j,k), the second factor being a
-// broadcast LDS read.  The forward solve L y = b is one more fused column.
+// The wave holds Lambda* in registers, S lanes per row: lane (h, i) = (l / K, l % K) owns the
+// entries (i, j) of the column pairs p = q*S + h (j = 2p, 2p+1), q = 0..QN-1, plus (lanes h = 0)
+// the rhs b_i as one more column.  Right-looking Cholesky, TWO columns per step: the 2x2 pivot
+// block comes through v_readlane, every lane factors it redundantly (two 1/sqrt), the owners
+// scale their pair of column entries and publish them to LDS (row-major L, one 16-byte store),
+// then each lane applies the rank-2 update to its remaining pairs, reading L(j,k),L(j,k+1) with
+// one broadcast 16-byte LDS load per row.  The forward solve L y = b is the same update applied
+// to the rhs column with the two y values (wave-uniform) in registers.  Backward solve, normal
+// draw and the coalesced 8K-byte store follow.
 // ---------------------------------------------------------------------------
 template <int K>
 __device__ __forceinline__ void finish_column(const SampleArgs &a, int col_local, const d4 (&acc)[Geo<K>::NTRI],
-                                              const double (&r)[Geo<K>::NT], double *lds, int lane)
+                                              const double (&r)[Geo<K>::NT], double *lds, int lane_in)
 {
-    constexpr int NT = Geo<K>::NT, LD = Geo<K>::LD;
-    constexpr int S = 64 / K, M = K / S;
-    static_assert(K * S == 64 && M * S == K, "K must be a power of two <= 64");
+    int lane = lane_in;
+    using G = Geo<K>;
+    constexpr int NT = G::NT, LD = G::FLD, S = G::S, NP = G::NP, QN = G::QN, M = G::M;
+    // The caller runs this inside its persistent work loop: make the lane id opaque here so that
+    // LLVM does not hoist every per-step address and lane mask out of that loop (and spill them).
+    asm volatile("" : "+v"(lane));
     const int kq = lane >> 4, li = lane & 15;
-    double *sA = lds, *sb = lds + K * LD, *sz = sb + K, *sdummy = sz + K;
+    double *sA = lds, *sb = lds + K * LD, *sz = sb + K, *sdummy = sz + K, *szero = sdummy + 2 * K;
     const int64_t idx = a.col_from + col_local;
 
     // z ~ N(0, I) from stream (idx+1)*K*(iter+1) truncated to 32 bits (c++/sample.cpp:266, c++/bpmf.h:67)
@@ -254,135 +267,182 @@ __device__ __forceinline__ void finish_column(const SampleArgs &a, int col_local
             for (int t = 0; t < NT; ++t)
                 if (t * 16 + li < K) sb[t * 16 + li] = r[t];
         }
+        if (lane == 0) szero[0] = 0.0;
     }
     __syncthreads();
 
-    const int h = lane / K, i = lane % K;
+    const int l = lane & (G::LANES - 1);                           // K=8: the upper half-wave mirrors the lower
+    const int h = l / K, i = l % K;
     // Lambda* = LambdaF + alpha * G (:298); b = LambdaF*mu + rr (:285,:256)
-    double row[M];
+    double row[M + 2];
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-        const int j = m * S + h;
-        row[m] = fma(a.alpha, sA[i * LD + j], a.LambdaF[i + j * K]);
+    for (int q = 0; q < QN; ++q) {
+        const int j = 2 * (q * S + h);
+        const double2 g = *reinterpret_cast<const double2 *>(&sA[i * LD + j]);
+        row[2 * q] = fma(a.alpha, g.x, a.LambdaF[i + j * K]);
+        row[2 * q + 1] = fma(a.alpha, g.y, a.LambdaF[i + (j + 1) * K]);
     }
-    double bi = a.Lmu[i] + sb[i];
+    row[M] = (h == 0) ? a.Lmu[i] + sb[i] : 0.0;
+    row[M + 1] = 0.0;
     const double zi = sz[i];
-    double my_dinv = 1.0, dmin = 1.0;
+    double yi = 0.0, dmin = 1.0;
     __syncthreads();
 
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int hk = k % S, mk = k / S;
-        const double d = bcast(row[mk], hk * K + k);
-        dmin = fmin(dmin, d);                                     // Eigen LLT: pivot <= 0 -> info() != Success (:308)
-        const double dinv = rsqrt_nr(d);
-        // owners publish column k (row k: sqrt(d); rows i>k: L(i,k)); the other lanes hit a dummy
-        // slot so that the step stays branch-free (branches let LLVM sink whole FMA chains)
-        double *dst = (h == hk) ? &sA[i * LD + k] : &sdummy[lane];
-        *dst = row[mk] * dinv;
-        my_dinv = (i == k) ? dinv : my_dinv;
+    for (int p = 0; p < NP; ++p) {
+        const int hk = p % S, qk = p / S, k = 2 * p;
+        const int src0 = hk * K + k, src1 = src0 + 1;
+        // 2x2 pivot block [a b; b c] and the two rhs entries, wave-uniform
+        const double pa = bcast(row[2 * qk], src0);
+        const double pb = bcast(row[2 * qk], src1);
+        const double pc = bcast(row[2 * qk + 1], src1);
+        const double bk = bcast(row[M], k), bk1 = bcast(row[M], k + 1);
+        const double dinv0 = rsqrt_nr(pa);
+        const double l10 = pb * dinv0;
+        const double c2 = fma(-l10, l10, pc);
+        const double dinv1 = rsqrt_nr(c2);
+        dmin = fmin(dmin, fmin(pa, c2));                           // Eigen LLT: pivot <= 0 -> info() != Success (:308)
+        // forward solve (:321) for these two rows: y_k, y_k+1
+        const double yk = bk * dinv0;
+        const double yk1 = fma(-l10, yk, bk1) * dinv1;
+        yi = (i == k) ? yk : yi;
+        yi = (i == k + 1) ? yk1 : yi;
+        // owners scale their entries of columns k, k+1 and publish them; the other lanes hit a
+        // dummy slot so that the step stays branch-free
+        double2 lp;
+        lp.x = row[2 * qk] * dinv0;
+        lp.y = fma(-lp.x, l10, row[2 * qk + 1]) * dinv1;
+        double *dst = (h == hk) ? &sA[i * LD + k] : &sdummy[2 * i];
+        *reinterpret_cast<double2 *>(dst) = lp;
         __syncthreads();
-        const double lik = sA[i * LD + k];
-        // fused forward solve (:321): y_k = b_k / L(k,k); b_i -= L(i,k) y_k for i>k
-        const double yk = bcast(bi, k) * dinv;
-        bi = (i == k) ? yk : ((i > k) ? fma(-lik, yk, bi) : bi);
-        // trailing update of this lane's entries j = m*S+h > k
-        {
-            const double u = fma(-lik, sA[(mk * S + h) * LD + k], row[mk]);
-            row[mk] = (h > hk) ? u : row[mk];
+        const double2 L = *reinterpret_cast<const double2 *>(&sA[i * LD + k]);     // L(i,k), L(i,k+1)
+        row[M] = fma(-L.y, yk1, fma(-L.x, yk, row[M]));            // rhs column: b_i -= L(i,k) y_k + L(i,k+1) y_k+1
+        if constexpr (S > 1) {                                     // pairs of this slot owned by higher h are still to come
+            const int j0 = 2 * (qk * S + h);
+            const double2 A0 = *reinterpret_cast<const double2 *>(&sA[j0 * LD + k]);
+            const double2 A1 = *reinterpret_cast<const double2 *>(&sA[(j0 + 1) * LD + k]);
+            const double u0 = fma(-L.y, A0.y, fma(-L.x, A0.x, row[2 * qk]));
+            const double u1 = fma(-L.y, A1.y, fma(-L.x, A1.x, row[2 * qk + 1]));
+            row[2 * qk] = (h > hk) ? u0 : row[2 * qk];
+            row[2 * qk + 1] = (h > hk) ? u1 : row[2 * qk + 1];
         }
 #pragma unroll
-        for (int m = mk + 1; m < M; ++m) row[m] = fma(-lik, sA[(m * S + h) * LD + k], row[m]);
+        for (int q = qk + 1; q < QN; ++q) {
+            const int j0 = 2 * (q * S + h);
+            const double2 A0 = *reinterpret_cast<const double2 *>(&sA[j0 * LD + k]);
+            const double2 A1 = *reinterpret_cast<const double2 *>(&sA[(j0 + 1) * LD + k]);
+            row[2 * q] = fma(-L.y, A0.y, fma(-L.x, A0.x, row[2 * q]));
+            row[2 * q + 1] = fma(-L.y, A1.y, fma(-L.x, A1.x, row[2 * q + 1]));
+        }
         // Pin this step's results: otherwise instruction selection defers every FMA chain to
-        // the step that finally needs row[m] and keeps (spills) all the L(j,k) it loaded meanwhile.
+        // the step that finally needs the entry and keeps (spills) all the L(j,k) it loaded meanwhile.
 #pragma unroll
-        for (int m = mk; m < M; ++m) asm volatile("" : "+v"(row[m]));
+        for (int m = 2 * qk; m < M + 1; ++m) asm volatile("" : "+v"(row[m]));
     }
 
-    bi += zi;                                                     // rr += nrandn(K)  (:322)
-
-    // backward solve L^T x = rr (:323): x_k = rr_k / L(k,k), then rr_i -= L(k,i) x_k for i<k
+    // rr += nrandn(K) (:322); backward solve L^T x = rr (:323): u_i = rr_i - sum_{k>i} L(k,i) x_k, x_i = u_i / L(i,i)
+    double bi = yi + zi;
+    const double my_dinv = 1.0 / sA[i * LD + i];
 #pragma unroll
-    for (int k = K - 1; k >= 0; --k) {
+    for (int k = K - 1; k >= 1; --k) {
         const double xk = bcast(bi * my_dinv, k);
-        const double lki = (i < k) ? sA[k * LD + i] : 0.0;
-        bi = (i == k) ? xk : fma(-lki, xk, bi);
+        const double *src = (i < k) ? &sA[k * LD + i] : szero;
+        bi = fma(-(*src), xk, bi);
     }
+    const double xi = bi * my_dinv;
 
-    if (h == 0) a.items[(size_t)idx * K + i] = bi;                // items().col(idx) = rr (:324)
-    const bool bad = !(dmin > 0.0) || !(fabs(bi) <= 1.79769313486231570815e+308);
+    if (lane < K) a.items[(size_t)idx * K + lane] = xi;           // items().col(idx) = rr (:324)
+    const bool bad = !(dmin > 0.0) || !(fabs(xi) <= 1.79769313486231570815e+308);
     if (__any(bad) && lane == 0) atomicMin(a.fail, (unsigned long long)idx);
 }
 
+// ---------------------------------------------------------------------------
+// The sampler: persistent single-wave workgroups walk a static, cost-sorted list of work
+// items (column, chunk).  A chunk of a heavy column parks its partial tiles with write-through stores and takes a
+// ticket; the wave that draws the last ticket sums the partials in chunk order (so the result
+// does not depend on who was last) and finishes the column.  No wave ever waits for another.
+// ---------------------------------------------------------------------------
+#define BPMF_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
 template <int K>
-__global__ __launch_bounds__(64, Geo<K>::WPS) void k_gram(SampleArgs a)
+__global__ __launch_bounds__(64, Geo<K>::WPS) void k_sample(SampleArgs a)
 {
-    constexpr int NT = Geo<K>::NT, NTRI = Geo<K>::NTRI, LD = Geo<K>::LD, PART = Geo<K>::PART;
-    __shared__ double lds[K * LD + 2 * K + 64];
-    const int lane = threadIdx.x;
-    const int w = blockIdx.x;
-    const int col = a.wi_col[w];
-    const int64_t p0 = a.wi_p0[w];
-    const int len = a.wi_len[w];
-    const int slot = a.wi_slot[w];
+    constexpr int NT = Geo<K>::NT, NTRI = Geo<K>::NTRI, PART = Geo<K>::PART;
+    __shared__ __attribute__((aligned(16))) double lds[Geo<K>::LDS_WORDS];
+    const int grid = gridDim.x;
 
-    d4 acc[NTRI];
-    double r[NT];
-#pragma unroll
-    for (int t = 0; t < NTRI; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int t = 0; t < NT; ++t) r[t] = 0.0;
+    // Static schedule: the items are sorted by decreasing cost; round r hands item r*grid + b
+    // (even r) or r*grid + grid-1-b (odd r) to workgroup b, so the workgroup that got the most
+    // expensive item of one round gets the cheapest of the next.  (A dynamic queue was measured
+    // slower here: a dequeue costs 1-3 us of exposed latency against ~5 us of work per column.)
+    for (int round = 0;; ++round) {
+        // a fresh, opaque copy of the lane id per work item keeps lane-derived addresses and
+        // masks from being hoisted out of this loop and held (spilled) across the whole kernel
+        int lane = threadIdx.x;
+        asm volatile("" : "+v"(lane));
+        const long long base = (long long)round * grid;
+        if (base >= a.nwork) return;
+        const long long wl = base + ((round & 1) ? (grid - 1 - (int)blockIdx.x) : (int)blockIdx.x);
+        if (wl >= a.nwork) { if (round & 1) continue; else return; }
+        const int w = (int)wl;
 
-    gram_chunk<K>(a.rowidx + p0, a.vals + p0, (a.ablate & 2u) ? 0 : len, a.other_items, a.mean_rating, a.alpha, acc, r, lane);
+        const int col = a.wi_col[w];
+        const int64_t p0 = a.wi_p0[w];
+        const int len = a.wi_len[w];
+        const int mc = a.wi_mc[w];
 
-    if (a.ablate & 1u) {                                           // timing ablation: keep the Gram live, skip the rest
-        double v = r[0];
+        d4 acc[NTRI];
+        double r[NT];
 #pragma unroll
-        for (int t = 0; t < NTRI; ++t) v += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
-        if (slot < 0 && lane < K) a.items[(size_t)(a.col_from + col) * K + lane] = v;
-        return;
-    }
-    if (slot >= 0) {                                               // chunk of a heavy column: park the partial
-        double *p = a.partials + (size_t)slot * PART;
+        for (int t = 0; t < NTRI; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int t = 0; t < NTRI; ++t)
+        for (int t = 0; t < NT; ++t) r[t] = 0.0;
+
+        gram_chunk<K>(a.rowidx + p0, a.vals + p0, (a.ablate & 2u) ? 0 : len, a.other_items, a.mean_rating, a.alpha, acc, r, lane);
+
+        if (a.ablate & 1u) {                                       // timing ablation: keep the Gram live, skip the rest
+            double v = r[0];
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) p[(t * 4 + reg) * 64 + lane] = acc[t][reg];
-        if (lane < 16) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) p[NTRI * 256 + t * 16 + lane] = r[t];
+            for (int t = 0; t < NTRI; ++t) v += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+            if (mc < 0 && lane < K) a.items[(size_t)(a.col_from + col) * K + lane] = v;
+            continue;
         }
-        return;
+        if (mc >= 0) {
+            const int nch = a.mc_nchunks[mc];
+            double *base = a.partials + (size_t)a.mc_slot0[mc] * PART;
+            double *p = base + (size_t)a.wi_chunk[w] * PART;
+            // write-through (sc1) stores: visible to every XCD once they have drained
+#pragma unroll
+            for (int t = 0; t < NTRI; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) __hip_atomic_store(&p[(t * 4 + reg) * 64 + lane], acc[t][reg], BPMF_RLX_AGENT);
+            if (lane < 16) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) __hip_atomic_store(&p[NTRI * 256 + t * 16 + lane], r[t], BPMF_RLX_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(&a.mc_count[mc], 1u, BPMF_RLX_AGENT);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if ((int)t != nch - 1) continue;                       // not the last chunk of this column
+            if (lane == 0) __hip_atomic_store(&a.mc_count[mc], 0u, BPMF_RLX_AGENT);     // re-arm for the next launch
+#pragma unroll
+            for (int t2 = 0; t2 < NTRI; ++t2) acc[t2] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t2 = 0; t2 < NT; ++t2) r[t2] = 0.0;
+            for (int c = 0; c < nch; ++c) {                        // fixed chunk order: deterministic
+                const double *pc = base + (size_t)c * PART;
+#pragma unroll
+                for (int t2 = 0; t2 < NTRI; ++t2)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) acc[t2][reg] += __hip_atomic_load(&pc[(t2 * 4 + reg) * 64 + lane], BPMF_RLX_AGENT);
+#pragma unroll
+                for (int t2 = 0; t2 < NT; ++t2) r[t2] += __hip_atomic_load(&pc[NTRI * 256 + t2 * 16 + (lane & 15)], BPMF_RLX_AGENT);
+            }
+        }
+        finish_column<K>(a, col, acc, r, lds, lane);
+        __syncthreads();                                           // LDS is reused by the next work item
     }
-    finish_column<K>(a, col, acc, r, lds, lane);
-}
-
-template <int K>
-__global__ __launch_bounds__(64, Geo<K>::WPS) void k_finish_multi(SampleArgs a)
-{
-    constexpr int NT = Geo<K>::NT, NTRI = Geo<K>::NTRI, LD = Geo<K>::LD, PART = Geo<K>::PART;
-    __shared__ double lds[K * LD + 2 * K + 64];
-    const int lane = threadIdx.x;
-    const int m = blockIdx.x;
-    const int col = a.mc_col[m];
-    const int nch = a.mc_nchunks[m];
-    const double *p = a.partials + (size_t)a.mc_slot0[m] * PART;
-
-    d4 acc[NTRI];
-    double r[NT];
-#pragma unroll
-    for (int t = 0; t < NTRI; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int t = 0; t < NT; ++t) r[t] = 0.0;
-    for (int c = 0; c < nch; ++c, p += PART) {                     // fixed chunk order: deterministic
-#pragma unroll
-        for (int t = 0; t < NTRI; ++t)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) acc[t][reg] += p[(t * 4 + reg) * 64 + lane];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) r[t] += p[NTRI * 256 + t * 16 + (lane & 15)];
-    }
-    finish_column<K>(a, col, acc, r, lds, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -554,6 +614,20 @@ __global__ __launch_bounds__(256) void k_predict_final(const double *__restrict_
         __syncthreads();
     }
     if (threadIdx.x == 0) { out[0] = red[0][0]; out[1] = red[1][0]; }
+}
+
+// hp.mu / hp.LambdaF blob: pinned host memory -> device memory (replaces a hipMemcpyAsync;
+// the sampler re-reads LambdaF per column, so it must sit behind the L2)
+__global__ __launch_bounds__(256) void k_stage(const double *__restrict__ src_host, double *__restrict__ dst, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src_host[i];
+}
+
+// tells the spinning host thread that everything enqueued before it has landed in its pinned buffer
+__global__ void k_signal(unsigned *flag_host, unsigned seq)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // test probe: the first n normals of stream `counter`
