@@ -31,23 +31,23 @@ namespace bpmf {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// offset of row i in the packed lower-triangular row-major storage of L: row i keeps its
+// i+1 entries padded to an even count (so that a pair of columns 2p, 2p+1 is 16-byte aligned)
+__host__ __device__ constexpr int tri_off(int i) { return 2 * ((i >> 1) + 1) * ((i >> 1) + (i & 1)); }
+
 template <int K>
 struct Geo {
     static constexpr int NT = (K + 15) / 16;             // 16-wide tiles per dimension (K=8 is zero-padded)
     static constexpr int NTRI = NT * (NT + 1) / 2;        // upper-triangular tiles incl. diagonal
-    static constexpr int LD = K + 1;                      // LDS leading dimension in doubles (odd: column walks hit distinct banks)
     static constexpr int PART = NTRI * 256 + NT * 16;     // doubles in one partial: tiles in accumulator layout + rhs
     // waves per SIMD the sampler is compiled for (bounds the VGPR budget: 512 / WPS)
     static constexpr int WPS = K <= 32 ? 4 : 2;
-    // factorisation layout: S lanes per row of Lambda*, each lane owns QN column pairs
-    static constexpr int S = (64 / K < K / 2) ? 64 / K : K / 2;
-    static constexpr int NP = K / 2;                      // column pairs
-    static constexpr int QN = NP / S;                     // pairs per lane
-    static constexpr int M = 2 * QN;                      // matrix entries per lane (+2 for the rhs column)
-    static constexpr int FLD = K + 2;                     // LDS leading dimension: even, so a pair is 16-B aligned
-    static constexpr int LANES = K * S;                   // lanes that carry distinct work (64, or 32 at K=8)
-    // LDS doubles: L (K rows) | rhs (K) | normals (K) | dummy pair slots (2K) | one zero
-    static constexpr int LDS_WORDS = K * FLD + 4 * K + 2;
+    // factorisation: one lane per row of Lambda*, C = 64/K columns side by side in one wave
+    static constexpr int C = 64 / K;
+    static constexpr int NP = K / 2;                      // column pairs = steps of the factorisation
+    static constexpr int PLEN = tri_off(K);               // packed L: 544 doubles at K=32
+    static constexpr int SLOT = PLEN + 2 * K;             // per column: L | rhs, later y [K] | normals [K]
+    static constexpr int LDS_WORDS = C * SLOT + 2 * C;    // + the global column id of each slot
 };
 
 // v_mfma_f64_16x16x4_f64 operand / result layout (lane l, kq = l>>4, li = l&15):
@@ -57,18 +57,25 @@ __device__ __forceinline__ d4 mfma16(double a, double b, d4 c)
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-// 1/sqrt(d) to <= 1 ulp: v_rsq_f64 (2^-26 relative) + two Newton steps, 10 dependent
-// instructions instead of the ~25 of sqrt followed by a divide.  d <= 0 or NaN gives NaN/inf,
-// which is what flags the column as "Cholesky failed".
+// 1/sqrt(d) to ~1 ulp: v_rsq_f64 (2^-23 relative) + one third-order (Halley) correction,
+// y = y0 (1 + e/2 + 3e^2/8) with e = 1 - d y0^2, error ~ e^3: 6 dependent instructions
+// instead of the ~25 of sqrt followed by a divide.  d <= 0 or NaN gives NaN/inf, which
+// propagates into the sample and flags the column as "Cholesky failed".
 __device__ __forceinline__ double rsqrt_nr(double d)
 {
-    double y = __builtin_amdgcn_rsq(d);
-    const double hd = 0.5 * d;
-    double e = fma(-hd * y, y, 0.5);      // 0.5 - 0.5*d*y^2
-    y = fma(y, e, y);
-    e = fma(-hd * y, y, 0.5);
-    y = fma(y, e, y);
-    return y;
+    const double y0 = __builtin_amdgcn_rsq(d);
+    const double e = fma(-d, y0 * y0, 1.0);
+    const double q = e * fma(0.375, e, 0.5);
+    return fma(y0, q, y0);
+}
+
+// value of `v` in lane `base + off` of the wave, base per lane (LDS crossbar, no VALU work
+// beyond the two moves): used for broadcasts inside one K-lane group of the factorisation
+__device__ __forceinline__ double gbcast(double v, int base_bytes, int off)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(base_bytes + 4 * off, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(base_bytes + 4 * off, __double2hiint(v));
+    return __hiloint2double(hi, lo);
 }
 
 // value of `v` in lane `src` (wave-uniform src) through v_readlane_b32: no LDS traffic
@@ -119,6 +126,13 @@ __device__ __forceinline__ double polar_r2(double x, double y)
 {
 #pragma clang fp contract(off)
     return x * x + y * y;      // two roundings + add, as the un-fused x86 reference build evaluates it
+}
+
+// stream id of a column: (idx+1)*K*(iter+1) truncated to 32 bits (c++/sample.cpp:266, c++/bpmf.h:67)
+template <int K>
+__device__ __forceinline__ uint32_t sample_counter(int64_t idx, uint32_t iter_plus_1)
+{
+    return (uint32_t)((uint64_t)(idx + 1) * (uint64_t)K * (uint64_t)iter_plus_1);
 }
 
 template <int NMAX>
@@ -217,159 +231,198 @@ __device__ __forceinline__ void gram_chunk(const int32_t *__restrict__ rowidx, c
 }
 
 // ---------------------------------------------------------------------------
-// Everything after the Gram for one column (c++/sample.cpp:285,297-324).
+// Everything after the Gram (c++/sample.cpp:285,297-324), in two parts.
 //
-// The wave holds Lambda* in registers, S lanes per row: lane (h, i) = (l / K, l % K) owns the
-// entries (i, j) of the column pairs p = q*S + h (j = 2p, 2p+1), q = 0..QN-1, plus (lanes h = 0)
-// the rhs b_i as one more column.  Right-looking Cholesky, TWO columns per step: the 2x2 pivot
-// block comes through v_readlane, every lane factors it redundantly (two 1/sqrt), the owners
-// scale their pair of column entries and publish them to LDS (row-major L, one 16-byte store),
-// then each lane applies the rank-2 update to its remaining pairs, reading L(j,k),L(j,k+1) with
-// one broadcast 16-byte LDS load per row.  The forward solve L y = b is the same update applied
-// to the rhs column with the two y values (wave-uniform) in registers.  Backward solve, normal
-// draw and the coalesced 8K-byte store follow.
+// deposit_column: the wave that holds a column's complete Gram parks
+//     Lambda* = LambdaF + alpha G   (lower triangle, packed, :297-298),
+//     b = LambdaF mu + rr           (:285,:256)   and   z ~ N(0,I)   (:322, stream :266)
+// in one of its C = 64/K LDS slots.
+//
+// finish_slots: the wave factorises all filled slots side by side, lane (c, i) = (lane / K,
+// lane % K) owning row i of slot c in registers.  Right-looking Cholesky, two columns per step:
+// the 2x2 pivot block is factored redundantly by every lane of the group (its entries arrive
+// through the LDS crossbar), each lane scales its two entries of columns k, k+1 and stores them
+// (row-major packed L, one 16-byte store), then applies the rank-2 update to the rest of its
+// row with L(j,k), L(j,k+1) read as one broadcast 16-byte LDS load per row j.  The forward
+// solve L y = b is the same update applied to one more column (the rhs).  Backward solve and
+// the coalesced 8K-byte store of the sample follow.  Per-step work that is identical for all
+// lanes of a group (two 1/sqrt, the pivot algebra) is thus shared by C columns.
 // ---------------------------------------------------------------------------
 template <int K>
-__device__ __forceinline__ void finish_column(const SampleArgs &a, int col_local, const d4 (&acc)[Geo<K>::NTRI],
-                                              const double (&r)[Geo<K>::NT], double *lds, int lane_in)
+__device__ __forceinline__ void deposit_column(const SampleArgs &a, int64_t idx, const d4 (&acc)[Geo<K>::NTRI],
+                                               const double (&r)[Geo<K>::NT], double *lds, int slot, int lane)
 {
-    int lane = lane_in;
     using G = Geo<K>;
-    constexpr int NT = G::NT, LD = G::FLD, S = G::S, NP = G::NP, QN = G::QN, M = G::M;
+    constexpr int NT = G::NT;
+    const int kq = lane >> 4, li = lane & 15;
+    double *sL = lds + slot * G::SLOT, *sY = sL + G::PLEN, *sZ = sY + K;
+
+    draw_normals<K>(sample_counter<K>(idx, a.iter_plus_1), K, sZ, lane);
+
+    int tri = 0;
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = I; J < NT; ++J, ++tri)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int gi = I * 16 + kq + 4 * reg, gj = J * 16 + li;
+                // G is symmetric and the upper tiles are what was accumulated: element (gi, gj) of
+                // an off-diagonal tile is entry (row gj, col gi) of the lower triangle
+                const int row = (I == J) ? gi : gj, col = (I == J) ? gj : gi;
+                if (row < K && col <= row)
+                    sL[tri_off(row) + col] = fma(a.alpha, acc[tri][reg], a.LambdaF[row + col * K]);
+            }
+    if (kq == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (t * 16 + li < K) sY[t * 16 + li] = a.Lmu[t * 16 + li] + r[t];
+    }
+    if (lane == 0) reinterpret_cast<long long *>(lds + G::C * G::SLOT)[slot] = idx;
+}
+
+template <int K>
+struct Pivot { double dinv0, dinv1, l10; };
+
+// Factors the 2x2 pivot block [a b; b c].  The two reciprocal square roots are independent --
+// the second goes through the determinant, 1/sqrt(c - b^2/a) = sqrt(a)/sqrt(a c - b^2).
+template <int K>
+__device__ __forceinline__ Pivot<K> factor_block(double pa, double pb, double pc)
+{
+    Pivot<K> v;
+    v.dinv0 = rsqrt_nr(pa);
+    const double rdet = rsqrt_nr(fma(pa, pc, -(pb * pb)));
+    v.dinv1 = rdet * (pa * v.dinv0);
+    v.l10 = pb * v.dinv0;
+    return v;
+}
+
+template <int K>
+__device__ __forceinline__ void finish_slots(const SampleArgs &a, double *lds, int nfilled, int lane_in)
+{
+    using G = Geo<K>;
+    constexpr int NP = G::NP;
+    int lane = lane_in;
     // The caller runs this inside its persistent work loop: make the lane id opaque here so that
     // LLVM does not hoist every per-step address and lane mask out of that loop (and spill them).
     asm volatile("" : "+v"(lane));
-    const int kq = lane >> 4, li = lane & 15;
-    double *sA = lds, *sb = lds + K * LD, *sz = sb + K, *sdummy = sz + K, *szero = sdummy + 2 * K;
-    const int64_t idx = a.col_from + col_local;
+    const int c = lane / K, i = lane % K;
+    double *sL = lds + c * G::SLOT, *sY = sL + G::PLEN, *sZ = sY + K;
+    double *myrow = sL + tri_off(i);
+    const int gbase = 4 * (c * K);                                 // byte index of lane (c, 0) for ds_bpermute
+    __syncthreads();                                               // the deposits are complete
 
-    // z ~ N(0, I) from stream (idx+1)*K*(iter+1) truncated to 32 bits (c++/sample.cpp:266, c++/bpmf.h:67)
-    const uint32_t counter = (uint32_t)((uint64_t)(idx + 1) * (uint64_t)K * (uint64_t)a.iter_plus_1);
-    draw_normals<K>(counter, K, sz, lane);
-
-    // G (upper tiles, accumulator layout) -> LDS, mirrored (c++/sample.cpp:297); rhs partial sums -> LDS
-    {
-        int tri = 0;
+    // this lane's row of Lambda* (entries right of the diagonal are never used), rhs, normal
+    double row[K + 1];
 #pragma unroll
-        for (int I = 0; I < NT; ++I)
-#pragma unroll
-            for (int J = I; J < NT; ++J, ++tri)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int i = I * 16 + kq + 4 * reg, j = J * 16 + li;
-                    if (i < K && j < K) {
-                        sA[i * LD + j] = acc[tri][reg];
-                        if (I != J) sA[j * LD + i] = acc[tri][reg];
-                    }
-                }
-        if (kq == 0) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (t * 16 + li < K) sb[t * 16 + li] = r[t];
-        }
-        if (lane == 0) szero[0] = 0.0;
+    for (int j = 0; j < K; j += 2) {
+        const double2 g = *reinterpret_cast<const double2 *>(&myrow[j]);
+        row[j] = g.x;
+        row[j + 1] = g.y;
     }
-    __syncthreads();
-
-    const int l = lane & (G::LANES - 1);                           // K=8: the upper half-wave mirrors the lower
-    const int h = l / K, i = l % K;
-    // Lambda* = LambdaF + alpha * G (:298); b = LambdaF*mu + rr (:285,:256)
-    double row[M + 2];
-#pragma unroll
-    for (int q = 0; q < QN; ++q) {
-        const int j = 2 * (q * S + h);
-        const double2 g = *reinterpret_cast<const double2 *>(&sA[i * LD + j]);
-        row[2 * q] = fma(a.alpha, g.x, a.LambdaF[i + j * K]);
-        row[2 * q + 1] = fma(a.alpha, g.y, a.LambdaF[i + (j + 1) * K]);
-    }
-    row[M] = (h == 0) ? a.Lmu[i] + sb[i] : 0.0;
-    row[M + 1] = 0.0;
-    const double zi = sz[i];
-    double yi = 0.0, dmin = 1.0;
+    row[K] = sY[i];
+    const double zi = sZ[i];
+    Pivot<K> pv = factor_block<K>(sL[0], sL[tri_off(1)], sL[tri_off(1) + 1]);
     __syncthreads();
 
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const int hk = p % S, qk = p / S, k = 2 * p;
-        const int src0 = hk * K + k, src1 = src0 + 1;
-        // 2x2 pivot block [a b; b c] and the two rhs entries, wave-uniform
-        const double pa = bcast(row[2 * qk], src0);
-        const double pb = bcast(row[2 * qk], src1);
-        const double pc = bcast(row[2 * qk + 1], src1);
-        const double bk = bcast(row[M], k), bk1 = bcast(row[M], k + 1);
-        const double dinv0 = rsqrt_nr(pa);
-        const double l10 = pb * dinv0;
-        const double c2 = fma(-l10, l10, pc);
-        const double dinv1 = rsqrt_nr(c2);
-        dmin = fmin(dmin, fmin(pa, c2));                           // Eigen LLT: pivot <= 0 -> info() != Success (:308)
-        // forward solve (:321) for these two rows: y_k, y_k+1
-        const double yk = bk * dinv0;
-        const double yk1 = fma(-l10, yk, bk1) * dinv1;
-        yi = (i == k) ? yk : yi;
-        yi = (i == k + 1) ? yk1 : yi;
-        // owners scale their entries of columns k, k+1 and publish them; the other lanes hit a
-        // dummy slot so that the step stays branch-free
+        const int k = 2 * p;
+        // scale this row's entries of columns k, k+1 and publish them; finished rows (i < k)
+        // have nothing to store (their slot in the packed triangle does not exist)
         double2 lp;
-        lp.x = row[2 * qk] * dinv0;
-        lp.y = fma(-lp.x, l10, row[2 * qk + 1]) * dinv1;
-        double *dst = (h == hk) ? &sA[i * LD + k] : &sdummy[2 * i];
-        *reinterpret_cast<double2 *>(dst) = lp;
-        __syncthreads();
-        const double2 L = *reinterpret_cast<const double2 *>(&sA[i * LD + k]);     // L(i,k), L(i,k+1)
-        row[M] = fma(-L.y, yk1, fma(-L.x, yk, row[M]));            // rhs column: b_i -= L(i,k) y_k + L(i,k+1) y_k+1
-        if constexpr (S > 1) {                                     // pairs of this slot owned by higher h are still to come
-            const int j0 = 2 * (qk * S + h);
-            const double2 A0 = *reinterpret_cast<const double2 *>(&sA[j0 * LD + k]);
-            const double2 A1 = *reinterpret_cast<const double2 *>(&sA[(j0 + 1) * LD + k]);
-            const double u0 = fma(-L.y, A0.y, fma(-L.x, A0.x, row[2 * qk]));
-            const double u1 = fma(-L.y, A1.y, fma(-L.x, A1.x, row[2 * qk + 1]));
-            row[2 * qk] = (h > hk) ? u0 : row[2 * qk];
-            row[2 * qk + 1] = (h > hk) ? u1 : row[2 * qk + 1];
+        lp.x = row[k] * pv.dinv0;
+        lp.y = fma(-lp.x, pv.l10, row[k + 1]) * pv.dinv1;
+        if (i >= k) *reinterpret_cast<double2 *>(&myrow[k]) = lp;
+
+        // Next pivot block [a b; b c] = entries (k+2..k+3, k+2..k+3) after this step's update.  Its
+        // three entries and the rhs entries of rows k, k+1 come from their owner lanes through
+        // the LDS crossbar, the four L values that update it from LDS after the barrier.
+        double na = 0.0, nb = 0.0, nc = 0.0;
+        if (p + 1 < NP) {
+            na = gbcast(row[k + 2], gbase, k + 2);
+            nb = gbcast(row[k + 2], gbase, k + 3);
+            nc = gbcast(row[k + 3], gbase, k + 3);
         }
+        const double rb0 = gbcast(row[K], gbase, k), rb1 = gbcast(row[K], gbase, k + 1);
+        __syncthreads();
+        const double2 L = *reinterpret_cast<const double2 *>(&myrow[k]);            // L(i,k), L(i,k+1)
+        Pivot<K> pn = pv;
+        if (p + 1 < NP) {
+            const double2 l0 = *reinterpret_cast<const double2 *>(&sL[tri_off(k + 2) + k]);   // L(k+2,k), L(k+2,k+1)
+            const double2 l1 = *reinterpret_cast<const double2 *>(&sL[tri_off(k + 3) + k]);   // L(k+3,k), L(k+3,k+1)
+            const double pa = fma(-l0.y, l0.y, fma(-l0.x, l0.x, na));
+            const double pb = fma(-l1.y, l0.y, fma(-l1.x, l0.x, nb));
+            const double pc = fma(-l1.y, l1.y, fma(-l1.x, l1.x, nc));
+            pn = factor_block<K>(pa, pb, pc);
+        }
+        // forward solve (:321) as one more column: y_k, y_k+1, then b_i -= L(i,k) y_k + L(i,k+1) y_k+1
+        const double yk = rb0 * pv.dinv0;
+        const double yk1 = fma(-pv.l10, yk, rb1) * pv.dinv1;
+        if (i == 0) *reinterpret_cast<double2 *>(&sY[k]) = double2{yk, yk1};
+        row[K] = fma(-L.y, yk1, fma(-L.x, yk, row[K]));
+        // rank-2 update of the rest of the row: (i,j) -= L(i,k) L(j,k) + L(i,k+1) L(j,k+1), j > k+1
 #pragma unroll
-        for (int q = qk + 1; q < QN; ++q) {
-            const int j0 = 2 * (q * S + h);
-            const double2 A0 = *reinterpret_cast<const double2 *>(&sA[j0 * LD + k]);
-            const double2 A1 = *reinterpret_cast<const double2 *>(&sA[(j0 + 1) * LD + k]);
-            row[2 * q] = fma(-L.y, A0.y, fma(-L.x, A0.x, row[2 * q]));
-            row[2 * q + 1] = fma(-L.y, A1.y, fma(-L.x, A1.x, row[2 * q + 1]));
+        for (int j = k + 2; j < K; ++j) {
+            const double2 A = *reinterpret_cast<const double2 *>(&sL[tri_off(j) + k]);
+            row[j] = fma(-L.y, A.y, fma(-L.x, A.x, row[j]));
         }
         // Pin this step's results: otherwise instruction selection defers every FMA chain to
         // the step that finally needs the entry and keeps (spills) all the L(j,k) it loaded meanwhile.
 #pragma unroll
-        for (int m = 2 * qk; m < M + 1; ++m) asm volatile("" : "+v"(row[m]));
+        for (int m = k + 2; m < K + 1; ++m) asm volatile("" : "+v"(row[m]));
+        pv = pn;
     }
+    __syncthreads();
 
-    // rr += nrandn(K) (:322); backward solve L^T x = rr (:323): u_i = rr_i - sum_{k>i} L(k,i) x_k, x_i = u_i / L(i,i)
-    double bi = yi + zi;
-    const double my_dinv = 1.0 / sA[i * LD + i];
+    // rr += nrandn(K) (:322); backward solve L^T x = rr (:323):
+    //   u_i = rr_i - sum_{k>i} L(k,i) x_k,  x_i = u_i / L(i,i)
+    // the L(k,i) a lane needs are fetched eight steps at a time (LDS latency once per batch)
+    double bi = sY[i] + zi;
+    const double my_dinv = 1.0 / myrow[i];
+    constexpr int BB = K < 8 ? K : 8;
 #pragma unroll
-    for (int k = K - 1; k >= 1; --k) {
-        const double xk = bcast(bi * my_dinv, k);
-        const double *src = (i < k) ? &sA[k * LD + i] : szero;
-        bi = fma(-(*src), xk, bi);
+    for (int kb = K - BB; kb >= 0; kb -= BB) {
+        double lv[BB];
+#pragma unroll
+        for (int t = 0; t < BB; ++t) lv[t] = sL[tri_off(kb + t) + i];               // garbage for i > k: masked below
+#pragma unroll
+        for (int t = BB - 1; t >= 0; --t) {
+            const int k = kb + t;
+            if (k == 0) continue;
+            const double xk = gbcast(bi * my_dinv, gbase, k);
+            bi = (i < k) ? fma(-lv[t], xk, bi) : bi;
+        }
     }
     const double xi = bi * my_dinv;
 
-    if (lane < K) a.items[(size_t)idx * K + lane] = xi;           // items().col(idx) = rr (:324)
-    const bool bad = !(dmin > 0.0) || !(fabs(xi) <= 1.79769313486231570815e+308);
-    if (__any(bad) && lane == 0) atomicMin(a.fail, (unsigned long long)idx);
+    if (c < nfilled) {
+        const long long idx = reinterpret_cast<const long long *>(lds + G::C * G::SLOT)[c];
+        a.items[(size_t)idx * K + i] = xi;                         // items().col(idx) = rr (:324)
+        // a non-positive (or NaN) pivot makes its 1/sqrt NaN or inf, which reaches every later entry
+        // and the sample itself: Eigen LLT's info() != Success -> THROWERROR("Cholesky failed") (:308)
+        if (!(fabs(xi) <= 1.79769313486231570815e+308)) atomicMin(a.fail, (unsigned long long)idx);
+    }
+    __syncthreads();                                               // the slots are free again
 }
 
 // ---------------------------------------------------------------------------
 // The sampler: persistent single-wave workgroups walk a static, cost-sorted list of work
-// items (column, chunk).  A chunk of a heavy column parks its partial tiles with write-through stores and takes a
-// ticket; the wave that draws the last ticket sums the partials in chunk order (so the result
-// does not depend on who was last) and finishes the column.  No wave ever waits for another.
+// items (column, chunk).  A chunk of a heavy column parks its partial tiles with write-through
+// stores and takes a ticket; the wave that draws the last ticket sums the partials in chunk
+// order (so the result does not depend on who was last).  A wave that holds a complete Gram
+// deposits the column in an LDS slot and factorises C = 64/K deposited columns together.
+// No wave ever waits for another.
 // ---------------------------------------------------------------------------
 #define BPMF_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 template <int K>
 __global__ __launch_bounds__(64, Geo<K>::WPS) void k_sample(SampleArgs a)
 {
-    constexpr int NT = Geo<K>::NT, NTRI = Geo<K>::NTRI, PART = Geo<K>::PART;
+    constexpr int NT = Geo<K>::NT, NTRI = Geo<K>::NTRI, PART = Geo<K>::PART, C = Geo<K>::C;
     __shared__ __attribute__((aligned(16))) double lds[Geo<K>::LDS_WORDS];
     const int grid = gridDim.x;
+    int nfilled = 0;
 
     // Static schedule: the items are sorted by decreasing cost; round r hands item r*grid + b
     // (even r) or r*grid + grid-1-b (odd r) to workgroup b, so the workgroup that got the most
@@ -381,9 +434,9 @@ __global__ __launch_bounds__(64, Geo<K>::WPS) void k_sample(SampleArgs a)
         int lane = threadIdx.x;
         asm volatile("" : "+v"(lane));
         const long long base = (long long)round * grid;
-        if (base >= a.nwork) return;
+        if (base >= a.nwork) break;
         const long long wl = base + ((round & 1) ? (grid - 1 - (int)blockIdx.x) : (int)blockIdx.x);
-        if (wl >= a.nwork) { if (round & 1) continue; else return; }
+        if (wl >= a.nwork) { if (round & 1) continue; else break; }
         const int w = (int)wl;
 
         const int col = a.wi_col[w];
@@ -409,8 +462,8 @@ __global__ __launch_bounds__(64, Geo<K>::WPS) void k_sample(SampleArgs a)
         }
         if (mc >= 0) {
             const int nch = a.mc_nchunks[mc];
-            double *base = a.partials + (size_t)a.mc_slot0[mc] * PART;
-            double *p = base + (size_t)a.wi_chunk[w] * PART;
+            double *pbase = a.partials + (size_t)a.mc_slot0[mc] * PART;
+            double *p = pbase + (size_t)a.wi_chunk[w] * PART;
             // write-through (sc1) stores: visible to every XCD once they have drained
 #pragma unroll
             for (int t = 0; t < NTRI; ++t)
@@ -430,8 +483,8 @@ __global__ __launch_bounds__(64, Geo<K>::WPS) void k_sample(SampleArgs a)
             for (int t2 = 0; t2 < NTRI; ++t2) acc[t2] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int t2 = 0; t2 < NT; ++t2) r[t2] = 0.0;
-            for (int c = 0; c < nch; ++c) {                        // fixed chunk order: deterministic
-                const double *pc = base + (size_t)c * PART;
+            for (int ch = 0; ch < nch; ++ch) {                     // fixed chunk order: deterministic
+                const double *pc = pbase + (size_t)ch * PART;
 #pragma unroll
                 for (int t2 = 0; t2 < NTRI; ++t2)
 #pragma unroll
@@ -440,9 +493,13 @@ __global__ __launch_bounds__(64, Geo<K>::WPS) void k_sample(SampleArgs a)
                 for (int t2 = 0; t2 < NT; ++t2) r[t2] += __hip_atomic_load(&pc[NTRI * 256 + t2 * 16 + (lane & 15)], BPMF_RLX_AGENT);
             }
         }
-        finish_column<K>(a, col, acc, r, lds, lane);
-        __syncthreads();                                           // LDS is reused by the next work item
+        deposit_column<K>(a, a.col_from + col, acc, r, lds, nfilled, lane);
+        if (++nfilled == C) {
+            finish_slots<K>(a, lds, C, lane);
+            nfilled = 0;
+        }
     }
+    if (nfilled > 0) finish_slots<K>(a, lds, nfilled, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------
