@@ -112,12 +112,9 @@ def main():
         users = Sys("users", eng, Mt, nusers, nmovies, mean_rating=mean)
         dom_m, dom_u = (0, nmovies), (0, nusers)
     else:
-        bm = synth.balanced_ranges(M[0], world); bu = synth.balanced_ranges(Mt[0], world)
-        dom_m, dom_u = (bm[rank], bm[rank + 1]), (bu[rank], bu[rank + 1])
-        movies = Sys("movs", eng, synth.slice_cols(M, *dom_m), nmovies, nusers, T=synth.slice_cols(T, *dom_m),
-                     dom=dom_m, mean_rating=mean, comm=comm)
-        users = Sys("users", eng, synth.slice_cols(Mt, *dom_u), nusers, nmovies, dom=dom_u, mean_rating=mean, comm=comm)
-        comm.register(movies, bm); comm.register(users, bu)
+        from bpmf_amd.dist import build_sharded
+        movies, users = build_sharded(eng, comm, M, Mt, T, nusers, nmovies, mean_rating=mean)
+        dom_m, dom_u = movies.dom, users.dom
 
     def step():
         movies.sample(users)

@@ -45,3 +45,41 @@ class TorchComm:
         t = torch.as_tensor(np.ascontiguousarray(arr, np.float64)).to(self.device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t.cpu().numpy()
+
+
+def build_sharded(engine, comm, M, Mt, T, nusers, nmovies, mean_rating=None):
+    """Creates the two `Sys` of this rank: contiguous nnz-balanced column ranges of both sides
+    (the reference's assign(), c++/assign.cpp:52-58,109-120, without the permutation), CSC
+    slices of exactly those ranges, full factor replicas bound to tensors the collectives use."""
+    from . import synth
+    from .sys import Sys
+    world, rank = comm.size, comm.rank
+    if mean_rating is None:
+        mean_rating = float(np.sum(M[2])) / len(M[2])
+    bm = synth.balanced_ranges(M[0], world)
+    bu = synth.balanced_ranges(Mt[0], world)
+    dom_m, dom_u = (bm[rank], bm[rank + 1]), (bu[rank], bu[rank + 1])
+    movies = Sys("movs", engine, synth.slice_cols(M, *dom_m), nmovies, nusers,
+                 T=synth.slice_cols(T, *dom_m) if T is not None else None, dom=dom_m, mean_rating=mean_rating, comm=comm)
+    users = Sys("users", engine, synth.slice_cols(Mt, *dom_u), nusers, nmovies, dom=dom_u, mean_rating=mean_rating, comm=comm)
+    comm.register(movies, bm)
+    comm.register(users, bu)
+    return movies, users
+
+
+def gibbs_sharded(engine, comm, M, Mt, T, nusers, nmovies, nsims=20, burnin=5, alpha=2.0):
+    """main()'s loop (c++/bpmf.cpp:180-253) with the columns sharded over comm.size ranks."""
+    from .sys import Sys
+    Sys.nsims, Sys.burnin, Sys.alpha = nsims, burnin, alpha
+    movies, users = build_sharded(engine, comm, M, Mt, T, nusers, nmovies)
+    res = dict(rmse=[], rmse_avg=[], norm_u=[], norm_m=[])
+    for _ in range(nsims):
+        movies.sample(users)
+        users.sample(movies)
+        movies.predict(users, True)          # all-reduced partial sums: every rank reports the global RMSE
+        res["rmse"].append(movies.rmse); res["rmse_avg"].append(movies.rmse_avg)
+        res["norm_u"].append(float(np.sqrt(users.norm))); res["norm_m"].append(float(np.sqrt(movies.norm)))
+    movies.predict(users, True)
+    res["final_rmse_avg"] = movies.rmse_avg
+    res["U"] = users.items(); res["V"] = movies.items()
+    return res
