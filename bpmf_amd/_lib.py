@@ -45,6 +45,14 @@ _SIGNATURES = {
     "bpmf_randn_stream": (None, [C.c_uint32, C.c_int, C.c_void_p]),
     "bpmf_hip_randn_stream": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
     "bpmf_hip_side_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    # include/bpmf_io.h
+    "bpmf_io_last_error": (C.c_char_p, []),
+    "bpmf_io_read_sparse": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                      C.POINTER(c_i64p), C.POINTER(c_i32p), C.POINTER(c_f64p)]),
+    "bpmf_io_write_sparse": (C.c_int, [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bpmf_io_read_dense": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(c_f64p)]),
+    "bpmf_io_write_dense": (C.c_int, [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "bpmf_io_free": (None, [C.c_void_p]),
 }
 
 

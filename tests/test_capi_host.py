@@ -14,8 +14,11 @@ from tests.conftest import ROOT
 
 
 def header_symbols():
-    text = open(os.path.join(ROOT, "include", "bpmf_hip.h")).read()
-    return sorted(set(re.findall(r"^BPMF_API[^;(]*?\b(bpmf_\w+)\s*\(", text, re.M)))
+    names = set()
+    for h in ("bpmf_hip.h", "bpmf_io.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        names |= set(re.findall(r"^BPMF(?:_IO)?_API[^;(]*?\b(bpmf_\w+)\s*\(", text, re.M))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():

@@ -1,0 +1,89 @@
+"""The `bpmf` executable: the reference's command line and outputs (c++/bpmf.cpp) on the HIP path.
+CPU part: usage / error exits (the conda recipe's test: no arguments => non-zero exit,
+ci/conda-recipes/bpmf-0.2/run_test.sh:3-6).  GPU part: the reference's own two tests --
+data/tiny/run_test.sh and the CTest run on MovieLens-100K (CMakeLists.txt:174-182) -- plus the
+output files against the oracle."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from bpmf_amd import io as bio
+from tests import util
+from tests.conftest import ROOT
+
+BPMF = os.path.join(ROOT, "bpmf_amd", "bpmf")
+G = util.GOLDEN
+
+
+def run(args, cwd):
+    return subprocess.run([BPMF] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+
+
+def test_no_arguments_prints_usage_and_fails(tmp_path):
+    r = run([], tmp_path)
+    assert r.returncode != 0 and "Usage: bpmf -n <MTX> -p <MTX>" in r.stdout
+    r = run(["-n", os.path.join(G, "tiny-train.mtx")], tmp_path)              # -p missing
+    assert r.returncode != 0 and "Usage" in r.stdout
+    r = run(["-x"], tmp_path)
+    assert r.returncode != 0
+
+
+def test_missing_file_and_bad_k(tmp_path):
+    r = run(["-n", "nope.mtx", "-p", os.path.join(G, "tiny-test.mtx")], tmp_path)
+    assert r.returncode != 0 and "File 'nope.mtx' not found" in r.stderr
+    r = run(["-n", os.path.join(G, "tiny-train.mtx"), "-p", os.path.join(G, "tiny-test.mtx"), "-d", "12"], tmp_path)
+    assert r.returncode != 0 and "unsupported number of latent dimensions" in r.stderr
+
+
+@pytest.mark.gpu
+def test_tiny_run_test_sh(oracle, tmp_path):
+    """data/tiny/run_test.sh: bpmf -r -k -i 9 -b 0 -v -n train.mtx -p test.mtx -o output/ ; RMSE < 3."""
+    (tmp_path / "output").mkdir()
+    r = run(["-r", "-k", "-i", "9", "-b", "0", "-v", "-d", "8", "-n", os.path.join(G, "tiny-train.mtx"),
+             "-p", os.path.join(G, "tiny-test.mtx"), "-o", "output/"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    out = (tmp_path / "bpmf_0.out").read_text()
+    final = float(re.search(r"Final Avg RMSE: (\S+)", out).group(1))
+    assert final < 3.0
+    M, Mt, T, Tt, nu, nm = util.tiny()
+    ref = oracle.gibbs(8, M, Mt, T, Tt, nsims=9, burnin=0)
+    assert abs(final - ref["final_rmse_avg"]) < 1e-4                          # printed with 6 significant digits
+    lines = [l for l in out.splitlines() if "iteration" in l]
+    assert len(lines) == 9 and lines[0].startswith("0: Sampling iteration 0:")
+    rm = [float(re.search(r"\t RMSE: (\S+)", l).group(1)) for l in lines]
+    assert np.allclose(rm, ref["rmse"], atol=1e-4)
+    for needle in ("mean rating: 3.66667", "total number of ratings in train: 6", "num movs: 2", "num users: 4",
+                   "num_latent: 8", "nsims: 9", "burnin: 0", "alpha: 2", "computed on 2 items (100% of total items in test set)"):
+        assert needle in out, needle
+    # -v: every sample; the last one equals the oracle's final factors (K x N column-major on disk)
+    U8 = bio.read_dense(tmp_path / "output" / "U-8.ddm"); V8 = bio.read_dense(tmp_path / "output" / "V-8.ddm")
+    assert U8.shape == (8, nu) and V8.shape == (8, nm)
+    assert np.allclose(U8.T, ref["U"], rtol=1e-8, atol=1e-10) and np.allclose(V8.T, ref["V"], rtol=1e-8, atol=1e-10)
+    # -o: predictions in the sparsity of the test matrix, posterior means of the 9 samples
+    nr, nc, pavg = bio.read_sparse(tmp_path / "output" / "Pavg.sdm")
+    assert (nr, nc) == (nu, nm) and np.array_equal(pavg[1], T[1]) and np.allclose(pavg[2], ref["Pavg"], rtol=1e-9)
+    nr, nc, pm2 = bio.read_sparse(tmp_path / "output" / "Pm2.sdm")
+    assert np.allclose(pm2[2], ref["Pm2"], rtol=1e-7, atol=1e-9)
+    samples = np.stack([bio.read_dense(tmp_path / "output" / ("U-%d.ddm" % i)) for i in range(9)])
+    assert np.allclose(bio.read_dense(tmp_path / "output" / "U-mu.ddm"), samples.mean(0), rtol=1e-10, atol=1e-12)
+    lam = bio.read_dense(tmp_path / "output" / "U-Lambda.ddm")
+    assert lam.shape == (64, nu)
+    cov0 = np.cov(samples[:, :, 0].T)                                          # 9 samples of an 8-vector: invertible
+    assert np.allclose(lam[:, 0].reshape(8, 8, order="F"), np.linalg.inv(cov0), rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("suffix", [".mtx.gz"])
+def test_movielens_ctest(tmp_path, suffix):
+    """CTest `bpmf_compressed`: ./bpmf -i 4 -n ml-train.mtx.gz -p ml-test.mtx.gz must exit 0."""
+    r = run(["-i", "4", "-n", os.path.join(G, "ml100k-train" + suffix), "-p", os.path.join(G, "ml100k-test" + suffix)], tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert "num_latent: 32" in r.stdout and "total number of ratings in train: 80000" in r.stdout
+    assert "mean rating: 3.52835" in r.stdout and "num movs: 1682" in r.stdout and "num users: 943" in r.stdout
+    lines = [l for l in r.stdout.splitlines() if "iteration" in l]
+    assert len(lines) == 4 and all("Burnin" in l for l in lines)
+    assert abs(float(re.search(r"\t RMSE: (\S+)", lines[0]).group(1)) - 1.1537) < 2e-3
+    assert re.search(r"Average items/sec: \S+", r.stdout) and re.search(r"Final Avg RMSE: 1\.15", r.stdout)
