@@ -7,7 +7,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -56,6 +60,7 @@ int env_int(const char *name, int dflt)
 }  // namespace
 
 extern "C" void bpmf_hip_set_error_(const char *msg) { g_err = msg; }
+static void settle_predraw_public(struct bpmf_hip_side *s);
 
 struct bpmf_hip_ctx {
     int device = 0;
@@ -70,7 +75,15 @@ struct bpmf_hip_ctx {
     // prod[K*K] | sum[K] | - | fail (u64) | se | se_avg | flag (u32)
     double *h_out = nullptr, *h_out_dev = nullptr;
     size_t in_words = 0, out_words = 0;
-    unsigned seq = 0;                    // value the next k_signal will publish
+    // host worker that pre-draws a side's next hyper-parameters while the GPU samples the other side
+    std::thread worker;
+    std::mutex wm;
+    std::condition_variable wcv;
+    bpmf_hip_side *job = nullptr;        // posted, not yet taken
+    bpmf_hip_side *running = nullptr;    // being computed
+    bool wstop = false;
+    unsigned seq = 0;                    // value the next publishing kernel writes behind its results
+    unsigned *d_ticket = nullptr;        // arrival counter of k_colstats_final's blocks
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 };
 
@@ -81,7 +94,7 @@ struct bpmf_hip_side {
     int32_t *d_rowidx = nullptr; double *d_vals = nullptr; bool own_csc = true;
     double *d_items = nullptr; bool own_items = true;
     // schedule
-    int nwork = 0, nmulti = 0, nslots = 0;
+    int nwork = 0, nmulti = 0, nslots = 0, mode = 0;
     int32_t *d_wi_col = nullptr, *d_wi_len = nullptr, *d_wi_mc = nullptr, *d_wi_chunk = nullptr;
     int64_t *d_wi_p0 = nullptr;
     int32_t *d_mc_slot0 = nullptr, *d_mc_nch = nullptr;
@@ -125,17 +138,10 @@ size_t part_words_rt(int K)
     return 0;
 }
 
-// The kernels write their few result words straight into pinned host memory; a one-thread
-// kernel then publishes a sequence number and the host thread spins on it.  This replaces
+// The kernels write their few result words straight into pinned host memory; the last block
+// of the last kernel then publishes a sequence number and the host thread spins on it.  This replaces
 // hipMemcpyAsync(D2H) + hipStreamSynchronize (a copy-engine hop and a sleeping wait per
 // half-iteration) on a path whose device work is only tens of microseconds.
-void signal_host(bpmf_hip_ctx *c)
-{
-    c->seq++;
-    unsigned *flag = reinterpret_cast<unsigned *>(c->h_out_dev + c->out_words - 1);
-    hipLaunchKernelGGL(bpmf::k_signal, dim3(1), dim3(64), 0, c->stream, flag, c->seq);
-}
-
 int wait_host(bpmf_hip_ctx *c)
 {
     unsigned *flag = reinterpret_cast<unsigned *>(c->h_out + c->out_words - 1);
@@ -159,13 +165,20 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
 {
     const int64_t nloc = s->to - s->from;
     const int K = s->ctx->K;
+    // Form of the sampler: with a few thousand columns per side the launch is bound by the
+    // latency of single columns, so every column gets its own wave and the hardware dispatcher
+    // balances the items (k_sample1); with very many columns the persistent form that
+    // factorises C = 64/K columns per wave has the higher throughput (k_sample).
+    const int mode_env = env_int("BPMF_HIP_MODE", -1);
+    s->mode = mode_env >= 0 ? mode_env : ((K <= 32 && nloc < 65536) ? 1 : 0);
     int chunk = env_int("BPMF_HIP_CHUNK", 0);
     if (chunk <= 0) {
-        // aim at >= 8 work items per SIMD so the tail of the launch stays short
         const int64_t simds = (int64_t)s->ctx->num_cu * 4;
-        int64_t c = s->nnz / (simds * 8);
-        c = (c + 15) / 16 * 16;
-        chunk = (int)std::min<int64_t>(std::max<int64_t>(c, 128), 4096);
+        // mode 1: ~1.5 chunks of work per SIMD (measured best on the ML-1M shape: 512-768);
+        // mode 0: >= 8 work items per SIMD so the tail of the launch stays short
+        int64_t c = s->mode == 1 ? (s->nnz * 2) / (simds * 3) : s->nnz / (simds * 8);
+        c = (c + 63) / 64 * 64;
+        chunk = (int)std::min<int64_t>(std::max<int64_t>(c, s->mode == 1 ? 256 : 128), 4096);
     }
     chunk = (chunk + 15) / 16 * 16;
 
@@ -256,6 +269,8 @@ extern "C" int bpmf_hip_ctx_create(int device, int K, void *stream, bpmf_hip_ctx
     HIP_TRY(hipHostGetDevicePointer((void **)&c->h_out_dev, c->h_out, 0));
     memset(c->h_out, 0, c->out_words * sizeof(double));
     HIP_TRY(hipMalloc((void **)&c->d_in, c->in_words * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&c->d_ticket, 64));
+    HIP_TRY(hipMemset(c->d_ticket, 0, 64));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     *out = c;
     return BPMF_HIP_OK;
@@ -264,12 +279,18 @@ extern "C" int bpmf_hip_ctx_create(int device, int K, void *stream, bpmf_hip_ctx
 extern "C" int bpmf_hip_ctx_destroy(bpmf_hip_ctx *c)
 {
     if (!c) return BPMF_HIP_OK;
+    if (c->worker.joinable()) {
+        { std::lock_guard<std::mutex> lk(c->wm); c->wstop = true; c->job = nullptr; }
+        c->wcv.notify_all();
+        c->worker.join();
+    }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->d_in) (void)hipFree(c->d_in);
+    if (c->d_ticket) (void)hipFree(c->d_ticket);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return BPMF_HIP_OK;
@@ -339,6 +360,7 @@ extern "C" int bpmf_hip_side_create_dev(bpmf_hip_ctx *ctx, int64_t ncols, int64_
 extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
 {
     if (!s) return BPMF_HIP_OK;
+    settle_predraw_public(s);
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->own_csc) { if (s->d_rowidx) (void)hipFree(s->d_rowidx); if (s->d_vals) (void)hipFree(s->d_vals); }
@@ -399,7 +421,9 @@ int do_launch(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double 
     a.ablate = c->ablate;
 
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
-    if (self->nwork > 0) {
+    if (self->nwork > 0 && self->mode == 1) {
+        hipLaunchKernelGGL(k_sample1<K>, dim3(self->nwork), dim3(64), 0, c->stream, a);
+    } else if (self->nwork > 0) {
         // persistent waves: as many single-wave workgroups as the chip holds at this kernel's occupancy
         const int resident = c->num_cu * 4 * Geo<K>::WPS;
         const int grid = std::min(self->nwork, env_int("BPMF_HIP_GRID", resident));
@@ -409,7 +433,8 @@ int do_launch(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double 
     hipLaunchKernelGGL(k_colstats<K>, dim3(self->nstat_waves), dim3(64), 0, c->stream,
                        (const double *)self->d_items, self->from, self->to, self->nstat_waves, self->d_stat_partials);
     hipLaunchKernelGGL(k_colstats_final<K>, dim3((K * K + K + 63) / 64), dim3(256), 0, c->stream,
-                       (const double *)self->d_stat_partials, self->nstat_waves, (const unsigned long long *)a.fail, c->h_out_dev);
+                       (const double *)self->d_stat_partials, self->nstat_waves, (const unsigned long long *)a.fail, c->h_out_dev,
+                       c->d_ticket, reinterpret_cast<unsigned *>(c->h_out_dev + c->out_words - 1), ++c->seq);
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -449,8 +474,8 @@ extern "C" int bpmf_hip_sample_side_launch(bpmf_hip_side *self, const bpmf_hip_s
     default: return fail(BPMF_HIP_EINVAL, "sample_side: unsupported K");
     }
     if (rc) return rc;
-    // prod | sum | - | fail word land in the pinned result blob; publish the sequence number behind them
-    signal_host(c);
+    // prod | sum | - | fail word land in the pinned result blob; the last block of k_colstats_final
+    // publishes the sequence number behind them
     HIP_TRY(hipGetLastError());
     self->pending = true;
     return BPMF_HIP_OK;
@@ -524,6 +549,50 @@ void ensure_state(bpmf_hip_side *s)
 }
 }  // namespace
 
+namespace {
+// Pre-draw of a side's next hyper-parameters on the context's worker thread.  Legal as soon as
+// the side's own half-iteration is over: the draw depends only on its cov and iteration counter.
+void worker_main(bpmf_hip_ctx *c)
+{
+    std::unique_lock<std::mutex> lk(c->wm);
+    for (;;) {
+        c->wcv.wait(lk, [c] { return c->wstop || c->job != nullptr; });
+        if (c->wstop) return;
+        bpmf_hip_side *s = c->job;
+        c->job = nullptr;
+        c->running = s;
+        lk.unlock();
+        const int K = c->K;
+        const int next = s->iter + 1;
+        const int rc = bpmf_hyper_sample(K, s->ncols, s->cov.data(), nullptr, (uint32_t)next, s->nx_mu.data(),
+                                         s->nx_LambdaU.data(), s->nx_LambdaF.data());
+        lk.lock();
+        s->nx_iter = rc ? -2 : next;
+        c->running = nullptr;
+        c->wcv.notify_all();
+    }
+}
+
+void post_predraw(bpmf_hip_side *s)
+{
+    bpmf_hip_ctx *c = s->ctx;
+    std::lock_guard<std::mutex> lk(c->wm);
+    if (!c->worker.joinable()) c->worker = std::thread(worker_main, c);
+    if (c->job == nullptr) { c->job = s; c->wcv.notify_all(); }     // at most one pending job: otherwise drawn inline later
+}
+
+// waits until no pre-draw touches `s`
+void settle_predraw(bpmf_hip_side *s)
+{
+    bpmf_hip_ctx *c = s->ctx;
+    std::unique_lock<std::mutex> lk(c->wm);
+    if (c->job == s) c->job = nullptr;                                // not started yet: drop it, draw inline
+    c->wcv.wait(lk, [c, s] { return c->running != s; });
+}
+}  // namespace
+
+static void settle_predraw_public(bpmf_hip_side *s) { settle_predraw(s); }
+
 extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, double alpha)
 {
     if (!self || !other) return fail(BPMF_HIP_EINVAL, "sys_sample: NULL argument");
@@ -531,9 +600,10 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
         return fail(BPMF_HIP_EINVAL, "sys_sample: the side is a shard; use bpmf_hip_sample_side + an all-reduce");
     const int K = self->ctx->K;
     ensure_state(self); ensure_state(other);
+    settle_predraw(self);
     self->iter++;                                                     // :344
     int rc;
-    if (self->nx_iter == self->iter) {                                // drawn while the device was busy
+    if (self->nx_iter == self->iter) {                                // drawn by the worker while the device was busy
         self->hp_mu.swap(self->nx_mu); self->hp_LambdaU.swap(self->nx_LambdaU); self->hp_LambdaF.swap(self->nx_LambdaF);
     } else {                                                          // rng_set_pos(iter); hp.sample(num(), sum, cov)  (:349-350)
         rc = bpmf_hyper_sample(K, self->ncols, self->cov.data(), nullptr, (uint32_t)self->iter,
@@ -541,21 +611,26 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
         if (rc) { self->iter--; return rc; }
     }
     self->nx_iter = -2;
+    static const bool trace = env_int("BPMF_HIP_TRACE", 0) != 0;
+    const auto t0 = std::chrono::steady_clock::now();
     rc = bpmf_hip_sample_side_launch(self, other, self->iter, alpha, self->hp_mu.data(), self->hp_LambdaF.data());
     if (rc) { self->iter--; return rc; }
-    // While the GPU samples this side, draw the OTHER side's next hyper-parameters: they depend
-    // only on its own cov and iteration counter, both final until its next sys_sample.
-    if (other != self && other->nx_iter != other->iter + 1) {
-        const int rc2 = bpmf_hyper_sample(K, other->ncols, other->cov.data(), nullptr, (uint32_t)(other->iter + 1),
-                                          other->nx_mu.data(), other->nx_LambdaU.data(), other->nx_LambdaF.data());
-        other->nx_iter = rc2 ? -2 : other->iter + 1;
-    }
+    const auto t1 = std::chrono::steady_clock::now();
+    const auto t2 = std::chrono::steady_clock::now();
     std::vector<double> sum(K), prod((size_t)K * K);
     double norm = 0.0;
     rc = bpmf_hip_sample_side_finish(self, sum.data(), prod.data(), &norm);
     if (rc) return rc;
+    if (trace) {
+        const auto t3 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        fprintf(stderr, "[bpmf_hip] sys_sample iter %d: launch %.1f us, wait %.1f us\n", self->iter, us(t0, t1), us(t2, t3));
+    }
     self->norm = norm;                                                // :381
     bpmf_cov_from_sums(K, self->ncols, sum.data(), prod.data(), self->cov.data());   // :383-384
+    // this side's next hyper-parameters depend only on the cov just formed and on iter+1:
+    // draw them on the worker thread while the caller samples the other side / evaluates RMSE
+    post_predraw(self);
     return BPMF_HIP_OK;
 }
 
@@ -563,6 +638,7 @@ extern "C" int bpmf_hip_sys_state(const bpmf_hip_side *s, int *iter, double *nor
                                   double *LambdaF, double *LambdaU)
 {
     if (!s) return fail(BPMF_HIP_EINVAL, "sys_state: NULL");
+    settle_predraw(const_cast<bpmf_hip_side *>(s));
     const size_t K = (size_t)s->ctx->K;
     if (iter) *iter = s->iter;
     if (norm) *norm = s->norm;
@@ -631,7 +707,7 @@ void launch_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const bpmf_hip_
                        (const double *)self->d_items, (const double *)other->d_items, self->from, self->mean_rating, n,
                        t->d_pavg, t->d_pm2, t->d_partial);
     hipLaunchKernelGGL(bpmf::k_predict_final, dim3(1), dim3(256), 0, c->stream, (const double *)t->d_partial, t->nblocks,
-                       c->h_out_dev + c->out_words - 3);
+                       c->h_out_dev + c->out_words - 3, reinterpret_cast<unsigned *>(c->h_out_dev + c->out_words - 1), ++c->seq);
 }
 }  // namespace
 
@@ -651,7 +727,6 @@ extern "C" int bpmf_hip_predict(bpmf_hip_test *t, const bpmf_hip_side *self, con
     case 64: launch_predict<64>(t, self, other, n); break;
     default: return fail(BPMF_HIP_EINVAL, "predict: unsupported K");
     }
-    signal_host(c);
     HIP_TRY(hipGetLastError());
     { const int rcw = wait_host(c); if (rcw) return rcw; }
     *se = c->h_out[c->out_words - 3];

@@ -502,6 +502,254 @@ __global__ __launch_bounds__(64, Geo<K>::WPS) void k_sample(SampleArgs a)
     if (nfilled > 0) finish_slots<K>(a, lds, nfilled, threadIdx.x);
 }
 
+// geometry of the one-column-per-wave factorisation (finish_single): S lanes per row
+template <int K>
+struct Geo1 {
+    static constexpr int S = (64 / K < K / 2) ? 64 / K : K / 2;
+    static constexpr int NP = K / 2;
+    static constexpr int QN = NP / S;
+    static constexpr int M = 2 * QN;
+    static constexpr int FLD = K + 2;
+    static constexpr int LANES = K * S;
+    static constexpr int LDS_WORDS = K * FLD + 4 * K + 2;
+};
+
+// ---------------------------------------------------------------------------
+// Everything after the Gram for one column (c++/sample.cpp:285,297-324).
+//
+// The wave holds Lambda* in registers, S lanes per row: lane (h, i) = (l / K, l % K) owns the
+// entries (i, j) of the column pairs p = q*S + h (j = 2p, 2p+1), q = 0..QN-1, plus (lanes h = 0)
+// the rhs b_i as one more column.  Right-looking Cholesky, TWO columns per step: the 2x2 pivot
+// block comes through v_readlane, every lane factors it redundantly (two 1/sqrt), the owners
+// scale their pair of column entries and publish them to LDS (row-major L, one 16-byte store),
+// then each lane applies the rank-2 update to its remaining pairs, reading L(j,k),L(j,k+1) with
+// one broadcast 16-byte LDS load per row.  The forward solve L y = b is the same update applied
+// to the rhs column with the two y values (wave-uniform) in registers.  Backward solve, normal
+// draw and the coalesced 8K-byte store follow.
+// ---------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ void finish_single(const SampleArgs &a, int col_local, const d4 (&acc)[Geo<K>::NTRI],
+                                              const double (&r)[Geo<K>::NT], double *lds, int lane_in, bool have_z)
+{
+    int lane = lane_in;
+    using G = Geo1<K>;
+    constexpr int NT = Geo<K>::NT, LD = G::FLD, S = G::S, NP = G::NP, QN = G::QN, M = G::M;
+    // The caller runs this inside its persistent work loop: make the lane id opaque here so that
+    // LLVM does not hoist every per-step address and lane mask out of that loop (and spill them).
+    asm volatile("" : "+v"(lane));
+    const int kq = lane >> 4, li = lane & 15;
+    double *sA = lds, *sb = lds + K * LD, *sz = sb + K, *sdummy = sz + K, *szero = sdummy + 2 * K;
+    const int64_t idx = a.col_from + col_local;
+
+    // z ~ N(0, I) from stream (idx+1)*K*(iter+1) truncated to 32 bits (c++/sample.cpp:266, c++/bpmf.h:67)
+    if (!have_z) draw_normals<K>(sample_counter<K>(idx, a.iter_plus_1), K, sz, lane);
+
+    const int l = lane & (G::LANES - 1);                           // K=8: the upper half-wave mirrors the lower
+    const int h = l / K, i = l % K;
+    // this lane's entries of LambdaF and LambdaF*mu: issued before the LDS round trip below
+    double lf[M];
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+        const int j = 2 * (q * S + h);
+        lf[2 * q] = a.LambdaF[i + j * K];
+        lf[2 * q + 1] = a.LambdaF[i + (j + 1) * K];
+    }
+    const double lmu = a.Lmu[i];
+
+    // G (upper tiles, accumulator layout) -> LDS, mirrored (c++/sample.cpp:297); rhs partial sums -> LDS
+    {
+        int tri = 0;
+#pragma unroll
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int J = I; J < NT; ++J, ++tri)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int gi = I * 16 + kq + 4 * reg, gj = J * 16 + li;
+                    if (gi < K && gj < K) {
+                        sA[gi * LD + gj] = acc[tri][reg];
+                        if (I != J) sA[gj * LD + gi] = acc[tri][reg];
+                    }
+                }
+        if (kq == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (t * 16 + li < K) sb[t * 16 + li] = r[t];
+        }
+        if (lane == 0) szero[0] = 0.0;
+    }
+    __syncthreads();
+
+    // Lambda* = LambdaF + alpha * G (:298); b = LambdaF*mu + rr (:285,:256)
+    double row[M + 2];
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+        const double2 g = *reinterpret_cast<const double2 *>(&sA[i * LD + 2 * (q * S + h)]);
+        row[2 * q] = fma(a.alpha, g.x, lf[2 * q]);
+        row[2 * q + 1] = fma(a.alpha, g.y, lf[2 * q + 1]);
+    }
+    row[M] = (h == 0) ? lmu + sb[i] : 0.0;
+    row[M + 1] = 0.0;
+    const double zi = sz[i];
+    double yi = 0.0;
+    __syncthreads();
+
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int hk = p % S, qk = p / S, k = 2 * p;
+        const int src0 = hk * K + k, src1 = src0 + 1;
+        // 2x2 pivot block [a b; b c] and the two rhs entries, wave-uniform
+        const double pa = bcast(row[2 * qk], src0);
+        const double pb = bcast(row[2 * qk], src1);
+        const double pc = bcast(row[2 * qk + 1], src1);
+        const double bk = bcast(row[M], k), bk1 = bcast(row[M], k + 1);
+        // the two reciprocal square roots are independent (the second through the determinant:
+        // 1/sqrt(c - b^2/a) = sqrt(a)/sqrt(a c - b^2)), so their latencies overlap
+        const double dinv0 = rsqrt_nr(pa);
+        const double rdet = rsqrt_nr(fma(pa, pc, -(pb * pb)));
+        const double dinv1 = rdet * (pa * dinv0);
+        const double l10 = pb * dinv0;
+        // forward solve (:321) for these two rows: y_k, y_k+1
+        const double yk = bk * dinv0;
+        const double yk1 = fma(-l10, yk, bk1) * dinv1;
+        yi = (i == k) ? yk : yi;
+        yi = (i == k + 1) ? yk1 : yi;
+        // owners scale their entries of columns k, k+1 and publish them; the other lanes hit a
+        // dummy slot so that the step stays branch-free
+        double2 lp;
+        lp.x = row[2 * qk] * dinv0;
+        lp.y = fma(-lp.x, l10, row[2 * qk + 1]) * dinv1;
+        double *dst = (h == hk) ? &sA[i * LD + k] : &sdummy[2 * i];
+        *reinterpret_cast<double2 *>(dst) = lp;
+        __syncthreads();
+        const double2 L = *reinterpret_cast<const double2 *>(&sA[i * LD + k]);     // L(i,k), L(i,k+1)
+        row[M] = fma(-L.y, yk1, fma(-L.x, yk, row[M]));            // rhs column: b_i -= L(i,k) y_k + L(i,k+1) y_k+1
+        if constexpr (S > 1) {                                     // pairs of this slot owned by higher h are still to come
+            const int j0 = 2 * (qk * S + h);
+            const double2 A0 = *reinterpret_cast<const double2 *>(&sA[j0 * LD + k]);
+            const double2 A1 = *reinterpret_cast<const double2 *>(&sA[(j0 + 1) * LD + k]);
+            const double u0 = fma(-L.y, A0.y, fma(-L.x, A0.x, row[2 * qk]));
+            const double u1 = fma(-L.y, A1.y, fma(-L.x, A1.x, row[2 * qk + 1]));
+            row[2 * qk] = (h > hk) ? u0 : row[2 * qk];
+            row[2 * qk + 1] = (h > hk) ? u1 : row[2 * qk + 1];
+        }
+#pragma unroll
+        for (int q = qk + 1; q < QN; ++q) {
+            const int j0 = 2 * (q * S + h);
+            const double2 A0 = *reinterpret_cast<const double2 *>(&sA[j0 * LD + k]);
+            const double2 A1 = *reinterpret_cast<const double2 *>(&sA[(j0 + 1) * LD + k]);
+            row[2 * q] = fma(-L.y, A0.y, fma(-L.x, A0.x, row[2 * q]));
+            row[2 * q + 1] = fma(-L.y, A1.y, fma(-L.x, A1.x, row[2 * q + 1]));
+        }
+        // Pin this step's results: otherwise instruction selection defers every FMA chain to
+        // the step that finally needs the entry and keeps (spills) all the L(j,k) it loaded meanwhile.
+#pragma unroll
+        for (int m = 2 * qk; m < M + 1; ++m) asm volatile("" : "+v"(row[m]));
+    }
+
+    // rr += nrandn(K) (:322); backward solve L^T x = rr (:323):
+    //   u_i = rr_i - sum_{k>i} L(k,i) x_k,  x_i = u_i / L(i,i)
+    // the L(k,i) a lane needs are fetched eight steps at a time (LDS latency once per batch)
+    double bi = yi + zi;
+    const double my_dinv = 1.0 / sA[i * LD + i];
+    constexpr int BB = K < 8 ? K : 8;
+#pragma unroll
+    for (int kb = K - BB; kb >= 0; kb -= BB) {
+        double lv[BB];
+#pragma unroll
+        for (int t = 0; t < BB; ++t) lv[t] = *((i < kb + t) ? &sA[(kb + t) * LD + i] : szero);
+#pragma unroll
+        for (int t = BB - 1; t >= 0; --t) {
+            const int k = kb + t;
+            if (k == 0) continue;
+            const double xk = bcast(bi * my_dinv, k);
+            bi = fma(-lv[t], xk, bi);
+        }
+    }
+    const double xi = bi * my_dinv;
+
+    if (lane < K) a.items[(size_t)idx * K + lane] = xi;           // items().col(idx) = rr (:324)
+    // a non-positive (or NaN) pivot makes its 1/sqrt NaN or inf, which reaches every later entry
+    // and the sample itself: Eigen LLT's info() != Success -> THROWERROR("Cholesky failed") (:308)
+    const bool bad = !(fabs(xi) <= 1.79769313486231570815e+308);
+    if (__any(bad) && lane == 0) atomicMin(a.fail, (unsigned long long)idx);
+}
+
+// ---------------------------------------------------------------------------
+// One-item-per-workgroup form of the sampler (BPMF_HIP_MODE=1): the hardware dispatcher hands
+// the cost-sorted items to whatever wave slot frees up (dynamic balance without a software
+// queue); the last chunk of a heavy column sums the partials; every column is factorised by
+// one wave alone (finish_single: S lanes per row, lowest latency per column), which is what a
+// matrix with only a few thousand columns per side needs.
+// ---------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(64, Geo<K>::WPS) void k_sample1(SampleArgs a)
+{
+    constexpr int NT = Geo<K>::NT, NTRI = Geo<K>::NTRI, PART = Geo<K>::PART;
+    __shared__ __attribute__((aligned(16))) double lds[Geo1<K>::LDS_WORDS];
+    const int lane = threadIdx.x;
+    const int w = blockIdx.x;
+    const int col = a.wi_col[w];
+    const int64_t p0 = a.wi_p0[w];
+    const int len = a.wi_len[w];
+    const int mc = a.wi_mc[w];
+
+    d4 acc[NTRI];
+    double r[NT];
+#pragma unroll
+    for (int t = 0; t < NTRI; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) r[t] = 0.0;
+
+    // whole column in one item: its normals do not depend on the Gram -- draw them first so that
+    // the Philox / log / sqrt chain is off the critical path between the last MFMA and the factorisation
+    if (mc < 0 && !(a.ablate & 1u))
+        draw_normals<K>(sample_counter<K>(a.col_from + col, a.iter_plus_1), K, lds + K * Geo1<K>::FLD + K, lane);
+
+    gram_chunk<K>(a.rowidx + p0, a.vals + p0, (a.ablate & 2u) ? 0 : len, a.other_items, a.mean_rating, a.alpha, acc, r, lane);
+
+    if (a.ablate & 1u) {
+        double v = r[0];
+#pragma unroll
+        for (int t = 0; t < NTRI; ++t) v += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+        if (mc < 0 && lane < K) a.items[(size_t)(a.col_from + col) * K + lane] = v;
+        return;
+    }
+    if (mc >= 0) {
+        const int nch = a.mc_nchunks[mc];
+        double *pbase = a.partials + (size_t)a.mc_slot0[mc] * PART;
+        double *p = pbase + (size_t)a.wi_chunk[w] * PART;
+#pragma unroll
+        for (int t = 0; t < NTRI; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) __hip_atomic_store(&p[(t * 4 + reg) * 64 + lane], acc[t][reg], BPMF_RLX_AGENT);
+        if (lane < 16) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) __hip_atomic_store(&p[NTRI * 256 + t * 16 + lane], r[t], BPMF_RLX_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(&a.mc_count[mc], 1u, BPMF_RLX_AGENT);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if ((int)t != nch - 1) return;
+        if (lane == 0) __hip_atomic_store(&a.mc_count[mc], 0u, BPMF_RLX_AGENT);
+#pragma unroll
+        for (int t2 = 0; t2 < NTRI; ++t2) acc[t2] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t2 = 0; t2 < NT; ++t2) r[t2] = 0.0;
+        for (int ch = 0; ch < nch; ++ch) {
+            const double *pc = pbase + (size_t)ch * PART;
+#pragma unroll
+            for (int t2 = 0; t2 < NTRI; ++t2)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) acc[t2][reg] += __hip_atomic_load(&pc[(t2 * 4 + reg) * 64 + lane], BPMF_RLX_AGENT);
+#pragma unroll
+            for (int t2 = 0; t2 < NT; ++t2) r[t2] += __hip_atomic_load(&pc[NTRI * 256 + t2 * 16 + (lane & 15)], BPMF_RLX_AGENT);
+        }
+    }
+    finish_single<K>(a, col, acc, r, lds, lane, mc < 0);
+}
+
 // ---------------------------------------------------------------------------
 // sum x, sum x x^T over the columns [c0, c1) of `items` (thread_vector reducers,
 // c++/sample.cpp:345-347,359-362,379-381).  Wave w takes a contiguous slice and
@@ -566,10 +814,27 @@ __global__ __launch_bounds__(64) void k_colstats(const double *__restrict__ item
 
 // out: prod[K*K] col-major | sum[K] | (unused) | fail word.  64 outputs per block, the
 // partials of the waves are split over 4 thread groups and combined in a fixed order.
+// The last block to finish (device-scope ticket) publishes the sequence number the host thread
+// spins on: every block makes its stores to the pinned result blob visible at system scope first.
+__device__ __forceinline__ void publish_when_last(unsigned *ticket, unsigned nblocks, unsigned *flag_host, unsigned seq)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == nblocks - 1) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm
+            __threadfence_system();
+            __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 template <int K>
 __global__ __launch_bounds__(256) void k_colstats_final(const double *__restrict__ partials, int nwaves,
                                                         const unsigned long long *__restrict__ fail_in,
-                                                        double *__restrict__ out)
+                                                        double *__restrict__ out, unsigned *ticket,
+                                                        unsigned *flag_host, unsigned seq)
 {
     constexpr int NT = Geo<K>::NT, NTRI = Geo<K>::NTRI, PART = Geo<K>::PART;
     __shared__ double red[4][64];
@@ -608,6 +873,7 @@ __global__ __launch_bounds__(256) void k_colstats_final(const double *__restrict
         out[K * K + K] = 0.0;
         reinterpret_cast<unsigned long long *>(out)[K * K + K + 1] = *fail_in;
     }
+    publish_when_last(ticket, gridDim.x, flag_host, seq);
 }
 
 // ---------------------------------------------------------------------------
@@ -659,7 +925,8 @@ __global__ __launch_bounds__(256) void k_predict(const int32_t *__restrict__ tco
 }
 
 // fixed-shape tree over the block partials (deterministic)
-__global__ __launch_bounds__(256) void k_predict_final(const double *__restrict__ partial, int64_t nblocks, double *__restrict__ out)
+__global__ __launch_bounds__(256) void k_predict_final(const double *__restrict__ partial, int64_t nblocks, double *__restrict__ out,
+                                                       unsigned *flag_host, unsigned seq)
 {
     __shared__ double red[2][256];
     double se = 0.0, sa = 0.0;
@@ -670,7 +937,11 @@ __global__ __launch_bounds__(256) void k_predict_final(const double *__restrict_
         if ((int)threadIdx.x < st) { red[0][threadIdx.x] += red[0][threadIdx.x + st]; red[1][threadIdx.x] += red[1][threadIdx.x + st]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out[0] = red[0][0]; out[1] = red[1][0]; }
+    if (threadIdx.x == 0) {
+        out[0] = red[0][0]; out[1] = red[1][0];
+        __threadfence_system();
+        __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);     // single block: publish directly
+    }
 }
 
 // hp.mu / hp.LambdaF blob: pinned host memory -> device memory (replaces a hipMemcpyAsync;
@@ -679,12 +950,6 @@ __global__ __launch_bounds__(256) void k_stage(const double *__restrict__ src_ho
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = src_host[i];
-}
-
-// tells the spinning host thread that everything enqueued before it has landed in its pinned buffer
-__global__ void k_signal(unsigned *flag_host, unsigned seq)
-{
-    if (threadIdx.x == 0) __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // test probe: the first n normals of stream `counter`

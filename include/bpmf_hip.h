@@ -127,9 +127,10 @@ BPMF_API int bpmf_hip_sample_side_finish(bpmf_hip_side *self, double *sum_out, d
  * rng_set_pos(iter) + hp.sample(num(), sum = 0, cov) on the host (:349-350), the column loop
  * on the device, and cov = (prod - sum sum^T/N)/(N-1), norm (:379-384).  iter starts at -1
  * (:113), cov at 0 (:188).  Only for a side that owns all its columns (NO_COMM); a shard uses
- * bpmf_hip_sample_side and all-reduces the sums.  While the device is busy the call pre-draws
- * `other`'s next hyper-parameters (they depend only on other's own cov and iter), which is
- * invisible to the caller except in time. */
+ * bpmf_hip_sample_side and all-reduces the sums.  When the call returns, a host worker thread of
+ * the context starts drawing this side's NEXT hyper-parameters (they depend only on the cov just
+ * formed and on iter+1), so that they are ready when the caller comes back after sampling the
+ * other side; this is invisible to the caller except in time. */
 BPMF_API int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, double alpha);
 /* Sys::iter, Sys::norm, Sys::cov, hp.mu, hp.LambdaF, hp.LambdaU (c++/bpmf.h:86-89,139,222-223);
  * any output pointer may be NULL */

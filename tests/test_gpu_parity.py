@@ -15,6 +15,23 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-9
 
 
+@pytest.fixture(params=[None, 0, 1], ids=["auto", "persistent", "per-item"])
+def sampler_mode(request):
+    """Both forms of the sampler (BPMF_HIP_MODE, read when a side is created): 0 = persistent
+    waves with C = 64/K columns factorised side by side, 1 = one work item per workgroup."""
+    import os
+    old = os.environ.get("BPMF_HIP_MODE")
+    if request.param is None:
+        os.environ.pop("BPMF_HIP_MODE", None)
+    else:
+        os.environ["BPMF_HIP_MODE"] = str(request.param)
+    yield request.param
+    if old is None:
+        os.environ.pop("BPMF_HIP_MODE", None)
+    else:
+        os.environ["BPMF_HIP_MODE"] = old
+
+
 def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
 
@@ -56,7 +73,7 @@ def test_device_normal_stream(oracle, hip_engine_factory, counter):
 
 
 @pytest.mark.parametrize("K", [8, 16, 32, 64])
-def test_tiny_first_half_iterations(oracle, hip_engine_factory, K):
+def test_tiny_first_half_iterations(oracle, hip_engine_factory, K, sampler_mode):
     M, Mt, T, Tt, nu, nm = util.tiny()
     eng = hip_engine_factory(K)
     rng = np.random.default_rng(K)
@@ -68,7 +85,7 @@ def test_tiny_first_half_iterations(oracle, hip_engine_factory, K):
 
 
 @pytest.mark.parametrize("K", [16, 32, 64])
-def test_ml100k_half_iterations(oracle, hip_engine_factory, K):
+def test_ml100k_half_iterations(oracle, hip_engine_factory, K, sampler_mode):
     M, Mt, T, Tt, nu, nm = util.ml100k()
     eng = hip_engine_factory(K)
     rng = np.random.default_rng(100 + K)
@@ -79,15 +96,27 @@ def test_ml100k_half_iterations(oracle, hip_engine_factory, K):
     check_half_iteration(*half_iteration_pair(oracle, eng, K, Mt, nm, V, 7, cov=cov))
 
 
-def test_heavy_column_is_chunked(oracle, hip_engine_factory):
-    """A column far above the chunk size goes through partial tiles + k_finish_multi."""
+def test_heavy_column_is_chunked(oracle, hip_engine_factory, sampler_mode):
+    """A column far above the chunk size is cut into chunks; the last-arriving chunk sums the
+    partial tiles.  Several launches with different inputs on the same side: a stale partial
+    (previous launch's tiles served from another XCD's L2) would show up as a mismatch."""
     K = 32
     M, Mt, T, Tt, nu, nm = util.synthetic(6000, 300, 60000, seed=3, heavy=(7, 5000))
     assert np.diff(M[0]).max() >= 5000
     eng = hip_engine_factory(K)
     rng = np.random.default_rng(5)
-    U = 0.2 * rng.standard_normal((nu, K))
-    check_half_iteration(*half_iteration_pair(oracle, eng, K, M, nu, U, 1))
+    mean = util.mean_rating(M)
+    me = eng.side_create(nm, nu, *M, mean)
+    ot = eng.side_create(nu, nm, np.zeros(nu + 1, np.int64), np.zeros(0, np.int32), np.zeros(0), 0.0)
+    for it in range(4):
+        U = (0.2 + 0.1 * it) * rng.standard_normal((nu, K))
+        mu, LU, LF = oracle.hyper_sample(K, nm, np.eye(K) * (0.5 + it), it)
+        ref = np.zeros((nm, K))
+        s_ref, p_ref, n_ref = oracle.sample_side(K, M, mean, 2.0, U, ref, it, mu, LF)
+        eng.set_items(ot, U)
+        s, p, n = eng.sample_side(me, ot, it, 2.0, mu, LF)
+        check_half_iteration((eng.get_items(me), s, p, n), (ref, s_ref, p_ref, n_ref))
+    eng.side_destroy(me); eng.side_destroy(ot)
 
 
 def test_ragged_and_empty(oracle, hip_engine_factory):
@@ -152,7 +181,7 @@ def test_full_run_tiny_reference_smoke(oracle, hip_engine_factory):
     assert rel_err(res["U"], ref["U"]) < 1e-7 and rel_err(res["V"], ref["V"]) < 1e-7
 
 
-def test_full_run_ml100k_matches_oracle(oracle, hip_engine_factory):
+def test_full_run_ml100k_matches_oracle(oracle, hip_engine_factory, sampler_mode):
     """Default run (-i 20 -b 5, K = 32) on the shipped MovieLens-100K split: RMSE trace,
     final averaged RMSE and the sampled factors against the CPU path on identical seeds."""
     import bpmf_amd
