@@ -9,8 +9,9 @@ reference's `items/sec` covers.  value = (N_users + N_movies) * steps / seconds.
 
 N = 1: the ML-1M-shaped synthetic R (6040 x 3706, 1 000 209 ratings, 90/10 split),
 K = 32, fp64 -- BASELINE.json configs[1] (the reference ships only ML-100K).
-N > 1: the same matrix, columns of both sides sharded over the ranks (strong
-scaling), factors exchanged by RCCL between half-iterations.
+N > 1: weak scaling -- N times the users and ratings (6040*N x 3706, 1 000 209*N ratings, same
+generator and seed), columns of both sides sharded over the ranks in nnz-balanced contiguous
+ranges, fresh columns exchanged and [prod|sum|norm] all-reduced over RCCL between half-iterations.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the per-column
 sampler k_gram<K> [+ k_finish_multi], timed with HIP events on its stream) and
@@ -94,20 +95,26 @@ def main():
         raise SystemExit("bench.py needs a HIP device (bpmf_amd has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     comm = None
-    if world > 1:
+    if world > 1 or os.environ.get("BPMF_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         from bpmf_amd.dist import TorchComm
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         comm = TorchComm(torch.device("cuda", local_rank))
 
     K = args.K
-    M, Mt, T, Tt, nusers, nmovies = synth.ml1m_shaped(seed=42)
+    force_dist = os.environ.get("BPMF_BENCH_FORCE_DIST") == "1"        # test hook: run the sharded path with 1 rank
+    if world == 1 and not force_dist:
+        M, Mt, T, Tt, nusers, nmovies = synth.ml1m_shaped(seed=42)
+    else:
+        M, Mt, T, Tt, nusers, nmovies = synth.ratings(6040 * world, 3706, 1_000_209 * world, seed=42)
     nnz = int(M[0][-1])
     mean = float(np.sum(M[2])) / nnz
 
     eng = bpmf_amd.HipEngine(K, device=local_rank)
     Sys.nsims, Sys.burnin, Sys.alpha = args.steps + args.warmup, 5, 2.0
-    if world == 1:
+    if world == 1 and not force_dist:
         movies = Sys("movs", eng, M, nmovies, nusers, T=T, mean_rating=mean)
         users = Sys("users", eng, Mt, nusers, nmovies, mean_rating=mean)
         dom_m, dom_u = (0, nmovies), (0, nusers)
@@ -164,12 +171,13 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "ML-1M-shaped synthetic R (6040 users x 3706 movies, 1000209 ratings, 90/10 split), "
-                               "K=%d, alpha=2, full Gibbs iteration incl. host Normal-Wishart draws and RMSE" % K,
+        "config": {"workload": "ML-1M-shaped synthetic R (%d users x %d movies, %d ratings, 90/10 split), "
+                               "K=%d, alpha=2, full Gibbs iteration incl. host Normal-Wishart draws and RMSE"
+                               % (nusers, nmovies, nnz + int(T[0][-1]), K),
                    "nnz_train": nnz, "nnz_test": int(T[0][-1]), "K": K,
                    "parallelism": "columns of U and V sharded over %d GPU(s)" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -190,7 +198,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if comm is not None:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -114,7 +114,7 @@ class Sys:
         self.hp.sample(self.num(), self.sum, self.cov, self.iter)          # :349-350
         t0 = time.perf_counter()
         s, prod, norm = self.engine.sample_side(self.side, other.side, self.iter, Sys.alpha, self.hp.mu, self.hp.LambdaF)
-        if self.comm is not None and self.comm.size > 1:
+        if self.comm is not None:
             # exchange the fresh columns (send_item / bcast of the MPI back-ends) and
             # all-reduce sum | prod | norm, then form cov once from the global sums
             self.comm.exchange_items(self)
@@ -133,7 +133,7 @@ class Sys:
         if self.test is None:
             return
         se, se_avg, nump = self.engine.predict(self.test, self.side, other.side, n)
-        if self.comm is not None and self.comm.size > 1 and all:
+        if self.comm is not None and all:
             red = self.comm.allreduce(np.array([se, se_avg, float(nump)]))
             se, se_avg, nump = float(red[0]), float(red[1]), int(round(red[2]))
         self.num_predict = nump

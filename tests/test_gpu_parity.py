@@ -251,3 +251,26 @@ def test_bad_arguments_are_rejected(hip_engine_factory):
         eng.side_create(2, 4, np.array([0, 1, 2], np.int64), np.array([0, 9], np.int32), np.ones(2), 1.0)   # row 9 >= nrows
     with pytest.raises(bpmf_amd.BpmfHipError):
         bpmf_amd.HipEngine(24)                                                                              # unsupported K
+
+
+def test_sharded_path_over_rccl_single_rank(tmp_path):
+    """bench.py's N > 1 code path (torch.distributed nccl = RCCL, factor tensors bound to the
+    library, broadcast of the owned range, all-reduce of the sums) with world_size 1: everything
+    except a second GPU.  Its RMSE must equal the single-process path's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    env = dict(os.environ, BPMF_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    a = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert a.returncode == 0, a.stderr[-2000:]
+    b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
+                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert b.returncode == 0, b.stderr[-2000:]
+    pick = lambda out: json.loads([l for l in out.splitlines() if l.startswith('{"metric"')][-1])
+    ja, jb = pick(a.stdout), pick(b.stdout)
+    assert abs(ja["rmse"] - jb["rmse"]) < 1e-9 and abs(ja["rmse_avg"] - jb["rmse_avg"]) < 1e-9
+    assert ja["value"] > 0 and ja["n_gpus"] == 1
