@@ -43,6 +43,25 @@ def algorithmic_flops(nnz, ncols, K):
     return nnz * (K * (K + 1) + 2 * K) + ncols * (K ** 3 / 3.0 + 4 * K * K + 3 * K)
 
 
+def profiled_traffic():
+    """HBM-side bytes per launch of the sampler from the committed rocprofv3 PMC pass
+    (profiles/r*_pmc_sampler.txt: FETCH_SIZE and WRITE_SIZE in KB, separate --pmc passes of this
+    same workload).  Not a live measurement: counters need rocprofv3.  Uncalibrated for 8-byte
+    gathers (MI355X_MICROARCH.md: FETCH_SIZE halves wide coalesced reads only)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sampler.txt")))
+    if not files:
+        return None
+    vals = {}
+    for line in open(files[-1]):
+        f = line.split()
+        if len(f) >= 3 and f[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+            vals[f[1]] = float(f[2].split("=")[1])
+    if len(vals) != 2:
+        return None
+    return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+
+
 def cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies, budget_s=15.0):
     """Times the oracle's -O3/OpenMP build (a restatement of c++/sample.cpp; the real
     reference needs Eigen3 and cannot be built here) on all host cores."""
@@ -181,8 +200,8 @@ def main():
                    "nnz_train": nnz, "nnz_test": int(T[0][-1]), "K": K,
                    "parallelism": "columns of U and V sharded over %d GPU(s)" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_gram<%d>+k_finish_multi<%d>" % (K, K),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": profiled_traffic() if world == 1 else None,
+                     "kernel": "k_sample1<%d>" % K,
                      "launch_ms": launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_launch,
                      "fp64_tflops": flops_launch / launch_s / 1e12 if launch_s > 0 else 0.0,
                      "fp64_frac": (flops_launch / launch_s / 1e12) / FP64_PEAK_TFLOPS if launch_s > 0 else 0.0,
