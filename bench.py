@@ -54,9 +54,9 @@ def profiled_traffic():
         return None
     vals = {}
     for line in open(files[-1]):
-        f = line.split()
-        if len(f) >= 3 and f[1] in ("FETCH_SIZE", "WRITE_SIZE"):
-            vals[f[1]] = float(f[2].split("=")[1])
+        f = line.replace("avg=", "avg= ").split()
+        if len(f) >= 4 and f[1] in ("FETCH_SIZE", "WRITE_SIZE"):
+            vals[f[1]] = float(f[3])
     if len(vals) != 2:
         return None
     return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
