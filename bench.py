@@ -118,9 +118,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        from bpmf_amd.dist import TorchComm
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        comm = TorchComm(torch.device("cuda", local_rank))
 
     K = args.K
     force_dist = os.environ.get("BPMF_BENCH_FORCE_DIST") == "1"        # test hook: run the sharded path with 1 rank
@@ -132,6 +130,11 @@ def main():
     mean = float(np.sum(M[2])) / nnz
 
     eng = bpmf_amd.HipEngine(K, device=local_rank)
+    if world > 1 or force_dist:
+        from bpmf_amd.dist import NativeComm, TorchComm
+        # default: RCCL inside the library (exchange + all-reduce behind the sampling call);
+        # BPMF_DIST=torch keeps the collectives in torch.distributed (same results, slower host path)
+        comm = TorchComm(torch.device("cuda", local_rank)) if os.environ.get("BPMF_DIST") == "torch" else NativeComm(eng)
     Sys.nsims, Sys.burnin, Sys.alpha = args.steps + args.warmup, 5, 2.0
     if world == 1 and not force_dist:
         movies = Sys("movs", eng, M, nmovies, nusers, T=T, mean_rating=mean)

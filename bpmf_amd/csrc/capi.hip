@@ -5,6 +5,8 @@
 // cut into nnz chunks), upload hp.mu / hp.LambdaF per half-iteration, launch
 // the kernels on one stream and bring the K*K+K+1 reduction words back.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is dlopen'ed on first use
 
 #include <algorithm>
 #include <atomic>
@@ -57,6 +59,50 @@ int env_int(const char *name, int dflt)
     return (s && *s) ? atoi(s) : dflt;
 }
 
+// RCCL entry points, resolved at run time: single-GPU users never load the library, and inside a
+// torch process the already-loaded librccl.so.1 is reused (one communicator runtime per process).
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+Rccl *rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.handle) break;
+        }
+        if (r.handle) {
+#define BPMF_SYM(f) r.f = reinterpret_cast<decltype(r.f)>(dlsym(r.handle, "nccl" #f))
+            BPMF_SYM(GetUniqueId); BPMF_SYM(CommInitRank); BPMF_SYM(CommDestroy); BPMF_SYM(AllReduce);
+            BPMF_SYM(Broadcast); BPMF_SYM(GroupStart); BPMF_SYM(GroupEnd); BPMF_SYM(GetErrorString);
+#undef BPMF_SYM
+            if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.Broadcast || !r.GroupStart || !r.GroupEnd)
+                r.handle = nullptr;
+        }
+    }
+    return r.handle ? &r : nullptr;
+}
+
+#define NCCL_TRY(expr)                                                                                 \
+    do {                                                                                               \
+        ncclResult_t r_ = (expr);                                                                      \
+        if (r_ != ncclSuccess)                                                                         \
+            return fail(BPMF_HIP_ENODEV, std::string(#expr) + ": " +                                   \
+                        (rccl() && rccl()->GetErrorString ? rccl()->GetErrorString(r_) : "RCCL error")); \
+    } while (0)
+
 }  // namespace
 
 extern "C" void bpmf_hip_set_error_(const char *msg) { g_err = msg; }
@@ -82,6 +128,11 @@ struct bpmf_hip_ctx {
     bpmf_hip_side *job = nullptr;        // posted, not yet taken
     bpmf_hip_side *running = nullptr;    // being computed
     bool wstop = false;
+    // multi-GPU: RCCL communicator (one rank per process / GPU) and a device staging blob for the
+    // all-reduced sums: prod[K*K] | sum[K] | - | fail (u64) | se | se_avg | count
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+    double *d_red = nullptr;
     unsigned seq = 0;                    // value the next publishing kernel writes behind its results
     unsigned *d_ticket = nullptr;        // arrival counter of k_colstats_final's blocks
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -102,6 +153,7 @@ struct bpmf_hip_side {
     double *d_partials = nullptr;
     int nstat_waves = 0;
     double *d_stat_partials = nullptr;
+    std::vector<int64_t> bounds;         // multi-GPU: column range of every rank (nranks + 1 entries)
     int64_t failed_column = -1;
     bool pending = false;
     float last_sample_ms = 0.f, last_reduce_ms = 0.f;
@@ -120,6 +172,7 @@ struct bpmf_hip_test {
     int32_t *d_tcol = nullptr, *d_trow = nullptr;
     double *d_tval = nullptr, *d_pavg = nullptr, *d_pm2 = nullptr, *d_partial = nullptr;
     int64_t nblocks = 0;
+    int64_t global_nnz = -1;             // multi-GPU: test ratings over all ranks (all-reduced once)
 };
 
 namespace {
@@ -269,6 +322,7 @@ extern "C" int bpmf_hip_ctx_create(int device, int K, void *stream, bpmf_hip_ctx
     HIP_TRY(hipHostGetDevicePointer((void **)&c->h_out_dev, c->h_out, 0));
     memset(c->h_out, 0, c->out_words * sizeof(double));
     HIP_TRY(hipMalloc((void **)&c->d_in, c->in_words * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&c->d_red, (c->out_words + 8) * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&c->d_ticket, 64));
     HIP_TRY(hipMemset(c->d_ticket, 0, 64));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
@@ -291,6 +345,8 @@ extern "C" int bpmf_hip_ctx_destroy(bpmf_hip_ctx *c)
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
+    if (c->d_red) (void)hipFree(c->d_red);
+    if (c->comm && rccl()) (void)rccl()->CommDestroy(c->comm);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return BPMF_HIP_OK;
@@ -430,11 +486,40 @@ int do_launch(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double 
         hipLaunchKernelGGL(k_sample<K>, dim3(grid), dim3(64), 0, c->stream, a);
     }
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    const bool dist = c->comm != nullptr && !self->bounds.empty();
+    if (dist) {
+        // every rank broadcasts the range it just sampled (= all-gather-v of disjoint, uneven
+        // ranges), in place in the replicated factor matrix, on the sampler's stream
+        Rccl *R = rccl();
+        NCCL_TRY(R->GroupStart());
+        for (int r = 0; r < c->nranks; ++r) {
+            const int64_t lo = self->bounds[(size_t)r], hi = self->bounds[(size_t)r + 1];
+            if (hi > lo) {
+                double *p = self->d_items + (size_t)lo * K;
+                NCCL_TRY(R->Broadcast(p, p, (size_t)(hi - lo) * K, ncclDouble, r, c->comm, c->stream));
+            }
+        }
+        NCCL_TRY(R->GroupEnd());
+    }
     hipLaunchKernelGGL(k_colstats<K>, dim3(self->nstat_waves), dim3(64), 0, c->stream,
                        (const double *)self->d_items, self->from, self->to, self->nstat_waves, self->d_stat_partials);
-    hipLaunchKernelGGL(k_colstats_final<K>, dim3((K * K + K + 63) / 64), dim3(256), 0, c->stream,
-                       (const double *)self->d_stat_partials, self->nstat_waves, (const unsigned long long *)a.fail, c->h_out_dev,
-                       c->d_ticket, reinterpret_cast<unsigned *>(c->h_out_dev + c->out_words - 1), ++c->seq);
+    unsigned *flag = reinterpret_cast<unsigned *>(c->h_out_dev + c->out_words - 1);
+    if (!dist) {
+        hipLaunchKernelGGL(k_colstats_final<K>, dim3((K * K + K + 63) / 64), dim3(256), 0, c->stream,
+                           (const double *)self->d_stat_partials, self->nstat_waves, (const unsigned long long *)a.fail, c->h_out_dev,
+                           c->d_ticket, flag, ++c->seq);
+    } else {
+        // local sums into a device blob, all-reduce them (cov is then formed once from the GLOBAL
+        // sums: SURVEY Q19), min-reduce the failed-column word, publish to the host
+        Rccl *R = rccl();
+        unsigned *dummy_flag = c->d_ticket + 8;
+        hipLaunchKernelGGL(k_colstats_final<K>, dim3((K * K + K + 63) / 64), dim3(256), 0, c->stream,
+                           (const double *)self->d_stat_partials, self->nstat_waves, (const unsigned long long *)a.fail, c->d_red,
+                           c->d_ticket, dummy_flag, 0u);
+        NCCL_TRY(R->AllReduce(c->d_red, c->d_red, (size_t)K * K + K, ncclDouble, ncclSum, c->comm, c->stream));
+        NCCL_TRY(R->AllReduce(c->d_red + (size_t)K * K + K + 1, c->d_red + (size_t)K * K + K + 1, 1, ncclUint64, ncclMin, c->comm, c->stream));
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, c->stream, (const double *)c->d_red, c->h_out_dev, K * K + K + 2, flag, ++c->seq);
+    }
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -596,8 +681,10 @@ static void settle_predraw_public(bpmf_hip_side *s) { settle_predraw(s); }
 extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, double alpha)
 {
     if (!self || !other) return fail(BPMF_HIP_EINVAL, "sys_sample: NULL argument");
-    if (self->to - self->from != self->ncols)
-        return fail(BPMF_HIP_EINVAL, "sys_sample: the side is a shard; use bpmf_hip_sample_side + an all-reduce");
+    if (self->to - self->from != self->ncols && !(self->ctx->comm && !self->bounds.empty()))
+        return fail(BPMF_HIP_EINVAL, "sys_sample: the side is a shard: give the context a communicator "
+                                     "(bpmf_hip_ctx_comm_init) and the side its ranges (bpmf_hip_side_set_ranges), "
+                                     "or use bpmf_hip_sample_side and all-reduce the sums yourself");
     const int K = self->ctx->K;
     ensure_state(self); ensure_state(other);
     settle_predraw(self);
@@ -647,6 +734,48 @@ extern "C" int bpmf_hip_sys_state(const bpmf_hip_side *s, int *iter, double *nor
     if (mu) { if (have) memcpy(mu, s->hp_mu.data(), sizeof(double) * K); else memset(mu, 0, sizeof(double) * K); }
     if (LambdaF) { if (have) memcpy(LambdaF, s->hp_LambdaF.data(), sizeof(double) * K * K); else memset(LambdaF, 0, sizeof(double) * K * K); }
     if (LambdaU) { if (have) memcpy(LambdaU, s->hp_LambdaU.data(), sizeof(double) * K * K); else memset(LambdaU, 0, sizeof(double) * K * K); }
+    return BPMF_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Multi-GPU: one process per GPU, RCCL over xGMI (stands in for the reference's MPI/GASPI
+// back-ends: send_item + reduce_sum_cov_norm, c++/mpi_common.h:44-50, c++/mpi_bcast.h:21-30).
+extern "C" int bpmf_hip_comm_unique_id(void *id128)
+{
+    if (!id128) return fail(BPMF_HIP_EINVAL, "comm_unique_id: NULL");
+    Rccl *R = rccl();
+    if (!R) return fail(BPMF_HIP_ENODEV, "RCCL (librccl.so.1) could not be loaded");
+    ncclUniqueId id;
+    NCCL_TRY(R->GetUniqueId(&id));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id128, &id, sizeof id);
+    return BPMF_HIP_OK;
+}
+
+extern "C" int bpmf_hip_ctx_comm_init(bpmf_hip_ctx *c, int nranks, int rank, const void *id128)
+{
+    if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(BPMF_HIP_EINVAL, "ctx_comm_init: bad argument");
+    if (c->comm) return fail(BPMF_HIP_EINVAL, "ctx_comm_init: the context already has a communicator");
+    Rccl *R = rccl();
+    if (!R) return fail(BPMF_HIP_ENODEV, "RCCL (librccl.so.1) could not be loaded");
+    HIP_TRY(hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    NCCL_TRY(R->CommInitRank(&c->comm, nranks, id, rank));
+    c->nranks = nranks; c->rank = rank;
+    return BPMF_HIP_OK;
+}
+
+extern "C" int bpmf_hip_side_set_ranges(bpmf_hip_side *s, const int64_t *bounds)
+{
+    if (!s || !bounds) return fail(BPMF_HIP_EINVAL, "side_set_ranges: NULL");
+    bpmf_hip_ctx *c = s->ctx;
+    if (!c->comm) return fail(BPMF_HIP_EINVAL, "side_set_ranges: the context has no communicator");
+    if (bounds[0] != 0 || bounds[c->nranks] != s->ncols || bounds[c->rank] != s->from || bounds[c->rank + 1] != s->to)
+        return fail(BPMF_HIP_EINVAL, "side_set_ranges: ranges do not tile the columns or disagree with this rank's slice");
+    for (int r = 0; r < c->nranks; ++r)
+        if (bounds[r + 1] < bounds[r]) return fail(BPMF_HIP_EINVAL, "side_set_ranges: ranges are not monotone");
+    s->bounds.assign(bounds, bounds + c->nranks + 1);
     return BPMF_HIP_OK;
 }
 
@@ -706,8 +835,18 @@ void launch_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const bpmf_hip_
                        (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz,
                        (const double *)self->d_items, (const double *)other->d_items, self->from, self->mean_rating, n,
                        t->d_pavg, t->d_pm2, t->d_partial);
-    hipLaunchKernelGGL(bpmf::k_predict_final, dim3(1), dim3(256), 0, c->stream, (const double *)t->d_partial, t->nblocks,
-                       c->h_out_dev + c->out_words - 3, reinterpret_cast<unsigned *>(c->h_out_dev + c->out_words - 1), ++c->seq);
+    unsigned *flag = reinterpret_cast<unsigned *>(c->h_out_dev + c->out_words - 1);
+    if (!(c->comm && !self->bounds.empty())) {
+        hipLaunchKernelGGL(bpmf::k_predict_final, dim3(1), dim3(256), 0, c->stream, (const double *)t->d_partial, t->nblocks,
+                           c->h_out_dev + c->out_words - 3, flag, ++c->seq);
+    } else {
+        // se | se_avg of this rank's test ratings -> all-reduce -> host
+        double *red = c->d_red + c->out_words;      // 2 spare words behind the sampler's blob
+        hipLaunchKernelGGL(bpmf::k_predict_final, dim3(1), dim3(256), 0, c->stream, (const double *)t->d_partial, t->nblocks,
+                           red, c->d_ticket + 8, 0u);
+        if (rccl()->AllReduce(red, red, 2, ncclDouble, ncclSum, c->comm, c->stream) != ncclSuccess) return;
+        hipLaunchKernelGGL(bpmf::k_publish, dim3(1), dim3(256), 0, c->stream, (const double *)red, c->h_out_dev + c->out_words - 3, 2, flag, ++c->seq);
+    }
 }
 }  // namespace
 
@@ -719,7 +858,7 @@ extern "C" int bpmf_hip_predict(bpmf_hip_test *t, const bpmf_hip_side *self, con
     if (n < 0) return fail(BPMF_HIP_EINVAL, "predict: n < 0");
     bpmf_hip_ctx *c = self->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    if (t->nnz == 0) { *se = 0.0; *se_avg = 0.0; *count = 0; return BPMF_HIP_OK; }
+    if (t->nnz == 0 && !(c->comm && !self->bounds.empty())) { *se = 0.0; *se_avg = 0.0; *count = 0; return BPMF_HIP_OK; }
     switch (c->K) {
     case 8: launch_predict<8>(t, self, other, n); break;
     case 16: launch_predict<16>(t, self, other, n); break;
@@ -732,6 +871,17 @@ extern "C" int bpmf_hip_predict(bpmf_hip_test *t, const bpmf_hip_side *self, con
     *se = c->h_out[c->out_words - 3];
     *se_avg = c->h_out[c->out_words - 2];
     *count = t->nnz;
+    if (c->comm && !self->bounds.empty()) {
+        if (t->global_nnz < 0) {                                   // once: number of test ratings over all ranks
+            long long v = (long long)t->nnz, *d = reinterpret_cast<long long *>(c->d_red + c->out_words + 4);
+            HIP_TRY(hipMemcpyAsync(d, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
+            NCCL_TRY(rccl()->AllReduce(d, d, 1, ncclInt64, ncclSum, c->comm, c->stream));
+            HIP_TRY(hipMemcpyAsync(&v, d, sizeof v, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            t->global_nnz = v;
+        }
+        *count = t->global_nnz;
+    }
     return BPMF_HIP_OK;
 }
 

@@ -952,6 +952,19 @@ __global__ __launch_bounds__(256) void k_stage(const double *__restrict__ src_ho
     if (i < n) dst[i] = src_host[i];
 }
 
+// multi-GPU: the all-reduced sums sit in device memory; copy them to the pinned result blob and
+// publish the sequence number behind them
+__global__ __launch_bounds__(256) void k_publish(const double *__restrict__ src, double *__restrict__ dst_host, int n,
+                                                 unsigned *flag_host, unsigned seq)
+{
+    for (int i = threadIdx.x; i < n; i += 256) dst_host[i] = src[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // test probe: the first n normals of stream `counter`
 __global__ __launch_bounds__(64) void k_randn_probe(uint32_t counter, int n, double *out)
 {

@@ -17,6 +17,26 @@ import torch
 import torch.distributed as dist
 
 
+class NativeComm:
+    """The exchange runs inside libbpmf_hip.so over RCCL (bpmf_hip_ctx_comm_init): the fresh column
+    range of every rank is broadcast in place and sum | prod | norm are all-reduced on the device,
+    behind the same C-ABI call that samples.  torch.distributed is only the launcher here: it
+    ships rank 0's 128-byte RCCL id to the other ranks."""
+
+    native = True
+
+    def __init__(self, engine):
+        self.rank = dist.get_rank()
+        self.size = dist.get_world_size()
+        box = [engine.comm_unique_id() if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        engine.comm_init(self.size, self.rank, box[0])
+        self.engine = engine
+
+    def register(self, sys, bounds):
+        self.engine.side_set_ranges(sys.side, bounds)
+
+
 class TorchComm:
     def __init__(self, device):
         self.device = torch.device(device)

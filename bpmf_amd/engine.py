@@ -48,6 +48,21 @@ class HipEngine:
     def sync(self):
         _lib.check(self.lib.bpmf_hip_ctx_sync(self.ctx))
 
+    # -- multi-GPU (RCCL inside the library) -------------------------------------
+    def comm_unique_id(self):
+        buf = (C.c_char * 128)()
+        _lib.check(self.lib.bpmf_hip_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, nranks, rank, unique_id):
+        buf = (C.c_char * 128).from_buffer_copy(unique_id)
+        _lib.check(self.lib.bpmf_hip_ctx_comm_init(self.ctx, int(nranks), int(rank), buf))
+        self.nranks, self.rank = int(nranks), int(rank)
+
+    def side_set_ranges(self, side, bounds):
+        b = np.ascontiguousarray(bounds, np.int64)
+        _lib.check(self.lib.bpmf_hip_side_set_ranges(side.handle, _ptr(b)))
+
     # -- sides ----------------------------------------------------------------
     def side_create(self, ncols, nrows, colptr, rowidx, vals, mean_rating, col_from=0, col_to=None):
         col_to = ncols if col_to is None else col_to

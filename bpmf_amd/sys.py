@@ -103,7 +103,7 @@ class Sys:
 
     # -- Sys::sample(Sys&), c++/sample.cpp:341-385 ------------------------------
     def sample(self, other):
-        if self.comm is None and hasattr(self.engine, "sys_sample"):
+        if (self.comm is None or getattr(self.comm, "native", False)) and hasattr(self.engine, "sys_sample"):
             # NO_COMM: the whole of Sys::sample(Sys&) (iter++, hyper draw, column loop, cov) runs
             # behind one C-ABI call, which also overlaps the host draws with the kernels
             self.engine.sys_sample(self.side, other.side, Sys.alpha)
@@ -133,7 +133,7 @@ class Sys:
         if self.test is None:
             return
         se, se_avg, nump = self.engine.predict(self.test, self.side, other.side, n)
-        if self.comm is not None and all:
+        if self.comm is not None and not getattr(self.comm, "native", False) and all:
             red = self.comm.allreduce(np.array([se, se_avg, float(nump)]))
             se, se_avg, nump = float(red[0]), float(red[1]), int(round(red[2]))
         self.num_predict = nump

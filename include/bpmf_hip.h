@@ -70,6 +70,21 @@ BPMF_API int bpmf_hip_ctx_destroy(bpmf_hip_ctx *ctx);
 BPMF_API int bpmf_hip_ctx_sync(bpmf_hip_ctx *ctx);
 BPMF_API void *bpmf_hip_ctx_stream(bpmf_hip_ctx *ctx);
 
+/* ---- multi-GPU -----------------------------------------------------------------
+ * One process per GPU.  Replaces the reference's MPI/GASPI/ArgoDSM back-ends (send_item of every
+ * fresh column + reduce_sum_cov_norm, c++/mpi_common.h:44-50, c++/mpi_bcast.h:21-30) by RCCL:
+ * rank 0 calls _comm_unique_id and ships the 128 bytes to the other ranks (torch.distributed,
+ * MPI, a file ...); every rank calls _ctx_comm_init.  A side that holds a shard is then given the
+ * column range of EVERY rank (_side_set_ranges, nranks+1 bounds, contiguous, tiling [0, ncols));
+ * from then on bpmf_hip_sample_side / bpmf_hip_sys_sample additionally broadcast each rank's fresh
+ * range in place (all-gather-v over xGMI) and all-reduce sum | prod | norm on the device, so that
+ * the values returned (and the cov formed from them) are the GLOBAL ones on every rank, and
+ * bpmf_hip_predict returns the all-reduced se / se_avg / count.  RCCL is loaded on first use
+ * (dlopen of librccl.so.1), single-GPU use never touches it. */
+BPMF_API int bpmf_hip_comm_unique_id(void *id128);
+BPMF_API int bpmf_hip_ctx_comm_init(bpmf_hip_ctx *ctx, int nranks, int rank, const void *id128);
+BPMF_API int bpmf_hip_side_set_ranges(bpmf_hip_side *side, const int64_t *bounds);
+
 /* ---- one side (= one Sys) ---------------------------------------------------
  * Replaces Sys::Sys + alloc_and_init + Sys::init (c++/sample.cpp:112-137,179-226,
  * c++/nocomm.h:29-33).  The factor matrix has `ncols` columns (all of them,

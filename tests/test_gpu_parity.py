@@ -254,9 +254,10 @@ def test_bad_arguments_are_rejected(hip_engine_factory):
 
 
 def test_sharded_path_over_rccl_single_rank(tmp_path):
-    """bench.py's N > 1 code path (torch.distributed nccl = RCCL, factor tensors bound to the
-    library, broadcast of the owned range, all-reduce of the sums) with world_size 1: everything
-    except a second GPU.  Its RMSE must equal the single-process path's."""
+    """bench.py's N > 1 code paths with world_size 1 (everything except a second GPU): (a) RCCL
+    inside the library (bpmf_hip_ctx_comm_init: in-place broadcast of the owned range, device
+    all-reduce of the sums, all-reduced RMSE), (b) the same exchange through torch.distributed.
+    Both must give the single-process path's RMSE."""
     import json
     import os
     import subprocess
@@ -264,13 +265,17 @@ def test_sharded_path_over_rccl_single_rank(tmp_path):
     from tests.conftest import ROOT
     env = dict(os.environ, BPMF_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1",
                LOCAL_RANK="0")
-    a = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
-                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    a = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert a.returncode == 0, a.stderr[-2000:]
+    t = subprocess.run(cmd, env=dict(env, BPMF_DIST="torch", MASTER_PORT="29534"), cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    assert t.returncode == 0, t.stderr[-2000:]
     b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
                        cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert b.returncode == 0, b.stderr[-2000:]
     pick = lambda out: json.loads([l for l in out.splitlines() if l.startswith('{"metric"')][-1])
-    ja, jb = pick(a.stdout), pick(b.stdout)
+    ja, jb, jt = pick(a.stdout), pick(b.stdout), pick(t.stdout)
+    assert abs(jt["rmse"] - jb["rmse"]) < 1e-9 and abs(jt["rmse_avg"] - jb["rmse_avg"]) < 1e-9
     assert abs(ja["rmse"] - jb["rmse"]) < 1e-9 and abs(ja["rmse_avg"] - jb["rmse_avg"]) < 1e-9
     assert ja["value"] > 0 and ja["n_gpus"] == 1
