@@ -42,11 +42,16 @@ _SIGNATURES = {
     "bpmf_hip_test_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "bpmf_hip_test_destroy": (C.c_int, [C.c_void_p]),
     "bpmf_hip_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bpmf_hip_predict_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "bpmf_hip_predict_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bpmf_hip_test_get": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "bpmf_hyper_sample": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bpmf_hyper_draws": (C.c_int, [C.c_int, C.c_int64, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "bpmf_hyper_finish": (C.c_int, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bpmf_cov_from_sums": (None, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bpmf_randn_stream": (None, [C.c_uint32, C.c_int, C.c_void_p]),
     "bpmf_hip_randn_stream": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
+    "bpmf_hip_side_kernel_ms_sum": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "bpmf_hip_side_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     # include/bpmf_io.h
     "bpmf_io_last_error": (C.c_char_p, []),

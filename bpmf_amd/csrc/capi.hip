@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <new>
 #include <numeric>
 #include <string>
@@ -106,12 +107,39 @@ Rccl *rccl()
 }  // namespace
 
 extern "C" void bpmf_hip_set_error_(const char *msg) { g_err = msg; }
-static void settle_predraw_public(struct bpmf_hip_side *s);
+static int settle_async(struct bpmf_hip_side *s);      // waits until the worker is done with `s`; returns its deferred error
+
+struct bpmf_hip_side;
+// host-side timeline for BPMF_HIP_TRACE=1: (time, tag, side) records, printed when the context dies
+namespace {
+struct TraceRec { double us; const char *tag; const void *side; int iter; };
+std::vector<TraceRec> g_trace;
+std::mutex g_trace_mutex;
+const bool g_trace_on = env_int("BPMF_HIP_TRACE", 0) != 0;
+const std::chrono::steady_clock::time_point g_trace_t0 = std::chrono::steady_clock::now();
+inline void trace(const char *tag, const bpmf_hip_side *s, int iter)
+{
+    if (!g_trace_on) return;
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - g_trace_t0).count();
+    std::lock_guard<std::mutex> lk(g_trace_mutex);
+    if (g_trace.size() < (1u << 20)) g_trace.push_back({us, tag, s, iter});
+}
+void trace_dump()
+{
+    std::lock_guard<std::mutex> lk(g_trace_mutex);
+    const size_t from = g_trace.size() > 160 ? g_trace.size() - 160 : 0;
+    for (size_t i = from; i < g_trace.size(); ++i)
+        fprintf(stderr, "[bpmf_hip] %12.1f us  side %04x  iter %4d  %s\n", g_trace[i].us, (unsigned)((uintptr_t)g_trace[i].side >> 4) & 0xFFFF, g_trace[i].iter, g_trace[i].tag);
+    g_trace.clear();
+}
+struct TraceAtExit { ~TraceAtExit() { if (g_trace_on) trace_dump(); } } g_trace_at_exit;
+}  // namespace
 
 struct bpmf_hip_ctx {
     int device = 0;
     int K = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;        // S0: samplers, exchange, predict
+    std::vector<bpmf_hip_side *> sides;  // stateful sides with a statistics stream of their own (for ctx_sync)
     bool own_stream = false;
     int num_cu = 256;
     unsigned ablate = 0;
@@ -121,20 +149,14 @@ struct bpmf_hip_ctx {
     // prod[K*K] | sum[K] | - | fail (u64) | se | se_avg | flag (u32)
     double *h_out = nullptr, *h_out_dev = nullptr;
     size_t in_words = 0, out_words = 0;
-    // host worker that pre-draws a side's next hyper-parameters while the GPU samples the other side
-    std::thread worker;
-    std::mutex wm;
-    std::condition_variable wcv;
-    bpmf_hip_side *job = nullptr;        // posted, not yet taken
-    bpmf_hip_side *running = nullptr;    // being computed
-    bool wstop = false;
+    std::mutex launch_mutex;             // kernel launches come from the caller's thread and from the sides' workers
     // multi-GPU: RCCL communicator (one rank per process / GPU) and a device staging blob for the
     // all-reduced sums: prod[K*K] | sum[K] | - | fail (u64) | se | se_avg | count
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
     double *d_red = nullptr;
     unsigned seq = 0;                    // value the next publishing kernel writes behind its results
-    unsigned *d_ticket = nullptr;        // arrival counter of k_colstats_final's blocks
+    unsigned *d_ticket = nullptr;        // arrival counters of k_colstats' waves (stateless path)
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 };
 
@@ -158,12 +180,36 @@ struct bpmf_hip_side {
     bool pending = false;
     float last_sample_ms = 0.f, last_reduce_ms = 0.f;
     bool timing_valid = true;
+    // asynchronous (stateful) path: own parameter / result blobs, gate word, events
+    double *a_h_in = nullptr, *a_h_in_dev = nullptr, *a_d_in = nullptr;
+    double *a_h_out = nullptr, *a_h_out_dev = nullptr;
+    unsigned *a_gate = nullptr, *a_gate_dev = nullptr;   // pinned word the host sets to iter + 1 when a_h_in holds that iteration's parameters
+    unsigned *a_ticket = nullptr;                        // arrival counters of this side's k_colstats waves
+    unsigned a_seq = 0;
+    hipEvent_t evs[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // (start, sampled, stats, staged) of the two half-iterations that may be in flight
+    hipStream_t saux = nullptr;          // this side's statistics stream (high priority: its few blocks must not queue behind the other side's sampler)
+    // host worker of this side: collects its sums when they land, forms cov, draws its next
+    // hyper-parameters and releases the gate of its next sampler, all while the GPU samples the other side
+    struct Job { int iter; unsigned seq; int evset; bool timed; };
+    std::thread worker;
+    std::mutex wm;
+    std::condition_variable wcv;
+    std::deque<Job> jobs;
+    int in_flight = 0;                   // half-iterations enqueued and not collected yet (at most 2)
+    bool wstop = false;
+    int async_rc = 0;                    // deferred error of a half-iteration (e.g. Cholesky failed)
+    std::string async_msg;
+    int gate_iter = -2;                  // iteration whose parameters the gate has been opened for
+    double tot_sample_ms = 0.0, tot_reduce_ms = 0.0;
+    long long n_launches = 0;
     // state of the reference's Sys (c++/bpmf.h:139,221-226) for bpmf_hip_sys_sample
     int iter = -1;
     double norm = 0.0;
     std::vector<double> cov, hp_mu, hp_LambdaU, hp_LambdaF;      // current
     std::vector<double> nx_mu, nx_LambdaU, nx_LambdaF;           // pre-drawn for iteration nx_iter
     int nx_iter = -2;
+    std::vector<double> rd_au, rd_z;                             // cov-independent random part, drawn for iteration rd_iter
+    int rd_iter = -2;
 };
 
 struct bpmf_hip_test {
@@ -173,6 +219,10 @@ struct bpmf_hip_test {
     double *d_tval = nullptr, *d_pavg = nullptr, *d_pm2 = nullptr, *d_partial = nullptr;
     int64_t nblocks = 0;
     int64_t global_nnz = -1;             // multi-GPU: test ratings over all ranks (all-reduced once)
+    double *h_res = nullptr, *h_res_dev = nullptr;       // pinned: se | se_avg | flag
+    unsigned *d_ticket = nullptr;                        // arrival counter of k_predict's blocks
+    unsigned seq = 0;
+    bool launched = false;
 };
 
 namespace {
@@ -228,10 +278,12 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     if (chunk <= 0) {
         const int64_t simds = (int64_t)s->ctx->num_cu * 4;
         // mode 1: ~1.5 chunks of work per SIMD (measured best on the ML-1M shape: 512-768);
-        // mode 0: >= 8 work items per SIMD so the tail of the launch stays short
+        // mode 0: >= 8 work items per SIMD so the tail of the launch stays short.  Lower bound
+        // 16 K: a chunk's partial tiles are ~1.3 K^2 doubles written and read back, against 8 K
+        // bytes gathered per rating, so shorter chunks make the partials a first-order traffic term.
         int64_t c = s->mode == 1 ? (s->nnz * 2) / (simds * 3) : s->nnz / (simds * 8);
         c = (c + 63) / 64 * 64;
-        chunk = (int)std::min<int64_t>(std::max<int64_t>(c, s->mode == 1 ? 256 : 128), 4096);
+        chunk = (int)std::min<int64_t>(std::max<int64_t>(c, 16 * K), 4096);
     }
     chunk = (chunk + 15) / 16 * 16;
 
@@ -314,7 +366,7 @@ extern "C" int bpmf_hip_ctx_create(int device, int K, void *stream, bpmf_hip_ctx
     c->ablate = (unsigned)env_int("BPMF_HIP_ABLATE", 0);
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
-    c->in_words = (size_t)K * K + K + 1;
+    c->in_words = (size_t)K * K + K + 2;                               // LambdaF | Lmu | fail | pad (even: staged as 16-byte words)
     c->out_words = (size_t)K * K + K + 1 + 1 + 2 + 1;
     HIP_TRY(hipHostMalloc((void **)&c->h_in, c->in_words * sizeof(double), hipHostMallocMapped));
     HIP_TRY(hipHostMalloc((void **)&c->h_out, c->out_words * sizeof(double), hipHostMallocMapped));
@@ -333,11 +385,7 @@ extern "C" int bpmf_hip_ctx_create(int device, int K, void *stream, bpmf_hip_ctx
 extern "C" int bpmf_hip_ctx_destroy(bpmf_hip_ctx *c)
 {
     if (!c) return BPMF_HIP_OK;
-    if (c->worker.joinable()) {
-        { std::lock_guard<std::mutex> lk(c->wm); c->wstop = true; c->job = nullptr; }
-        c->wcv.notify_all();
-        c->worker.join();
-    }
+    if (g_trace_on) trace_dump();
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -355,8 +403,13 @@ extern "C" int bpmf_hip_ctx_destroy(bpmf_hip_ctx *c)
 extern "C" int bpmf_hip_ctx_sync(bpmf_hip_ctx *c)
 {
     if (!c) return fail(BPMF_HIP_EINVAL, "ctx_sync: NULL");
+    std::vector<bpmf_hip_side *> sides;
+    { std::lock_guard<std::mutex> lk(c->launch_mutex); sides = c->sides; }
+    int rc = 0;
+    for (bpmf_hip_side *s : sides) { const int r = settle_async(s); if (r && !rc) rc = r; }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return BPMF_HIP_OK;
+    for (bpmf_hip_side *s : sides) HIP_TRY(hipStreamSynchronize(s->saux));
+    return rc;
 }
 
 extern "C" void *bpmf_hip_ctx_stream(bpmf_hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
@@ -416,13 +469,29 @@ extern "C" int bpmf_hip_side_create_dev(bpmf_hip_ctx *ctx, int64_t ncols, int64_
 extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
 {
     if (!s) return BPMF_HIP_OK;
-    settle_predraw_public(s);
+    (void)settle_async(s);
+    if (s->worker.joinable()) {
+        { std::lock_guard<std::mutex> lk(s->wm); s->wstop = true; }
+        s->wcv.notify_all();
+        s->worker.join();
+    }
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
+    if (s->saux) {
+        (void)hipStreamSynchronize(s->saux); (void)hipStreamDestroy(s->saux);
+        std::lock_guard<std::mutex> lk(s->ctx->launch_mutex);
+        auto &v = s->ctx->sides;
+        v.erase(std::remove(v.begin(), v.end(), s), v.end());
+    }
     if (s->own_csc) { if (s->d_rowidx) (void)hipFree(s->d_rowidx); if (s->d_vals) (void)hipFree(s->d_vals); }
     if (s->own_items && s->d_items) (void)hipFree(s->d_items);
-    void *ptrs[] = {s->d_wi_col, s->d_wi_len, s->d_wi_mc, s->d_wi_chunk, s->d_wi_p0, s->d_mc_slot0, s->d_mc_nch, s->d_mc_count, s->d_partials, s->d_stat_partials};
+    void *ptrs[] = {s->d_wi_col, s->d_wi_len, s->d_wi_mc, s->d_wi_chunk, s->d_wi_p0, s->d_mc_slot0, s->d_mc_nch, s->d_mc_count, s->d_partials, s->d_stat_partials, s->a_d_in};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (s->a_h_in) (void)hipHostFree(s->a_h_in);
+    if (s->a_h_out) (void)hipHostFree(s->a_h_out);
+    for (auto &set : s->evs) for (hipEvent_t e : set) if (e) (void)hipEventDestroy(e);
+    if (s->a_gate) (void)hipHostFree(s->a_gate);
+    if (s->a_ticket) (void)hipFree(s->a_ticket);
     delete s;
     return BPMF_HIP_OK;
 }
@@ -433,7 +502,9 @@ extern "C" int bpmf_hip_side_bind_items(bpmf_hip_side *s, double *items_dev)
 {
     if (!s || !items_dev) return fail(BPMF_HIP_EINVAL, "bind_items: NULL");
     HIP_TRY(hipSetDevice(s->ctx->device));
+    (void)settle_async(s);
     HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    if (s->saux) HIP_TRY(hipStreamSynchronize(s->saux));
     if (s->own_items && s->d_items) (void)hipFree(s->d_items);
     s->d_items = items_dev; s->own_items = false;
     return BPMF_HIP_OK;
@@ -452,7 +523,9 @@ extern "C" int bpmf_hip_side_set_items(bpmf_hip_side *s, const double *h)
 {
     if (!s || !h) return fail(BPMF_HIP_EINVAL, "set_items: NULL");
     HIP_TRY(hipSetDevice(s->ctx->device));
+    { const int rc = settle_async(s); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    if (s->saux) HIP_TRY(hipStreamSynchronize(s->saux));
     HIP_TRY(hipMemcpy(s->d_items, h, (size_t)s->ctx->K * s->ncols * sizeof(double), hipMemcpyHostToDevice));
     return BPMF_HIP_OK;
 }
@@ -460,8 +533,13 @@ extern "C" int bpmf_hip_side_set_items(bpmf_hip_side *s, const double *h)
 // ---------------------------------------------------------------------------
 namespace {
 
+// The device work of one half-iteration, in three pieces that the synchronous (stateless) and
+// the asynchronous (stateful) paths put on their streams:
+//   launch_sampler: the per-column update, reading the parameter blob `d_in`
+//   launch_exchange: multi-GPU only, in-place broadcast of every rank's fresh column range
+//   launch_stats: sum x / sum x x^T of this rank's columns (+ all-reduce), published to `out_host_dev`
 template <int K>
-int do_launch(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double alpha)
+int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double alpha, double *d_in, hipStream_t st)
 {
     using namespace bpmf;
     bpmf_hip_ctx *c = self->ctx;
@@ -471,58 +549,88 @@ int do_launch(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double 
     a.mc_slot0 = self->d_mc_slot0; a.mc_nchunks = self->d_mc_nch; a.mc_count = self->d_mc_count;
     a.partials = self->d_partials; a.nwork = self->nwork;
     a.other_items = other->d_items; a.items = self->d_items; a.col_from = self->from;
-    a.LambdaF = c->d_in; a.Lmu = c->d_in + (size_t)K * K;
-    a.fail = (unsigned long long *)(c->d_in + (size_t)K * K + K);
+    a.LambdaF = d_in; a.Lmu = d_in + (size_t)K * K;
+    a.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
     a.mean_rating = self->mean_rating; a.alpha = alpha; a.iter_plus_1 = (uint32_t)(iter + 1);
     a.ablate = c->ablate;
-
-    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     if (self->nwork > 0 && self->mode == 1) {
-        hipLaunchKernelGGL(k_sample1<K>, dim3(self->nwork), dim3(64), 0, c->stream, a);
+        hipLaunchKernelGGL(k_sample1<K>, dim3(self->nwork), dim3(64), 0, st, a);
     } else if (self->nwork > 0) {
         // persistent waves: as many single-wave workgroups as the chip holds at this kernel's occupancy
         const int resident = c->num_cu * 4 * Geo<K>::WPS;
         const int grid = std::min(self->nwork, env_int("BPMF_HIP_GRID", resident));
-        hipLaunchKernelGGL(k_sample<K>, dim3(grid), dim3(64), 0, c->stream, a);
+        hipLaunchKernelGGL(k_sample<K>, dim3(grid), dim3(64), 0, st, a);
     }
-    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
-    const bool dist = c->comm != nullptr && !self->bounds.empty();
-    if (dist) {
-        // every rank broadcasts the range it just sampled (= all-gather-v of disjoint, uneven
-        // ranges), in place in the replicated factor matrix, on the sampler's stream
-        Rccl *R = rccl();
-        NCCL_TRY(R->GroupStart());
-        for (int r = 0; r < c->nranks; ++r) {
-            const int64_t lo = self->bounds[(size_t)r], hi = self->bounds[(size_t)r + 1];
-            if (hi > lo) {
-                double *p = self->d_items + (size_t)lo * K;
-                NCCL_TRY(R->Broadcast(p, p, (size_t)(hi - lo) * K, ncclDouble, r, c->comm, c->stream));
-            }
+    return 0;
+}
+
+template <int K>
+int launch_exchange(bpmf_hip_side *self, hipStream_t st)
+{
+    bpmf_hip_ctx *c = self->ctx;
+    if (!(c->comm != nullptr && !self->bounds.empty())) return 0;
+    // every rank broadcasts the range it just sampled (= all-gather-v of disjoint, uneven
+    // ranges), in place in the replicated factor matrix, on the sampler's stream
+    Rccl *R = rccl();
+    NCCL_TRY(R->GroupStart());
+    for (int r = 0; r < c->nranks; ++r) {
+        const int64_t lo = self->bounds[(size_t)r], hi = self->bounds[(size_t)r + 1];
+        if (hi > lo) {
+            double *p = self->d_items + (size_t)lo * K;
+            NCCL_TRY(R->Broadcast(p, p, (size_t)(hi - lo) * K, ncclDouble, r, c->comm, st));
         }
-        NCCL_TRY(R->GroupEnd());
     }
-    hipLaunchKernelGGL(k_colstats<K>, dim3(self->nstat_waves), dim3(64), 0, c->stream,
-                       (const double *)self->d_items, self->from, self->to, self->nstat_waves, self->d_stat_partials);
-    unsigned *flag = reinterpret_cast<unsigned *>(c->h_out_dev + c->out_words - 1);
-    if (!dist) {
-        hipLaunchKernelGGL(k_colstats_final<K>, dim3((K * K + K + 63) / 64), dim3(256), 0, c->stream,
-                           (const double *)self->d_stat_partials, self->nstat_waves, (const unsigned long long *)a.fail, c->h_out_dev,
-                           c->d_ticket, flag, ++c->seq);
+    NCCL_TRY(R->GroupEnd());
+    return 0;
+}
+
+template <int K>
+int launch_stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_host_dev, unsigned *flag, unsigned seq, unsigned *ticket)
+{
+    using namespace bpmf;
+    bpmf_hip_ctx *c = self->ctx;
+    const unsigned long long *failp = (const unsigned long long *)(d_in + (size_t)K * K + K);
+    if (!(c->comm != nullptr && !self->bounds.empty())) {
+        hipLaunchKernelGGL(k_colstats<K>, dim3(self->nstat_waves), dim3(64), 0, st,
+                           (const double *)self->d_items, self->from, self->to, self->nstat_waves, self->d_stat_partials,
+                           failp, out_host_dev, ticket, flag, seq);
     } else {
         // local sums into a device blob, all-reduce them (cov is then formed once from the GLOBAL
         // sums: SURVEY Q19), min-reduce the failed-column word, publish to the host
         Rccl *R = rccl();
-        unsigned *dummy_flag = c->d_ticket + 8;
-        hipLaunchKernelGGL(k_colstats_final<K>, dim3((K * K + K + 63) / 64), dim3(256), 0, c->stream,
-                           (const double *)self->d_stat_partials, self->nstat_waves, (const unsigned long long *)a.fail, c->d_red,
-                           c->d_ticket, dummy_flag, 0u);
-        NCCL_TRY(R->AllReduce(c->d_red, c->d_red, (size_t)K * K + K, ncclDouble, ncclSum, c->comm, c->stream));
-        NCCL_TRY(R->AllReduce(c->d_red + (size_t)K * K + K + 1, c->d_red + (size_t)K * K + K + 1, 1, ncclUint64, ncclMin, c->comm, c->stream));
-        hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, c->stream, (const double *)c->d_red, c->h_out_dev, K * K + K + 2, flag, ++c->seq);
+        hipLaunchKernelGGL(k_colstats<K>, dim3(self->nstat_waves), dim3(64), 0, st,
+                           (const double *)self->d_items, self->from, self->to, self->nstat_waves, self->d_stat_partials,
+                           failp, c->d_red, ticket, ticket + 8, 0u);
+        NCCL_TRY(R->AllReduce(c->d_red, c->d_red, (size_t)K * K + K, ncclDouble, ncclSum, c->comm, st));
+        NCCL_TRY(R->AllReduce(c->d_red + (size_t)K * K + K + 1, c->d_red + (size_t)K * K + K + 1, 1, ncclUint64, ncclMin, c->comm, st));
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, st, (const double *)c->d_red, out_host_dev, K * K + K + 2, flag, seq);
     }
-    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-    HIP_TRY(hipGetLastError());
     return 0;
+}
+
+#define BPMF_DISPATCH_K(K_, CALL)                                                    \
+    [&]() -> int {                                                                   \
+        switch (K_) {                                                                \
+        case 8: { constexpr int KK = 8; return CALL; }                               \
+        case 16: { constexpr int KK = 16; return CALL; }                             \
+        case 32: { constexpr int KK = 32; return CALL; }                             \
+        case 64: { constexpr int KK = 64; return CALL; }                             \
+        default: return fail(BPMF_HIP_EINVAL, "unsupported K");                     \
+        }                                                                            \
+    }()
+
+// parameter blob of one half-iteration: LambdaF | LambdaF*mu | "no column failed"
+void fill_blob(int K, const double *mu, const double *LambdaF, double *h_in)
+{
+    // rr = hp_LambdaF * hp.mu is the same for every column (c++/sample.cpp:285)
+    memcpy(h_in, LambdaF, sizeof(double) * K * K);
+    for (int i = 0; i < K; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < K; ++j) s += LambdaF[(size_t)j * K + i] * mu[j];
+        h_in[(size_t)K * K + i] = s;
+    }
+    const unsigned long long nofail = ~0ull;
+    memcpy(&h_in[(size_t)K * K + K], &nofail, sizeof(nofail));
 }
 
 }  // namespace
@@ -538,28 +646,22 @@ extern "C" int bpmf_hip_sample_side_launch(bpmf_hip_side *self, const bpmf_hip_s
     if (self->pending) return fail(BPMF_HIP_EINVAL, "sample_side_launch: previous launch not finished");
     const int K = c->K;
     HIP_TRY(hipSetDevice(c->device));
-    // rr = hp_LambdaF * hp.mu is the same for every column (c++/sample.cpp:285)
-    for (int j = 0; j < K; ++j)
-        for (int i = 0; i < K; ++i) c->h_in[(size_t)j * K + i] = LambdaF[(size_t)j * K + i];
-    for (int i = 0; i < K; ++i) {
-        double s = 0.0;
-        for (int j = 0; j < K; ++j) s += LambdaF[(size_t)j * K + i] * mu[j];
-        c->h_in[(size_t)K * K + i] = s;
-    }
-    const unsigned long long nofail = ~0ull;
-    memcpy(&c->h_in[(size_t)K * K + K], &nofail, sizeof(nofail));
+    { const int rs = settle_async(self); if (rs) return rs; }
+    if (self->saux) HIP_TRY(hipStreamSynchronize(self->saux));
+    fill_blob(K, mu, LambdaF, c->h_in);
     hipLaunchKernelGGL(bpmf::k_stage, dim3((unsigned)((c->in_words + 255) / 256)), dim3(256), 0, c->stream,
                        (const double *)c->h_in_dev, c->d_in, (int)c->in_words);
-    int rc = 0;
-    switch (K) {
-    case 8: rc = do_launch<8>(self, other, iter, alpha); break;
-    case 16: rc = do_launch<16>(self, other, iter, alpha); break;
-    case 32: rc = do_launch<32>(self, other, iter, alpha); break;
-    case 64: rc = do_launch<64>(self, other, iter, alpha); break;
-    default: return fail(BPMF_HIP_EINVAL, "sample_side: unsupported K");
-    }
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    int rc = BPMF_DISPATCH_K(K, launch_sampler<KK>(self, other, iter, alpha, c->d_in, c->stream));
     if (rc) return rc;
-    // prod | sum | - | fail word land in the pinned result blob; the last block of k_colstats_final
+    rc = BPMF_DISPATCH_K(K, launch_exchange<KK>(self, c->stream));
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    unsigned *flag = reinterpret_cast<unsigned *>(c->h_out_dev + c->out_words - 1);
+    rc = BPMF_DISPATCH_K(K, launch_stats<KK>(self, c->stream, c->d_in, c->h_out_dev, flag, ++c->seq, c->d_ticket));
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    // prod | sum | - | fail word land in the pinned result blob; the last wave of k_colstats
     // publishes the sequence number behind them
     HIP_TRY(hipGetLastError());
     self->pending = true;
@@ -607,11 +709,15 @@ extern "C" int64_t bpmf_hip_failed_column(const bpmf_hip_side *s) { return s ? s
 extern "C" int bpmf_hip_side_last_kernel_ms(bpmf_hip_side *s, float *sample_ms, float *reduce_ms)
 {
     if (!s) return fail(BPMF_HIP_EINVAL, "last_kernel_ms: NULL");
-    if (!s->timing_valid) {          // the events of the last launch on this context
+    { const int rc = settle_async(s); if (rc) return rc; }      // stateful path: the worker has stored the times
+    if (!s->timing_valid) {          // stateless path: the events of the last launch on this context
         bpmf_hip_ctx *c = s->ctx;
         HIP_TRY(hipEventSynchronize(c->ev[2]));
-        (void)hipEventElapsedTime(&s->last_sample_ms, c->ev[0], c->ev[1]);
-        (void)hipEventElapsedTime(&s->last_reduce_ms, c->ev[1], c->ev[2]);
+        if (hipEventElapsedTime(&s->last_sample_ms, c->ev[0], c->ev[1]) != hipSuccess ||
+            hipEventElapsedTime(&s->last_reduce_ms, c->ev[1], c->ev[2]) != hipSuccess) {
+            (void)hipGetLastError();                                  // nothing was launched (or timed) yet
+            s->last_sample_ms = s->last_reduce_ms = 0.f;
+        }
         s->timing_valid = true;
     }
     if (sample_ms) *sample_ms = s->last_sample_ms;
@@ -622,110 +728,256 @@ extern "C" int bpmf_hip_side_last_kernel_ms(bpmf_hip_side *s, float *sample_ms, 
 // ---------------------------------------------------------------------------
 // Stateful form = the virtual the reference's back-ends override: Sys::sample(Sys&)
 // (c++/sample.cpp:341-385) including iter++, the host hyper-parameter draw and the cov update.
+//
+// It is asynchronous inside.  One call enqueues, for half-iteration i of the side,
+//     [S0]  k_gate_stage(i)  ->  sampler(i) (+ exchange)        [S1 = the side's own stream]  column statistics(i) -> pinned result blob
+// and returns.  The side's host worker thread picks the sums up when they land, forms cov(i), draws
+// the hyper-parameters of iteration i+1 (they depend only on cov(i) and on the counter i+1), writes
+// them into the side's pinned parameter blob and opens the gate: a word in pinned memory that
+// k_gate_stage(i+1) -- usually already queued on S0 behind the other side's sampler -- is polling.
+// The gate kernel then copies the blob into device memory and the sampler behind it starts; no
+// host thread wake-up, kernel launch or cross-stream event sits between "parameters known" and
+// "sampler running".  The caller may run one half-iteration ahead per side (sys_sample(i+1) needs
+// collect(i-1) only), so in steady state the GPU never waits for an enqueue and the host work
+// (70 us of Normal-Wishart arithmetic per half-iteration) hides behind the other side's sampler.
+// Anything that needs host-side state (bpmf_hip_sys_state, destroy, set_items) first drains the
+// worker; an error of a half-iteration (Cholesky failed) surfaces at the next such point or at
+// the side's next-but-one sys_sample, and the chain is not to be continued after it.
 namespace {
-void ensure_state(bpmf_hip_side *s)
-{
-    const size_t K = (size_t)s->ctx->K;
-    if (s->cov.size() != K * K) {
-        s->cov.assign(K * K, 0.0);                                   // cov.setZero(), c++/sample.cpp:188
-        s->hp_mu.assign(K, 0.0); s->hp_LambdaU.assign(K * K, 0.0); s->hp_LambdaF.assign(K * K, 0.0);
-        s->nx_mu.assign(K, 0.0); s->nx_LambdaU.assign(K * K, 0.0); s->nx_LambdaF.assign(K * K, 0.0);
-    }
-}
-}  // namespace
 
-namespace {
-// Pre-draw of a side's next hyper-parameters on the context's worker thread.  Legal as soon as
-// the side's own half-iteration is over: the draw depends only on its cov and iteration counter.
-void worker_main(bpmf_hip_ctx *c)
+int ensure_state(bpmf_hip_side *s)
 {
-    std::unique_lock<std::mutex> lk(c->wm);
+    bpmf_hip_ctx *c = s->ctx;
+    const size_t K = (size_t)c->K;
+    if (s->cov.size() == K * K) return 0;
+    HIP_TRY(hipHostMalloc((void **)&s->a_h_in, c->in_words * sizeof(double), hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc((void **)&s->a_h_out, c->out_words * sizeof(double), hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc((void **)&s->a_gate, 64, hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void **)&s->a_h_in_dev, s->a_h_in, 0));
+    HIP_TRY(hipHostGetDevicePointer((void **)&s->a_h_out_dev, s->a_h_out, 0));
+    HIP_TRY(hipHostGetDevicePointer((void **)&s->a_gate_dev, s->a_gate, 0));
+    memset(s->a_h_out, 0, c->out_words * sizeof(double));
+    memset(s->a_gate, 0, 64);
+    HIP_TRY(hipMalloc((void **)&s->a_d_in, c->in_words * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&s->a_ticket, 64));
+    HIP_TRY(hipMemset(s->a_ticket, 0, 64));
+    static const unsigned evflags = env_int("BPMF_HIP_EVENT_FENCE", 0) ? 0u : hipEventDisableSystemFence;
+    for (auto &set : s->evs) for (hipEvent_t &e : set) HIP_TRY(hipEventCreateWithFlags(&e, evflags));
+    int lo = 0, hi = 0;                                              // numerically lowest = most urgent
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_TRY(hipStreamCreateWithPriority(&s->saux, hipStreamNonBlocking, hi));
+    { std::lock_guard<std::mutex> lk(c->launch_mutex); c->sides.push_back(s); }
+    s->hp_mu.assign(K, 0.0); s->hp_LambdaU.assign(K * K, 0.0); s->hp_LambdaF.assign(K * K, 0.0);
+    s->nx_mu.assign(K, 0.0); s->nx_LambdaU.assign(K * K, 0.0); s->nx_LambdaF.assign(K * K, 0.0);
+    s->cov.assign(K * K, 0.0);                                       // cov.setZero(), c++/sample.cpp:188
+    return 0;
+}
+
+// hyper-parameters of iteration `iter` from the side's current cov, into (mu, LU, LF); the matching
+// parameter blob goes into the side's pinned memory and the gate of that iteration is opened
+int draw_and_release(bpmf_hip_side *s, int iter, double *mu, double *LU, double *LF)
+{
+    bpmf_hip_ctx *c = s->ctx;
+    const int K = c->K;
+    // rng_set_pos(iter); hp.sample(num(), sum = 0, cov)  (c++/sample.cpp:349-350); the random part
+    // may have been drawn ahead of time (it does not depend on cov)
+    int rc = 0;
+    if (s->rd_iter != iter) {
+        s->rd_au.resize((size_t)K * K); s->rd_z.resize(K);
+        rc = bpmf_hyper_draws(K, s->ncols, (uint32_t)iter, s->rd_au.data(), s->rd_z.data());
+        if (!rc) s->rd_iter = iter;
+    }
+    if (!rc) rc = bpmf_hyper_finish(K, s->ncols, s->cov.data(), nullptr, s->rd_au.data(), s->rd_z.data(), mu, LU, LF);
+    if (!rc) fill_blob(K, mu, LF, s->a_h_in);
+    // the gate is opened even after an error: a sampler may already be queued behind it and must
+    // not be left spinning (its results are never looked at: the error is reported first)
+    __atomic_store_n(s->a_gate, (unsigned)(iter + 1), __ATOMIC_RELEASE);
+    s->gate_iter = iter;
+    return rc;
+}
+
+// worker side of one half-iteration: wait for the sums, cov, next hyper-parameters, open the gate
+void collect(bpmf_hip_side *s, const bpmf_hip_side::Job &job)
+{
+    bpmf_hip_ctx *c = s->ctx;
+    const int K = c->K;
+    trace("collect: start", s, job.iter);
+    unsigned *flag = reinterpret_cast<unsigned *>(s->a_h_out + c->out_words - 1);
+    // while the device is still sampling: the random part of the next draw (gamma / normal stream
+    // of WishartUnitChol and MvNormalChol_prec), which needs no result of this half-iteration
+    if (s->rd_iter != job.iter + 1) {
+        s->rd_au.resize((size_t)K * K); s->rd_z.resize(K);
+        if (bpmf_hyper_draws(K, s->ncols, (uint32_t)(job.iter + 1), s->rd_au.data(), s->rd_z.data()) == 0) s->rd_iter = job.iter + 1;
+    }
+    if (s->nx_iter == job.iter) {                                     // the parameters this half-iteration ran with
+        s->hp_mu.swap(s->nx_mu); s->hp_LambdaU.swap(s->nx_LambdaU); s->hp_LambdaF.swap(s->nx_LambdaF);
+        s->nx_iter = -2;
+    }
+    trace("collect: draws ready, spinning", s, job.iter);
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (unsigned spins = 0; !seen; ++spins) {
+        seen = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == job.seq;
+        if (seen) break;
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFu) == 0xFFFu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05) break;
+    }
+    trace("collect: sums landed", s, job.iter);
+    (void)hipSetDevice(c->device);
+    hipEvent_t *ev = s->evs[job.evset];
+    int rc = 0;
+    std::string msg;
+    if (!seen) {                                                      // long kernel or an error: blocking wait
+        (void)hipEventSynchronize(ev[2]);                             // (not the stream: our own next gate may be queued on it)
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != job.seq) { rc = BPMF_HIP_ENODEV; msg = "device did not publish its results"; }
+    }
+    if (!rc) {
+        const double *prod = s->a_h_out, *sum = s->a_h_out + (size_t)K * K;
+        unsigned long long f;
+        memcpy(&f, &s->a_h_out[(size_t)K * K + K + 1], sizeof f);
+        if (f != ~0ull) {
+            s->failed_column = (int64_t)f;
+            rc = BPMF_HIP_ECHOL; msg = "Cholesky failed in column " + std::to_string((long long)f);
+        } else {
+            s->failed_column = -1;
+            double nn = 0.0;                                          // sum |x|^2 = trace(sum x x^T)  (:381)
+            for (int i = 0; i < K; ++i) nn += prod[(size_t)i * K + i];
+            s->norm = nn;
+            bpmf_cov_from_sums(K, s->ncols, sum, prod, s->cov.data());   // :383-384
+        }
+    }
+    // the next half-iteration of this side: parameters + gate (opened in every case, see above)
+    const int rd = draw_and_release(s, job.iter + 1, s->nx_mu.data(), s->nx_LambdaU.data(), s->nx_LambdaF.data());
+    trace("collect: gate of the next half-iteration opened", s, job.iter);
+    if (!rc && rd) { rc = rd; msg = g_err; }
+    if (!rc) s->nx_iter = job.iter + 1;
+    {   // kernel times of this launch (its events are complete: the flag is published behind them)
+        float a = 0.f, b = 0.f;
+        if (job.timed && hipEventSynchronize(ev[2]) == hipSuccess && hipEventElapsedTime(&a, ev[0], ev[1]) == hipSuccess) {
+            (void)hipEventElapsedTime(&b, ev[1], ev[2]);
+            s->last_sample_ms = a; s->last_reduce_ms = b; s->timing_valid = true;
+            s->tot_sample_ms += a; s->tot_reduce_ms += b; s->n_launches++;
+        }
+    }
+    if (rc && !s->async_rc) { s->async_rc = rc; s->async_msg = msg; }
+    trace("collect: done", s, job.iter);
+}
+
+void worker_main(bpmf_hip_side *s)
+{
+    std::unique_lock<std::mutex> lk(s->wm);
     for (;;) {
-        c->wcv.wait(lk, [c] { return c->wstop || c->job != nullptr; });
-        if (c->wstop) return;
-        bpmf_hip_side *s = c->job;
-        c->job = nullptr;
-        c->running = s;
+        s->wcv.wait(lk, [s] { return s->wstop || !s->jobs.empty(); });
+        if (s->jobs.empty()) return;                                  // stop requested and nothing left
+        const bpmf_hip_side::Job job = s->jobs.front();
+        s->jobs.pop_front();
         lk.unlock();
-        const int K = c->K;
-        const int next = s->iter + 1;
-        const int rc = bpmf_hyper_sample(K, s->ncols, s->cov.data(), nullptr, (uint32_t)next, s->nx_mu.data(),
-                                         s->nx_LambdaU.data(), s->nx_LambdaF.data());
+        collect(s, job);
         lk.lock();
-        s->nx_iter = rc ? -2 : next;
-        c->running = nullptr;
-        c->wcv.notify_all();
+        s->in_flight--;
+        s->wcv.notify_all();
     }
 }
 
-void post_predraw(bpmf_hip_side *s)
+void post_collect(bpmf_hip_side *s, const bpmf_hip_side::Job &job)
 {
-    bpmf_hip_ctx *c = s->ctx;
-    std::lock_guard<std::mutex> lk(c->wm);
-    if (!c->worker.joinable()) c->worker = std::thread(worker_main, c);
-    if (c->job == nullptr) { c->job = s; c->wcv.notify_all(); }     // at most one pending job: otherwise drawn inline later
+    std::lock_guard<std::mutex> lk(s->wm);
+    if (!s->worker.joinable()) s->worker = std::thread(worker_main, s);
+    s->jobs.push_back(job);
+    s->in_flight++;
+    s->wcv.notify_all();
 }
 
-// waits until no pre-draw touches `s`
-void settle_predraw(bpmf_hip_side *s)
+// waits until at most `depth` half-iterations of the side are uncollected; returns a deferred error
+int wait_async(bpmf_hip_side *s, int depth)
 {
-    bpmf_hip_ctx *c = s->ctx;
-    std::unique_lock<std::mutex> lk(c->wm);
-    if (c->job == s) c->job = nullptr;                                // not started yet: drop it, draw inline
-    c->wcv.wait(lk, [c, s] { return c->running != s; });
+    {
+        std::unique_lock<std::mutex> lk(s->wm);
+        s->wcv.wait(lk, [s, depth] { return s->in_flight <= depth; });
+        if (!s->async_rc) return 0;
+        s->wcv.wait(lk, [s] { return s->in_flight == 0; });           // an error ends the chain: drain it
+    }
+    const int rc = s->async_rc;
+    g_err = s->async_msg;
+    s->async_rc = 0;
+    return rc;
 }
+
 }  // namespace
 
-static void settle_predraw_public(bpmf_hip_side *s) { settle_predraw(s); }
+static int settle_async(bpmf_hip_side *s) { return wait_async(s, 0); }
 
 extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, double alpha)
 {
     if (!self || !other) return fail(BPMF_HIP_EINVAL, "sys_sample: NULL argument");
-    if (self->to - self->from != self->ncols && !(self->ctx->comm && !self->bounds.empty()))
+    bpmf_hip_ctx *c = self->ctx;
+    if (other->ctx != c) return fail(BPMF_HIP_EINVAL, "sys_sample: sides belong to different contexts");
+    if (other->ncols != self->nrows) return fail(BPMF_HIP_EINVAL, "sys_sample: other side has the wrong number of columns");
+    if (self->to - self->from != self->ncols && !(c->comm && !self->bounds.empty()))
         return fail(BPMF_HIP_EINVAL, "sys_sample: the side is a shard: give the context a communicator "
                                      "(bpmf_hip_ctx_comm_init) and the side its ranges (bpmf_hip_side_set_ranges), "
                                      "or use bpmf_hip_sample_side and all-reduce the sums yourself");
-    const int K = self->ctx->K;
-    ensure_state(self); ensure_state(other);
-    settle_predraw(self);
-    self->iter++;                                                     // :344
+    const int K = c->K;
+    HIP_TRY(hipSetDevice(c->device));
     int rc;
-    if (self->nx_iter == self->iter) {                                // drawn by the worker while the device was busy
-        self->hp_mu.swap(self->nx_mu); self->hp_LambdaU.swap(self->nx_LambdaU); self->hp_LambdaF.swap(self->nx_LambdaF);
-    } else {                                                          // rng_set_pos(iter); hp.sample(num(), sum, cov)  (:349-350)
-        rc = bpmf_hyper_sample(K, self->ncols, self->cov.data(), nullptr, (uint32_t)self->iter,
-                               self->hp_mu.data(), self->hp_LambdaU.data(), self->hp_LambdaF.data());
-        if (rc) { self->iter--; return rc; }
+    if ((rc = ensure_state(self)) || (rc = ensure_state(other))) return rc;
+    trace("sys_sample: enter", self, self->iter + 1);
+    // one half-iteration of this side may still be uncollected: its worker opens our gate
+    if ((rc = wait_async(self, 1))) return rc;
+    trace("sys_sample: may enqueue", self, self->iter + 1);
+
+    const int iter = self->iter + 1;                                  // :344
+    bool chained;
+    { std::lock_guard<std::mutex> lk(self->wm); chained = self->in_flight > 0; }
+    if (!chained && self->gate_iter != iter) {
+        // first half-iteration (or the chain was broken): draw here, nothing to overlap with
+        rc = draw_and_release(self, iter, self->nx_mu.data(), self->nx_LambdaU.data(), self->nx_LambdaF.data());
+        if (rc) return rc;
+        self->nx_iter = iter;
     }
-    self->nx_iter = -2;
-    static const bool trace = env_int("BPMF_HIP_TRACE", 0) != 0;
-    const auto t0 = std::chrono::steady_clock::now();
-    rc = bpmf_hip_sample_side_launch(self, other, self->iter, alpha, self->hp_mu.data(), self->hp_LambdaF.data());
-    if (rc) { self->iter--; return rc; }
-    const auto t1 = std::chrono::steady_clock::now();
-    const auto t2 = std::chrono::steady_clock::now();
-    std::vector<double> sum(K), prod((size_t)K * K);
-    double norm = 0.0;
-    rc = bpmf_hip_sample_side_finish(self, sum.data(), prod.data(), &norm);
+    self->iter = iter;
+
+    hipStream_t s0 = c->stream, s1 = c->comm ? c->stream : self->saux;   // one stream when RCCL is in play
+    const unsigned seq = ++self->a_seq;
+    const int evset = (int)(seq & 1u);
+    hipEvent_t *ev = self->evs[evset];
+    // S1 (behind the statistics of the previous half-iteration): gate + staging of this
+    // half-iteration's parameters.  S0: sampler, exchange.  S1: statistics -> pinned result blob.
+    // (The previous statistics pass has finished reading the columns the sampler overwrites: the
+    // gate only opens after its sums were seen.)
+    hipLaunchKernelGGL(bpmf::k_gate_stage, dim3(1), dim3(64), 0, s1, (const unsigned *)self->a_gate_dev, (unsigned)(iter + 1),
+                       (const double *)self->a_h_in_dev, self->a_d_in, (int)c->in_words);
+    if (s1 != s0) {
+        HIP_TRY(hipEventRecord(ev[3], s1));
+        HIP_TRY(hipStreamWaitEvent(s0, ev[3], 0));
+    }
+    // kernel times come from events around every n-th launch of the side (BPMF_HIP_TIMING_EVERY,
+    // default 4; 1 = every launch; 0 = never): the start marker costs a few microseconds on S0
+    static const int every = env_int("BPMF_HIP_TIMING_EVERY", 4);
+    const bool timed = every > 0 && seq % (unsigned)every == 0;
+    if (timed) HIP_TRY(hipEventRecord(ev[0], s0));
+    rc = BPMF_DISPATCH_K(K, launch_sampler<KK>(self, other, iter, alpha, self->a_d_in, s0));
+    if (!rc) rc = BPMF_DISPATCH_K(K, launch_exchange<KK>(self, s0));
     if (rc) return rc;
-    if (trace) {
-        const auto t3 = std::chrono::steady_clock::now();
-        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-        fprintf(stderr, "[bpmf_hip] sys_sample iter %d: launch %.1f us, wait %.1f us\n", self->iter, us(t0, t1), us(t2, t3));
-    }
-    self->norm = norm;                                                // :381
-    bpmf_cov_from_sums(K, self->ncols, sum.data(), prod.data(), self->cov.data());   // :383-384
-    // this side's next hyper-parameters depend only on the cov just formed and on iter+1:
-    // draw them on the worker thread while the caller samples the other side / evaluates RMSE
-    post_predraw(self);
+    HIP_TRY(hipEventRecord(ev[1], s0));
+    if (s1 != s0) HIP_TRY(hipStreamWaitEvent(s1, ev[1], 0));
+    unsigned *flag = reinterpret_cast<unsigned *>(self->a_h_out_dev + c->out_words - 1);
+    rc = BPMF_DISPATCH_K(K, launch_stats<KK>(self, s1, self->a_d_in, self->a_h_out_dev, flag, seq, self->a_ticket));
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ev[2], s1));
+    HIP_TRY(hipGetLastError());
+    self->timing_valid = false;
+    post_collect(self, {iter, seq, evset, timed});
+    trace("sys_sample: enqueued", self, iter);
     return BPMF_HIP_OK;
 }
 
-extern "C" int bpmf_hip_sys_state(const bpmf_hip_side *s, int *iter, double *norm, double *cov, double *mu,
+extern "C" int bpmf_hip_sys_state(const bpmf_hip_side *cs, int *iter, double *norm, double *cov, double *mu,
                                   double *LambdaF, double *LambdaU)
 {
-    if (!s) return fail(BPMF_HIP_EINVAL, "sys_state: NULL");
-    settle_predraw(const_cast<bpmf_hip_side *>(s));
+    if (!cs) return fail(BPMF_HIP_EINVAL, "sys_state: NULL");
+    bpmf_hip_side *s = const_cast<bpmf_hip_side *>(cs);
+    { const int rc = settle_async(s); if (rc) return rc; }
     const size_t K = (size_t)s->ctx->K;
     if (iter) *iter = s->iter;
     if (norm) *norm = s->norm;
@@ -734,6 +986,17 @@ extern "C" int bpmf_hip_sys_state(const bpmf_hip_side *s, int *iter, double *nor
     if (mu) { if (have) memcpy(mu, s->hp_mu.data(), sizeof(double) * K); else memset(mu, 0, sizeof(double) * K); }
     if (LambdaF) { if (have) memcpy(LambdaF, s->hp_LambdaF.data(), sizeof(double) * K * K); else memset(LambdaF, 0, sizeof(double) * K * K); }
     if (LambdaU) { if (have) memcpy(LambdaU, s->hp_LambdaU.data(), sizeof(double) * K * K); else memset(LambdaU, 0, sizeof(double) * K * K); }
+    return BPMF_HIP_OK;
+}
+
+// sum of the sampler / statistics kernel times over all collected launches of the stateful path
+extern "C" int bpmf_hip_side_kernel_ms_sum(bpmf_hip_side *s, double *sample_ms, double *reduce_ms, int64_t *launches)
+{
+    if (!s) return fail(BPMF_HIP_EINVAL, "kernel_ms_sum: NULL");
+    { const int rc = settle_async(s); if (rc) return rc; }
+    if (sample_ms) *sample_ms = s->tot_sample_ms;
+    if (reduce_ms) *reduce_ms = s->tot_reduce_ms;
+    if (launches) *launches = s->n_launches;
     return BPMF_HIP_OK;
 }
 
@@ -802,6 +1065,17 @@ extern "C" int bpmf_hip_test_create(bpmf_hip_side *side, const int64_t *tcolptr,
     bpmf_hip_test *t = new (std::nothrow) bpmf_hip_test();
     if (!t) return fail(BPMF_HIP_ENOMEM, "test_create: out of host memory");
     t->side = side; t->nnz = nnz;
+    if (hipHostMalloc((void **)&t->h_res, 4 * sizeof(double), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&t->h_res_dev, t->h_res, 0) != hipSuccess) {
+        delete t;
+        return fail(BPMF_HIP_ENOMEM, "test_create: pinned result allocation failed");
+    }
+    memset(t->h_res, 0, 4 * sizeof(double));
+    if (hipMalloc((void **)&t->d_ticket, 64) != hipSuccess || hipMemset(t->d_ticket, 0, 64) != hipSuccess) {
+        (void)hipHostFree(t->h_res);
+        delete t;
+        return fail(BPMF_HIP_ENOMEM, "test_create: device allocation failed");
+    }
     t->nblocks = std::max<int64_t>(1, (nnz + 255) / 256);       // one lane per test rating
     const int64_t nw = t->nblocks;
     int rc;
@@ -820,8 +1094,9 @@ extern "C" int bpmf_hip_test_destroy(bpmf_hip_test *t)
     if (!t) return BPMF_HIP_OK;
     (void)hipSetDevice(t->side->ctx->device);
     (void)hipStreamSynchronize(t->side->ctx->stream);
-    void *ptrs[] = {t->d_tcol, t->d_trow, t->d_tval, t->d_pavg, t->d_pm2, t->d_partial};
+    void *ptrs[] = {t->d_tcol, t->d_trow, t->d_tval, t->d_pavg, t->d_pm2, t->d_partial, t->d_ticket};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (t->h_res) (void)hipHostFree(t->h_res);
     delete t;
     return BPMF_HIP_OK;
 }
@@ -831,34 +1106,31 @@ template <int K>
 void launch_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const bpmf_hip_side *other, int n)
 {
     bpmf_hip_ctx *c = self->ctx;
+    unsigned *flag = reinterpret_cast<unsigned *>(t->h_res_dev + 2);
+    const bool dist = c->comm && !self->bounds.empty();
+    // se | se_avg of this rank's test ratings: straight to the host, or -> all-reduce -> host
+    double *red = c->d_red + c->out_words;          // 2 spare words behind the sampler's blob
     hipLaunchKernelGGL(bpmf::k_predict<K>, dim3((unsigned)t->nblocks), dim3(256), 0, c->stream,
                        (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz,
                        (const double *)self->d_items, (const double *)other->d_items, self->from, self->mean_rating, n,
-                       t->d_pavg, t->d_pm2, t->d_partial);
-    unsigned *flag = reinterpret_cast<unsigned *>(c->h_out_dev + c->out_words - 1);
-    if (!(c->comm && !self->bounds.empty())) {
-        hipLaunchKernelGGL(bpmf::k_predict_final, dim3(1), dim3(256), 0, c->stream, (const double *)t->d_partial, t->nblocks,
-                           c->h_out_dev + c->out_words - 3, flag, ++c->seq);
-    } else {
-        // se | se_avg of this rank's test ratings -> all-reduce -> host
-        double *red = c->d_red + c->out_words;      // 2 spare words behind the sampler's blob
-        hipLaunchKernelGGL(bpmf::k_predict_final, dim3(1), dim3(256), 0, c->stream, (const double *)t->d_partial, t->nblocks,
-                           red, c->d_ticket + 8, 0u);
+                       t->d_pavg, t->d_pm2, t->d_partial, dist ? red : t->h_res_dev, t->d_ticket,
+                       dist ? t->d_ticket + 8 : flag, dist ? 0u : ++t->seq);
+    if (dist) {
         if (rccl()->AllReduce(red, red, 2, ncclDouble, ncclSum, c->comm, c->stream) != ncclSuccess) return;
-        hipLaunchKernelGGL(bpmf::k_publish, dim3(1), dim3(256), 0, c->stream, (const double *)red, c->h_out_dev + c->out_words - 3, 2, flag, ++c->seq);
+        hipLaunchKernelGGL(bpmf::k_publish, dim3(1), dim3(256), 0, c->stream, (const double *)red, t->h_res_dev, 2, flag, ++t->seq);
     }
 }
 }  // namespace
 
-extern "C" int bpmf_hip_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const bpmf_hip_side *other, int n,
-                                double *se, double *se_avg, int64_t *count)
+extern "C" int bpmf_hip_predict_launch(bpmf_hip_test *t, const bpmf_hip_side *self, const bpmf_hip_side *other, int n)
 {
-    if (!t || !self || !other || !se || !se_avg || !count) return fail(BPMF_HIP_EINVAL, "predict: NULL argument");
+    if (!t || !self || !other) return fail(BPMF_HIP_EINVAL, "predict: NULL argument");
     if (t->side != self) return fail(BPMF_HIP_EINVAL, "predict: test matrix belongs to another side");
     if (n < 0) return fail(BPMF_HIP_EINVAL, "predict: n < 0");
+    if (t->launched) return fail(BPMF_HIP_EINVAL, "predict_launch: previous launch not finished");
     bpmf_hip_ctx *c = self->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    if (t->nnz == 0 && !(c->comm && !self->bounds.empty())) { *se = 0.0; *se_avg = 0.0; *count = 0; return BPMF_HIP_OK; }
+    if (t->nnz == 0 && !(c->comm && !self->bounds.empty())) { t->launched = true; return BPMF_HIP_OK; }
     switch (c->K) {
     case 8: launch_predict<8>(t, self, other, n); break;
     case 16: launch_predict<16>(t, self, other, n); break;
@@ -867,11 +1139,41 @@ extern "C" int bpmf_hip_predict(bpmf_hip_test *t, const bpmf_hip_side *self, con
     default: return fail(BPMF_HIP_EINVAL, "predict: unsupported K");
     }
     HIP_TRY(hipGetLastError());
-    { const int rcw = wait_host(c); if (rcw) return rcw; }
-    *se = c->h_out[c->out_words - 3];
-    *se_avg = c->h_out[c->out_words - 2];
+    t->launched = true;
+    trace("predict: enqueued", self, n);
+    return BPMF_HIP_OK;
+}
+
+extern "C" int bpmf_hip_predict_finish(bpmf_hip_test *t, double *se, double *se_avg, int64_t *count)
+{
+    if (!t || !se || !se_avg || !count) return fail(BPMF_HIP_EINVAL, "predict_finish: NULL argument");
+    if (!t->launched) return fail(BPMF_HIP_EINVAL, "predict_finish: nothing launched");
+    t->launched = false;
+    bpmf_hip_side *self = t->side;
+    bpmf_hip_ctx *c = self->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const bool dist = c->comm && !self->bounds.empty();
+    if (t->nnz == 0 && !dist) { *se = 0.0; *se_avg = 0.0; *count = 0; return BPMF_HIP_OK; }
+    {   // spin on the sequence number published behind the two sums
+        unsigned *flag = reinterpret_cast<unsigned *>(t->h_res + 2);
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
+        for (unsigned spins = 0; !seen; ++spins) {
+            seen = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == t->seq;
+            if (seen) break;
+            __builtin_ia32_pause();
+            if ((spins & 0xFFFu) == 0xFFFu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05) break;
+        }
+        if (!seen) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != t->seq) return fail(BPMF_HIP_ENODEV, "device did not publish its results");
+        }
+    }
+    trace("predict: sums landed", self, 0);
+    *se = t->h_res[0];
+    *se_avg = t->h_res[1];
     *count = t->nnz;
-    if (c->comm && !self->bounds.empty()) {
+    if (dist) {
         if (t->global_nnz < 0) {                                   // once: number of test ratings over all ranks
             long long v = (long long)t->nnz, *d = reinterpret_cast<long long *>(c->d_red + c->out_words + 4);
             HIP_TRY(hipMemcpyAsync(d, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
@@ -883,6 +1185,15 @@ extern "C" int bpmf_hip_predict(bpmf_hip_test *t, const bpmf_hip_side *self, con
         *count = t->global_nnz;
     }
     return BPMF_HIP_OK;
+}
+
+extern "C" int bpmf_hip_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const bpmf_hip_side *other, int n,
+                                double *se, double *se_avg, int64_t *count)
+{
+    if (!se || !se_avg || !count) return fail(BPMF_HIP_EINVAL, "predict: NULL argument");
+    const int rc = bpmf_hip_predict_launch(t, self, other, n);
+    if (rc) return rc;
+    return bpmf_hip_predict_finish(t, se, se_avg, count);
 }
 
 extern "C" int bpmf_hip_test_get(bpmf_hip_test *t, double *pavg, double *pm2)

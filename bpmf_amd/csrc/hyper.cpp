@@ -85,44 +85,71 @@ bool invert(int K, const double *A_in, double *inv)
     return true;
 }
 
-// lower Cholesky factor from the lower triangle (sigma.llt(), c++/mvnormal.cpp:78)
+// lower Cholesky factor from the lower triangle (sigma.llt(), c++/mvnormal.cpp:78); right-looking,
+// every inner loop runs down a column (contiguous)
 bool cholesky_lower(int K, const double *S_in, double *L_out)
 {
-    Mat S{const_cast<double *>(S_in), K}, L{L_out, K};
     std::memset(L_out, 0, sizeof(double) * K * K);
+    Mat L{L_out, K};
+    for (int c = 0; c < K; ++c)
+        for (int r = c; r < K; ++r) L(r, c) = S_in[(size_t)c * K + r];
     for (int c = 0; c < K; ++c) {
-        double d = S(c, c);
-        for (int j = 0; j < c; ++j) d -= L(c, j) * L(c, j);
+        double *lc = &L(0, c);
+        const double d = lc[c];
         if (!(d > 0.0)) return false;
-        L(c, c) = std::sqrt(d);
-        for (int r = c + 1; r < K; ++r) {
-            double s = S(r, c);
-            for (int j = 0; j < c; ++j) s -= L(r, j) * L(c, j);
-            L(r, c) = s / L(c, c);
+        const double sd = std::sqrt(d);
+        lc[c] = sd;
+        for (int r = c + 1; r < K; ++r) lc[r] /= sd;
+        for (int j = c + 1; j < K; ++j) {
+            double *lj = &L(0, j);
+            const double f = lc[j];
+            for (int r = j; r < K; ++r) lj[r] -= lc[r] * f;
         }
     }
     return true;
 }
 
-thread_local char g_hyper_err[256];
-
 }  // namespace
 
 extern "C" void bpmf_hip_set_error_(const char *msg);   // capi.cpp
 
-extern "C" int bpmf_hyper_sample(int K, int64_t N, const double *cov, const double *Um, uint32_t counter,
+// The random part of the draw does not depend on cov: the unit-Wishart factor `au` (gamma and
+// normal draws of WishartUnitChol, c++/mvnormal.cpp:64-73, with df = K + N) and the K normals `z`
+// of MvNormalChol_prec (:58) consume the Philox stream `counter` in a data-independent way.  It
+// can therefore be produced ahead of time, before the sums of the half-iteration have arrived.
+extern "C" int bpmf_hyper_draws(int K, int64_t N, uint32_t counter, double *au_out, double *z_out)
+{
+    if (K <= 0 || K > 1024 || N <= 0 || !au_out || !z_out) {
+        bpmf_hip_set_error_("bpmf_hyper_draws: bad argument");
+        return BPMF_HIP_EINVAL;
+    }
+    bpmf::MicroPhilox rng(counter);                      // rng_set_pos(iter), c++/sample.cpp:349
+    const double nu_c = (double)((int64_t)K + N);          // nu + N with nu = df = K
+    std::memset(au_out, 0, sizeof(double) * K * K);
+    Mat AU{au_out, K};
+    for (int i = 0; i < K; ++i) {                         // WishartUnitChol (c++/mvnormal.cpp:64-73)
+        std::gamma_distribution<> gam(0.5 * (nu_c - i));
+        AU(i, i) = std::sqrt(2.0 * gam(rng));
+        skip_randn(rng, K - i - 1);                               // `VectorXd r = nrandn(...)`, drawn and dropped (:70)
+        for (int j = i + 1; j < K; ++j) AU(i, j) = randn(rng);
+    }
+    for (int i = 0; i < K; ++i) z_out[i] = randn(rng);    // nrandn(num_latent) of MvNormalChol_prec (:58)
+    return BPMF_HIP_OK;
+}
+
+// The part that needs cov: CondNormalWishart's posterior parameters, WishartChol's product and
+// the triangular solve of MvNormalChol_prec (c++/mvnormal.cpp:56-61,75-92,116-135), LambdaF.
+extern "C" int bpmf_hyper_finish(int K, int64_t N, const double *cov, const double *Um, const double *au, const double *z_in,
                                  double *mu, double *LambdaU, double *LambdaF)
 {
-    if (K <= 0 || K > 1024 || N <= 0 || !cov || !mu || !LambdaU || !LambdaF) {
-        bpmf_hip_set_error_("bpmf_hyper_sample: bad argument");
+    if (K <= 0 || K > 1024 || N <= 0 || !cov || !au || !z_in || !mu || !LambdaU || !LambdaF) {
+        bpmf_hip_set_error_("bpmf_hyper_finish: bad argument");
         return BPMF_HIP_EINVAL;
     }
     const size_t KK = (size_t)K * K;
-    bpmf::MicroPhilox rng(counter);                      // rng_set_pos(iter), c++/sample.cpp:349
-
     // fixed prior (c++/bpmf.h:80-96): mu0 = 0, kappa = b0 = 2, T = WI = I, nu = df = K
     const double kappa = 2.0, dN = (double)N;
-    std::vector<double> mu_m(K), mu_c(K), X(KK), Tc(KK), R(KK), au(KK, 0.0), z(K);
+    std::vector<double> mu_m(K), mu_c(K), X(KK), Tc(KK), R(KK), z(z_in, z_in + K);
     for (int i = 0; i < K; ++i) {
         const double um = Um ? Um[i] : 0.0;
         mu_m[i] = 0.0 - um;
@@ -137,29 +164,25 @@ extern "C" int bpmf_hyper_sample(int K, int64_t N, const double *cov, const doub
         bpmf_hip_set_error_("bpmf_hyper_sample: singular posterior scale matrix");
         return BPMF_HIP_ENUM;
     }
-    const double nu_c = (double)((int64_t)K + N);
-
-    // WishartChol (c++/mvnormal.cpp:75-92)
+    // WishartChol (c++/mvnormal.cpp:75-92): U = au * chol(T_c).matrixU()
     if (!cholesky_lower(K, Tc.data(), R.data())) {
         bpmf_hip_set_error_("bpmf_hyper_sample: posterior scale matrix not positive definite");
         return BPMF_HIP_ENUM;
     }
-    Mat AU{au.data(), K}, Rl{R.data(), K}, U{LambdaU, K}, F{LambdaF, K};
-    for (int i = 0; i < K; ++i) {                         // WishartUnitChol (c++/mvnormal.cpp:64-73)
-        std::gamma_distribution<> gam(0.5 * (nu_c - i));
-        AU(i, i) = std::sqrt(2.0 * gam(rng));
-        skip_randn(rng, K - i - 1);                               // `VectorXd r = nrandn(...)`, drawn and dropped (:70)
-        for (int j = i + 1; j < K; ++j) AU(i, j) = randn(rng);
+    Mat U{LambdaU, K}, F{LambdaF, K};
+    {   // U(i,j) = sum_{k=i..j} au(i,k) * matrixU(k,j), matrixU(k,j) = R(j,k); transposed copies make both factors contiguous in k
+        std::vector<double> aut(KK), rt(KK);
+        for (int k = 0; k < K; ++k)
+            for (int i = 0; i < K; ++i) { aut[(size_t)i * K + k] = au[(size_t)k * K + i]; rt[(size_t)i * K + k] = R[(size_t)k * K + i]; }
+        for (int j = 0; j < K; ++j)
+            for (int i = 0; i < K; ++i) {
+                double s = 0.0;
+                const double *a = &aut[(size_t)i * K], *r = &rt[(size_t)j * K];
+                for (int k = i; k <= j; ++k) s += a[k] * r[k];
+                U(i, j) = s;
+            }
     }
-    for (int j = 0; j < K; ++j)                           // U = au * chol.matrixU()
-        for (int i = 0; i < K; ++i) {
-            double s = 0.0;
-            for (int k = i; k <= j; ++k) s += AU(i, k) * Rl(j, k);
-            U(i, j) = s;
-        }
-
     // MvNormalChol_prec (c++/mvnormal.cpp:56-61)
-    for (int i = 0; i < K; ++i) z[i] = randn(rng);
     for (int i = K - 1; i >= 0; --i) {
         double s = z[i];
         for (int j = i + 1; j < K; ++j) s -= U(i, j) * z[j];
@@ -167,7 +190,6 @@ extern "C" int bpmf_hyper_sample(int K, int64_t N, const double *cov, const doub
     }
     const double sk = std::sqrt(kappa_c);
     for (int i = 0; i < K; ++i) mu[i] = z[i] / sk + mu_c[i];
-
     for (int j = 0; j < K; ++j)                           // LambdaF = LambdaU^T LambdaU (c++/bpmf.h:101)
         for (int i = 0; i < K; ++i) {
             double s = 0.0;
@@ -175,8 +197,20 @@ extern "C" int bpmf_hyper_sample(int K, int64_t N, const double *cov, const doub
             for (int k = 0; k <= m; ++k) s += U(k, i) * U(k, j);
             F(i, j) = s;
         }
-    (void)g_hyper_err;
     return BPMF_HIP_OK;
+}
+
+extern "C" int bpmf_hyper_sample(int K, int64_t N, const double *cov, const double *Um, uint32_t counter,
+                                 double *mu, double *LambdaU, double *LambdaF)
+{
+    if (K <= 0 || K > 1024 || N <= 0 || !cov || !mu || !LambdaU || !LambdaF) {
+        bpmf_hip_set_error_("bpmf_hyper_sample: bad argument");
+        return BPMF_HIP_EINVAL;
+    }
+    std::vector<double> au((size_t)K * K), z(K);
+    int rc = bpmf_hyper_draws(K, N, counter, au.data(), z.data());
+    if (rc) return rc;
+    return bpmf_hyper_finish(K, N, cov, Um, au.data(), z.data(), mu, LambdaU, LambdaF);
 }
 
 extern "C" void bpmf_cov_from_sums(int K, int64_t N, const double *sum, const double *prod, double *cov)

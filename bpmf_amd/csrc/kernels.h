@@ -753,14 +753,45 @@ __global__ __launch_bounds__(64, Geo<K>::WPS) void k_sample1(SampleArgs a)
 // ---------------------------------------------------------------------------
 // sum x, sum x x^T over the columns [c0, c1) of `items` (thread_vector reducers,
 // c++/sample.cpp:345-347,359-362,379-381).  Wave w takes a contiguous slice and
-// writes a partial in accumulator layout; k_colstats_final adds the partials
+// writes a partial in accumulator layout; the last waves to arrive add the partials
 // in wave order and unpacks to column-major prod | sum | norm.
 // ---------------------------------------------------------------------------
+// After its partial a wave takes a ticket; the last NFIN arrivers wait until every partial is
+// written and then each adds up slices of 16 outputs over all partials (4 lane groups split the
+// partials, combined in a fixed order), straight into `out`:
+//     prod[K*K] col-major | sum[K] | (unused) | fail word
+// and the last of those publishes `seq` to `flag` (the word a host thread spins on).  One kernel
+// instead of two: the whole statistics pass is dispatched in the few microseconds before the next
+// sampler floods the chip with workgroups, and its result is independent of the arrival order.
+// Hand-off idiom of this file (see k_sample): data another workgroup will read is written with
+// relaxed device-scope atomic stores (write-through, no cache flush), the writer waits for them
+// (s_waitcnt vmcnt(0)) and only then bumps a relaxed device-scope counter; readers use relaxed
+// device-scope atomic loads.  A release / acquire FENCE instead would write back and invalidate
+// the whole L2 once per workgroup.  Results for the host go out as system-scope relaxed stores to
+// pinned memory, the sequence number last.
+#define BPMF_RLX_SYSTEM __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
+__device__ __forceinline__ void publish_when_last(unsigned *ticket, unsigned nblocks, unsigned *flag_host, unsigned seq,
+                                                  unsigned *rearm = nullptr)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's result stores have landed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, BPMF_RLX_AGENT);
+        if (t == nblocks - 1) {
+            __hip_atomic_store(ticket, 0u, BPMF_RLX_AGENT);          // re-arm
+            if (rearm) __hip_atomic_store(rearm, 0u, BPMF_RLX_AGENT);
+            __hip_atomic_store(flag_host, seq, BPMF_RLX_SYSTEM);
+        }
+    }
+}
+
 template <int K>
 __global__ __launch_bounds__(64) void k_colstats(const double *__restrict__ items, int64_t c0, int64_t c1, int nwaves,
-                                                 double *__restrict__ partials)
+                                                 double *partials, const unsigned long long *__restrict__ fail_in,
+                                                 double *__restrict__ out, unsigned *ticket, unsigned *flag, unsigned seq)
 {
     constexpr int NT = Geo<K>::NT, NTRI = Geo<K>::NTRI, PART = Geo<K>::PART;
+    constexpr int NSLICE = (K * K + K + 15) / 16;
     const int lane = threadIdx.x, kq = lane >> 4, li = lane & 15;
     const int w = blockIdx.x;
     const int64_t n = c1 - c0;
@@ -768,112 +799,109 @@ __global__ __launch_bounds__(64) void k_colstats(const double *__restrict__ item
     const int64_t b = c0 + w * per;
     const int64_t e = (b + per < c1) ? b + per : c1;
 
-    d4 acc[NTRI];
-    double r[NT];
+    {
+        d4 acc[NTRI];
+        double r[NT];
 #pragma unroll
-    for (int t = 0; t < NTRI; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int t = 0; t < NTRI; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int t = 0; t < NT; ++t) r[t] = 0.0;
+        for (int t = 0; t < NT; ++t) r[t] = 0.0;
 
-    for (int64_t c = b; c < e; c += 8) {
-        double y[2][NT];
+        for (int64_t c = b; c < e; c += 8) {
+            double y[2][NT];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int64_t col = c + s * 4 + kq;
-            const bool ok = col < e;
+            for (int s = 0; s < 2; ++s) {
+                const int64_t col = c + s * 4 + kq;
+                const bool ok = col < e;
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                y[s][t] = (ok && (t * 16 + li < K)) ? items[(size_t)col * K + t * 16 + li] : 0.0;
+                for (int t = 0; t < NT; ++t)
+                    y[s][t] = (ok && (t * 16 + li < K)) ? items[(size_t)col * K + t * 16 + li] : 0.0;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) r[t] += y[s][t];
+                int tri = 0;
+#pragma unroll
+                for (int I = 0; I < NT; ++I)
+#pragma unroll
+                    for (int J = I; J < NT; ++J, ++tri) acc[tri] = mfma16(y[s][I], y[s][J], acc[tri]);
+            }
         }
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int t = 0; t < NT; ++t) {
+            r[t] += __shfl_xor(r[t], 16);
+            r[t] += __shfl_xor(r[t], 32);
+        }
+        double *p = partials + (size_t)w * PART;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) r[t] += y[s][t];
-            int tri = 0;
+        for (int t = 0; t < NTRI; ++t)
 #pragma unroll
-            for (int I = 0; I < NT; ++I)
+            for (int reg = 0; reg < 4; ++reg) __hip_atomic_store(&p[(t * 4 + reg) * 64 + lane], acc[t][reg], BPMF_RLX_AGENT);
+        if (lane < 16) {
 #pragma unroll
-                for (int J = I; J < NT; ++J, ++tri) acc[tri] = mfma16(y[s][I], y[s][J], acc[tri]);
+            for (int t = 0; t < NT; ++t) __hip_atomic_store(&p[NTRI * 256 + t * 16 + lane], r[t], BPMF_RLX_AGENT);
         }
     }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        r[t] += __shfl_xor(r[t], 16);
-        r[t] += __shfl_xor(r[t], 32);
-    }
-    double *p = partials + (size_t)w * PART;
-#pragma unroll
-    for (int t = 0; t < NTRI; ++t)
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) p[(t * 4 + reg) * 64 + lane] = acc[t][reg];
-    if (lane < 16) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) p[NTRI * 256 + t * 16 + lane] = r[t];
-    }
-}
 
-// out: prod[K*K] col-major | sum[K] | (unused) | fail word.  64 outputs per block, the
-// partials of the waves are split over 4 thread groups and combined in a fixed order.
-// The last block to finish (device-scope ticket) publishes the sequence number the host thread
-// spins on: every block makes its stores to the pinned result blob visible at system scope first.
-__device__ __forceinline__ void publish_when_last(unsigned *ticket, unsigned nblocks, unsigned *flag_host, unsigned seq)
-{
+    // arrival: the partial has landed before the ticket is taken
+    const int nfin = nwaves < NSLICE ? nwaves : NSLICE;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned tk = 0;
+    if (lane == 0) tk = __hip_atomic_fetch_add(ticket, 1u, BPMF_RLX_AGENT);
+    tk = __builtin_amdgcn_readfirstlane(tk);
+    if ((int)tk < nwaves - nfin) return;
+    const int f = (int)tk - (nwaves - nfin);                          // finisher 0 .. nfin-1
+    // every wave takes its ticket before it waits, so the count reaches nwaves as soon as all
+    // waves have run (those not yet resident get the slots the samplers' workgroups free)
+    if (lane == 0)
+        while (__hip_atomic_load(ticket, BPMF_RLX_AGENT) < (unsigned)nwaves) __builtin_amdgcn_s_sleep(1);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence_system();
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == nblocks - 1) {
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm
-            __threadfence_system();
-            __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-}
 
-template <int K>
-__global__ __launch_bounds__(256) void k_colstats_final(const double *__restrict__ partials, int nwaves,
-                                                        const unsigned long long *__restrict__ fail_in,
-                                                        double *__restrict__ out, unsigned *ticket,
-                                                        unsigned *flag_host, unsigned seq)
-{
-    constexpr int NT = Geo<K>::NT, NTRI = Geo<K>::NTRI, PART = Geo<K>::PART;
-    __shared__ double red[4][64];
-    const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + o;
-    double s = 0.0;
-    if (e < K * K + K) {
-        int off;
-        if (e < K * K) {
-            int i = e % K, j = e / K;
-            if (i > j) { const int t = i; i = j; j = t; }          // symmetric: read the upper tile
-            const int I = i >> 4, J = j >> 4;
-            const int tri = I * NT - (I * (I - 1)) / 2 + (J - I);
-            const int ii = i & 15, jj = j & 15;
-            off = (tri * 4 + (ii >> 2)) * 64 + (ii & 3) * 16 + jj;
-        } else {
-            off = NTRI * 256 + (e - K * K);
+    const int o = lane & 15, grp = lane >> 4;
+    for (int slice = f; slice < NSLICE; slice += nfin) {
+        const int eo = slice * 16 + o;
+        double s = 0.0;
+        if (eo < K * K + K) {
+            int off;
+            if (eo < K * K) {
+                int i = eo % K, j = eo / K;
+                if (i > j) { const int t = i; i = j; j = t; }      // symmetric: read the upper tile
+                const int I = i >> 4, J = j >> 4;
+                const int tri = I * NT - (I * (I - 1)) / 2 + (J - I);
+                const int ii = i & 15, jj = j & 15;
+                off = (tri * 4 + (ii >> 2)) * 64 + (ii & 3) * 16 + jj;
+            } else {
+                off = NTRI * 256 + (eo - K * K);
+            }
+            const int pw = (nwaves + 3) >> 2;
+            const int w0 = grp * pw, w1 = (w0 + pw < nwaves) ? w0 + pw : nwaves;
+            double acc[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+            for (int ww = w0; ww < w1; ww += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    v[u] = (ww + u < w1) ? __hip_atomic_load(&partials[(size_t)(ww + u) * PART + off], BPMF_RLX_AGENT) : 0.0;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc[u] += v[u];
+            }
+#pragma unroll
+            for (int h = 8; h >= 1; h >>= 1)
+#pragma unroll
+                for (int u = 0; u < h; ++u) acc[u] += acc[u + h];
+            s = acc[0];
         }
-        const int per = (nwaves + 3) >> 2;
-        const int w0 = grp * per, w1 = (w0 + per < nwaves) ? w0 + per : nwaves;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int w = w0;
-        for (; w + 3 < w1; w += 4) {
-            s0 += partials[(size_t)(w + 0) * PART + off];
-            s1 += partials[(size_t)(w + 1) * PART + off];
-            s2 += partials[(size_t)(w + 2) * PART + off];
-            s3 += partials[(size_t)(w + 3) * PART + off];
-        }
-        for (; w < w1; ++w) s0 += partials[(size_t)w * PART + off];
-        s = (s0 + s1) + (s2 + s3);
+        s += __shfl_xor(s, 16);                                      // (g0 + g1), (g2 + g3)
+        s += __shfl_xor(s, 32);                                      // fixed order: ((g0 + g1) + (g2 + g3))
+        if (grp == 0 && eo < K * K + K) __hip_atomic_store(&out[eo], s, BPMF_RLX_SYSTEM);
     }
-    red[grp][o] = s;
-    __syncthreads();
-    if (grp == 0 && e < K * K + K) out[e] = (red[0][o] + red[1][o]) + (red[2][o] + red[3][o]);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        out[K * K + K] = 0.0;
-        reinterpret_cast<unsigned long long *>(out)[K * K + K + 1] = *fail_in;
+    if (f == 0 && lane == 0) {
+        __hip_atomic_store(&out[K * K + K], 0.0, BPMF_RLX_SYSTEM);
+        __hip_atomic_store(&reinterpret_cast<unsigned long long *>(out)[K * K + K + 1], *fail_in, BPMF_RLX_SYSTEM);
     }
-    publish_when_last(ticket, gridDim.x, flag_host, seq);
+    publish_when_last(ticket + 1, (unsigned)nfin, flag, seq, ticket);
 }
 
 // ---------------------------------------------------------------------------
@@ -885,9 +913,12 @@ __global__ __launch_bounds__(256) void k_predict(const int32_t *__restrict__ tco
                                                  const double *__restrict__ tval, int64_t nnz,
                                                  const double *__restrict__ items, const double *__restrict__ other,
                                                  int64_t col_from, double mean, int n, double *__restrict__ pavg,
-                                                 double *__restrict__ pm2, double *__restrict__ partial)
+                                                 double *__restrict__ pm2, double *partial, double *__restrict__ out,
+                                                 unsigned *ticket, unsigned *flag, unsigned seq)
 {
     __shared__ double red[2][4];
+    __shared__ double fin[2][256];
+    __shared__ unsigned last;
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double se = 0.0, se_avg = 0.0;
     if (q < nnz) {
@@ -919,28 +950,36 @@ __global__ __launch_bounds__(256) void k_predict(const int32_t *__restrict__ tco
     if ((threadIdx.x & 63) == 0) { red[0][wv] = se; red[1][wv] = se_avg; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        partial[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        partial[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        __hip_atomic_store(&partial[2 * blockIdx.x], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), BPMF_RLX_AGENT);
+        __hip_atomic_store(&partial[2 * blockIdx.x + 1], (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]), BPMF_RLX_AGENT);
+        // the last block to arrive adds the block partials up (fixed-shape tree: the result does
+        // not depend on which block that is) and publishes the two sums
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, BPMF_RLX_AGENT);
+        last = (t == gridDim.x - 1) ? 1u : 0u;
     }
-}
-
-// fixed-shape tree over the block partials (deterministic)
-__global__ __launch_bounds__(256) void k_predict_final(const double *__restrict__ partial, int64_t nblocks, double *__restrict__ out,
-                                                       unsigned *flag_host, unsigned seq)
-{
-    __shared__ double red[2][256];
-    double se = 0.0, sa = 0.0;
-    for (int64_t w = threadIdx.x; w < nblocks; w += 256) { se += partial[2 * w]; sa += partial[2 * w + 1]; }
-    red[0][threadIdx.x] = se; red[1][threadIdx.x] = sa;
     __syncthreads();
-    for (int st = 128; st >= 1; st >>= 1) {
-        if ((int)threadIdx.x < st) { red[0][threadIdx.x] += red[0][threadIdx.x + st]; red[1][threadIdx.x] += red[1][threadIdx.x + st]; }
+    if (!last) return;
+    {
+        const int64_t nblocks = gridDim.x;
+        double a = 0.0, b = 0.0;
+        for (int64_t w = threadIdx.x; w < nblocks; w += 256) {
+            a += __hip_atomic_load(&partial[2 * w], BPMF_RLX_AGENT);
+            b += __hip_atomic_load(&partial[2 * w + 1], BPMF_RLX_AGENT);
+        }
+        fin[0][threadIdx.x] = a; fin[1][threadIdx.x] = b;
         __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        out[0] = red[0][0]; out[1] = red[1][0];
-        __threadfence_system();
-        __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);     // single block: publish directly
+        for (int st = 128; st >= 1; st >>= 1) {
+            if ((int)threadIdx.x < st) { fin[0][threadIdx.x] += fin[0][threadIdx.x + st]; fin[1][threadIdx.x] += fin[1][threadIdx.x + st]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(&out[0], fin[0][0], BPMF_RLX_SYSTEM);
+            __hip_atomic_store(&out[1], fin[1][0], BPMF_RLX_SYSTEM);
+            __hip_atomic_store(ticket, 0u, BPMF_RLX_AGENT);          // re-arm
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(flag, seq, BPMF_RLX_SYSTEM);
+        }
     }
 }
 
@@ -950,6 +989,44 @@ __global__ __launch_bounds__(256) void k_stage(const double *__restrict__ src_ho
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = src_host[i];
+}
+
+// Gate + staging of the stateful path.  The kernel is queued ahead of a sampler whose
+// hyper-parameters the host may still be computing: one lane polls a word in pinned host memory
+// until the host has stored `want` there (release; after it wrote the parameter blob), then the
+// block copies the blob into device memory.  The poll gives up after ~20 s of wall clock (host
+// gone): the sampler then runs on stale parameters and the host side reports the error.
+__global__ __launch_bounds__(64) void k_gate_stage(const unsigned *gate_host, unsigned want, const double *src_host,
+                                                   double *__restrict__ dst, int n)
+{
+    const int lane = threadIdx.x;
+    if (lane == 0) {
+        const unsigned long long t0 = wall_clock64();                 // 100 MHz
+        while (__hip_atomic_load(gate_host, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != want) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > 2000000000ull) break;
+        }
+    }
+    __syncthreads();
+    // uncached host memory, read after the acquire: 16-byte PCIe reads, four in flight per lane
+    // (one wave only: it is launched beside a sampler that fills the chip with single-wave workgroups).  n is even.
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 *src = reinterpret_cast<const d2 *>(src_host);
+    d2 *out = reinterpret_cast<d2 *>(dst);
+    const int n2 = n >> 1;
+    for (int base = 0; base < n2; base += 256) {
+        d2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * 64 + lane;
+            v[u] = (i < n2) ? __builtin_nontemporal_load(src + i) : d2{0.0, 0.0};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + u * 64 + lane;
+            if (i < n2) out[i] = v[u];
+        }
+    }
 }
 
 // multi-GPU: the all-reduced sums sit in device memory; copy them to the pinned result blob and

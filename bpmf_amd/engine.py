@@ -149,6 +149,12 @@ class HipEngine:
         _lib.check(self.lib.bpmf_hip_sys_state(side.handle, C.byref(it), C.byref(nrm), _ptr(cov), _ptr(mu), _ptr(LF), _ptr(LU)))
         return it.value, nrm.value, cov, mu, LF, LU
 
+    def kernel_ms_sum(self, side):
+        """(sampler ms, statistics ms, launches) summed over the half-iterations run through sys_sample."""
+        a = C.c_double(); b = C.c_double(); n = C.c_int64()
+        _lib.check(self.lib.bpmf_hip_side_kernel_ms_sum(side.handle, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
+
     def last_kernel_ms(self, side):
         a = C.c_float(); b = C.c_float()
         _lib.check(self.lib.bpmf_hip_side_last_kernel_ms(side.handle, C.byref(a), C.byref(b)))
@@ -166,6 +172,14 @@ class HipEngine:
     def predict(self, test, side, other, n):
         se = C.c_double(); sea = C.c_double(); cnt = C.c_int64()
         _lib.check(self.lib.bpmf_hip_predict(test[0], side.handle, other.handle, int(n), C.byref(se), C.byref(sea), C.byref(cnt)))
+        return se.value, sea.value, cnt.value
+
+    def predict_launch(self, test, side, other, n):
+        _lib.check(self.lib.bpmf_hip_predict_launch(test[0], side.handle, other.handle, int(n)))
+
+    def predict_finish(self, test):
+        se = C.c_double(); sea = C.c_double(); cnt = C.c_int64()
+        _lib.check(self.lib.bpmf_hip_predict_finish(test[0], C.byref(se), C.byref(sea), C.byref(cnt)))
         return se.value, sea.value, cnt.value
 
     def test_get(self, test):

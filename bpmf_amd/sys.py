@@ -140,6 +140,21 @@ class Sys:
         self.rmse = math.sqrt(se / nump) if nump else float("nan")
         self.rmse_avg = math.sqrt(se_avg / nump) if nump else float("nan")
 
+    def predict_launch(self, other):
+        """First half of predict(): enqueue the evaluation behind the samplers.  The caller may start
+        the next half-iteration before predict_finish() (software pipelining of main()'s loop)."""
+        n = 0 if self.iter < Sys.burnin else self.iter - Sys.burnin
+        if self.test is not None:
+            self.engine.predict_launch(self.test, self.side, other.side, n)
+
+    def predict_finish(self):
+        if self.test is None:
+            return
+        se, se_avg, nump = self.engine.predict_finish(self.test)
+        self.num_predict = nump
+        self.rmse = math.sqrt(se / nump) if nump else float("nan")
+        self.rmse_avg = math.sqrt(se_avg / nump) if nump else float("nan")
+
     # -- Sys::print, c++/sample.cpp:101-107 --------------------------------------
     def format_line(self, items_per_sec, ratings_per_sec, norm_u, norm_m):
         phase = "Burnin" if self.iter < Sys.burnin else "Sampling"

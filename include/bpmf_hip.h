@@ -142,10 +142,13 @@ BPMF_API int bpmf_hip_sample_side_finish(bpmf_hip_side *self, double *sum_out, d
  * rng_set_pos(iter) + hp.sample(num(), sum = 0, cov) on the host (:349-350), the column loop
  * on the device, and cov = (prod - sum sum^T/N)/(N-1), norm (:379-384).  iter starts at -1
  * (:113), cov at 0 (:188).  Only for a side that owns all its columns (NO_COMM); a shard uses
- * bpmf_hip_sample_side and all-reduces the sums.  When the call returns, a host worker thread of
- * the context starts drawing this side's NEXT hyper-parameters (they depend only on the cov just
- * formed and on iter+1), so that they are ready when the caller comes back after sampling the
- * other side; this is invisible to the caller except in time. */
+ * bpmf_hip_sample_side and all-reduces the sums (or gives the context a communicator, see above).
+ * The call is asynchronous inside: it enqueues the sampler and the column statistics and returns;
+ * a host worker thread of the context collects the sums when they land, forms cov, draws this
+ * side's NEXT hyper-parameters (they depend only on that cov and on iter+1) and stages them on the
+ * device, while the caller samples the other side.  The only observable differences from a blocking
+ * call: bpmf_hip_sys_state / the side's next bpmf_hip_sys_sample wait for that collection, and an
+ * error of the half-iteration (BPMF_HIP_ECHOL) is reported by whichever of them comes first. */
 BPMF_API int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, double alpha);
 /* Sys::iter, Sys::norm, Sys::cov, hp.mu, hp.LambdaF, hp.LambdaU (c++/bpmf.h:86-89,139,222-223);
  * any output pointer may be NULL */
@@ -165,6 +168,11 @@ BPMF_API int bpmf_hip_test_create(bpmf_hip_side *side, const int64_t *tcolptr, c
 BPMF_API int bpmf_hip_test_destroy(bpmf_hip_test *test);
 BPMF_API int bpmf_hip_predict(bpmf_hip_test *test, const bpmf_hip_side *self, const bpmf_hip_side *other, int n,
                      double *se, double *se_avg, int64_t *count);
+/* the same in two halves: _launch enqueues the kernels behind the samplers, _finish waits for the
+ * two sums.  A caller may enqueue the next half-iteration in between (it is ordered behind the
+ * prediction kernels on the device), which hides the host round trip of the RMSE evaluation. */
+BPMF_API int bpmf_hip_predict_launch(bpmf_hip_test *test, const bpmf_hip_side *self, const bpmf_hip_side *other, int n);
+BPMF_API int bpmf_hip_predict_finish(bpmf_hip_test *test, double *se, double *se_avg, int64_t *count);
 /* Pavg / Pm2 in the nnz order of the slice passed to _test_create (Pavg.sdm /
  * Pm2.sdm outputs, c++/bpmf.cpp:229-230) */
 BPMF_API int bpmf_hip_test_get(bpmf_hip_test *test, double *pavg_host, double *pm2_host);
@@ -180,6 +188,13 @@ BPMF_API int bpmf_hip_test_get(bpmf_hip_test *test, double *pavg_host, double *p
  * (upper Cholesky factor, K x K), LambdaF = LambdaU^T LambdaU. */
 BPMF_API int bpmf_hyper_sample(int K, int64_t N, const double *cov, const double *Um, uint32_t counter,
                       double *mu, double *LambdaU, double *LambdaF);
+/* The same draw in two steps, so that the expensive, cov-independent part can be produced ahead of
+ * time: _draws consumes the whole Philox stream `counter` (unit-Wishart factor au[K*K], upper, and
+ * the K normals z of MvNormalChol_prec), _finish does the algebra once cov is known.
+ * bpmf_hyper_sample(...) == _draws followed by _finish. */
+BPMF_API int bpmf_hyper_draws(int K, int64_t N, uint32_t counter, double *au, double *z);
+BPMF_API int bpmf_hyper_finish(int K, int64_t N, const double *cov, const double *Um, const double *au, const double *z,
+                               double *mu, double *LambdaU, double *LambdaF);
 /* cov = (prod - sum sum^T / N) / (N - 1)  (c++/sample.cpp:383-384) */
 BPMF_API void bpmf_cov_from_sums(int K, int64_t N, const double *sum, const double *prod, double *cov);
 /* the per-column normal stream, for tests: out[i] = i-th randn() after
@@ -188,6 +203,9 @@ BPMF_API void bpmf_randn_stream(uint32_t counter, int n, double *out);
 /* the same n draws produced by the device sampler (n <= 128) */
 BPMF_API int bpmf_hip_randn_stream(bpmf_hip_ctx *ctx, uint32_t counter, int n, double *out);
 
+/* sums of the sampler / statistics kernel times (ms, HIP events on their streams) over all
+ * half-iterations of the stateful path collected so far, and their number */
+BPMF_API int bpmf_hip_side_kernel_ms_sum(bpmf_hip_side *side, double *sample_ms, double *reduce_ms, int64_t *launches);
 /* kernel timing of the last _sample_side on this side, in milliseconds, from
  * HIP events recorded on the context's stream (for bench.py's roofline line) */
 BPMF_API int bpmf_hip_side_last_kernel_ms(bpmf_hip_side *side, float *sample_ms, float *reduce_ms);

@@ -200,6 +200,32 @@ def test_full_run_ml100k_matches_oracle(oracle, hip_engine_factory, sampler_mode
     assert rel_err(res["U"], ref["U"]) < 1e-6 and rel_err(res["V"], ref["V"]) < 1e-6
 
 
+def test_pipelined_predict_is_the_same_chain(hip_engine_factory):
+    """predict_launch / predict_finish around the next half-iteration (the loop bench.py times)
+    gives the RMSE trace and factors of the plain loop: the device runs the kernels in program order."""
+    import bpmf_amd
+    from bpmf_amd.sys import Sys
+    K = 16
+    M, Mt, T, Tt, nu, nm = util.ml100k()
+    eng = hip_engine_factory(K)
+    ref = bpmf_amd.gibbs(eng, M, Mt, T, nu, nm, nsims=8, burnin=3)
+    Sys.nsims, Sys.burnin, Sys.alpha = 8, 3, 2.0
+    movies = Sys("movs", eng, M, nm, nu, T=T)
+    users = Sys("users", eng, Mt, nu, nm)
+    rmse, rmse_avg = [], []
+    for i in range(8):
+        movies.sample(users)
+        if i > 0:
+            movies.predict_finish(); rmse.append(movies.rmse); rmse_avg.append(movies.rmse_avg)
+        users.sample(movies)
+        movies.predict_launch(users)
+    movies.predict_finish(); rmse.append(movies.rmse); rmse_avg.append(movies.rmse_avg)
+    assert rmse == ref["rmse"] and rmse_avg == ref["rmse_avg"]
+    assert np.array_equal(users.items(), ref["U"]) or rel_err(users.items(), ref["U"]) < 1e-12
+    with pytest.raises(RuntimeError):
+        movies.predict_finish()                       # nothing launched
+
+
 def test_posterior_moments_of_one_column(hip_engine_factory):
     """Statistical check that does not involve the oracle: many draws of the same column
     (different iter => different streams) have mean Lambda*^-1 b and covariance Lambda*^-1."""

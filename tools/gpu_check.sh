@@ -15,9 +15,9 @@ import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 rows = list(db.execute("select name, start, end from kernels order by start"))
 mid = len(rows) // 2
-while 'k_stage' not in rows[mid][0]: mid += 1
+while 'stage' not in rows[mid][0]: mid += 1
 t0 = rows[mid][1]
-for r in rows[mid:mid + 16]: print("%-50s start=%9.1f us dur=%8.1f us" % (r[0][:50], (r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3))
+for r in rows[mid:mid + 24]: print("%-50s start=%9.1f us dur=%8.1f us" % (r[0][:50], (r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3))
 PY
       rm -rf $O/prof ;;
 esac
