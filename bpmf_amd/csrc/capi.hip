@@ -157,6 +157,7 @@ struct bpmf_hip_ctx {
     double *d_red = nullptr;
     unsigned seq = 0;                    // value the next publishing kernel writes behind its results
     unsigned *d_ticket = nullptr;        // arrival counters of k_colstats' waves (stateless path)
+    double *d_zero = nullptr;            // K zeros: the row padding slots of a ragged rating group gather from
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 };
 
@@ -227,8 +228,15 @@ struct bpmf_hip_test {
 
 namespace {
 
+// doubles in the partial of one chunk of a heavy column: the larger of the two accumulator layouts
+// (16x16x4 tiles of k_sample, 4x4x4 blocks of k_sample1 for K <= 32)
 template <int K>
-size_t part_words() { return (size_t)bpmf::Geo<K>::PART; }
+size_t part_words()
+{
+    size_t w = (size_t)bpmf::Geo<K>::PART;
+    if constexpr (K <= 32) w = std::max(w, (size_t)bpmf::Geo44<K>::PART);
+    return w;
+}
 
 size_t part_words_rt(int K)
 {
@@ -377,6 +385,8 @@ extern "C" int bpmf_hip_ctx_create(int device, int K, void *stream, bpmf_hip_ctx
     HIP_TRY(hipMalloc((void **)&c->d_red, (c->out_words + 8) * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&c->d_ticket, 64));
     HIP_TRY(hipMemset(c->d_ticket, 0, 64));
+    HIP_TRY(hipMalloc((void **)&c->d_zero, 1024));
+    HIP_TRY(hipMemset(c->d_zero, 0, 1024));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     *out = c;
     return BPMF_HIP_OK;
@@ -393,6 +403,7 @@ extern "C" int bpmf_hip_ctx_destroy(bpmf_hip_ctx *c)
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
+    if (c->d_zero) (void)hipFree(c->d_zero);
     if (c->d_red) (void)hipFree(c->d_red);
     if (c->comm && rccl()) (void)rccl()->CommDestroy(c->comm);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -553,6 +564,7 @@ int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, do
     a.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
     a.mean_rating = self->mean_rating; a.alpha = alpha; a.iter_plus_1 = (uint32_t)(iter + 1);
     a.ablate = c->ablate;
+    a.zero_row = c->d_zero;
     if (self->nwork > 0 && self->mode == 1) {
         hipLaunchKernelGGL(k_sample1<K>, dim3(self->nwork), dim3(64), 0, st, a);
     } else if (self->nwork > 0) {

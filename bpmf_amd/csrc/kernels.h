@@ -57,6 +57,32 @@ __device__ __forceinline__ d4 mfma16(double a, double b, d4 c)
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products per instruction.  Lane l = 16 k + 4 b + x:
+//   A[b][i=x][k], B[b][k][j=x] one double each;  D[b][i][j] sits in lane 16 i + 4 b + j.
+// (Found by brute force on gfx950: tools/probes/layout44_probe.hip.)  On MI355X it sustains
+// ~18 cycles per instruction and SIMD (28 flop/cycle) against ~105 cycles for the 16x16x4 shape
+// (19.5 flop/cycle) -- tools/probes/mfma44_probe.hip -- and its 4x4 granularity wastes nothing on
+// the diagonal of a symmetric Gram.
+__device__ __forceinline__ double mfma44(double a, double b, double c)
+{
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
+// Gram of the one-column-per-wave sampler (K <= 32) on the 4x4x4 shape.  The four blocks of an
+// instruction take four DIFFERENT ratings each (16 ratings per instruction) and the same 4x4
+// block (g, g') of the Gram; lane (k, b, x) feeds rating slot s = 4 k + b with the latent index
+// idx(g, x) = 8 (g / 2) + 2 x + (g & 1)  (so that one 16-byte load per lane brings the operands of
+// two groups).  The NB = NG (NG + 1) / 2 upper blocks are NB accumulator registers per lane, each
+// holding the contribution of the lane's b; the four b are added once per column (DPP row rotates).
+template <int K>
+struct Geo44 {
+    static constexpr int NG = K / 4;                      // groups of 4 latent indices
+    static constexpr int NB = NG * (NG + 1) / 2;          // upper blocks incl. diagonal
+    static constexpr int NL = K / 8;                      // 16-byte loads per lane and 16 ratings
+    static constexpr int PART = (NB + NG) * 64;           // doubles in one partial of a chunked column
+    __host__ __device__ static constexpr int idx(int g, int x) { return 8 * (g >> 1) + 2 * x + (g & 1); }
+};
+
 // 1/sqrt(d) to ~1 ulp: v_rsq_f64 (2^-23 relative) + one third-order (Halley) correction,
 // y = y0 (1 + e/2 + 3e^2/8) with e = 1 - d y0^2, error ~ e^3: 6 dependent instructions
 // instead of the ~25 of sqrt followed by a divide.  d <= 0 or NaN gives NaN/inf, which
@@ -103,6 +129,7 @@ struct SampleArgs {
     int nwork;
     // factors
     const double *other_items;  // K x nrows
+    const double *zero_row;     // K zeros (gather target of the padding slots of a ragged group of ratings)
     double *items;              // K x ncols
     int64_t col_from;           // global id of local column 0
     // per-call
@@ -112,7 +139,7 @@ struct SampleArgs {
     double mean_rating;
     double alpha;
     uint32_t iter_plus_1;
-    uint32_t ablate;            // profiling only (BPMF_HIP_ABLATE): 1 = skip the factorisation, 2 = skip the Gram
+    uint32_t ablate;            // profiling only (BPMF_HIP_ABLATE): 1 = skip the factorisation, 2 = skip the Gram, 4 = gather from 64 hot rows only
 };
 
 // ---------------------------------------------------------------------------
@@ -163,7 +190,7 @@ __device__ __forceinline__ void draw_normals(uint32_t counter, int n, double *ou
 template <int K>
 __device__ __forceinline__ void gram_chunk(const int32_t *__restrict__ rowidx, const double *__restrict__ vals, int len,
                                            const double *__restrict__ other, double mean, double alpha,
-                                           d4 (&acc)[Geo<K>::NTRI], double (&r)[Geo<K>::NT], int lane)
+                                           d4 (&acc)[Geo<K>::NTRI], double (&r)[Geo<K>::NT], int lane, int rowmask = -1)
 {
     constexpr int NT = Geo<K>::NT;
     const int kq = lane >> 4, li = lane & 15;
@@ -190,7 +217,7 @@ __device__ __forceinline__ void gram_chunk(const int32_t *__restrict__ rowidx, c
                 const int row = __shfl(ri, src);
                 ww[s] = __shfl(wv, src);
                 const bool ok = row >= 0;
-                const double *col = other + (size_t)(ok ? row : 0) * K + li;
+                const double *col = other + (size_t)(ok ? (row & rowmask) : 0) * K + li;   // rowmask: profiling only (ablate 4)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) yy[s][t] = (ok && (t * 16 + li < K)) ? col[t * 16] : 0.0;
             }
@@ -227,6 +254,134 @@ __device__ __forceinline__ void gram_chunk(const int32_t *__restrict__ rowidx, c
     for (int t = 0; t < NT; ++t) {
         r[t] += __shfl_xor(r[t], 16);
         r[t] += __shfl_xor(r[t], 32);
+    }
+}
+
+// x + (x rotated by n lanes inside each row of 16 lanes), through DPP moves of the two halves
+template <int CTRL>
+__device__ __forceinline__ double row_ror_add(double x)
+{
+    const long long v = __builtin_bit_cast(long long, x);
+    const int lo = (int)v, hi = (int)(v >> 32);
+    const int rlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    const int rhi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    const long long rv = ((long long)rhi << 32) | (unsigned int)rlo;
+    return x + __builtin_bit_cast(double, rv);
+}
+
+// first two 64-rating index blocks of a chunk: issued by the caller ahead of the normal draw, whose
+// Philox / log / sqrt arithmetic then runs in the shadow of these loads
+struct IdxBlock { int ri; double wv; };
+__device__ __forceinline__ IdxBlock load_idx_block(const int32_t *__restrict__ rowidx, const double *__restrict__ vals, int q, int len,
+                                                   double mean, double alpha)
+{
+    IdxBlock r;
+    r.ri = (q < len) ? rowidx[q] : -1;
+    r.wv = (q < len) ? (vals[q] - mean) * alpha : 0.0;                          // c++/sample.cpp:256
+    return r;
+}
+
+template <int K>
+__device__ __forceinline__ void gram_chunk44(const int32_t *__restrict__ rowidx, const double *__restrict__ vals, int len,
+                                             const double *__restrict__ other, const double *__restrict__ zero_row,
+                                             double mean, double alpha, IdxBlock cur, IdxBlock nxt,
+                                             double (&acc)[Geo44<K>::NB], double (&rr)[Geo44<K>::NG], int lane, int rowmask = -1)
+{
+    using G = Geo44<K>;
+    constexpr int NG = G::NG, NL = G::NL;
+    typedef double dd2 __attribute__((ext_vector_type(2)));
+    const int slot = lane >> 2, x = lane & 3;
+    // 64 ratings per coalesced index block (lane l holds rating b0 + l, loaded two blocks ahead);
+    // the four 16-rating groups of a block fetch their row ids with a cross-lane permute.  The
+    // gathers run one group ahead of the MFMAs in two alternating operand sets, across block
+    // boundaries too; padding slots of a ragged last group gather a row of zeros.
+    auto gather = [&](const IdxBlock &ib, int gg, dd2 (&yy)[NL], double &ww) {
+        const int src = gg * 16 + slot;
+        const int row = __shfl(ib.ri, src);
+        ww = __shfl(ib.wv, src);
+        const double *base = (row >= 0) ? other + (size_t)(row & rowmask) * K : zero_row;
+        const dd2 *p = reinterpret_cast<const dd2 *>(base + 2 * x);
+#pragma unroll
+        for (int h = 0; h < NL; ++h) yy[h] = p[4 * h];
+    };
+    auto contract = [&](const dd2 (&yy)[NL], double ww) {
+        double R[NG];
+#pragma unroll
+        for (int h = 0; h < NL; ++h) { R[2 * h] = yy[h].x; R[2 * h + 1] = yy[h].y; }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) rr[g] = fma(R[g], ww, rr[g]);
+        int blk = 0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int g2 = g; g2 < NG; ++g2, ++blk) acc[blk] = mfma44(R[g], R[g2], acc[blk]);
+    };
+    if (len <= 0) return;
+    dd2 yA[NL], yB[NL];
+    double wA, wB = 0.0;
+    gather(cur, 0, yA, wA);
+    int b0 = 0;
+    // full blocks that have a successor: straight-line code, the operand sets simply alternate
+    for (; b0 + 64 < len; b0 += 64) {
+        IdxBlock nn;                                                             // index block after the next one
+        nn.ri = -1; nn.wv = 0.0;
+        if (b0 + 128 < len) nn = load_idx_block(rowidx, vals, b0 + 128 + lane, len, mean, alpha);   // wave-uniform
+        gather(cur, 1, yB, wB);
+        contract(yA, wA);
+        gather(cur, 2, yA, wA);
+        contract(yB, wB);
+        gather(cur, 3, yB, wB);
+        contract(yA, wA);
+        gather(nxt, 0, yA, wA);                                                  // first group of the next block
+        contract(yB, wB);
+        cur = nxt;
+        nxt = nn;
+    }
+    // last block: 1..4 groups
+    const int ng = (len - b0 + 15) >> 4;
+    if (ng > 1) gather(cur, 1, yB, wB);
+    contract(yA, wA);
+    if (ng > 1) {
+        if (ng > 2) gather(cur, 2, yA, wA);
+        contract(yB, wB);
+        if (ng > 2) {
+            if (ng > 3) gather(cur, 3, yB, wB);
+            contract(yA, wA);
+            if (ng > 3) contract(yB, wB);
+        }
+    }
+}
+
+// The four b of every accumulator are added (fixed order: (b + b^2) + the same of b^1), then the
+// lanes b = 0 write the full symmetric G into the K x LD LDS matrix finish_single reads, and
+// the rhs sums (also over the four k) into sb.
+template <int K>
+__device__ __forceinline__ void assemble44(double (&acc)[Geo44<K>::NB], double (&rr)[Geo44<K>::NG], double *sA, double *sb,
+                                           int LD, int lane)
+{
+    using G = Geo44<K>;
+    constexpr int NG = G::NG;
+    const int i = lane >> 4, b = (lane >> 2) & 3, j = lane & 3;
+    int blk = 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int g2 = g; g2 < NG; ++g2, ++blk) {
+            double v = row_ror_add<0x128>(acc[blk]);                              // row_ror:8
+            v = row_ror_add<0x124>(v);                                            // row_ror:4
+            if (b == 0) {
+                const int gi = G::idx(g, i), gj = G::idx(g2, j);
+                sA[gi * LD + gj] = v;
+                if (g != g2) sA[gj * LD + gi] = v;
+            }
+        }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        double v = row_ror_add<0x128>(rr[g]);
+        v = row_ror_add<0x124>(v);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane < 4) sb[G::idx(g, lane)] = v;
     }
 }
 
@@ -451,7 +606,7 @@ __global__ __launch_bounds__(64, Geo<K>::WPS) void k_sample(SampleArgs a)
 #pragma unroll
         for (int t = 0; t < NT; ++t) r[t] = 0.0;
 
-        gram_chunk<K>(a.rowidx + p0, a.vals + p0, (a.ablate & 2u) ? 0 : len, a.other_items, a.mean_rating, a.alpha, acc, r, lane);
+        gram_chunk<K>(a.rowidx + p0, a.vals + p0, (a.ablate & 2u) ? 0 : len, a.other_items, a.mean_rating, a.alpha, acc, r, lane, (a.ablate & 4u) ? 63 : -1);
 
         if (a.ablate & 1u) {                                       // timing ablation: keep the Gram live, skip the rest
             double v = r[0];
@@ -512,6 +667,9 @@ struct Geo1 {
     static constexpr int FLD = K + 2;
     static constexpr int LANES = K * S;
     static constexpr int LDS_WORDS = K * FLD + 4 * K + 2;
+    // waves per SIMD k_sample1 is compiled for: the 4x4x4 Gram of K = 32 keeps 36 + 8 accumulators
+    // and two operand sets in registers (<= 168 VGPRs)
+    static constexpr int WPS = K == 32 ? 3 : (K < 32 ? 4 : 2);
 };
 
 // ---------------------------------------------------------------------------
@@ -527,17 +685,44 @@ struct Geo1 {
 // to the rhs column with the two y values (wave-uniform) in registers.  Backward solve, normal
 // draw and the coalesced 8K-byte store follow.
 // ---------------------------------------------------------------------------
+// `assemble(sA, sb, LD, lane)` writes the full symmetric G (K x LD, row-major) and the rhs sums
+// into LDS: from 16x16x4 accumulator tiles (assemble16) or from the 4x4x4 blocks (assemble44).
 template <int K>
-__device__ __forceinline__ void finish_single(const SampleArgs &a, int col_local, const d4 (&acc)[Geo<K>::NTRI],
-                                              const double (&r)[Geo<K>::NT], double *lds, int lane_in, bool have_z)
+__device__ __forceinline__ void assemble16(const d4 (&acc)[Geo<K>::NTRI], const double (&r)[Geo<K>::NT], double *sA, double *sb,
+                                           int LD, int lane)
+{
+    constexpr int NT = Geo<K>::NT;
+    const int kq = lane >> 4, li = lane & 15;
+    int tri = 0;
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int J = I; J < NT; ++J, ++tri)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int gi = I * 16 + kq + 4 * reg, gj = J * 16 + li;
+                if (gi < K && gj < K) {
+                    sA[gi * LD + gj] = acc[tri][reg];
+                    if (I != J) sA[gj * LD + gi] = acc[tri][reg];
+                }
+            }
+    if (kq == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (t * 16 + li < K) sb[t * 16 + li] = r[t];
+    }
+}
+
+template <int K, typename Assemble>
+__device__ __forceinline__ void finish_single(const SampleArgs &a, int col_local, double *lds, int lane_in, bool have_z,
+                                              Assemble &&assemble)
 {
     int lane = lane_in;
     using G = Geo1<K>;
-    constexpr int NT = Geo<K>::NT, LD = G::FLD, S = G::S, NP = G::NP, QN = G::QN, M = G::M;
+    constexpr int LD = G::FLD, S = G::S, NP = G::NP, QN = G::QN, M = G::M;
     // The caller runs this inside its persistent work loop: make the lane id opaque here so that
     // LLVM does not hoist every per-step address and lane mask out of that loop (and spill them).
     asm volatile("" : "+v"(lane));
-    const int kq = lane >> 4, li = lane & 15;
     double *sA = lds, *sb = lds + K * LD, *sz = sb + K, *sdummy = sz + K, *szero = sdummy + 2 * K;
     const int64_t idx = a.col_from + col_local;
 
@@ -556,28 +741,9 @@ __device__ __forceinline__ void finish_single(const SampleArgs &a, int col_local
     }
     const double lmu = a.Lmu[i];
 
-    // G (upper tiles, accumulator layout) -> LDS, mirrored (c++/sample.cpp:297); rhs partial sums -> LDS
-    {
-        int tri = 0;
-#pragma unroll
-        for (int I = 0; I < NT; ++I)
-#pragma unroll
-            for (int J = I; J < NT; ++J, ++tri)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int gi = I * 16 + kq + 4 * reg, gj = J * 16 + li;
-                    if (gi < K && gj < K) {
-                        sA[gi * LD + gj] = acc[tri][reg];
-                        if (I != J) sA[gj * LD + gi] = acc[tri][reg];
-                    }
-                }
-        if (kq == 0) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (t * 16 + li < K) sb[t * 16 + li] = r[t];
-        }
-        if (lane == 0) szero[0] = 0.0;
-    }
+    // G -> LDS, mirrored (c++/sample.cpp:297); rhs sums -> LDS
+    assemble(sA, sb, LD, lane);
+    if (lane == 0) szero[0] = 0.0;
     __syncthreads();
 
     // Lambda* = LambdaF + alpha * G (:298); b = LambdaF*mu + rr (:285,:256)
@@ -683,9 +849,8 @@ __device__ __forceinline__ void finish_single(const SampleArgs &a, int col_local
 // matrix with only a few thousand columns per side needs.
 // ---------------------------------------------------------------------------
 template <int K>
-__global__ __launch_bounds__(64, Geo<K>::WPS) void k_sample1(SampleArgs a)
+__global__ __launch_bounds__(64, Geo1<K>::WPS) void k_sample1(SampleArgs a)
 {
-    constexpr int NT = Geo<K>::NT, NTRI = Geo<K>::NTRI, PART = Geo<K>::PART;
     __shared__ __attribute__((aligned(16))) double lds[Geo1<K>::LDS_WORDS];
     const int lane = threadIdx.x;
     const int w = blockIdx.x;
@@ -694,60 +859,115 @@ __global__ __launch_bounds__(64, Geo<K>::WPS) void k_sample1(SampleArgs a)
     const int len = a.wi_len[w];
     const int mc = a.wi_mc[w];
 
-    d4 acc[NTRI];
-    double r[NT];
-#pragma unroll
-    for (int t = 0; t < NTRI; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int t = 0; t < NT; ++t) r[t] = 0.0;
+    // the first index blocks of the chunk are requested before anything else
+    const int glen = (a.ablate & 2u) ? 0 : len;
+    const IdxBlock ib0 = load_idx_block(a.rowidx + p0, a.vals + p0, lane, glen, a.mean_rating, a.alpha);
+    const IdxBlock ib1 = load_idx_block(a.rowidx + p0, a.vals + p0, 64 + lane, glen, a.mean_rating, a.alpha);
 
     // whole column in one item: its normals do not depend on the Gram -- draw them first so that
     // the Philox / log / sqrt chain is off the critical path between the last MFMA and the factorisation
     if (mc < 0 && !(a.ablate & 1u))
         draw_normals<K>(sample_counter<K>(a.col_from + col, a.iter_plus_1), K, lds + K * Geo1<K>::FLD + K, lane);
 
-    gram_chunk<K>(a.rowidx + p0, a.vals + p0, (a.ablate & 2u) ? 0 : len, a.other_items, a.mean_rating, a.alpha, acc, r, lane);
+    if constexpr (K <= 32) {
+        // Gram on the 4x4x4 MFMA shape: NB block accumulators + NG rhs sums per lane
+        using G4 = Geo44<K>;
+        constexpr int NB = G4::NB, NG = G4::NG, PART = G4::PART;
+        double acc[NB], rr[NG];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) acc[t] = 0.0;
+#pragma unroll
+        for (int t = 0; t < NG; ++t) rr[t] = 0.0;
+        gram_chunk44<K>(a.rowidx + p0, a.vals + p0, glen, a.other_items, a.zero_row, a.mean_rating, a.alpha, ib0, ib1, acc, rr, lane,
+                        (a.ablate & 4u) ? 63 : -1);
+        if (a.ablate & 1u) {
+            double v = rr[0];
+#pragma unroll
+            for (int t = 0; t < NB; ++t) v += acc[t];
+            if (mc < 0 && lane < K) a.items[(size_t)(a.col_from + col) * K + lane] = v;
+            return;
+        }
+        if (mc >= 0) {
+            // chunk of a heavy column: park the accumulators; whichever chunk arrives last adds them up
+            const int nch = a.mc_nchunks[mc];
+            double *pbase = a.partials + (size_t)a.mc_slot0[mc] * PART;
+            double *p = pbase + (size_t)a.wi_chunk[w] * PART;
+#pragma unroll
+            for (int t = 0; t < NB; ++t) __hip_atomic_store(&p[t * 64 + lane], acc[t], BPMF_RLX_AGENT);
+#pragma unroll
+            for (int t = 0; t < NG; ++t) __hip_atomic_store(&p[(NB + t) * 64 + lane], rr[t], BPMF_RLX_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(&a.mc_count[mc], 1u, BPMF_RLX_AGENT);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if ((int)t != nch - 1) return;
+            if (lane == 0) __hip_atomic_store(&a.mc_count[mc], 0u, BPMF_RLX_AGENT);
+#pragma unroll
+            for (int t2 = 0; t2 < NB; ++t2) acc[t2] = 0.0;
+#pragma unroll
+            for (int t2 = 0; t2 < NG; ++t2) rr[t2] = 0.0;
+            for (int ch = 0; ch < nch; ++ch) {
+                const double *pc = pbase + (size_t)ch * PART;
+#pragma unroll
+                for (int t2 = 0; t2 < NB; ++t2) acc[t2] += __hip_atomic_load(&pc[t2 * 64 + lane], BPMF_RLX_AGENT);
+#pragma unroll
+                for (int t2 = 0; t2 < NG; ++t2) rr[t2] += __hip_atomic_load(&pc[(NB + t2) * 64 + lane], BPMF_RLX_AGENT);
+            }
+        }
+        finish_single<K>(a, col, lds, lane, mc < 0,
+                         [&](double *sA, double *sb, int LD, int ln) { assemble44<K>(acc, rr, sA, sb, LD, ln); });
+    } else {
+        constexpr int NT = Geo<K>::NT, NTRI = Geo<K>::NTRI, PART = Geo<K>::PART;
+        d4 acc[NTRI];
+        double r[NT];
+#pragma unroll
+        for (int t = 0; t < NTRI; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) r[t] = 0.0;
+        gram_chunk<K>(a.rowidx + p0, a.vals + p0, (a.ablate & 2u) ? 0 : len, a.other_items, a.mean_rating, a.alpha, acc, r, lane, (a.ablate & 4u) ? 63 : -1);
 
-    if (a.ablate & 1u) {
-        double v = r[0];
+        if (a.ablate & 1u) {
+            double v = r[0];
 #pragma unroll
-        for (int t = 0; t < NTRI; ++t) v += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
-        if (mc < 0 && lane < K) a.items[(size_t)(a.col_from + col) * K + lane] = v;
-        return;
-    }
-    if (mc >= 0) {
-        const int nch = a.mc_nchunks[mc];
-        double *pbase = a.partials + (size_t)a.mc_slot0[mc] * PART;
-        double *p = pbase + (size_t)a.wi_chunk[w] * PART;
-#pragma unroll
-        for (int t = 0; t < NTRI; ++t)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) __hip_atomic_store(&p[(t * 4 + reg) * 64 + lane], acc[t][reg], BPMF_RLX_AGENT);
-        if (lane < 16) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) __hip_atomic_store(&p[NTRI * 256 + t * 16 + lane], r[t], BPMF_RLX_AGENT);
+            for (int t = 0; t < NTRI; ++t) v += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+            if (mc < 0 && lane < K) a.items[(size_t)(a.col_from + col) * K + lane] = v;
+            return;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned t = 0;
-        if (lane == 0) t = __hip_atomic_fetch_add(&a.mc_count[mc], 1u, BPMF_RLX_AGENT);
-        t = __builtin_amdgcn_readfirstlane(t);
-        if ((int)t != nch - 1) return;
-        if (lane == 0) __hip_atomic_store(&a.mc_count[mc], 0u, BPMF_RLX_AGENT);
+        if (mc >= 0) {
+            const int nch = a.mc_nchunks[mc];
+            double *pbase = a.partials + (size_t)a.mc_slot0[mc] * PART;
+            double *p = pbase + (size_t)a.wi_chunk[w] * PART;
 #pragma unroll
-        for (int t2 = 0; t2 < NTRI; ++t2) acc[t2] = d4{0.0, 0.0, 0.0, 0.0};
+            for (int t = 0; t < NTRI; ++t)
 #pragma unroll
-        for (int t2 = 0; t2 < NT; ++t2) r[t2] = 0.0;
-        for (int ch = 0; ch < nch; ++ch) {
-            const double *pc = pbase + (size_t)ch * PART;
+                for (int reg = 0; reg < 4; ++reg) __hip_atomic_store(&p[(t * 4 + reg) * 64 + lane], acc[t][reg], BPMF_RLX_AGENT);
+            if (lane < 16) {
 #pragma unroll
-            for (int t2 = 0; t2 < NTRI; ++t2)
+                for (int t = 0; t < NT; ++t) __hip_atomic_store(&p[NTRI * 256 + t * 16 + lane], r[t], BPMF_RLX_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(&a.mc_count[mc], 1u, BPMF_RLX_AGENT);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if ((int)t != nch - 1) return;
+            if (lane == 0) __hip_atomic_store(&a.mc_count[mc], 0u, BPMF_RLX_AGENT);
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) acc[t2][reg] += __hip_atomic_load(&pc[(t2 * 4 + reg) * 64 + lane], BPMF_RLX_AGENT);
+            for (int t2 = 0; t2 < NTRI; ++t2) acc[t2] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int t2 = 0; t2 < NT; ++t2) r[t2] += __hip_atomic_load(&pc[NTRI * 256 + t2 * 16 + (lane & 15)], BPMF_RLX_AGENT);
+            for (int t2 = 0; t2 < NT; ++t2) r[t2] = 0.0;
+            for (int ch = 0; ch < nch; ++ch) {
+                const double *pc = pbase + (size_t)ch * PART;
+#pragma unroll
+                for (int t2 = 0; t2 < NTRI; ++t2)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) acc[t2][reg] += __hip_atomic_load(&pc[(t2 * 4 + reg) * 64 + lane], BPMF_RLX_AGENT);
+#pragma unroll
+                for (int t2 = 0; t2 < NT; ++t2) r[t2] += __hip_atomic_load(&pc[NTRI * 256 + t2 * 16 + (lane & 15)], BPMF_RLX_AGENT);
+            }
         }
+        finish_single<K>(a, col, lds, lane, mc < 0,
+                         [&](double *sA, double *sb, int LD, int ln) { assemble16<K>(acc, r, sA, sb, LD, ln); });
     }
-    finish_single<K>(a, col, acc, r, lds, lane, mc < 0);
 }
 
 // ---------------------------------------------------------------------------
