@@ -3,7 +3,7 @@
 # (separate --pmc passes, as MI355X_MICROARCH.md prescribes).  Output: gpurun_out/profiles/
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 R=${1:-r01}
-O=gpurun_out/profiles; mkdir -p $O
+O=gpurun_out/profiles; mkdir -p $O; rm -f $O/${R}_pmc_sampler.txt
 CMD="python bench.py --no-cpu-baseline"
 rm -rf /tmp/prof_kt; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o kt -- $CMD > $O/${R}_bench_under_rocprof.json 2> /tmp/prof_kt.err
 find /tmp/prof_kt -name "*kernel_stats.csv" -exec cp {} $O/${R}_kernel_stats.csv \;
