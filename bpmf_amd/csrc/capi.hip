@@ -608,14 +608,13 @@ int launch_stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double
                            failp, out_host_dev, ticket, flag, seq);
     } else {
         // local sums into a device blob, all-reduce them (cov is then formed once from the GLOBAL
-        // sums: SURVEY Q19), min-reduce the failed-column word, publish to the host
+        // sums: SURVEY Q19) together with the failed-column word, publish to the host
         Rccl *R = rccl();
         hipLaunchKernelGGL(k_colstats<K>, dim3(self->nstat_waves), dim3(64), 0, st,
                            (const double *)self->d_items, self->from, self->to, self->nstat_waves, self->d_stat_partials,
                            failp, c->d_red, ticket, ticket + 8, 0u);
-        NCCL_TRY(R->AllReduce(c->d_red, c->d_red, (size_t)K * K + K, ncclDouble, ncclSum, c->comm, st));
-        NCCL_TRY(R->AllReduce(c->d_red + (size_t)K * K + K + 1, c->d_red + (size_t)K * K + K + 1, 1, ncclUint64, ncclMin, c->comm, st));
-        hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, st, (const double *)c->d_red, out_host_dev, K * K + K + 2, flag, seq);
+        NCCL_TRY(R->AllReduce(c->d_red, c->d_red, (size_t)K * K + K + 1, ncclDouble, ncclSum, c->comm, st));   // prod | sum | failed-column word
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, st, (const double *)c->d_red, out_host_dev, K * K + K + 1, flag, seq, K * K + K);
     }
     return 0;
 }
@@ -1129,7 +1128,7 @@ void launch_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const bpmf_hip_
                        dist ? t->d_ticket + 8 : flag, dist ? 0u : ++t->seq);
     if (dist) {
         if (rccl()->AllReduce(red, red, 2, ncclDouble, ncclSum, c->comm, c->stream) != ncclSuccess) return;
-        hipLaunchKernelGGL(bpmf::k_publish, dim3(1), dim3(256), 0, c->stream, (const double *)red, t->h_res_dev, 2, flag, ++t->seq);
+        hipLaunchKernelGGL(bpmf::k_publish, dim3(1), dim3(256), 0, c->stream, (const double *)red, t->h_res_dev, 2, flag, ++t->seq, -1);
     }
 }
 }  // namespace

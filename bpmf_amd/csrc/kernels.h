@@ -1118,8 +1118,11 @@ __global__ __launch_bounds__(64) void k_colstats(const double *__restrict__ item
         if (grp == 0 && eo < K * K + K) __hip_atomic_store(&out[eo], s, BPMF_RLX_SYSTEM);
     }
     if (f == 0 && lane == 0) {
-        __hip_atomic_store(&out[K * K + K], 0.0, BPMF_RLX_SYSTEM);
-        __hip_atomic_store(&reinterpret_cast<unsigned long long *>(out)[K * K + K + 1], *fail_in, BPMF_RLX_SYSTEM);
+        // failed column: as the u64 word of the blob, and as a double (0 = none, id + 1 otherwise)
+        // that survives a SUM all-reduce of the blob over the ranks
+        const unsigned long long fw = *fail_in;
+        __hip_atomic_store(&out[K * K + K], (fw == ~0ull) ? 0.0 : (double)(fw + 1ull), BPMF_RLX_SYSTEM);
+        __hip_atomic_store(&reinterpret_cast<unsigned long long *>(out)[K * K + K + 1], fw, BPMF_RLX_SYSTEM);
     }
     publish_when_last(ticket + 1, (unsigned)nfin, flag, seq, ticket);
 }
@@ -1250,11 +1253,17 @@ __global__ __launch_bounds__(64) void k_gate_stage(const unsigned *gate_host, un
 }
 
 // multi-GPU: the all-reduced sums sit in device memory; copy them to the pinned result blob and
-// publish the sequence number behind them
+// publish the sequence number behind them.  fail_at >= 0: src[fail_at] is the summed "failed
+// column + 1" word of k_colstats (0 = no rank failed; with several failing ranks the id is only a
+// witness that something failed) and becomes the u64 word behind it.
 __global__ __launch_bounds__(256) void k_publish(const double *__restrict__ src, double *__restrict__ dst_host, int n,
-                                                 unsigned *flag_host, unsigned seq)
+                                                 unsigned *flag_host, unsigned seq, int fail_at)
 {
     for (int i = threadIdx.x; i < n; i += 256) dst_host[i] = src[i];
+    if (fail_at >= 0 && threadIdx.x == 0) {
+        const double d = src[fail_at];
+        reinterpret_cast<unsigned long long *>(dst_host)[fail_at + 1] = (d == 0.0) ? ~0ull : (unsigned long long)(d - 1.0);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence_system();
