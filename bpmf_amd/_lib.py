@@ -15,6 +15,8 @@ _SIGNATURES = {
     "bpmf_hip_last_error": (C.c_char_p, []),
     "bpmf_hip_abi_version": (C.c_int, []),
     "bpmf_hip_supports_k": (C.c_int, [C.c_int]),
+    "bpmf_hip_supports": (C.c_int, [C.c_int, C.c_int]),
+    "bpmf_hip_ctx_create_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "bpmf_hip_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "bpmf_hip_ctx_destroy": (C.c_int, [C.c_void_p]),
     "bpmf_hip_ctx_sync": (C.c_int, [C.c_void_p]),

@@ -25,6 +25,7 @@
 
 #include "../../include/bpmf_hip.h"
 #include "kernels.h"
+#include "kernels_f32.h"
 
 namespace {
 
@@ -138,6 +139,7 @@ struct TraceAtExit { ~TraceAtExit() { if (g_trace_on) trace_dump(); } } g_trace_
 struct bpmf_hip_ctx {
     int device = 0;
     int K = 0;
+    int dtype = BPMF_HIP_F64;            // arithmetic of the column loop and storage of the factors (BPMF_HIP_F32: K = 128)
     hipStream_t stream = nullptr;        // S0: samplers, exchange, predict
     std::vector<bpmf_hip_side *> sides;  // stateful sides with a statistics stream of their own (for ctx_sync)
     bool own_stream = false;
@@ -282,7 +284,9 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     // factorises C = 64/K columns per wave has the higher throughput (k_sample).
     const int mode_env = env_int("BPMF_HIP_MODE", -1);
     s->mode = mode_env >= 0 ? mode_env : ((K <= 32 && nloc < 65536) ? 1 : 0);
-    int chunk = env_int("BPMF_HIP_CHUNK", 0);
+    const bool f32 = s->ctx->dtype == BPMF_HIP_F32;
+    if (f32) s->mode = 2;                                // one workgroup per column (k_sample_wg), no chunking
+    int chunk = f32 ? (1 << 30) : env_int("BPMF_HIP_CHUNK", 0);
     if (chunk <= 0) {
         const int64_t simds = (int64_t)s->ctx->num_cu * 4;
         // mode 1: ~1.5 chunks of work per SIMD (measured best on the ML-1M shape: 512-768);
@@ -340,6 +344,12 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
         std::vector<unsigned> zeros(std::max<size_t>(mc_slot0.size(), 8 * 32), 0u);
         if ((rc = dev_upload(&s->d_mc_count, zeros.data(), std::max<size_t>(mc_slot0.size(), 1)))) return rc;
     }
+    if (f32) {
+        // column statistics: <= 128 workgroups, each writing one partial of K*K + K doubles
+        s->nstat_waves = (int)std::max<int64_t>(1, std::min<int64_t>((nloc + 15) / 16, 128));
+        if ((rc = dev_upload<double>(&s->d_stat_partials, nullptr, (size_t)s->nstat_waves * ((size_t)K * K + K)))) return rc;
+        return 0;
+    }
     const size_t pw = part_words_rt(K);
     if ((rc = dev_upload<double>(&s->d_partials, nullptr, (size_t)slots * pw))) return rc;
     // column statistics: one wave per 64+ columns, at most 2 waves per CU
@@ -355,11 +365,32 @@ extern "C" const char *bpmf_hip_last_error(void) { return g_err.c_str(); }
 extern "C" int bpmf_hip_abi_version(void) { return BPMF_HIP_ABI_VERSION; }
 extern "C" int bpmf_hip_supports_k(int K) { return K == 8 || K == 16 || K == 32 || K == 64; }
 
+extern "C" int bpmf_hip_supports(int K, int dtype)
+{
+    if (dtype == BPMF_HIP_F64) return bpmf_hip_supports_k(K);
+    if (dtype == BPMF_HIP_F32) return K == 128;
+    return 0;
+}
+
+static int ctx_create_impl(int device, int K, int dtype, void *stream, bpmf_hip_ctx **out);
+
 extern "C" int bpmf_hip_ctx_create(int device, int K, void *stream, bpmf_hip_ctx **out)
+{
+    return ctx_create_impl(device, K, BPMF_HIP_F64, stream, out);
+}
+
+extern "C" int bpmf_hip_ctx_create_ex(int device, int K, int dtype, void *stream, bpmf_hip_ctx **out)
+{
+    return ctx_create_impl(device, K, dtype, stream, out);
+}
+
+static int ctx_create_impl(int device, int K, int dtype, void *stream, bpmf_hip_ctx **out)
 {
     if (!out) return fail(BPMF_HIP_EINVAL, "ctx_create: out is NULL");
     *out = nullptr;
-    if (!bpmf_hip_supports_k(K)) return fail(BPMF_HIP_EINVAL, "ctx_create: unsupported num_latent " + std::to_string(K) + " (8, 16, 32, 64)");
+    if (!bpmf_hip_supports(K, dtype))
+        return fail(BPMF_HIP_EINVAL, "ctx_create: unsupported num_latent / dtype " + std::to_string(K) + " / " + std::to_string(dtype) +
+                                         " (fp64: 8, 16, 32, 64; fp32: 128)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(BPMF_HIP_ENODEV, "no HIP device available (the BPMF hot path has no CPU fallback)");
@@ -367,7 +398,7 @@ extern "C" int bpmf_hip_ctx_create(int device, int K, void *stream, bpmf_hip_ctx
     HIP_TRY(hipSetDevice(device));
     bpmf_hip_ctx *c = new (std::nothrow) bpmf_hip_ctx();
     if (!c) return fail(BPMF_HIP_ENOMEM, "ctx_create: out of host memory");
-    c->device = device; c->K = K;
+    c->device = device; c->K = K; c->dtype = dtype;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -454,9 +485,10 @@ static int side_create_common(bpmf_hip_ctx *ctx, int64_t ncols, int64_t nrows, i
         if ((rc = dev_upload(&s->d_rowidx, rowidx, (size_t)nnz)) || (rc = dev_upload(&s->d_vals, vals, (size_t)nnz))) { bpmf_hip_side_destroy(s); return rc; }
     }
     const size_t words = (size_t)ctx->K * (size_t)ncols;
-    hipError_t e = hipMalloc((void **)&s->d_items, words * sizeof(double));
+    const size_t esz = ctx->dtype == BPMF_HIP_F32 ? sizeof(float) : sizeof(double);
+    hipError_t e = hipMalloc((void **)&s->d_items, words * esz);
     if (e != hipSuccess) { bpmf_hip_side_destroy(s); return fail(BPMF_HIP_ENOMEM, "side_create: factor matrix allocation failed"); }
-    e = hipMemset(s->d_items, 0, words * sizeof(double));           // items().setZero(), c++/sample.cpp:185
+    e = hipMemset(s->d_items, 0, words * esz);                      // items().setZero(), c++/sample.cpp:185
     if (e != hipSuccess) { bpmf_hip_side_destroy(s); return fail(BPMF_HIP_ENODEV, "side_create: memset failed"); }
     if ((rc = build_schedule(s, colptr))) { bpmf_hip_side_destroy(s); return rc; }
     *out = s;
@@ -507,11 +539,12 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
     return BPMF_HIP_OK;
 }
 
-extern "C" double *bpmf_hip_side_items_dev(bpmf_hip_side *s) { return s ? s->d_items : nullptr; }
+extern "C" double *bpmf_hip_side_items_dev(bpmf_hip_side *s) { return (s && s->ctx->dtype == BPMF_HIP_F64) ? s->d_items : nullptr; }
 
 extern "C" int bpmf_hip_side_bind_items(bpmf_hip_side *s, double *items_dev)
 {
     if (!s || !items_dev) return fail(BPMF_HIP_EINVAL, "bind_items: NULL");
+    if (s->ctx->dtype != BPMF_HIP_F64) return fail(BPMF_HIP_EINVAL, "bind_items: fp64 contexts only");
     HIP_TRY(hipSetDevice(s->ctx->device));
     (void)settle_async(s);
     HIP_TRY(hipStreamSynchronize(s->ctx->stream));
@@ -526,7 +559,14 @@ extern "C" int bpmf_hip_side_get_items(bpmf_hip_side *s, double *h)
     if (!s || !h) return fail(BPMF_HIP_EINVAL, "get_items: NULL");
     HIP_TRY(hipSetDevice(s->ctx->device));
     HIP_TRY(hipStreamSynchronize(s->ctx->stream));
-    HIP_TRY(hipMemcpy(h, s->d_items, (size_t)s->ctx->K * s->ncols * sizeof(double), hipMemcpyDeviceToHost));
+    const size_t words = (size_t)s->ctx->K * s->ncols;
+    if (s->ctx->dtype == BPMF_HIP_F32) {                            // fp32 factors: widen on the host
+        std::vector<float> tmp(words);
+        HIP_TRY(hipMemcpy(tmp.data(), s->d_items, words * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < words; ++i) h[i] = (double)tmp[i];
+        return BPMF_HIP_OK;
+    }
+    HIP_TRY(hipMemcpy(h, s->d_items, words * sizeof(double), hipMemcpyDeviceToHost));
     return BPMF_HIP_OK;
 }
 
@@ -537,7 +577,14 @@ extern "C" int bpmf_hip_side_set_items(bpmf_hip_side *s, const double *h)
     { const int rc = settle_async(s); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(s->ctx->stream));
     if (s->saux) HIP_TRY(hipStreamSynchronize(s->saux));
-    HIP_TRY(hipMemcpy(s->d_items, h, (size_t)s->ctx->K * s->ncols * sizeof(double), hipMemcpyHostToDevice));
+    const size_t words = (size_t)s->ctx->K * s->ncols;
+    if (s->ctx->dtype == BPMF_HIP_F32) {
+        std::vector<float> tmp(words);
+        for (size_t i = 0; i < words; ++i) tmp[i] = (float)h[i];
+        HIP_TRY(hipMemcpy(s->d_items, tmp.data(), words * sizeof(float), hipMemcpyHostToDevice));
+        return BPMF_HIP_OK;
+    }
+    HIP_TRY(hipMemcpy(s->d_items, h, words * sizeof(double), hipMemcpyHostToDevice));
     return BPMF_HIP_OK;
 }
 
@@ -554,6 +601,18 @@ int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, do
 {
     using namespace bpmf;
     bpmf_hip_ctx *c = self->ctx;
+    if constexpr (K == 128) {                           // fp32 large-K path: one workgroup per column
+        SampleArgsF f;
+        f.rowidx = self->d_rowidx; f.vals = self->d_vals;
+        f.wi_col = self->d_wi_col; f.wi_p0 = self->d_wi_p0; f.wi_len = self->d_wi_len;
+        f.other_items = reinterpret_cast<const float *>(other->d_items); f.items = reinterpret_cast<float *>(self->d_items);
+        f.col_from = self->from;
+        f.LambdaF = d_in; f.Lmu = d_in + (size_t)K * K;
+        f.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
+        f.mean_rating = self->mean_rating; f.alpha = alpha; f.iter_plus_1 = (uint32_t)(iter + 1);
+        if (self->nwork > 0) hipLaunchKernelGGL(k_sample_wg<K>, dim3(self->nwork), dim3(256), 0, st, f);
+        return 0;
+    } else {
     SampleArgs a;
     a.rowidx = self->d_rowidx; a.vals = self->d_vals;
     a.wi_col = self->d_wi_col; a.wi_p0 = self->d_wi_p0; a.wi_len = self->d_wi_len; a.wi_mc = self->d_wi_mc; a.wi_chunk = self->d_wi_chunk;
@@ -574,6 +633,7 @@ int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, do
         hipLaunchKernelGGL(k_sample<K>, dim3(grid), dim3(64), 0, st, a);
     }
     return 0;
+    }
 }
 
 template <int K>
@@ -581,6 +641,8 @@ int launch_exchange(bpmf_hip_side *self, hipStream_t st)
 {
     bpmf_hip_ctx *c = self->ctx;
     if (!(c->comm != nullptr && !self->bounds.empty())) return 0;
+    if constexpr (K == 128) return fail(BPMF_HIP_EINVAL, "the fp32 path is single-GPU for now");
+    else {
     // every rank broadcasts the range it just sampled (= all-gather-v of disjoint, uneven
     // ranges), in place in the replicated factor matrix, on the sampler's stream
     Rccl *R = rccl();
@@ -594,6 +656,7 @@ int launch_exchange(bpmf_hip_side *self, hipStream_t st)
     }
     NCCL_TRY(R->GroupEnd());
     return 0;
+    }
 }
 
 template <int K>
@@ -602,6 +665,14 @@ int launch_stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double
     using namespace bpmf;
     bpmf_hip_ctx *c = self->ctx;
     const unsigned long long *failp = (const unsigned long long *)(d_in + (size_t)K * K + K);
+    if constexpr (K == 128) {                           // fp32 factors, fp64 sums (single GPU)
+        if (c->comm != nullptr && !self->bounds.empty()) return fail(BPMF_HIP_EINVAL, "the fp32 path is single-GPU for now");
+        hipLaunchKernelGGL(k_colstats_f32<K>, dim3(self->nstat_waves), dim3(256), 0, st, reinterpret_cast<const float *>(self->d_items),
+                           self->from, self->to, self->nstat_waves, self->d_stat_partials);
+        hipLaunchKernelGGL(k_colstats_f32_final<K>, dim3((K * K + K + 255) / 256), dim3(256), 0, st,
+                           (const double *)self->d_stat_partials, self->nstat_waves, failp, out_host_dev, ticket, flag, seq);
+        return 0;
+    } else {
     if (!(c->comm != nullptr && !self->bounds.empty())) {
         hipLaunchKernelGGL(k_colstats<K>, dim3(self->nstat_waves), dim3(64), 0, st,
                            (const double *)self->d_items, self->from, self->to, self->nstat_waves, self->d_stat_partials,
@@ -617,6 +688,7 @@ int launch_stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double
         hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, st, (const double *)c->d_red, out_host_dev, K * K + K + 1, flag, seq, K * K + K);
     }
     return 0;
+    }
 }
 
 #define BPMF_DISPATCH_K(K_, CALL)                                                    \
@@ -626,6 +698,7 @@ int launch_stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double
         case 16: { constexpr int KK = 16; return CALL; }                             \
         case 32: { constexpr int KK = 32; return CALL; }                             \
         case 64: { constexpr int KK = 64; return CALL; }                             \
+        case 128: { constexpr int KK = 128; return CALL; }                           \
         default: return fail(BPMF_HIP_EINVAL, "unsupported K");                     \
         }                                                                            \
     }()
@@ -1121,6 +1194,14 @@ void launch_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const bpmf_hip_
     const bool dist = c->comm && !self->bounds.empty();
     // se | se_avg of this rank's test ratings: straight to the host, or -> all-reduce -> host
     double *red = c->d_red + c->out_words;          // 2 spare words behind the sampler's blob
+    if constexpr (K == 128) {
+        hipLaunchKernelGGL(bpmf::k_predict_f32<K>, dim3((unsigned)t->nblocks), dim3(256), 0, c->stream,
+                           (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz,
+                           reinterpret_cast<const float *>(self->d_items), reinterpret_cast<const float *>(other->d_items), self->from,
+                           self->mean_rating, n, t->d_pavg, t->d_pm2, t->d_partial, t->h_res_dev, t->d_ticket, flag, ++t->seq);
+        (void)red; (void)dist;
+        return;
+    } else {
     hipLaunchKernelGGL(bpmf::k_predict<K>, dim3((unsigned)t->nblocks), dim3(256), 0, c->stream,
                        (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz,
                        (const double *)self->d_items, (const double *)other->d_items, self->from, self->mean_rating, n,
@@ -1129,6 +1210,7 @@ void launch_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const bpmf_hip_
     if (dist) {
         if (rccl()->AllReduce(red, red, 2, ncclDouble, ncclSum, c->comm, c->stream) != ncclSuccess) return;
         hipLaunchKernelGGL(bpmf::k_publish, dim3(1), dim3(256), 0, c->stream, (const double *)red, t->h_res_dev, 2, flag, ++t->seq, -1);
+    }
     }
 }
 }  // namespace
@@ -1147,6 +1229,7 @@ extern "C" int bpmf_hip_predict_launch(bpmf_hip_test *t, const bpmf_hip_side *se
     case 16: launch_predict<16>(t, self, other, n); break;
     case 32: launch_predict<32>(t, self, other, n); break;
     case 64: launch_predict<64>(t, self, other, n); break;
+    case 128: launch_predict<128>(t, self, other, n); break;
     default: return fail(BPMF_HIP_EINVAL, "predict: unsupported K");
     }
     HIP_TRY(hipGetLastError());

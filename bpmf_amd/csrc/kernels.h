@@ -908,10 +908,13 @@ __global__ __launch_bounds__(64, Geo1<K>::WPS) void k_sample1(SampleArgs a)
             for (int t2 = 0; t2 < NG; ++t2) rr[t2] = 0.0;
             for (int ch = 0; ch < nch; ++ch) {
                 const double *pc = pbase + (size_t)ch * PART;
+                double tmp[NB + NG];                                  // all loads of a chunk in flight, then the adds (chunk order)
 #pragma unroll
-                for (int t2 = 0; t2 < NB; ++t2) acc[t2] += __hip_atomic_load(&pc[t2 * 64 + lane], BPMF_RLX_AGENT);
+                for (int t2 = 0; t2 < NB + NG; ++t2) tmp[t2] = __hip_atomic_load(&pc[t2 * 64 + lane], BPMF_RLX_AGENT);
 #pragma unroll
-                for (int t2 = 0; t2 < NG; ++t2) rr[t2] += __hip_atomic_load(&pc[(NB + t2) * 64 + lane], BPMF_RLX_AGENT);
+                for (int t2 = 0; t2 < NB; ++t2) acc[t2] += tmp[t2];
+#pragma unroll
+                for (int t2 = 0; t2 < NG; ++t2) rr[t2] += tmp[NB + t2];
             }
         }
         finish_single<K>(a, col, lds, lane, mc < 0,
@@ -1237,7 +1240,8 @@ __global__ __launch_bounds__(64) void k_gate_stage(const unsigned *gate_host, un
     const d2 *src = reinterpret_cast<const d2 *>(src_host);
     d2 *out = reinterpret_cast<d2 *>(dst);
     const int n2 = n >> 1;
-    for (int base = 0; base < n2; base += 256) {
+    // (big blobs, K = 128: several blocks, each polls the gate and copies every gridDim.x-th slab)
+    for (int base = (int)blockIdx.x * 256; base < n2; base += 256 * (int)gridDim.x) {
         d2 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {

@@ -26,11 +26,15 @@ class HipEngine:
 
     name = "hip"
 
-    def __init__(self, K, device=0, stream=None):
+    def __init__(self, K, device=0, stream=None, dtype="f64"):
+        """dtype "f64" (the reference's arithmetic; K = 8, 16, 32, 64) or "f32" (large-K mixed
+        precision path, K = 128: fp32 factors / Gram / factorisation, fp64 everything else)."""
         self.lib = _lib.load_library()
         self.K = int(K)
+        self.dtype = dtype
+        code = {"f64": 0, "f32": 1}[dtype]
         h = C.c_void_p()
-        _lib.check(self.lib.bpmf_hip_ctx_create(int(device), self.K, C.c_void_p(stream) if stream else None, C.byref(h)))
+        _lib.check(self.lib.bpmf_hip_ctx_create_ex(int(device), self.K, code, C.c_void_p(stream) if stream else None, C.byref(h)))
         self.ctx = h
         self.device = device
         self._sides = []

@@ -60,12 +60,20 @@ BPMF_API const char *bpmf_hip_last_error(void);
 BPMF_API int bpmf_hip_abi_version(void);
 /* 1 if K (BPMF_NUMLATENT, c++/bpmf.h:22-24,53) has an instantiated kernel: 8,16,32,64 */
 BPMF_API int bpmf_hip_supports_k(int K);
+/* arithmetic of the column loop / storage type of the factors on the device.  The reference is
+ * fp64 throughout (c++/bpmf.h:55-58); BPMF_HIP_F32 is the large-K mixed-precision path (K = 128:
+ * fp32 factors, Gram, factorisation and solves; fp64 hyper-parameters, statistics, RMSE sums and
+ * normal draws).  The host-side interface (items, sums) stays double in both cases. */
+#define BPMF_HIP_F64 0
+#define BPMF_HIP_F32 1
+BPMF_API int bpmf_hip_supports(int K, int dtype);
 
 /* ---- context --------------------------------------------------------------
  * Replaces Sys::Init / Sys::Finalize (c++/nocomm.h:19-27).  `stream` is a
  * hipStream_t to launch on (e.g. torch's current stream) or NULL to let the
  * context create its own non-blocking stream. */
-BPMF_API int bpmf_hip_ctx_create(int device, int K, void *stream, bpmf_hip_ctx **out);
+BPMF_API int bpmf_hip_ctx_create(int device, int K, void *stream, bpmf_hip_ctx **out);      /* fp64 */
+BPMF_API int bpmf_hip_ctx_create_ex(int device, int K, int dtype, void *stream, bpmf_hip_ctx **out);
 BPMF_API int bpmf_hip_ctx_destroy(bpmf_hip_ctx *ctx);
 BPMF_API int bpmf_hip_ctx_sync(bpmf_hip_ctx *ctx);
 BPMF_API void *bpmf_hip_ctx_stream(bpmf_hip_ctx *ctx);

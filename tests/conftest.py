@@ -24,10 +24,10 @@ def hip_engine_factory():
     import bpmf_amd
     cache = {}
 
-    def make(K):
-        if K not in cache:
-            cache[K] = bpmf_amd.HipEngine(K)
-        return cache[K]
+    def make(K, dtype="f64"):
+        if (K, dtype) not in cache:
+            cache[(K, dtype)] = bpmf_amd.HipEngine(K, dtype=dtype)
+        return cache[(K, dtype)]
     yield make
     for e in cache.values():
         e.close()

@@ -1,0 +1,63 @@
+"""Mixed-precision tolerance study of the fp32 large-K path (BASELINE config "MovieLens-1M, K=128,
+fp32"): the HIP kernels keep factors, Gram, factorisation and solves in fp32; the oracle is the
+fp64 restatement of the reference.  Tolerances are what fp32 costs, stated here:
+
+  * one half-iteration from identical inputs: sampled factors within 2e-3 of max|U| (observed
+    ~1e-4: the Cholesky of Lambda* in fp32 loses cond(Lambda*) * 6e-8), sums within 1e-3 relative;
+  * a full 10-iteration run on MovieLens-100K: every per-iteration RMSE and the final averaged RMSE
+    within 1e-3 of the fp64 chain (the north star's bar for RMSE).
+"""
+import numpy as np
+import pytest
+
+import util
+from test_gpu_parity import half_iteration_pair, rel_err
+
+pytestmark = pytest.mark.gpu
+
+K = 128
+
+
+def test_f32_context_and_bad_combinations(hip_engine_factory):
+    import bpmf_amd
+    lib = bpmf_amd._lib.load_library()
+    assert lib.bpmf_hip_supports(128, 1) == 1 and lib.bpmf_hip_supports(128, 0) == 0 and lib.bpmf_hip_supports(32, 1) == 0
+    with pytest.raises(RuntimeError):
+        bpmf_amd.HipEngine(32, dtype="f32")
+    with pytest.raises(RuntimeError):
+        bpmf_amd.HipEngine(128, dtype="f64")
+
+
+def test_f32_half_iterations_against_fp64_oracle(oracle, hip_engine_factory):
+    M, Mt, T, Tt, nu, nm = util.ml100k()
+    eng = hip_engine_factory(K, "f32")
+    rng = np.random.default_rng(7)
+    U = 0.3 * rng.standard_normal((nu, K)); V = 0.3 * rng.standard_normal((nm, K))
+    A = rng.standard_normal((K, 3 * K)); cov = A @ A.T / (3 * K)
+    for (mat, nrows, other, it) in ((M, nu, U, 5), (Mt, nm, V, 7)):
+        # the oracle sees the factors the device sees (rounded to fp32 once)
+        other32 = other.astype(np.float32).astype(np.float64)
+        (items, s, p, n), (items_ref, s_ref, p_ref, n_ref) = half_iteration_pair(oracle, eng, K, mat, nrows, other32, it, cov=cov)
+        assert np.all(np.isfinite(items))
+        err = rel_err(items, items_ref)
+        assert err < 2e-3, err
+        assert rel_err(s, s_ref) < 1e-3 and rel_err(p, p_ref) < 1e-3 and abs(n - n_ref) <= 1e-3 * abs(n_ref)
+
+
+def test_f32_tiny_and_empty_columns(oracle, hip_engine_factory):
+    """iteration 0 (zero factors: every column samples from the prior) and the shipped tiny matrix."""
+    M, Mt, T, Tt, nu, nm = util.tiny()
+    eng = hip_engine_factory(K, "f32")
+    (items, s, p, n), (items_ref, s_ref, p_ref, n_ref) = half_iteration_pair(oracle, eng, K, M, nu, np.zeros((nu, K)), 0)
+    assert rel_err(items, items_ref) < 2e-3
+
+
+def test_f32_full_run_rmse_within_1e3_of_fp64(oracle, hip_engine_factory):
+    import bpmf_amd
+    M, Mt, T, Tt, nu, nm = util.ml100k()
+    eng = hip_engine_factory(K, "f32")
+    res = bpmf_amd.gibbs(eng, M, Mt, T, nu, nm, nsims=10, burnin=3)
+    ref = oracle.gibbs(K, M, Mt, T, Tt, nsims=10, burnin=3)
+    assert np.allclose(res["rmse"], ref["rmse"], atol=1e-3), np.abs(np.array(res["rmse"]) - np.array(ref["rmse"])).max()
+    assert abs(res["final_rmse_avg"] - ref["final_rmse_avg"]) < 1e-3
+    assert 0.9 < res["final_rmse_avg"] < 1.1

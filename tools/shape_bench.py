@@ -13,7 +13,7 @@ real = len(sys.argv) > 6
 t0 = time.time()
 M, Mt, T, Tt, nu, nm = synth.ratings(nu, nm, nnz, seed=42, real_valued=real)
 print("generated %d x %d, %d train / %d test ratings in %.1f s" % (nu, nm, M[0][-1], T[0][-1], time.time() - t0), flush=True)
-eng = bpmf_amd.HipEngine(K)
+eng = bpmf_amd.HipEngine(K, dtype="f32" if K == 128 else "f64")
 movies = Sys("movs", eng, M, nm, nu, T=T); users = Sys("users", eng, Mt, nu, nm)
 for _ in range(3):
     movies.sample(users); users.sample(movies); movies.predict(users)
