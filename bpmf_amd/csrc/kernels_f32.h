@@ -11,10 +11,10 @@
 //     per wave; every wave walks all ratings of the column (operands come straight from the
 //     gathered registers: lane (kq, li) loads U[row_kq][16 t + li], 64 contiguous bytes per 16
 //     lanes), so no cross-wave reduction is needed.
-//   * Lambda* = LambdaF + alpha G lands as a packed lower triangle in LDS (33 KB fp32: four
-//     workgroups per CU), b = LambdaF mu + rr beside it.
-//   * right-looking Cholesky in LDS by all 256 threads (two barriers per column of L), forward
-//     solve, + z, backward solve by wave 0 (two rows per lane, no barriers), coalesced store.
+//   * Lambda* = LambdaF + alpha G is formed in the MFMA accumulator tiles and stays there: the
+//     blocked right-looking Cholesky (Lambda* = R^T R, 16-wide block rows) updates the register
+//     tiles with MFMAs whose operands are the finished block rows of R, parked in LDS (41 KB).
+//   * forward solve, + z, backward solve by wave 0 (two rows per lane, no barriers), coalesced store.
 // Operand / result layout of v_mfma_f32_16x16x4_f32 (tools/probes/layout16f32_probe.hip):
 //   A lane 16 k + i, B lane 16 k + j (one float each);  D[i = 4 (lane / 16) + reg][j = lane % 16].
 #pragma once
@@ -46,18 +46,34 @@ struct GeoF {
     static constexpr int NT = K / 16;                    // 16-wide tiles per dimension
     static constexpr int NTRI = NT * (NT + 1) / 2;
     static constexpr int TPW = (NTRI + 3) / 4;           // tiles per wave
-    static constexpr int PLEN = K * (K + 1) / 2;         // packed lower triangle, row i at i (i + 1) / 2
-    static constexpr size_t LDS_BYTES = (size_t)PLEN * 4 + K * 4 + K * 4 + K * 8;
+    // R (upper, Lambda* = R^T R) lives in LDS by block rows: block row s is 16 x (K - 16 s) floats
+    // with a row stride of K - 16 s + 8 (two-way bank conflicts at most for the MFMA operand reads)
+    __host__ __device__ static constexpr int width(int s) { return K - 16 * s; }
+    __host__ __device__ static constexpr int ld(int s) { return width(s) + 8; }
+    __host__ __device__ static constexpr int roff(int s) { return 16 * s * (K + 8) - 128 * s * (s - 1); }   // 16 * sum_{t<s} ld(t)
+    static constexpr int RWORDS = roff(NT);
+    static constexpr size_t LDS_BYTES = (size_t)K * 8 + (size_t)RWORDS * 4 + 2 * K * 4;
+    // row-major upper index of tile (I, J), I <= J; its owner is wave tri & 3, slot tri >> 2
+    __host__ __device__ static constexpr int tri(int I, int J) { return I * NT - (I * (I - 1)) / 2 + (J - I); }
 };
 
-__device__ __forceinline__ int ptri(int i) { return (i * (i + 1)) >> 1; }
-
-// Gram of one column and its assembly into LDS, for wave W of the workgroup (compile-time tile list)
+// ---------------------------------------------------------------------------
+// Per-wave part of one column: Gram of the wave's tiles, Lambda* in registers, blocked
+// right-looking Cholesky  Lambda* = R^T R  on the register tiles.  Block step s:
+//   A  the owners of the tiles (s, J >= s) park them in block row s of the LDS copy of R;
+//   B  wave 0 factors the 16x16 diagonal block (lane c < 16 holds column c; pivots and row
+//      entries travel through v_readlane) and stores R_ss and 1 / R_kk;
+//   C  one thread per remaining column of the block row solves R_ss^T x = a (16 steps);
+//   D  every wave applies  A_IJ -= R_sI^T R_sJ  to its own tiles (I, J), s < I <= J, with four
+//      v_mfma_f32_16x16x4_f32 per tile whose operands are read from block row s.
+// Three workgroup barriers per block step.
+// ---------------------------------------------------------------------------
 template <int K, int W>
-__device__ __forceinline__ void wg_gram(const SampleArgsF &a, int64_t p0, int len, float *A, float *bv, int lane)
+__device__ __forceinline__ bool wg_column(const SampleArgsF &a, int64_t p0, int len, float *R, float *dinv, float *bv, int tid)
 {
     using G = GeoF<K>;
     constexpr int NT = G::NT, TPW = G::TPW;
+    const int lane = tid & 63;
     const int kq = lane >> 4, li = lane & 15;
     f4 acc[TPW];
     float r[NT];
@@ -67,47 +83,71 @@ __device__ __forceinline__ void wg_gram(const SampleArgsF &a, int64_t p0, int le
     for (int t = 0; t < NT; ++t) r[t] = 0.f;
     const int32_t *rowidx = a.rowidx + p0;
     const double *vals = a.vals + p0;
+    // 64 ratings per coalesced index block = 4 groups of 4 k-steps (16 ratings); the operands of the
+    // next group (32 registers) are in flight while the 36 MFMAs of the current one issue
+    int ri_n = (lane < len) ? rowidx[lane] : -1;
+    float wv_n = (lane < len) ? (float)((vals[lane] - a.mean_rating) * a.alpha) : 0.f;        // c++/sample.cpp:256
     for (int b0 = 0; b0 < len; b0 += 64) {
-        const int q = b0 + lane;
-        const int ri = (q < len) ? rowidx[q] : -1;
-        const float wv = (q < len) ? (float)((vals[q] - a.mean_rating) * a.alpha) : 0.f;      // c++/sample.cpp:256
-        const int nsteps = (len - b0 >= 64) ? 16 : (len - b0 + 3) >> 2;
-        for (int g = 0; g < nsteps; ++g) {
-            const int src = g * 4 + kq;
-            const int row = __shfl(ri, src);
-            const float ww = __shfl(wv, src);
-            float y[NT];
-            const float *u = a.other_items + (size_t)(row >= 0 ? row : 0) * K + li;
+        const int ri = ri_n;
+        const float wv = wv_n;
+        if (b0 + 64 < len) {                                                     // workgroup-uniform
+            const int q = b0 + 64 + lane;
+            ri_n = (q < len) ? rowidx[q] : -1;
+            wv_n = (q < len) ? (float)((vals[q] - a.mean_rating) * a.alpha) : 0.f;
+        }
+        const int ngroups = (len - b0 >= 64) ? 4 : (len - b0 + 15) >> 4;
+        float y[4][NT], yn[4][NT], ww[4], wn[4];
+        auto gather = [&](int gg, float (&yy)[4][NT], float (&w1)[4]) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) y[t] = (row >= 0) ? u[16 * t] : 0.f;
-            if (W == 0) {
+            for (int st = 0; st < 4; ++st) {
+                const int src = (gg * 4 + st) * 4 + kq;
+                const int row = __shfl(ri, src);
+                w1[st] = __shfl(wv, src);
+                const float *u = a.other_items + (size_t)(row >= 0 ? row : 0) * K + li;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) r[t] = fmaf(y[t], ww, r[t]);
+                for (int t = 0; t < NT; ++t) yy[st][t] = (row >= 0) ? u[16 * t] : 0.f;
             }
-            int tri = 0, mine = 0;
+        };
+        gather(0, y, ww);
 #pragma unroll
-            for (int I = 0; I < NT; ++I)
+        for (int gg = 0; gg < 4; ++gg) {
+            if (gg >= ngroups) break;                                            // workgroup-uniform
+            const bool more = gg + 1 < ngroups;
+            if (gg < 3 && more) gather(gg + 1, yn, wn);
 #pragma unroll
-                for (int J = I; J < NT; ++J, ++tri)
-                    if ((tri & 3) == W) { acc[mine] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[I], y[J], acc[mine], 0, 0, 0); ++mine; }
+            for (int st = 0; st < 4; ++st) {
+                if (W == 0) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) r[t] = fmaf(y[st][t], ww[st], r[t]);
+                }
+#pragma unroll
+                for (int I = 0; I < NT; ++I)
+#pragma unroll
+                    for (int J = I; J < NT; ++J)
+                        if ((G::tri(I, J) & 3) == W)
+                            acc[G::tri(I, J) >> 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[st][I], y[st][J], acc[G::tri(I, J) >> 2], 0, 0, 0);
+            }
+            if (gg < 3 && more) {
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    ww[st] = wn[st];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) y[st][t] = yn[st][t];
+                }
+            }
         }
     }
-    // Lambda* = LambdaF + alpha G, lower triangle -> LDS (:297-298); b = LambdaF mu + rr (:285,:256)
-    int tri = 0, mine = 0;
+    // Lambda* = LambdaF + alpha G in the register tiles (:297-298); b = LambdaF mu + rr (:285,:256)
 #pragma unroll
     for (int I = 0; I < NT; ++I)
 #pragma unroll
-        for (int J = I; J < NT; ++J, ++tri)
-            if ((tri & 3) == W) {
+        for (int J = I; J < NT; ++J)
+            if ((G::tri(I, J) & 3) == W) {
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int gi = 16 * I + 4 * kq + reg, gj = 16 * J + li;
-                    // upper tile element (gi, gj): entry (row, col) = (max, min) of the lower triangle
-                    const int row = gi > gj ? gi : gj, cl = gi > gj ? gj : gi;
-                    if (I != J || gi >= gj)
-                        A[ptri(row) + cl] = (float)fma(a.alpha, (double)acc[mine][reg], a.LambdaF[row + (size_t)cl * K]);
+                    acc[G::tri(I, J) >> 2][reg] = (float)fma(a.alpha, (double)acc[G::tri(I, J) >> 2][reg], a.LambdaF[gi + (size_t)gj * K]);
                 }
-                ++mine;
             }
     if (W == 0) {
 #pragma unroll
@@ -118,17 +158,97 @@ __device__ __forceinline__ void wg_gram(const SampleArgsF &a, int64_t p0, int le
             if (kq == 0) bv[16 * t + li] = (float)(a.Lmu[16 * t + li] + (double)v);
         }
     }
+
+    bool bad = false;
+#pragma unroll
+    for (int s = 0; s < NT; ++s) {
+        float *Rs = R + G::roff(s);
+        const int LDs = G::ld(s), Ws = G::width(s);
+        // A: park the tiles of block row s
+#pragma unroll
+        for (int J = s; J < NT; ++J)
+            if ((G::tri(s, J) & 3) == W) {
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) Rs[(4 * kq + reg) * LDs + 16 * (J - s) + li] = acc[G::tri(s, J) >> 2][reg];
+            }
+        __syncthreads();
+        // B: diagonal block, upper Cholesky, by the first 16 lanes of wave 0 (column c in registers)
+        if (W == 0) {
+            const int c = lane & 15;
+            float col[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) col[k] = Rs[k * LDs + c];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, col[k]), k));
+                bad |= !(d > 0.f);
+                const float rinv = 1.0f / sqrtf(d);
+                col[k] *= rinv;                                       // R(k, c), c >= k (entries left of the diagonal are not used)
+                if (lane == k) dinv[16 * s + k] = rinv;
+#pragma unroll
+                for (int m = k + 1; m < 16; ++m) {
+                    const float rkm = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, col[k]), m));
+                    col[m] = fmaf(-rkm, col[k], col[m]);              // A(m, c) -= R(k, m) R(k, c)
+                }
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) Rs[k * LDs + c] = col[k];
+            }
+        }
+        __syncthreads();
+        // C: the other columns of the block row: R_ss^T x = a, one thread per column
+        if (tid < Ws - 16) {
+            float *cp = Rs + 16 + tid;
+            float x[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x[k] = cp[k * LDs];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                x[k] *= dinv[16 * s + k];
+#pragma unroll
+                for (int m = k + 1; m < 16; ++m) x[m] = fmaf(-Rs[k * LDs + m], x[k], x[m]);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) cp[k * LDs] = x[k];
+        }
+        __syncthreads();
+        // D: trailing update of this wave's tiles
+        if (s + 1 < NT) {
+#pragma unroll
+            for (int I = s + 1; I < NT; ++I) {
+                bool any = false;
+#pragma unroll
+                for (int J = I; J < NT; ++J) any |= (G::tri(I, J) & 3) == W;
+                if (!any) continue;                                  // compile-time
+                float opI[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) opI[q] = -Rs[(4 * q + kq) * LDs + 16 * (I - s) + li];
+#pragma unroll
+                for (int J = I; J < NT; ++J)
+                    if ((G::tri(I, J) & 3) == W) {
+                        float opJ[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) opJ[q] = Rs[(4 * q + kq) * LDs + 16 * (J - s) + li];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            acc[G::tri(I, J) >> 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(opI[q], opJ[q], acc[G::tri(I, J) >> 2], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    return bad;
 }
 
 template <int K>
-__global__ __launch_bounds__(256) void k_sample_wg(SampleArgsF a)
+__global__ __launch_bounds__(256, 3) void k_sample_wg(SampleArgsF a)
 {
     using G = GeoF<K>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
     double *zs = reinterpret_cast<double *>(smem);                   // K normals (fp64 draw, as the reference)
-    float *A = reinterpret_cast<float *>(zs + K);                    // packed lower triangle of Lambda*, then of L
-    float *bv = A + G::PLEN;                                         // rhs
-    float *dg = bv + K;                                              // L(k,k)
+    float *R = reinterpret_cast<float *>(zs + K);                    // R by block rows
+    float *bv = R + G::RWORDS;                                       // rhs
+    float *dinv = bv + K;                                            // 1 / R(k,k)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int w = blockIdx.x;
     const int col = a.wi_col[w];
@@ -138,50 +258,43 @@ __global__ __launch_bounds__(256) void k_sample_wg(SampleArgsF a)
 
     // z ~ N(0, I): stream (idx+1)*K*(iter+1) mod 2^32 (c++/sample.cpp:266); wave 3 has the fewest tiles
     if (wave == 3) draw_normals<K>(sample_counter<K>(idx, a.iter_plus_1), K, zs, lane);
+    bool bad;
     switch (wave) {
-    case 0: wg_gram<K, 0>(a, p0, len, A, bv, lane); break;
-    case 1: wg_gram<K, 1>(a, p0, len, A, bv, lane); break;
-    case 2: wg_gram<K, 2>(a, p0, len, A, bv, lane); break;
-    default: wg_gram<K, 3>(a, p0, len, A, bv, lane); break;
-    }
-
-    // ---- Cholesky, right-looking, in place (chol.compute, :306): two barriers per column of L
-    const int ti = tid >> 4, tj = tid & 15;
-    bool bad = false;
-    for (int k = 0; k < K; ++k) {
-        __syncthreads();                                             // trailing update of column k - 1 (or the assembly) is complete
-        const float d = A[ptri(k) + k];
-        bad |= !(d > 0.f);
-        const float rinv = 1.0f / sqrtf(d);
-        if (tid == k) dg[k] = d * rinv;
-        else if (tid > k && tid < K) A[ptri(tid) + k] *= rinv;
-        __syncthreads();
-        for (int i = k + 1 + ti; i < K; i += 16) {
-            const float lik = A[ptri(i) + k];
-            float *Ai = A + ptri(i);
-            for (int j = k + 1 + tj; j <= i; j += 16) Ai[j] = fmaf(-lik, A[ptri(j) + k], Ai[j]);
-        }
+    case 0: bad = wg_column<K, 0>(a, p0, len, R, dinv, bv, tid); break;
+    case 1: bad = wg_column<K, 1>(a, p0, len, R, dinv, bv, tid); break;
+    case 2: bad = wg_column<K, 2>(a, p0, len, R, dinv, bv, tid); break;
+    default: bad = wg_column<K, 3>(a, p0, len, R, dinv, bv, tid); break;
     }
     __syncthreads();
 
-    // ---- L y = b (:321), y += z (:322), L^T x = y (:323): wave 0, rows (lane, lane + 64)
+    // ---- R^T y = b (:321), y += z (:322), R x = y (:323): wave 0, rows (lane, lane + 64)
     if (wave == 0) {
         float y0 = bv[lane], y1 = (K > 64) ? bv[lane + 64] : 0.f;
+        // forward: after y_k is known, b_j -= R(k, j) y_k for j > k (row k of R: contiguous)
         for (int k = 0; k < K; ++k) {
+            const int s = k >> 4;
+            const float *row = R + G::roff(s) + (k & 15) * G::ld(s) - 16 * s;       // row[j] = R(k, j)
             const float own = (k < 64) ? y0 : y1;
-            const float yk = __shfl(own, k & 63) / dg[k];
+            const float yk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, own), k & 63)) * dinv[k];
             if (lane == (k & 63)) { if (k < 64) y0 = yk; else y1 = yk; }
-            if (lane > k) y0 = fmaf(-A[ptri(lane) + k], yk, y0);
-            if (K > 64 && lane + 64 > k) y1 = fmaf(-A[ptri(lane + 64) + k], yk, y1);
+            if (lane > k) y0 = fmaf(-row[lane], yk, y0);
+            if (K > 64 && lane + 64 > k) y1 = fmaf(-row[lane + 64], yk, y1);
         }
         y0 += (float)zs[lane];
         if (K > 64) y1 += (float)zs[lane + 64];
+        // backward: x_k = y_k / R(k,k); y_i -= R(i, k) x_k for i < k (column k of R: per-lane row bases)
+        int base0, base1;
+        {
+            const int s0 = lane >> 4, s1 = (lane + 64) >> 4;
+            base0 = G::roff(s0) + (lane & 15) * G::ld(s0) - 16 * s0;
+            base1 = G::roff(s1) + (lane & 15) * G::ld(s1) - 16 * s1;
+        }
         for (int k = K - 1; k >= 0; --k) {
             const float own = (k < 64) ? y0 : y1;
-            const float xk = __shfl(own, k & 63) / dg[k];
+            const float xk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, own), k & 63)) * dinv[k];
             if (lane == (k & 63)) { if (k < 64) y0 = xk; else y1 = xk; }
-            if (lane < k) y0 = fmaf(-A[ptri(k) + lane], xk, y0);                     // L(k, i), i < k: row k
-            if (K > 64 && lane + 64 < k) y1 = fmaf(-A[ptri(k) + lane + 64], xk, y1);
+            if (lane < k) y0 = fmaf(-R[base0 + k], xk, y0);
+            if (K > 64 && lane + 64 < k) y1 = fmaf(-R[base1 + k], xk, y1);
         }
         float *dst = a.items + (size_t)idx * K;                                     // items().col(idx) = rr (:324)
         dst[lane] = y0;
