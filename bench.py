@@ -129,7 +129,9 @@ def main():
     nnz = int(M[0][-1])
     mean = float(np.sum(M[2])) / nnz
 
-    eng = bpmf_amd.HipEngine(K, device=local_rank)
+    dtype = "f32" if K == 128 else "f64"                              # --K 128: the fp32 large-K path (BASELINE configs[4])
+    esz = 4 if dtype == "f32" else 8
+    eng = bpmf_amd.HipEngine(K, device=local_rank, dtype=dtype)
     if world > 1 or force_dist:
         from bpmf_amd.dist import NativeComm, TorchComm
         # default: RCCL inside the library (exchange + all-reduce behind the sampling call);
@@ -188,7 +190,7 @@ def main():
 
     # roofline of the dominant kernel (the sampler), per launch, this rank's shard
     nnz_m = movies.local_nnz; nnz_u = users.local_nnz
-    bytes_launch = 0.5 * (algorithmic_bytes(nnz_m, dom_m[1] - dom_m[0], K) + algorithmic_bytes(nnz_u, dom_u[1] - dom_u[0], K))
+    bytes_launch = 0.5 * (algorithmic_bytes(nnz_m, dom_m[1] - dom_m[0], K, esz) + algorithmic_bytes(nnz_u, dom_u[1] - dom_u[0], K, esz))
     flops_launch = 0.5 * (algorithmic_flops(nnz_m, dom_m[1] - dom_m[0], K) + algorithmic_flops(nnz_u, dom_u[1] - dom_u[0], K))
     # HIP-event times of the sampler / statistics kernels on their streams, summed by the library
     # over the timed steps (the stateless torch-collective path only keeps the last launch)
@@ -212,7 +214,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f64",
+        "dtype": dtype,
         "data": "synthetic",
         "config": {"workload": "ML-1M-shaped synthetic R (%d users x %d movies, %d ratings, 90/10 split), "
                                "K=%d, alpha=2, full Gibbs iteration incl. host Normal-Wishart draws and RMSE"
@@ -220,8 +222,8 @@ def main():
                    "nnz_train": nnz, "nnz_test": int(T[0][-1]), "K": K,
                    "parallelism": "columns of U and V sharded over %d GPU(s)" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": profiled_traffic() if world == 1 else None,
-                     "kernel": "k_sample1<%d>" % K,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": profiled_traffic() if (world == 1 and K == 32) else None,
+                     "kernel": ("k_sample_wg<%d>" if dtype == "f32" else ("k_sample1<%d>" if K <= 32 else "k_sample<%d>")) % K,
                      "launch_ms": launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_launch,
                      "fp64_tflops": flops_launch / launch_s / 1e12 if launch_s > 0 else 0.0,
                      "fp64_frac": (flops_launch / launch_s / 1e12) / FP64_PEAK_TFLOPS if launch_s > 0 else 0.0,
