@@ -286,7 +286,15 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     s->mode = mode_env >= 0 ? mode_env : ((K <= 32 && nloc < 65536) ? 1 : 0);
     const bool f32 = s->ctx->dtype == BPMF_HIP_F32;
     if (f32) s->mode = 2;                                // one workgroup per column (k_sample_wg), no chunking
-    int chunk = f32 ? (1 << 30) : env_int("BPMF_HIP_CHUNK", 0);
+    else if (K == 64) {
+        // K = 64 in the workgroup form (blocked factorisation on f64 MFMA tiles) is opt-in
+        // (BPMF_HIP_MODE=2): measured 2x slower than the persistent form on the column-dominated
+        // ChEMBL shape (three of its four waves idle through the serial phases), about equal on ML-1M.
+        // It has no chunking: not for columns far above 16 384 ratings.
+        if (mode_env == 2) s->mode = 2;
+    } else if (s->mode == 2) s->mode = (K <= 32 && nloc < 65536) ? 1 : 0;      // (BPMF_HIP_MODE=2 exists for K = 64 only)
+    const bool wg = s->mode == 2;
+    int chunk = wg ? (1 << 30) : env_int("BPMF_HIP_CHUNK", 0);
     if (chunk <= 0) {
         const int64_t simds = (int64_t)s->ctx->num_cu * 4;
         // mode 1: ~1.5 chunks of work per SIMD (measured best on the ML-1M shape: 512-768);
@@ -601,18 +609,26 @@ int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, do
 {
     using namespace bpmf;
     bpmf_hip_ctx *c = self->ctx;
-    if constexpr (K == 128) {                           // fp32 large-K path: one workgroup per column
-        SampleArgsF f;
+    // one workgroup per column (k_sample_wg): the fp32 large-K path, and K = 64 in fp64
+    auto launch_wg = [&](auto zero) {
+        typedef decltype(zero) T;
+        SampleArgsW<T> f;
         f.rowidx = self->d_rowidx; f.vals = self->d_vals;
         f.wi_col = self->d_wi_col; f.wi_p0 = self->d_wi_p0; f.wi_len = self->d_wi_len;
-        f.other_items = reinterpret_cast<const float *>(other->d_items); f.items = reinterpret_cast<float *>(self->d_items);
+        f.other_items = reinterpret_cast<const T *>(other->d_items); f.items = reinterpret_cast<T *>(self->d_items);
         f.col_from = self->from;
         f.LambdaF = d_in; f.Lmu = d_in + (size_t)K * K;
         f.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
         f.mean_rating = self->mean_rating; f.alpha = alpha; f.iter_plus_1 = (uint32_t)(iter + 1);
-        if (self->nwork > 0) hipLaunchKernelGGL(k_sample_wg<K>, dim3(self->nwork), dim3(256), 0, st, f);
+        if (self->nwork > 0) hipLaunchKernelGGL((k_sample_wg<K, T>), dim3(self->nwork), dim3(256), 0, st, f);
+    };
+    if constexpr (K == 128) {
+        launch_wg(0.0f);
         return 0;
     } else {
+    if constexpr (K == 64) {
+        if (self->mode == 2) { launch_wg(0.0); return 0; }
+    }
     SampleArgs a;
     a.rowidx = self->d_rowidx; a.vals = self->d_vals;
     a.wi_col = self->d_wi_col; a.wi_p0 = self->d_wi_p0; a.wi_len = self->d_wi_len; a.wi_mc = self->d_wi_mc; a.wi_chunk = self->d_wi_chunk;

@@ -24,14 +24,32 @@ namespace bpmf {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-struct SampleArgsF {
+// element type of the factors / tiles: float (K = 128) or double (K = 64: the reference's arithmetic)
+template <typename T> struct WgTraits;
+template <> struct WgTraits<float> {
+    typedef f4 acc_t;
+    __device__ static __forceinline__ f4 mfma(float x, float y, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, c, 0, 0, 0); }
+    __device__ static __forceinline__ int drow(int kq, int reg) { return 4 * kq + reg; }      // D[i = 4 (lane / 16) + reg][j = lane % 16]
+    __device__ static __forceinline__ float rsqrt_acc(float d) { return 1.0f / sqrtf(d); }
+    __device__ static __forceinline__ float bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+};
+template <> struct WgTraits<double> {
+    typedef d4 acc_t;
+    __device__ static __forceinline__ d4 mfma(double x, double y, d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, c, 0, 0, 0); }
+    __device__ static __forceinline__ int drow(int kq, int reg) { return kq + 4 * reg; }      // D[i = lane / 16 + 4 reg][j = lane % 16]
+    __device__ static __forceinline__ double rsqrt_acc(double d) { return 1.0 / sqrt(d); }
+    __device__ static __forceinline__ double bcast(double v, int l) { return ::bpmf::bcast(v, l); }
+};
+
+template <typename T>
+struct SampleArgsW {
     const int32_t *rowidx;
     const double *vals;
     const int32_t *wi_col;      // work item -> local column (cost-sorted; no chunking on this path)
     const int64_t *wi_p0;
     const int32_t *wi_len;
-    const float *other_items;   // K x nrows, fp32
-    float *items;               // K x ncols, fp32
+    const T *other_items;       // K x nrows
+    T *items;                   // K x ncols
     int64_t col_from;
     const double *LambdaF;      // K x K col-major (device, fp64)
     const double *Lmu;
@@ -52,7 +70,7 @@ struct GeoF {
     __host__ __device__ static constexpr int ld(int s) { return width(s) + 8; }
     __host__ __device__ static constexpr int roff(int s) { return 16 * s * (K + 8) - 128 * s * (s - 1); }   // 16 * sum_{t<s} ld(t)
     static constexpr int RWORDS = roff(NT);
-    static constexpr size_t LDS_BYTES = (size_t)K * 8 + (size_t)RWORDS * 4 + 2 * K * 4;
+    template <typename T> static constexpr size_t lds_bytes() { return (size_t)K * 8 + (size_t)RWORDS * sizeof(T) + 2 * K * sizeof(T); }
     // row-major upper index of tile (I, J), I <= J; its owner is wave tri & 3, slot tri >> 2
     __host__ __device__ static constexpr int tri(int I, int J) { return I * NT - (I * (I - 1)) / 2 + (J - I); }
 };
@@ -68,44 +86,46 @@ struct GeoF {
 //      v_mfma_f32_16x16x4_f32 per tile whose operands are read from block row s.
 // Three workgroup barriers per block step.
 // ---------------------------------------------------------------------------
-template <int K, int W>
-__device__ __forceinline__ bool wg_column(const SampleArgsF &a, int64_t p0, int len, float *R, float *dinv, float *bv, int tid)
+template <int K, typename T, int W>
+__device__ __forceinline__ bool wg_column(const SampleArgsW<T> &a, int64_t p0, int len, T *R, T *dinv, T *bv, int tid)
 {
     using G = GeoF<K>;
+    using X = WgTraits<T>;
+    typedef typename X::acc_t acc_t;
     constexpr int NT = G::NT, TPW = G::TPW;
     const int lane = tid & 63;
     const int kq = lane >> 4, li = lane & 15;
-    f4 acc[TPW];
-    float r[NT];
+    acc_t acc[TPW];
+    T r[NT];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < TPW; ++t) acc[t] = acc_t{0, 0, 0, 0};
 #pragma unroll
-    for (int t = 0; t < NT; ++t) r[t] = 0.f;
+    for (int t = 0; t < NT; ++t) r[t] = 0;
     const int32_t *rowidx = a.rowidx + p0;
     const double *vals = a.vals + p0;
     // 64 ratings per coalesced index block = 4 groups of 4 k-steps (16 ratings); the operands of the
     // next group (32 registers) are in flight while the 36 MFMAs of the current one issue
     int ri_n = (lane < len) ? rowidx[lane] : -1;
-    float wv_n = (lane < len) ? (float)((vals[lane] - a.mean_rating) * a.alpha) : 0.f;        // c++/sample.cpp:256
+    T wv_n = (lane < len) ? (T)((vals[lane] - a.mean_rating) * a.alpha) : (T)0;               // c++/sample.cpp:256
     for (int b0 = 0; b0 < len; b0 += 64) {
         const int ri = ri_n;
-        const float wv = wv_n;
+        const T wv = wv_n;
         if (b0 + 64 < len) {                                                     // workgroup-uniform
             const int q = b0 + 64 + lane;
             ri_n = (q < len) ? rowidx[q] : -1;
-            wv_n = (q < len) ? (float)((vals[q] - a.mean_rating) * a.alpha) : 0.f;
+            wv_n = (q < len) ? (T)((vals[q] - a.mean_rating) * a.alpha) : (T)0;
         }
         const int ngroups = (len - b0 >= 64) ? 4 : (len - b0 + 15) >> 4;
-        float y[4][NT], yn[4][NT], ww[4], wn[4];
-        auto gather = [&](int gg, float (&yy)[4][NT], float (&w1)[4]) {
+        T y[4][NT], yn[4][NT], ww[4], wn[4];
+        auto gather = [&](int gg, T (&yy)[4][NT], T (&w1)[4]) {
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 const int src = (gg * 4 + st) * 4 + kq;
                 const int row = __shfl(ri, src);
                 w1[st] = __shfl(wv, src);
-                const float *u = a.other_items + (size_t)(row >= 0 ? row : 0) * K + li;
+                const T *u = a.other_items + (size_t)(row >= 0 ? row : 0) * K + li;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) yy[st][t] = (row >= 0) ? u[16 * t] : 0.f;
+                for (int t = 0; t < NT; ++t) yy[st][t] = (row >= 0) ? u[16 * t] : (T)0;
             }
         };
         gather(0, y, ww);
@@ -118,14 +138,14 @@ __device__ __forceinline__ bool wg_column(const SampleArgsF &a, int64_t p0, int 
             for (int st = 0; st < 4; ++st) {
                 if (W == 0) {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) r[t] = fmaf(y[st][t], ww[st], r[t]);
+                    for (int t = 0; t < NT; ++t) r[t] = fma(y[st][t], ww[st], r[t]);
                 }
 #pragma unroll
                 for (int I = 0; I < NT; ++I)
 #pragma unroll
                     for (int J = I; J < NT; ++J)
                         if ((G::tri(I, J) & 3) == W)
-                            acc[G::tri(I, J) >> 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[st][I], y[st][J], acc[G::tri(I, J) >> 2], 0, 0, 0);
+                            acc[G::tri(I, J) >> 2] = X::mfma(y[st][I], y[st][J], acc[G::tri(I, J) >> 2]);
             }
             if (gg < 3 && more) {
 #pragma unroll
@@ -145,50 +165,50 @@ __device__ __forceinline__ bool wg_column(const SampleArgsF &a, int64_t p0, int 
             if ((G::tri(I, J) & 3) == W) {
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    const int gi = 16 * I + 4 * kq + reg, gj = 16 * J + li;
-                    acc[G::tri(I, J) >> 2][reg] = (float)fma(a.alpha, (double)acc[G::tri(I, J) >> 2][reg], a.LambdaF[gi + (size_t)gj * K]);
+                    const int gi = 16 * I + X::drow(kq, reg), gj = 16 * J + li;
+                    acc[G::tri(I, J) >> 2][reg] = (T)fma(a.alpha, (double)acc[G::tri(I, J) >> 2][reg], a.LambdaF[gi + (size_t)gj * K]);
                 }
             }
     if (W == 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            float v = r[t];
+            T v = r[t];
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            if (kq == 0) bv[16 * t + li] = (float)(a.Lmu[16 * t + li] + (double)v);
+            if (kq == 0) bv[16 * t + li] = (T)(a.Lmu[16 * t + li] + (double)v);
         }
     }
 
     bool bad = false;
 #pragma unroll
     for (int s = 0; s < NT; ++s) {
-        float *Rs = R + G::roff(s);
+        T *Rs = R + G::roff(s);
         const int LDs = G::ld(s), Ws = G::width(s);
         // A: park the tiles of block row s
 #pragma unroll
         for (int J = s; J < NT; ++J)
             if ((G::tri(s, J) & 3) == W) {
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) Rs[(4 * kq + reg) * LDs + 16 * (J - s) + li] = acc[G::tri(s, J) >> 2][reg];
+                for (int reg = 0; reg < 4; ++reg) Rs[X::drow(kq, reg) * LDs + 16 * (J - s) + li] = acc[G::tri(s, J) >> 2][reg];
             }
         __syncthreads();
         // B: diagonal block, upper Cholesky, by the first 16 lanes of wave 0 (column c in registers)
         if (W == 0) {
             const int c = lane & 15;
-            float col[16];
+            T col[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) col[k] = Rs[k * LDs + c];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, col[k]), k));
-                bad |= !(d > 0.f);
-                const float rinv = 1.0f / sqrtf(d);
+                const T d = X::bcast(col[k], k);
+                bad |= !(d > (T)0);
+                const T rinv = X::rsqrt_acc(d);
                 col[k] *= rinv;                                       // R(k, c), c >= k (entries left of the diagonal are not used)
                 if (lane == k) dinv[16 * s + k] = rinv;
 #pragma unroll
                 for (int m = k + 1; m < 16; ++m) {
-                    const float rkm = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, col[k]), m));
-                    col[m] = fmaf(-rkm, col[k], col[m]);              // A(m, c) -= R(k, m) R(k, c)
+                    const T rkm = X::bcast(col[k], m);
+                    col[m] = fma(-rkm, col[k], col[m]);               // A(m, c) -= R(k, m) R(k, c)
                 }
             }
             if (lane < 16) {
@@ -199,15 +219,15 @@ __device__ __forceinline__ bool wg_column(const SampleArgsF &a, int64_t p0, int 
         __syncthreads();
         // C: the other columns of the block row: R_ss^T x = a, one thread per column
         if (tid < Ws - 16) {
-            float *cp = Rs + 16 + tid;
-            float x[16];
+            T *cp = Rs + 16 + tid;
+            T x[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) x[k] = cp[k * LDs];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 x[k] *= dinv[16 * s + k];
 #pragma unroll
-                for (int m = k + 1; m < 16; ++m) x[m] = fmaf(-Rs[k * LDs + m], x[k], x[m]);
+                for (int m = k + 1; m < 16; ++m) x[m] = fma(-Rs[k * LDs + m], x[k], x[m]);
             }
 #pragma unroll
             for (int k = 0; k < 16; ++k) cp[k * LDs] = x[k];
@@ -221,18 +241,18 @@ __device__ __forceinline__ bool wg_column(const SampleArgsF &a, int64_t p0, int 
 #pragma unroll
                 for (int J = I; J < NT; ++J) any |= (G::tri(I, J) & 3) == W;
                 if (!any) continue;                                  // compile-time
-                float opI[4];
+                T opI[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) opI[q] = -Rs[(4 * q + kq) * LDs + 16 * (I - s) + li];
 #pragma unroll
                 for (int J = I; J < NT; ++J)
                     if ((G::tri(I, J) & 3) == W) {
-                        float opJ[4];
+                        T opJ[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) opJ[q] = Rs[(4 * q + kq) * LDs + 16 * (J - s) + li];
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            acc[G::tri(I, J) >> 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(opI[q], opJ[q], acc[G::tri(I, J) >> 2], 0, 0, 0);
+                            acc[G::tri(I, J) >> 2] = X::mfma(opI[q], opJ[q], acc[G::tri(I, J) >> 2]);
                     }
             }
         }
@@ -240,15 +260,16 @@ __device__ __forceinline__ bool wg_column(const SampleArgsF &a, int64_t p0, int 
     return bad;
 }
 
-template <int K>
-__global__ __launch_bounds__(256, 3) void k_sample_wg(SampleArgsF a)
+template <int K, typename T>
+__global__ __launch_bounds__(256, 3) void k_sample_wg(SampleArgsW<T> a)
 {
     using G = GeoF<K>;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[G::LDS_BYTES];
+    using X = WgTraits<T>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G::template lds_bytes<T>()];
     double *zs = reinterpret_cast<double *>(smem);                   // K normals (fp64 draw, as the reference)
-    float *R = reinterpret_cast<float *>(zs + K);                    // R by block rows
-    float *bv = R + G::RWORDS;                                       // rhs
-    float *dinv = bv + K;                                            // 1 / R(k,k)
+    T *R = reinterpret_cast<T *>(zs + K);                            // R by block rows
+    T *bv = R + G::RWORDS;                                           // rhs
+    T *dinv = bv + K;                                                // 1 / R(k,k)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int w = blockIdx.x;
     const int col = a.wi_col[w];
@@ -260,28 +281,28 @@ __global__ __launch_bounds__(256, 3) void k_sample_wg(SampleArgsF a)
     if (wave == 3) draw_normals<K>(sample_counter<K>(idx, a.iter_plus_1), K, zs, lane);
     bool bad;
     switch (wave) {
-    case 0: bad = wg_column<K, 0>(a, p0, len, R, dinv, bv, tid); break;
-    case 1: bad = wg_column<K, 1>(a, p0, len, R, dinv, bv, tid); break;
-    case 2: bad = wg_column<K, 2>(a, p0, len, R, dinv, bv, tid); break;
-    default: bad = wg_column<K, 3>(a, p0, len, R, dinv, bv, tid); break;
+    case 0: bad = wg_column<K, T, 0>(a, p0, len, R, dinv, bv, tid); break;
+    case 1: bad = wg_column<K, T, 1>(a, p0, len, R, dinv, bv, tid); break;
+    case 2: bad = wg_column<K, T, 2>(a, p0, len, R, dinv, bv, tid); break;
+    default: bad = wg_column<K, T, 3>(a, p0, len, R, dinv, bv, tid); break;
     }
     __syncthreads();
 
     // ---- R^T y = b (:321), y += z (:322), R x = y (:323): wave 0, rows (lane, lane + 64)
     if (wave == 0) {
-        float y0 = bv[lane], y1 = (K > 64) ? bv[lane + 64] : 0.f;
+        T y0 = bv[lane], y1 = (K > 64) ? bv[lane + 64] : (T)0;
         // forward: after y_k is known, b_j -= R(k, j) y_k for j > k (row k of R: contiguous)
         for (int k = 0; k < K; ++k) {
             const int s = k >> 4;
-            const float *row = R + G::roff(s) + (k & 15) * G::ld(s) - 16 * s;       // row[j] = R(k, j)
-            const float own = (k < 64) ? y0 : y1;
-            const float yk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, own), k & 63)) * dinv[k];
+            const T *row = R + G::roff(s) + (k & 15) * G::ld(s) - 16 * s;           // row[j] = R(k, j)
+            const T own = (k < 64) ? y0 : y1;
+            const T yk = X::bcast(own, k & 63) * dinv[k];
             if (lane == (k & 63)) { if (k < 64) y0 = yk; else y1 = yk; }
-            if (lane > k) y0 = fmaf(-row[lane], yk, y0);
-            if (K > 64 && lane + 64 > k) y1 = fmaf(-row[lane + 64], yk, y1);
+            if (lane > k) y0 = fma(-row[lane], yk, y0);
+            if (K > 64 && lane + 64 > k) y1 = fma(-row[lane + 64], yk, y1);
         }
-        y0 += (float)zs[lane];
-        if (K > 64) y1 += (float)zs[lane + 64];
+        y0 += (T)zs[lane];
+        if (K > 64) y1 += (T)zs[lane + 64];
         // backward: x_k = y_k / R(k,k); y_i -= R(i, k) x_k for i < k (column k of R: per-lane row bases)
         int base0, base1;
         {
@@ -290,17 +311,17 @@ __global__ __launch_bounds__(256, 3) void k_sample_wg(SampleArgsF a)
             base1 = G::roff(s1) + (lane & 15) * G::ld(s1) - 16 * s1;
         }
         for (int k = K - 1; k >= 0; --k) {
-            const float own = (k < 64) ? y0 : y1;
-            const float xk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, own), k & 63)) * dinv[k];
+            const T own = (k < 64) ? y0 : y1;
+            const T xk = X::bcast(own, k & 63) * dinv[k];
             if (lane == (k & 63)) { if (k < 64) y0 = xk; else y1 = xk; }
-            if (lane < k) y0 = fmaf(-R[base0 + k], xk, y0);
-            if (K > 64 && lane + 64 < k) y1 = fmaf(-R[base1 + k], xk, y1);
+            if (lane < k) y0 = fma(-R[base0 + k], xk, y0);
+            if (K > 64 && lane + 64 < k) y1 = fma(-R[base1 + k], xk, y1);
         }
-        float *dst = a.items + (size_t)idx * K;                                     // items().col(idx) = rr (:324)
+        T *dst = a.items + (size_t)idx * K;                                     // items().col(idx) = rr (:324)
         dst[lane] = y0;
         if (K > 64) dst[lane + 64] = y1;
         // non-positive pivot or a non-finite sample: "Cholesky failed" (:308)
-        const bool nf = !(fabsf(y0) <= 3.4e38f) || !(fabsf(y1) <= 3.4e38f);
+        const bool nf = !(fabs((double)y0) <= 1.7e308) || !(fabs((double)y1) <= 1.7e308);
         if (__any(nf || bad) && lane == 0) atomicMin(a.fail, (unsigned long long)idx);
     }
 }

@@ -15,10 +15,11 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-9
 
 
-@pytest.fixture(params=[None, 0, 1], ids=["auto", "persistent", "per-item"])
+@pytest.fixture(params=[None, 0, 1, 2], ids=["auto", "persistent", "per-item", "workgroup"])
 def sampler_mode(request):
-    """Both forms of the sampler (BPMF_HIP_MODE, read when a side is created): 0 = persistent
-    waves with C = 64/K columns factorised side by side, 1 = one work item per workgroup."""
+    """The forms of the sampler (BPMF_HIP_MODE, read when a side is created): 0 = persistent
+    waves with C = 64/K columns factorised side by side, 1 = one work item per single-wave
+    workgroup, 2 = one four-wave workgroup per column (K = 64 only; other K fall back to auto)."""
     import os
     old = os.environ.get("BPMF_HIP_MODE")
     if request.param is None:
