@@ -287,10 +287,11 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     const bool f32 = s->ctx->dtype == BPMF_HIP_F32;
     if (f32) s->mode = 2;                                // one workgroup per column (k_sample_wg), no chunking
     else if (K == 64) {
-        // K = 64 in the workgroup form (blocked factorisation on f64 MFMA tiles) is opt-in
-        // (BPMF_HIP_MODE=2): measured 2x slower than the persistent form on the column-dominated
-        // ChEMBL shape (three of its four waves idle through the serial phases), about equal on ML-1M.
-        // It has no chunking: not for columns far above 16 384 ratings.
+        // K = 64 with the blocked factorisation on f64 MFMA tiles (one wave owning all ten tiles) is
+        // opt-in (BPMF_HIP_MODE=2): measured 12.8 ms against 10.5 ms of the persistent form on the
+        // column-dominated ChEMBL shape (the serial phases -- diagonal blocks, triangular solves --
+        // are latency-bound at 6 waves per CU), about equal on ML-1M.  No chunking: not for columns
+        // far above 16 384 ratings.
         if (mode_env == 2) s->mode = 2;
     } else if (s->mode == 2) s->mode = (K <= 32 && nloc < 65536) ? 1 : 0;      // (BPMF_HIP_MODE=2 exists for K = 64 only)
     const bool wg = s->mode == 2;
@@ -620,7 +621,12 @@ int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, do
         f.LambdaF = d_in; f.Lmu = d_in + (size_t)K * K;
         f.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
         f.mean_rating = self->mean_rating; f.alpha = alpha; f.iter_plus_1 = (uint32_t)(iter + 1);
-        if (self->nwork > 0) hipLaunchKernelGGL((k_sample_wg<K, T>), dim3(self->nwork), dim3(256), 0, st, f);
+        // four waves per column at K = 128; one wave owning all tiles at K = 64 (no idle waves in the
+        // serial phases of the factorisation: the column-dominated shapes are what K = 64 is run on)
+        if (self->nwork > 0) {
+            if constexpr (K == 128) hipLaunchKernelGGL((k_sample_wg<K, T, 4>), dim3(self->nwork), dim3(256), 0, st, f);
+            else hipLaunchKernelGGL((k_sample_wg<K, T, 1>), dim3(self->nwork), dim3(64), 0, st, f);
+        }
     };
     if constexpr (K == 128) {
         launch_wg(0.0f);

@@ -63,7 +63,6 @@ template <int K>
 struct GeoF {
     static constexpr int NT = K / 16;                    // 16-wide tiles per dimension
     static constexpr int NTRI = NT * (NT + 1) / 2;
-    static constexpr int TPW = (NTRI + 3) / 4;           // tiles per wave
     // R (upper, Lambda* = R^T R) lives in LDS by block rows: block row s is 16 x (K - 16 s) floats
     // with a row stride of K - 16 s + 8 (two-way bank conflicts at most for the MFMA operand reads)
     __host__ __device__ static constexpr int width(int s) { return K - 16 * s; }
@@ -71,7 +70,7 @@ struct GeoF {
     __host__ __device__ static constexpr int roff(int s) { return 16 * s * (K + 8) - 128 * s * (s - 1); }   // 16 * sum_{t<s} ld(t)
     static constexpr int RWORDS = roff(NT);
     template <typename T> static constexpr size_t lds_bytes() { return (size_t)K * 8 + (size_t)RWORDS * sizeof(T) + 2 * K * sizeof(T); }
-    // row-major upper index of tile (I, J), I <= J; its owner is wave tri & 3, slot tri >> 2
+    // row-major upper index of tile (I, J), I <= J; with NW waves its owner is wave tri % NW, slot tri / NW
     __host__ __device__ static constexpr int tri(int I, int J) { return I * NT - (I * (I - 1)) / 2 + (J - I); }
 };
 
@@ -86,13 +85,13 @@ struct GeoF {
 //      v_mfma_f32_16x16x4_f32 per tile whose operands are read from block row s.
 // Three workgroup barriers per block step.
 // ---------------------------------------------------------------------------
-template <int K, typename T, int W>
+template <int K, typename T, int NW, int W>
 __device__ __forceinline__ bool wg_column(const SampleArgsW<T> &a, int64_t p0, int len, T *R, T *dinv, T *bv, int tid)
 {
     using G = GeoF<K>;
     using X = WgTraits<T>;
     typedef typename X::acc_t acc_t;
-    constexpr int NT = G::NT, TPW = G::TPW;
+    constexpr int NT = G::NT, TPW = (G::NTRI + NW - 1) / NW;
     const int lane = tid & 63;
     const int kq = lane >> 4, li = lane & 15;
     acc_t acc[TPW];
@@ -144,8 +143,8 @@ __device__ __forceinline__ bool wg_column(const SampleArgsW<T> &a, int64_t p0, i
                 for (int I = 0; I < NT; ++I)
 #pragma unroll
                     for (int J = I; J < NT; ++J)
-                        if ((G::tri(I, J) & 3) == W)
-                            acc[G::tri(I, J) >> 2] = X::mfma(y[st][I], y[st][J], acc[G::tri(I, J) >> 2]);
+                        if ((G::tri(I, J) % NW) == W)
+                            acc[G::tri(I, J) / NW] = X::mfma(y[st][I], y[st][J], acc[G::tri(I, J) / NW]);
             }
             if (gg < 3 && more) {
 #pragma unroll
@@ -162,11 +161,11 @@ __device__ __forceinline__ bool wg_column(const SampleArgsW<T> &a, int64_t p0, i
     for (int I = 0; I < NT; ++I)
 #pragma unroll
         for (int J = I; J < NT; ++J)
-            if ((G::tri(I, J) & 3) == W) {
+            if ((G::tri(I, J) % NW) == W) {
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int gi = 16 * I + X::drow(kq, reg), gj = 16 * J + li;
-                    acc[G::tri(I, J) >> 2][reg] = (T)fma(a.alpha, (double)acc[G::tri(I, J) >> 2][reg], a.LambdaF[gi + (size_t)gj * K]);
+                    acc[G::tri(I, J) / NW][reg] = (T)fma(a.alpha, (double)acc[G::tri(I, J) / NW][reg], a.LambdaF[gi + (size_t)gj * K]);
                 }
             }
     if (W == 0) {
@@ -187,9 +186,9 @@ __device__ __forceinline__ bool wg_column(const SampleArgsW<T> &a, int64_t p0, i
         // A: park the tiles of block row s
 #pragma unroll
         for (int J = s; J < NT; ++J)
-            if ((G::tri(s, J) & 3) == W) {
+            if ((G::tri(s, J) % NW) == W) {
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) Rs[X::drow(kq, reg) * LDs + 16 * (J - s) + li] = acc[G::tri(s, J) >> 2][reg];
+                for (int reg = 0; reg < 4; ++reg) Rs[X::drow(kq, reg) * LDs + 16 * (J - s) + li] = acc[G::tri(s, J) / NW][reg];
             }
         __syncthreads();
         // B: diagonal block, upper Cholesky, by the first 16 lanes of wave 0 (column c in registers)
@@ -218,8 +217,8 @@ __device__ __forceinline__ bool wg_column(const SampleArgsW<T> &a, int64_t p0, i
         }
         __syncthreads();
         // C: the other columns of the block row: R_ss^T x = a, one thread per column
-        if (tid < Ws - 16) {
-            T *cp = Rs + 16 + tid;
+        for (int cc = tid; cc < Ws - 16; cc += 64 * NW) {
+            T *cp = Rs + 16 + cc;
             T x[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) x[k] = cp[k * LDs];
@@ -239,20 +238,20 @@ __device__ __forceinline__ bool wg_column(const SampleArgsW<T> &a, int64_t p0, i
             for (int I = s + 1; I < NT; ++I) {
                 bool any = false;
 #pragma unroll
-                for (int J = I; J < NT; ++J) any |= (G::tri(I, J) & 3) == W;
+                for (int J = I; J < NT; ++J) any |= (G::tri(I, J) % NW) == W;
                 if (!any) continue;                                  // compile-time
                 T opI[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) opI[q] = -Rs[(4 * q + kq) * LDs + 16 * (I - s) + li];
 #pragma unroll
                 for (int J = I; J < NT; ++J)
-                    if ((G::tri(I, J) & 3) == W) {
+                    if ((G::tri(I, J) % NW) == W) {
                         T opJ[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) opJ[q] = Rs[(4 * q + kq) * LDs + 16 * (J - s) + li];
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            acc[G::tri(I, J) >> 2] = X::mfma(opI[q], opJ[q], acc[G::tri(I, J) >> 2]);
+                            acc[G::tri(I, J) / NW] = X::mfma(opI[q], opJ[q], acc[G::tri(I, J) / NW]);
                     }
             }
         }
@@ -260,8 +259,8 @@ __device__ __forceinline__ bool wg_column(const SampleArgsW<T> &a, int64_t p0, i
     return bad;
 }
 
-template <int K, typename T>
-__global__ __launch_bounds__(256, 3) void k_sample_wg(SampleArgsW<T> a)
+template <int K, typename T, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 1 ? 2 : 3)) void k_sample_wg(SampleArgsW<T> a)
 {
     using G = GeoF<K>;
     using X = WgTraits<T>;
@@ -277,14 +276,18 @@ __global__ __launch_bounds__(256, 3) void k_sample_wg(SampleArgsW<T> a)
     const int len = a.wi_len[w];
     const int64_t idx = a.col_from + col;
 
-    // z ~ N(0, I): stream (idx+1)*K*(iter+1) mod 2^32 (c++/sample.cpp:266); wave 3 has the fewest tiles
-    if (wave == 3) draw_normals<K>(sample_counter<K>(idx, a.iter_plus_1), K, zs, lane);
+    // z ~ N(0, I): stream (idx+1)*K*(iter+1) mod 2^32 (c++/sample.cpp:266); the last wave has the fewest tiles
+    if (wave == NW - 1) draw_normals<K>(sample_counter<K>(idx, a.iter_plus_1), K, zs, lane);
     bool bad;
-    switch (wave) {
-    case 0: bad = wg_column<K, T, 0>(a, p0, len, R, dinv, bv, tid); break;
-    case 1: bad = wg_column<K, T, 1>(a, p0, len, R, dinv, bv, tid); break;
-    case 2: bad = wg_column<K, T, 2>(a, p0, len, R, dinv, bv, tid); break;
-    default: bad = wg_column<K, T, 3>(a, p0, len, R, dinv, bv, tid); break;
+    if constexpr (NW == 1) {
+        bad = wg_column<K, T, 1, 0>(a, p0, len, R, dinv, bv, tid);
+    } else {
+        switch (wave) {
+        case 0: bad = wg_column<K, T, 4, 0>(a, p0, len, R, dinv, bv, tid); break;
+        case 1: bad = wg_column<K, T, 4, 1>(a, p0, len, R, dinv, bv, tid); break;
+        case 2: bad = wg_column<K, T, 4, 2>(a, p0, len, R, dinv, bv, tid); break;
+        default: bad = wg_column<K, T, 4, 3>(a, p0, len, R, dinv, bv, tid); break;
+        }
     }
     __syncthreads();
 
