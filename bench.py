@@ -230,6 +230,10 @@ def main():
                      "colstats_ms": red_ms / max(nl, 1),
                      "note": "factors fit in L2/MALL at this size, so achieved may exceed HBM peak (SURVEY 8d)"},
         "rmse": movies.rmse, "rmse_avg": movies.rmse_avg,
+        # secondary figures of SURVEY 8(d): the reference's ratings/s (nnz / t_iter, bpmf.cpp:195) and
+        # the sampling-only rate (columns of both sides / the two sampler launches of one iteration)
+        "ratings_per_s": nnz * world * args.steps / dt if world == 1 else None,
+        "sampling_only_samples_per_s": (nusers + nmovies) / (2.0 * launch_s) if (launch_s > 0 and world == 1) else None,
     }
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
