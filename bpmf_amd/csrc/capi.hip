@@ -5,6 +5,7 @@
 // cut into nnz chunks), upload hp.mu / hp.LambdaF per half-iteration, launch
 // the kernels on one stream and bring the K*K+K+1 reduction words back.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <dlfcn.h>
 #include <rccl/rccl.h>      // types and prototypes only: the library is dlopen'ed on first use
 
@@ -53,6 +54,15 @@ int dev_upload(T **dst, const T *src, size_t n)
     HIP_TRY(hipMalloc((void **)dst, n * sizeof(T)));
     if (src) HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
     return 0;
+}
+
+int env_int(const char *name, int dflt);
+// how long a host thread spins on a result word before it falls back to a blocking wait on the
+// event behind the kernels (BPMF_HIP_SPIN_MS, default 50; 0 = always block: used by the tests)
+double spin_limit_s()
+{
+    static const double v = env_int("BPMF_HIP_SPIN_MS", 50) * 1e-3;
+    return v;
 }
 
 int env_int(const char *name, int dflt)
@@ -261,10 +271,11 @@ int wait_host(bpmf_hip_ctx *c)
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; ++spins) {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == c->seq) return 0;
+        if (spin_limit_s() <= 0.0) break;
         __builtin_ia32_pause();
         if ((spins & 0xFFFu) == 0xFFFu) {
             const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (s > 0.05) break;                 // long kernel (big matrix) or an error: fall back to a blocking wait
+            if (s > spin_limit_s()) break;       // long kernel (big matrix) or an error: fall back to a blocking wait
         }
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -606,10 +617,18 @@ namespace {
 //   launch_exchange: multi-GPU only, in-place broadcast of every rank's fresh column range
 //   launch_stats: sum x / sum x x^T of this rank's columns (+ all-reduce), published to `out_host_dev`
 template <int K>
-int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double alpha, double *d_in, hipStream_t st)
+// ev_start / ev_stop (optional): recorded by the dispatch packet of the sampler itself
+// (hipExtLaunchKernel) instead of by marker packets before and after it -- every marker is a few
+// microseconds on the stream between two samplers.
+int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double alpha, double *d_in, hipStream_t st,
+                   hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr)
 {
     using namespace bpmf;
     bpmf_hip_ctx *c = self->ctx;
+    auto launch = [&](auto kernel, dim3 grid, dim3 block, auto args) {
+        if (ev_start || ev_stop) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, ev_start, ev_stop, 0, args);
+        else hipLaunchKernelGGL(kernel, grid, block, 0, st, args);
+    };
     // one workgroup per column (k_sample_wg): the fp32 large-K path, and K = 64 in fp64
     auto launch_wg = [&](auto zero) {
         typedef decltype(zero) T;
@@ -624,8 +643,8 @@ int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, do
         // four waves per column at K = 128; one wave owning all tiles at K = 64 (no idle waves in the
         // serial phases of the factorisation: the column-dominated shapes are what K = 64 is run on)
         if (self->nwork > 0) {
-            if constexpr (K == 128) hipLaunchKernelGGL((k_sample_wg<K, T, 4>), dim3(self->nwork), dim3(256), 0, st, f);
-            else hipLaunchKernelGGL((k_sample_wg<K, T, 1>), dim3(self->nwork), dim3(64), 0, st, f);
+            if constexpr (K == 128) launch(k_sample_wg<K, T, 4>, dim3(self->nwork), dim3(256), f);
+            else launch(k_sample_wg<K, T, 1>, dim3(self->nwork), dim3(64), f);
         }
     };
     if constexpr (K == 128) {
@@ -647,12 +666,12 @@ int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, do
     a.ablate = c->ablate;
     a.zero_row = c->d_zero;
     if (self->nwork > 0 && self->mode == 1) {
-        hipLaunchKernelGGL(k_sample1<K>, dim3(self->nwork), dim3(64), 0, st, a);
+        launch(k_sample1<K>, dim3(self->nwork), dim3(64), a);
     } else if (self->nwork > 0) {
         // persistent waves: as many single-wave workgroups as the chip holds at this kernel's occupancy
         const int resident = c->num_cu * 4 * Geo<K>::WPS;
         const int grid = std::min(self->nwork, env_int("BPMF_HIP_GRID", resident));
-        hipLaunchKernelGGL(k_sample<K>, dim3(grid), dim3(64), 0, st, a);
+        launch(k_sample<K>, dim3(grid), dim3(64), a);
     }
     return 0;
     }
@@ -924,9 +943,9 @@ void collect(bpmf_hip_side *s, const bpmf_hip_side::Job &job)
     bool seen = false;
     for (unsigned spins = 0; !seen; ++spins) {
         seen = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == job.seq;
-        if (seen) break;
+        if (seen || spin_limit_s() <= 0.0) break;
         __builtin_ia32_pause();
-        if ((spins & 0xFFFu) == 0xFFFu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05) break;
+        if ((spins & 0xFFFu) == 0xFFFu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > spin_limit_s()) break;
     }
     trace("collect: sums landed", s, job.iter);
     (void)hipSetDevice(c->device);
@@ -1061,11 +1080,13 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     // default 4; 1 = every launch; 0 = never): the start marker costs a few microseconds on S0
     static const int every = env_int("BPMF_HIP_TIMING_EVERY", 4);
     const bool timed = every > 0 && seq % (unsigned)every == 0;
-    if (timed) HIP_TRY(hipEventRecord(ev[0], s0));
-    rc = BPMF_DISPATCH_K(K, launch_sampler<KK>(self, other, iter, alpha, self->a_d_in, s0));
+    const bool ride = s1 != s0 && self->nwork > 0 && env_int("BPMF_HIP_EXT_EVENTS", 1) != 0;   // events on the sampler's own packet
+    if (timed && !ride) HIP_TRY(hipEventRecord(ev[0], s0));
+    rc = BPMF_DISPATCH_K(K, launch_sampler<KK>(self, other, iter, alpha, self->a_d_in, s0, (ride && timed) ? ev[0] : nullptr,
+                                               ride ? ev[1] : nullptr));
     if (!rc) rc = BPMF_DISPATCH_K(K, launch_exchange<KK>(self, s0));
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(ev[1], s0));
+    if (!ride) HIP_TRY(hipEventRecord(ev[1], s0));
     if (s1 != s0) HIP_TRY(hipStreamWaitEvent(s1, ev[1], 0));
     unsigned *flag = reinterpret_cast<unsigned *>(self->a_h_out_dev + c->out_words - 1);
     rc = BPMF_DISPATCH_K(K, launch_stats<KK>(self, s1, self->a_d_in, self->a_h_out_dev, flag, seq, self->a_ticket));
@@ -1276,9 +1297,9 @@ extern "C" int bpmf_hip_predict_finish(bpmf_hip_test *t, double *se, double *se_
         bool seen = false;
         for (unsigned spins = 0; !seen; ++spins) {
             seen = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == t->seq;
-            if (seen) break;
+            if (seen || spin_limit_s() <= 0.0) break;
             __builtin_ia32_pause();
-            if ((spins & 0xFFFu) == 0xFFFu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05) break;
+            if ((spins & 0xFFFu) == 0xFFFu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > spin_limit_s()) break;
         }
         if (!seen) {
             HIP_TRY(hipStreamSynchronize(c->stream));

@@ -306,3 +306,26 @@ def test_sharded_path_over_rccl_single_rank(tmp_path):
     assert abs(jt["rmse"] - jb["rmse"]) < 1e-9 and abs(jt["rmse_avg"] - jb["rmse_avg"]) < 1e-9
     assert abs(ja["rmse"] - jb["rmse"]) < 1e-9 and abs(ja["rmse_avg"] - jb["rmse_avg"]) < 1e-9
     assert ja["value"] > 0 and ja["n_gpus"] == 1
+
+
+def test_blocking_fallback_paths_give_the_same_chain():
+    """Long kernels (big matrices) make the host threads give up spinning on the result words and
+    block on an event instead.  BPMF_HIP_SPIN_MS=0 forces that path for every wait: the chain must
+    be the one of the spinning run (single-GPU and sharded forms of bench.py)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    pick = lambda out: json.loads([l for l in out.splitlines() if l.startswith('{"metric"')][-1])
+    runs = []
+    for extra in ({}, {"BPMF_HIP_SPIN_MS": "0"},
+                  {"BPMF_HIP_SPIN_MS": "0", "BPMF_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29541",
+                   "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"}):
+        r = subprocess.run(cmd, env=dict(os.environ, **extra), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                           timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs.append(pick(r.stdout))
+    for j in runs[1:]:
+        assert abs(j["rmse"] - runs[0]["rmse"]) < 1e-9 and abs(j["rmse_avg"] - runs[0]["rmse_avg"]) < 1e-9
