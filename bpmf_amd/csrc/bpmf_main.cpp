@@ -236,6 +236,48 @@ int main(int argc, char *argv[])
     int64_t num_predict = 0;
     int iter = -1;
     const double begin = tick();
+    // Sys::print, c++/sample.cpp:101-107
+    auto print_line = [&](int it, double rm, double rma, double nu, double nm, double secs) {
+        const double items_per_sec = (double)(nusers + nmovies) / secs;
+        const double ratings_per_sec = (double)M.nnz() / secs;
+        char buf[1024];
+        snprintf(buf, sizeof buf, "%d: %s iteration %d:\t RMSE: %3.4f\tavg RMSE: %3.4f\tFU(%6.2f)\tFM(%6.2f)\titems/sec: %6.2f\tratings/sec: %6.2fM\n",
+                 0, (it < burnin) ? "Burnin" : "Sampling", it, rm, rma, std::sqrt(nu), std::sqrt(nm), items_per_sec, ratings_per_sec / 1e6);
+        os << buf << std::flush;
+        average_items_sec += items_per_sec;
+        average_ratings_sec += ratings_per_sec;
+    };
+    if (!aggregate && !verbose) {
+        // Plain sampling run: the loop of c++/bpmf.cpp:180-198 software-pipelined by one half-iteration.
+        // The library only enqueues in bpmf_hip_sys_sample; the line of iteration i-1 (its RMSE sums
+        // and norms) is collected after the first half of iteration i has been queued, so the device
+        // never waits for the host's printing.  The per-iteration rate is the time between two lines.
+        double mark = tick(), norm_m = 0.0, norm_u = 0.0;
+        for (int i = 0; i < nsims; ++i) {
+            if (i > 0) check(bpmf_hip_sys_state(movies, nullptr, &norm_m, nullptr, nullptr, nullptr, nullptr));   // of iteration i-1
+            check(bpmf_hip_sys_sample(movies, users, alpha));   // movies.sample(users)
+            if (i > 0) {
+                check(bpmf_hip_predict_finish(test, &se, &se_avg, &num_predict));
+                rmse = std::sqrt(se / (double)num_predict);
+                rmse_avg = std::sqrt(se_avg / (double)num_predict);
+                check(bpmf_hip_sys_state(users, nullptr, &norm_u, nullptr, nullptr, nullptr, nullptr));
+                const double now = tick();
+                print_line(i - 1, rmse, rmse_avg, norm_u, norm_m, now - mark);
+                mark = now;
+            }
+            check(bpmf_hip_sys_sample(users, movies, alpha));   // users.sample(movies)
+            iter = i;
+            check(bpmf_hip_predict_launch(test, movies, users, (iter < burnin) ? 0 : (iter - burnin)));
+        }
+        if (nsims > 0) {
+            check(bpmf_hip_predict_finish(test, &se, &se_avg, &num_predict));
+            rmse = std::sqrt(se / (double)num_predict);
+            rmse_avg = std::sqrt(se_avg / (double)num_predict);
+            check(bpmf_hip_sys_state(movies, nullptr, &norm_m, nullptr, nullptr, nullptr, nullptr));
+            check(bpmf_hip_sys_state(users, nullptr, &norm_u, nullptr, nullptr, nullptr, nullptr));
+            print_line(nsims - 1, rmse, rmse_avg, norm_u, norm_m, tick() - mark);
+        }
+    } else
     for (int i = 0; i < nsims; ++i) {
         const double start = tick();
         check(bpmf_hip_sys_sample(movies, users, alpha));       // movies.sample(users)
@@ -246,18 +288,10 @@ int main(int argc, char *argv[])
         rmse = std::sqrt(se / (double)num_predict);
         rmse_avg = std::sqrt(se_avg / (double)num_predict);
         const double stop = tick();
-        const double items_per_sec = (double)(nusers + nmovies) / (stop - start);
-        const double ratings_per_sec = (double)M.nnz() / (stop - start);
         double norm_u, norm_m;
         check(bpmf_hip_sys_state(users, nullptr, &norm_u, nullptr, nullptr, nullptr, nullptr));
         check(bpmf_hip_sys_state(movies, nullptr, &norm_m, nullptr, nullptr, nullptr, nullptr));
-        char buf[1024];                                         // Sys::print, c++/sample.cpp:101-107
-        snprintf(buf, sizeof buf, "%d: %s iteration %d:\t RMSE: %3.4f\tavg RMSE: %3.4f\tFU(%6.2f)\tFM(%6.2f)\titems/sec: %6.2f\tratings/sec: %6.2fM\n",
-                 0, (iter < burnin) ? "Burnin" : "Sampling", iter, rmse, rmse_avg, std::sqrt(norm_u), std::sqrt(norm_m),
-                 items_per_sec, ratings_per_sec / 1e6);
-        os << buf << std::flush;
-        average_items_sec += items_per_sec;
-        average_ratings_sec += ratings_per_sec;
+        print_line(iter, rmse, rmse_avg, norm_u, norm_m, stop - start);
 
         if (aggregate && iter >= burnin) { agg_u.add(users); agg_m.add(movies); }
         if (verbose) {
