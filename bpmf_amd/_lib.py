@@ -28,6 +28,7 @@ _SIGNATURES = {
                                        C.c_void_p, C.c_double, C.POINTER(C.c_void_p)]),
     "bpmf_hip_side_create_dev": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_double, C.POINTER(C.c_void_p)]),
+    "bpmf_hip_side_set_prop_posterior": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "bpmf_hip_side_destroy": (C.c_int, [C.c_void_p]),
     "bpmf_hip_side_items_dev": (C.c_void_p, [C.c_void_p]),
     "bpmf_hip_side_bind_items": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -4,7 +4,7 @@
 // Host C++ only: it reads the matrices (io.cpp), mirrors them to the device through the C ABI of
 // include/bpmf_hip.h and runs main()'s Gibbs loop; every column update happens in the HIP kernels.
 // Flags: -n TRAIN -p TEST [-o DIR] [-i N] [-b N] [-a F] [-d K] [-t N] [-f N] [-k] [-r] [-v]
-// (-m / -l propagated posteriors are not implemented yet and are rejected).
+// -m / -l "MU_FILE,LAMBDA_FILE": propagated posteriors of a previous run (c++/bpmf.cpp:134-135).
 // K (the reference's compile-time BPMF_NUMLATENT) is chosen at run time: -d K, else the
 // environment variable BPMF_NUMLATENT, else 32.
 #include <getopt.h>
@@ -179,7 +179,6 @@ int main(int argc, char *argv[])
     }
     (void)k_given;
     if (fname.empty() || probename.empty()) { usage(); return 1; }
-    if (!mname.empty() || !lname.empty()) die("propagated posteriors (-m / -l) are not supported by this build");
     if (!bpmf_hip_supports_k(K)) die("unsupported number of latent dimensions " + std::to_string(K) + " (8, 16, 32, 64)");
 
     std::ofstream redirected;
@@ -211,6 +210,20 @@ int main(int argc, char *argv[])
     check(bpmf_hip_side_create(ctx, nmovies, nusers, 0, nmovies, M.colptr.data(), M.rowidx.data(), M.vals.data(), mean_m, &movies));
     print_init(os, "movs", M, T.nnz(), mean_m);
     check(bpmf_hip_side_create(ctx, nusers, nmovies, 0, nusers, Mt.colptr.data(), Mt.rowidx.data(), Mt.vals.data(), mean_u, &users));
+    // Sys::add_prop_posterior (c++/sample.cpp:157-174): "mu_file,lambda_file"; K x N and K*K x N dense matrices
+    auto add_prop_posterior = [&](bpmf_hip_side *side, const std::string &fnames, int64_t n, const char *what) {
+        if (fnames.empty()) return;
+        const size_t pos = fnames.find_first_of(",");
+        if (pos == std::string::npos) die(std::string("-") + what + " expects MU_FILE,LAMBDA_FILE");
+        const Dense mu = bpmf::io::read_dense(fnames.substr(0, pos));
+        const Dense lambda = bpmf::io::read_dense(fnames.substr(pos + 1));
+        if (mu.ncols != n || lambda.ncols != n || mu.nrows != K || lambda.nrows != (int64_t)K * K)
+            die(std::string("propagated posterior (-") + what + "): expected " + std::to_string(K) + " x " + std::to_string(n) + " and " +
+                std::to_string(K * K) + " x " + std::to_string(n) + " matrices");
+        check(bpmf_hip_side_set_prop_posterior(side, mu.data.data(), lambda.data.data()));
+    };
+    add_prop_posterior(movies, mname, nmovies, "m");
+    add_prop_posterior(users, lname, nusers, "l");
     print_init(os, "users", Mt, T.nnz(), mean_u);
     check(bpmf_hip_test_create(movies, T.colptr.data(), T.rowidx.data(), T.vals.data(), &test));
 

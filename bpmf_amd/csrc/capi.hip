@@ -179,6 +179,7 @@ struct bpmf_hip_side {
     double mean_rating = 0.0;
     int32_t *d_rowidx = nullptr; double *d_vals = nullptr; bool own_csc = true;
     double *d_items = nullptr; bool own_items = true;
+    double *d_prop = nullptr;            // propagated posterior (-m / -l): K x K prior precision per local column, or NULL
     // schedule
     int nwork = 0, nmulti = 0, nslots = 0, mode = 0;
     int32_t *d_wi_col = nullptr, *d_wi_len = nullptr, *d_wi_mc = nullptr, *d_wi_chunk = nullptr;
@@ -425,7 +426,7 @@ static int ctx_create_impl(int device, int K, int dtype, void *stream, bpmf_hip_
     c->ablate = (unsigned)env_int("BPMF_HIP_ABLATE", 0);
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
-    c->in_words = (size_t)K * K + K + 2;                               // LambdaF | Lmu | fail | pad (even: staged as 16-byte words)
+    c->in_words = (size_t)K * K + K + 2 + K;                           // LambdaF | Lmu | fail | pad | mu (even: staged as 16-byte words)
     c->out_words = (size_t)K * K + K + 1 + 1 + 2 + 1;
     HIP_TRY(hipHostMalloc((void **)&c->h_in, c->in_words * sizeof(double), hipHostMallocMapped));
     HIP_TRY(hipHostMalloc((void **)&c->h_out, c->out_words * sizeof(double), hipHostMallocMapped));
@@ -548,6 +549,7 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
     }
     if (s->own_csc) { if (s->d_rowidx) (void)hipFree(s->d_rowidx); if (s->d_vals) (void)hipFree(s->d_vals); }
     if (s->own_items && s->d_items) (void)hipFree(s->d_items);
+    if (s->d_prop) (void)hipFree(s->d_prop);
     void *ptrs[] = {s->d_wi_col, s->d_wi_len, s->d_wi_mc, s->d_wi_chunk, s->d_wi_p0, s->d_mc_slot0, s->d_mc_nch, s->d_mc_count, s->d_partials, s->d_stat_partials, s->a_d_in};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (s->a_h_in) (void)hipHostFree(s->a_h_in);
@@ -556,6 +558,25 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
     if (s->a_gate) (void)hipHostFree(s->a_gate);
     if (s->a_ticket) (void)hipFree(s->a_ticket);
     delete s;
+    return BPMF_HIP_OK;
+}
+
+// Sys::add_prop_posterior (c++/sample.cpp:157-174): per-column priors from a previous run's
+// *-mu.ddm / *-Lambda.ddm.  Like the reference, only Lambda takes part in the update (the loaded
+// mu is never used: rr = hp_LambdaF * hp.mu, c++/sample.cpp:285).
+extern "C" int bpmf_hip_side_set_prop_posterior(bpmf_hip_side *s, const double *mu, const double *Lambda)
+{
+    if (!s) return fail(BPMF_HIP_EINVAL, "set_prop_posterior: NULL");
+    (void)mu;
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    { const int rc = settle_async(s); if (rc) return rc; }
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    if (s->d_prop) { (void)hipFree(s->d_prop); s->d_prop = nullptr; }
+    if (!Lambda) return BPMF_HIP_OK;
+    const size_t words = (size_t)s->ctx->K * s->ctx->K * (size_t)(s->to - s->from);
+    if (hipMalloc((void **)&s->d_prop, words * sizeof(double)) != hipSuccess)
+        return fail(BPMF_HIP_ENOMEM, "set_prop_posterior: device allocation failed");
+    HIP_TRY(hipMemcpy(s->d_prop, Lambda, words * sizeof(double), hipMemcpyHostToDevice));
     return BPMF_HIP_OK;
 }
 
@@ -639,6 +660,7 @@ int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, do
         f.col_from = self->from;
         f.LambdaF = d_in; f.Lmu = d_in + (size_t)K * K;
         f.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
+        f.mu = d_in + (size_t)K * K + K + 2; f.prop_lambda = self->d_prop;
         f.mean_rating = self->mean_rating; f.alpha = alpha; f.iter_plus_1 = (uint32_t)(iter + 1);
         // four waves per column at K = 128; one wave owning all tiles at K = 64 (no idle waves in the
         // serial phases of the factorisation: the column-dominated shapes are what K = 64 is run on)
@@ -662,6 +684,7 @@ int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, do
     a.other_items = other->d_items; a.items = self->d_items; a.col_from = self->from;
     a.LambdaF = d_in; a.Lmu = d_in + (size_t)K * K;
     a.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
+    a.mu = d_in + (size_t)K * K + K + 2; a.prop_lambda = self->d_prop;
     a.mean_rating = self->mean_rating; a.alpha = alpha; a.iter_plus_1 = (uint32_t)(iter + 1);
     a.ablate = c->ablate;
     a.zero_row = c->d_zero;
@@ -756,6 +779,8 @@ void fill_blob(int K, const double *mu, const double *LambdaF, double *h_in)
     }
     const unsigned long long nofail = ~0ull;
     memcpy(&h_in[(size_t)K * K + K], &nofail, sizeof(nofail));
+    h_in[(size_t)K * K + K + 1] = 0.0;
+    memcpy(&h_in[(size_t)K * K + K + 2], mu, sizeof(double) * K);       // hp.mu itself: the propagated-posterior columns need it
 }
 
 }  // namespace

@@ -135,6 +135,10 @@ struct SampleArgs {
     // per-call
     const double *LambdaF;      // K x K col-major (device)
     const double *Lmu;          // LambdaF * mu (device)
+    const double *mu;           // hp.mu (device)
+    // propagated posterior (-m / -l, c++/sample.cpp:152-174,272-277): one K x K col-major prior
+    // precision per LOCAL column replaces LambdaF; rr = Lambda_i * hp.mu keeps the global mu (Q2)
+    const double *prop_lambda;
     unsigned long long *fail;   // min global column id whose factorisation failed
     double mean_rating;
     double alpha;
@@ -413,6 +417,7 @@ __device__ __forceinline__ void deposit_column(const SampleArgs &a, int64_t idx,
     double *sL = lds + slot * G::SLOT, *sY = sL + G::PLEN, *sZ = sY + K;
 
     draw_normals<K>(sample_counter<K>(idx, a.iter_plus_1), K, sZ, lane);
+    const double *LF = a.prop_lambda ? a.prop_lambda + (size_t)(idx - a.col_from) * K * K : a.LambdaF;
 
     int tri = 0;
 #pragma unroll
@@ -426,12 +431,19 @@ __device__ __forceinline__ void deposit_column(const SampleArgs &a, int64_t idx,
                 // an off-diagonal tile is entry (row gj, col gi) of the lower triangle
                 const int row = (I == J) ? gi : gj, col = (I == J) ? gj : gi;
                 if (row < K && col <= row)
-                    sL[tri_off(row) + col] = fma(a.alpha, acc[tri][reg], a.LambdaF[row + col * K]);
+                    sL[tri_off(row) + col] = fma(a.alpha, acc[tri][reg], LF[row + col * K]);
             }
     if (kq == 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-            if (t * 16 + li < K) sY[t * 16 + li] = a.Lmu[t * 16 + li] + r[t];
+            if (t * 16 + li < K) {
+                double lm = a.Lmu[t * 16 + li];
+                if (a.prop_lambda) {                               // rr = Lambda_i * hp.mu (:285)
+                    lm = 0.0;
+                    for (int j = 0; j < K; ++j) lm = fma(LF[t * 16 + li + j * K], a.mu[j], lm);
+                }
+                sY[t * 16 + li] = lm + r[t];
+            }
     }
     if (lane == 0) reinterpret_cast<long long *>(lds + G::C * G::SLOT)[slot] = idx;
 }
@@ -732,14 +744,19 @@ __device__ __forceinline__ void finish_single(const SampleArgs &a, int col_local
     const int l = lane & (G::LANES - 1);                           // K=8: the upper half-wave mirrors the lower
     const int h = l / K, i = l % K;
     // this lane's entries of LambdaF and LambdaF*mu: issued before the LDS round trip below
+    const double *LF = a.prop_lambda ? a.prop_lambda + (size_t)col_local * K * K : a.LambdaF;
     double lf[M];
 #pragma unroll
     for (int q = 0; q < QN; ++q) {
         const int j = 2 * (q * S + h);
-        lf[2 * q] = a.LambdaF[i + j * K];
-        lf[2 * q + 1] = a.LambdaF[i + (j + 1) * K];
+        lf[2 * q] = LF[i + j * K];
+        lf[2 * q + 1] = LF[i + (j + 1) * K];
     }
-    const double lmu = a.Lmu[i];
+    double lmu = a.Lmu[i];
+    if (a.prop_lambda) {                                           // wave-uniform: rr = Lambda_i * hp.mu (:285)
+        lmu = 0.0;
+        for (int j = 0; j < K; ++j) lmu = fma(LF[i + j * K], a.mu[j], lmu);
+    }
 
     // G -> LDS, mirrored (c++/sample.cpp:297); rhs sums -> LDS
     assemble(sA, sb, LD, lane);

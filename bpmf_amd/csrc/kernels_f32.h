@@ -53,6 +53,8 @@ struct SampleArgsW {
     int64_t col_from;
     const double *LambdaF;      // K x K col-major (device, fp64)
     const double *Lmu;
+    const double *mu;
+    const double *prop_lambda;  // propagated posterior: K x K per local column, or NULL (see SampleArgs)
     unsigned long long *fail;
     double mean_rating;
     double alpha;
@@ -86,7 +88,7 @@ struct GeoF {
 // Three workgroup barriers per block step.
 // ---------------------------------------------------------------------------
 template <int K, typename T, int NW, int W>
-__device__ __forceinline__ bool wg_column(const SampleArgsW<T> &a, int64_t p0, int len, T *R, T *dinv, T *bv, int tid)
+__device__ __forceinline__ bool wg_column(const SampleArgsW<T> &a, int col_local, int64_t p0, int len, T *R, T *dinv, T *bv, int tid)
 {
     using G = GeoF<K>;
     using X = WgTraits<T>;
@@ -157,6 +159,7 @@ __device__ __forceinline__ bool wg_column(const SampleArgsW<T> &a, int64_t p0, i
         }
     }
     // Lambda* = LambdaF + alpha G in the register tiles (:297-298); b = LambdaF mu + rr (:285,:256)
+    const double *LF = a.prop_lambda ? a.prop_lambda + (size_t)col_local * K * K : a.LambdaF;
 #pragma unroll
     for (int I = 0; I < NT; ++I)
 #pragma unroll
@@ -165,7 +168,7 @@ __device__ __forceinline__ bool wg_column(const SampleArgsW<T> &a, int64_t p0, i
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int gi = 16 * I + X::drow(kq, reg), gj = 16 * J + li;
-                    acc[G::tri(I, J) / NW][reg] = (T)fma(a.alpha, (double)acc[G::tri(I, J) / NW][reg], a.LambdaF[gi + (size_t)gj * K]);
+                    acc[G::tri(I, J) / NW][reg] = (T)fma(a.alpha, (double)acc[G::tri(I, J) / NW][reg], LF[gi + (size_t)gj * K]);
                 }
             }
     if (W == 0) {
@@ -174,7 +177,14 @@ __device__ __forceinline__ bool wg_column(const SampleArgsW<T> &a, int64_t p0, i
             T v = r[t];
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            if (kq == 0) bv[16 * t + li] = (T)(a.Lmu[16 * t + li] + (double)v);
+            if (kq == 0) {
+                double lm = a.Lmu[16 * t + li];
+                if (a.prop_lambda) {                                 // rr = Lambda_i * hp.mu (:285)
+                    lm = 0.0;
+                    for (int j = 0; j < K; ++j) lm = fma(LF[16 * t + li + (size_t)j * K], a.mu[j], lm);
+                }
+                bv[16 * t + li] = (T)(lm + (double)v);
+            }
         }
     }
 
@@ -280,13 +290,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? 2 : 3)) void k_sample_wg(Sample
     if (wave == NW - 1) draw_normals<K>(sample_counter<K>(idx, a.iter_plus_1), K, zs, lane);
     bool bad;
     if constexpr (NW == 1) {
-        bad = wg_column<K, T, 1, 0>(a, p0, len, R, dinv, bv, tid);
+        bad = wg_column<K, T, 1, 0>(a, col, p0, len, R, dinv, bv, tid);
     } else {
         switch (wave) {
-        case 0: bad = wg_column<K, T, 4, 0>(a, p0, len, R, dinv, bv, tid); break;
-        case 1: bad = wg_column<K, T, 4, 1>(a, p0, len, R, dinv, bv, tid); break;
-        case 2: bad = wg_column<K, T, 4, 2>(a, p0, len, R, dinv, bv, tid); break;
-        default: bad = wg_column<K, T, 4, 3>(a, p0, len, R, dinv, bv, tid); break;
+        case 0: bad = wg_column<K, T, 4, 0>(a, col, p0, len, R, dinv, bv, tid); break;
+        case 1: bad = wg_column<K, T, 4, 1>(a, col, p0, len, R, dinv, bv, tid); break;
+        case 2: bad = wg_column<K, T, 4, 2>(a, col, p0, len, R, dinv, bv, tid); break;
+        default: bad = wg_column<K, T, 4, 3>(a, col, p0, len, R, dinv, bv, tid); break;
         }
     }
     __syncthreads();

@@ -113,6 +113,15 @@ class HipEngine:
         self.bind_items(side, t.data_ptr(), keep=t)
         return t
 
+    def set_prop_posterior(self, side, Lambda):
+        """Per-column prior precisions of the side's local columns: [ncols_local, K*K] (each row a
+        column-major K x K matrix, as in *-Lambda.ddm), or None to remove them."""
+        if Lambda is None:
+            _lib.check(self.lib.bpmf_hip_side_set_prop_posterior(side.handle, None, None))
+            return
+        L = np.ascontiguousarray(Lambda, np.float64).reshape(side.col_to - side.col_from, self.K * self.K)
+        _lib.check(self.lib.bpmf_hip_side_set_prop_posterior(side.handle, None, _ptr(L)))
+
     def get_items(self, side):
         """[ncols, K] C-order array = the K x ncols column-major factor matrix."""
         out = np.empty((side.ncols, self.K), np.float64)

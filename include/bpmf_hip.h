@@ -110,6 +110,12 @@ BPMF_API int bpmf_hip_side_create(bpmf_hip_ctx *ctx, int64_t ncols, int64_t nrow
 BPMF_API int bpmf_hip_side_create_dev(bpmf_hip_ctx *ctx, int64_t ncols, int64_t nrows, int64_t col_from, int64_t col_to,
                              const int64_t *colptr_host, const int32_t *rowidx_dev, const double *vals_dev,
                              double mean_rating, bpmf_hip_side **out);
+/* Propagated-posterior priors (-m / -l of the reference: Sys::add_prop_posterior,
+ * c++/sample.cpp:157-174, used at :272-277).  Lambda: K*K doubles per column of the side's slice
+ * [from, to) (each a column-major K x K precision, the layout of U-Lambda.ddm / V-Lambda.ddm); it
+ * replaces hp.LambdaF in those columns' updates.  mu (K per column) is accepted and, like in the
+ * reference, not used (rr = hp_LambdaF * hp.mu, c++/sample.cpp:285).  Lambda = NULL removes them. */
+BPMF_API int bpmf_hip_side_set_prop_posterior(bpmf_hip_side *side, const double *mu, const double *Lambda);
 BPMF_API int bpmf_hip_side_destroy(bpmf_hip_side *side);
 
 /* items(): device address of the K x ncols factor matrix (c++/bpmf.h:193-194);

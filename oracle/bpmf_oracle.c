@@ -403,7 +403,7 @@ static inline __attribute__((always_inline)) int64_t
 sample_side_K(const int K, int64_t from, int64_t to, const int64_t *colptr, const int32_t *rowidx,
               const double *vals, double mean_rating, double alpha, const double *other_items,
               double *items, int iter, const double *mu, const double *LambdaF,
-              double *sum_out, double *prod_out, double *norm_out, int nthreads)
+              double *sum_out, double *prod_out, double *norm_out, int nthreads, const double *propLambda)
 {
     int64_t failed = 0;
     double *Lmu = (double *)malloc(sizeof(double) * K);
@@ -430,10 +430,24 @@ sample_side_K(const int K, int64_t from, int64_t to, const int64_t *colptr, cons
         double *MM = (double *)malloc(sizeof(double) * K * K);
         double *L = (double *)malloc(sizeof(double) * K * K);
         double *r = (double *)malloc(sizeof(double) * K);
+        double *Lmu_i = (double *)malloc(sizeof(double) * K);
         double *pp = part + per * tid, *ps = pp + (size_t)K * K, *pn = ps + K;
 #pragma omp for schedule(guided)
         for (int64_t i = from; i < to; ++i) {                          /* c++/sample.cpp:352-372 */
-            if (sample_col(K, i, colptr, rowidx, vals, mean_rating, alpha, other_items, iter, Lmu, LambdaF, MM, L, r)) {
+            /* propagated posterior (c++/sample.cpp:272-277): the column's own Lambda replaces
+             * hp.LambdaF; rr = hp_LambdaF * hp.mu keeps the GLOBAL mu (:285; propMu is loaded but
+             * never used: SURVEY Q2) */
+            const double *LF_i = propLambda ? propLambda + (size_t)i * K * K : LambdaF;
+            const double *Lm = Lmu;
+            if (propLambda) {
+                for (int a = 0; a < K; ++a) {
+                    double sacc = 0.0;
+                    for (int b = 0; b < K; ++b) sacc += AT(LF_i, a, b) * mu[b];
+                    Lmu_i[a] = sacc;
+                }
+                Lm = Lmu_i;
+            }
+            if (sample_col(K, i, colptr, rowidx, vals, mean_rating, alpha, other_items, iter, Lm, LF_i, MM, L, r)) {
 #pragma omp critical
                 if (!failed || -(i + 1) > failed) failed = -(i + 1);
                 continue;
@@ -447,7 +461,7 @@ sample_side_K(const int K, int64_t from, int64_t to, const int64_t *colptr, cons
             *pn += nn;
             memcpy(items + (size_t)i * K, r, sizeof(double) * K);      /* :324 */
         }
-        free(MM); free(L); free(r);
+        free(MM); free(L); free(r); free(Lmu_i);
     }
     for (size_t q = 0; q < per; ++q) {                                  /* combine(): thread-id order */
         double s = 0.0;
@@ -471,14 +485,27 @@ ORACLE_API int64_t bpmf_oracle_sample_side(int K, int64_t from, int64_t to, cons
                                            const double *mu, const double *LambdaF, double *sum_out,
                                            double *prod_out, double *norm_out, int nthreads)
 {
-#define DISPATCH(KK) case KK: return sample_side_K(KK, from, to, colptr, rowidx, vals, mean_rating, alpha, other_items, items, iter, mu, LambdaF, sum_out, prod_out, norm_out, nthreads)
+#define DISPATCH(KK) case KK: return sample_side_K(KK, from, to, colptr, rowidx, vals, mean_rating, alpha, other_items, items, iter, mu, LambdaF, sum_out, prod_out, norm_out, nthreads, NULL)
     switch (K) {
         DISPATCH(8); DISPATCH(16); DISPATCH(32); DISPATCH(64); DISPATCH(128);
     default:
-        return sample_side_K(K, from, to, colptr, rowidx, vals, mean_rating, alpha, other_items, items, iter, mu, LambdaF, sum_out, prod_out, norm_out, nthreads);
+        return sample_side_K(K, from, to, colptr, rowidx, vals, mean_rating, alpha, other_items, items, iter, mu, LambdaF, sum_out, prod_out, norm_out, nthreads, NULL);
     }
 #undef DISPATCH
 }
+
+/* the same with propagated-posterior priors (-m / -l, c++/sample.cpp:152-174,272-277):
+ * propLambda holds one column-major K x K matrix per column of this side (global column index) */
+ORACLE_API int64_t bpmf_oracle_sample_side_prop(int K, int64_t from, int64_t to, const int64_t *colptr,
+                                                const int32_t *rowidx, const double *vals, double mean_rating,
+                                                double alpha, const double *other_items, double *items, int iter,
+                                                const double *mu, const double *LambdaF, const double *propLambda,
+                                                double *sum_out, double *prod_out, double *norm_out, int nthreads)
+{
+    return sample_side_K(K, from, to, colptr, rowidx, vals, mean_rating, alpha, other_items, items, iter, mu, LambdaF, sum_out,
+                         prod_out, norm_out, nthreads, propLambda);
+}
+
 
 /* cov = (prod - sum sum^T / N) / (N-1), c++/sample.cpp:383-384 */
 ORACLE_API void bpmf_oracle_cov(int K, int64_t N, const double *sum, const double *prod, double *cov)

@@ -50,6 +50,10 @@ class Oracle:
             C.c_int, C.c_int64, C.c_int64, _i64p, _i32p, _f64p, C.c_double, C.c_double, _f64p, _f64p,
             C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_int]
         lib.bpmf_oracle_sample_side.restype = C.c_int64
+        lib.bpmf_oracle_sample_side_prop.argtypes = [
+            C.c_int, C.c_int64, C.c_int64, _i64p, _i32p, _f64p, C.c_double, C.c_double, _f64p, _f64p,
+            C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_int]
+        lib.bpmf_oracle_sample_side_prop.restype = C.c_int64
         lib.bpmf_oracle_cov.argtypes = [C.c_int, C.c_int64, _f64p, _f64p, _f64p]
         lib.bpmf_oracle_predict.argtypes = [
             C.c_int, C.c_int64, C.c_int64, _i64p, _i32p, _f64p, _f64p, _f64p, C.c_double, C.c_int,
@@ -98,14 +102,24 @@ class Oracle:
 
     # -- sampling ------------------------------------------------------------
     def sample_side(self, K, csc, mean_rating, alpha, other_items, items, it, mu, LambdaF,
-                    from_=0, to=None, nthreads=1):
+                    from_=0, to=None, nthreads=1, prop_lambda=None):
         """Samples columns [from_,to) of `items` in place ([N,K] C-order arrays =
-        column-major K x N); returns (sum[K], prod[K,K], norm)."""
+        column-major K x N); returns (sum[K], prod[K,K], norm).  prop_lambda: [N, K, K] array of
+        per-column prior precisions (the propagated posterior of -m / -l), each stored transposed,
+        i.e. prop_lambda[i].T is the matrix (column-major K x K per column, like *-Lambda.ddm)."""
         colptr, rowidx, vals = csc
         n = len(colptr) - 1
         to = n if to is None else to
         s = np.zeros(K); prod = np.zeros((K, K), order="F"); nrm = np.zeros(1)
         LF = np.asfortranarray(LambdaF, np.float64)
+        if prop_lambda is not None:
+            pl = np.ascontiguousarray(prop_lambda, np.float64)
+            rc = self.lib.bpmf_oracle_sample_side_prop(
+                K, from_, to, colptr, rowidx, vals, float(mean_rating), float(alpha), other_items, items,
+                int(it), np.ascontiguousarray(mu, np.float64), LF.T, pl, s, prod.T, nrm, nthreads)
+            if rc:
+                raise RuntimeError("Cholesky failed in column %d" % (-rc - 1))
+            return s, prod, float(nrm[0])
         rc = self.lib.bpmf_oracle_sample_side(
             K, from_, to, colptr, rowidx, vals, float(mean_rating), float(alpha), other_items, items,
             int(it), np.ascontiguousarray(mu, np.float64), LF.T, s, prod.T, nrm, nthreads)

@@ -87,3 +87,38 @@ def test_movielens_ctest(tmp_path, suffix):
     assert len(lines) == 4 and all("Burnin" in l for l in lines)
     assert abs(float(re.search(r"\t RMSE: (\S+)", lines[0]).group(1)) - 1.1537) < 2e-3
     assert re.search(r"Average items/sec: \S+", r.stdout) and re.search(r"Final Avg RMSE: 1\.15", r.stdout)
+
+
+@pytest.mark.gpu
+def test_propagated_posterior_workflow(hip_engine_factory, tmp_path):
+    """The workflow -m / -l exist for (c++/bpmf.cpp:134-135): a first run writes U/V-mu.ddm and
+    U/V-Lambda.ddm with -o, a second run takes them as per-column priors.  The second run's chain
+    must be the one the library gives when the same Lambda matrices are set through the C ABI."""
+    import bpmf_amd
+    from bpmf_amd.sys import Sys
+    K = 8
+    train, test = os.path.join(G, "ml100k-train.mtx.gz"), os.path.join(G, "ml100k-test.mtx.gz")
+    (tmp_path / "o1").mkdir()
+    r = run(["-i", "14", "-b", "2", "-d", str(K), "-n", train, "-p", test, "-o", "o1/"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    lam_u = bio.read_dense(tmp_path / "o1" / "U-Lambda.ddm"); lam_v = bio.read_dense(tmp_path / "o1" / "V-Lambda.ddm")
+    assert np.all(np.isfinite(lam_u)) and np.all(np.isfinite(lam_v))
+    r = run(["-i", "5", "-b", "1", "-d", str(K), "-n", train, "-p", test,
+             "-m", "o1/V-mu.ddm,o1/V-Lambda.ddm", "-l", "o1/U-mu.ddm,o1/U-Lambda.ddm"], tmp_path)
+    assert r.returncode == 0, r.stderr
+    final = float(re.search(r"Final Avg RMSE: (\S+)", r.stdout).group(1))
+    # the same through the Python mirror
+    M, Mt, T, Tt, nu, nm = util.ml100k()
+    eng = hip_engine_factory(K)
+    Sys.nsims, Sys.burnin, Sys.alpha = 5, 1, 2.0
+    movies = Sys("movs", eng, M, nm, nu, T=T); users = Sys("users", eng, Mt, nu, nm)
+    eng.set_prop_posterior(movies.side, lam_v.T); eng.set_prop_posterior(users.side, lam_u.T)
+    for _ in range(5):
+        movies.sample(users); users.sample(movies); movies.predict(users)
+    movies.predict(users, True)
+    assert abs(final - movies.rmse_avg) < 1e-4
+    # malformed argument / wrong shape
+    r = run(["-i", "1", "-d", str(K), "-n", train, "-p", test, "-m", "o1/V-mu.ddm"], tmp_path)
+    assert r.returncode != 0 and "MU_FILE,LAMBDA_FILE" in r.stderr
+    r = run(["-i", "1", "-d", str(K), "-n", train, "-p", test, "-m", "o1/U-mu.ddm,o1/U-Lambda.ddm"], tmp_path)
+    assert r.returncode != 0 and "expected" in r.stderr

@@ -308,6 +308,41 @@ def test_sharded_path_over_rccl_single_rank(tmp_path):
     assert ja["value"] > 0 and ja["n_gpus"] == 1
 
 
+@pytest.mark.parametrize("K", [16, 32, 64])
+def test_propagated_posterior_priors(oracle, hip_engine_factory, K, sampler_mode):
+    """-m / -l of the reference (c++/sample.cpp:157-174,272-277): every column has its own prior
+    precision Lambda_i (from a previous run's *-Lambda.ddm); rr = Lambda_i * hp.mu keeps the
+    global mu (the loaded per-column mu is never used: SURVEY Q2)."""
+    M, Mt, T, Tt, nu, nm = util.ml100k()
+    eng = hip_engine_factory(K)
+    rng = np.random.default_rng(300 + K)
+    U = 0.3 * rng.standard_normal((nu, K))
+    ncols = len(M[0]) - 1
+    B = rng.standard_normal((ncols, K, K)) * 0.2
+    prop = np.einsum("nij,nkj->nik", B, B) + 2.0 * np.eye(K)[None]        # SPD per column; symmetric => layout-neutral
+    A = rng.standard_normal((K, 3 * K)); cov = A @ A.T / (3 * K)
+    it, alpha = 4, 2.0
+    mu, LU, LF = oracle.hyper_sample(K, ncols, cov, it)
+    mean = util.mean_rating(M)
+    items_ref = np.zeros((ncols, K))
+    s_ref, p_ref, n_ref = oracle.sample_side(K, M, mean, alpha, U, items_ref, it, mu, LF, prop_lambda=prop)
+    me = eng.side_create(ncols, nu, *M, mean)
+    ot = eng.side_create(nu, ncols, np.zeros(nu + 1, np.int64), np.zeros(0, np.int32), np.zeros(0), 0.0)
+    eng.set_items(ot, U)
+    eng.set_prop_posterior(me, prop.reshape(ncols, K * K))
+    s1, p1, n1 = eng.sample_side(me, ot, it, alpha, mu, LF)
+    items = eng.get_items(me)
+    assert rel_err(items, items_ref) < RTOL
+    assert rel_err(s1, s_ref) < 1e-8 and rel_err(p1, p_ref) < 1e-8
+    # and they can be removed again
+    eng.set_prop_posterior(me, None)
+    items_ref2 = np.zeros((ncols, K))
+    oracle.sample_side(K, M, mean, alpha, U, items_ref2, it, mu, LF)
+    eng.sample_side(me, ot, it, alpha, mu, LF)
+    assert rel_err(eng.get_items(me), items_ref2) < RTOL
+    eng.side_destroy(me); eng.side_destroy(ot)
+
+
 def test_blocking_fallback_paths_give_the_same_chain():
     """Long kernels (big matrices) make the host threads give up spinning on the result words and
     block on an event instead.  BPMF_HIP_SPIN_MS=0 forces that path for every wait: the chain must
