@@ -18,6 +18,7 @@ _SIGNATURES = {
     "bpmf_hip_supports": (C.c_int, [C.c_int, C.c_int]),
     "bpmf_hip_ctx_create_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "bpmf_hip_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bpmf_hip_ctx_set_no_covariance": (C.c_int, [C.c_void_p, C.c_int]),
     "bpmf_hip_ctx_destroy": (C.c_int, [C.c_void_p]),
     "bpmf_hip_ctx_sync": (C.c_int, [C.c_void_p]),
     "bpmf_hip_ctx_stream": (C.c_void_p, [C.c_void_p]),

@@ -155,6 +155,7 @@ struct bpmf_hip_ctx {
     bool own_stream = false;
     int num_cu = 256;
     unsigned ablate = 0;
+    unsigned diag_only = 0;              // BPMF_NO_COVARIANCE variant (bpmf_hip_ctx_set_no_covariance)
     // per-call parameter blob: LambdaF[K*K] | Lmu[K] | fail (u64); pinned host copy + device copy
     double *h_in = nullptr, *h_in_dev = nullptr, *d_in = nullptr;
     // result blob in pinned host memory the kernels write directly (zero-copy):
@@ -444,6 +445,14 @@ static int ctx_create_impl(int device, int K, int dtype, void *stream, bpmf_hip_
     return BPMF_HIP_OK;
 }
 
+// the BPMF_NO_COVARIANCE build of the reference (c++/sample.cpp:300-304) as a run-time switch
+extern "C" int bpmf_hip_ctx_set_no_covariance(bpmf_hip_ctx *c, int on)
+{
+    if (!c) return fail(BPMF_HIP_EINVAL, "set_no_covariance: NULL");
+    c->diag_only = on ? 1u : 0u;
+    return BPMF_HIP_OK;
+}
+
 extern "C" int bpmf_hip_ctx_destroy(bpmf_hip_ctx *c)
 {
     if (!c) return BPMF_HIP_OK;
@@ -660,7 +669,7 @@ int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, do
         f.col_from = self->from;
         f.LambdaF = d_in; f.Lmu = d_in + (size_t)K * K;
         f.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
-        f.mu = d_in + (size_t)K * K + K + 2; f.prop_lambda = self->d_prop;
+        f.mu = d_in + (size_t)K * K + K + 2; f.prop_lambda = self->d_prop; f.diag_only = c->diag_only;
         f.mean_rating = self->mean_rating; f.alpha = alpha; f.iter_plus_1 = (uint32_t)(iter + 1);
         // four waves per column at K = 128; one wave owning all tiles at K = 64 (no idle waves in the
         // serial phases of the factorisation: the column-dominated shapes are what K = 64 is run on)
@@ -684,7 +693,7 @@ int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, do
     a.other_items = other->d_items; a.items = self->d_items; a.col_from = self->from;
     a.LambdaF = d_in; a.Lmu = d_in + (size_t)K * K;
     a.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
-    a.mu = d_in + (size_t)K * K + K + 2; a.prop_lambda = self->d_prop;
+    a.mu = d_in + (size_t)K * K + K + 2; a.prop_lambda = self->d_prop; a.diag_only = c->diag_only;
     a.mean_rating = self->mean_rating; a.alpha = alpha; a.iter_plus_1 = (uint32_t)(iter + 1);
     a.ablate = c->ablate;
     a.zero_row = c->d_zero;

@@ -139,6 +139,7 @@ struct SampleArgs {
     // propagated posterior (-m / -l, c++/sample.cpp:152-174,272-277): one K x K col-major prior
     // precision per LOCAL column replaces LambdaF; rr = Lambda_i * hp.mu keeps the global mu (Q2)
     const double *prop_lambda;
+    uint32_t diag_only;         // BPMF_NO_COVARIANCE build of the reference (c++/sample.cpp:300-304): keep only the diagonal of Lambda*
     unsigned long long *fail;   // min global column id whose factorisation failed
     double mean_rating;
     double alpha;
@@ -431,7 +432,7 @@ __device__ __forceinline__ void deposit_column(const SampleArgs &a, int64_t idx,
                 // an off-diagonal tile is entry (row gj, col gi) of the lower triangle
                 const int row = (I == J) ? gi : gj, col = (I == J) ? gj : gi;
                 if (row < K && col <= row)
-                    sL[tri_off(row) + col] = fma(a.alpha, acc[tri][reg], LF[row + col * K]);
+                    sL[tri_off(row) + col] = (a.diag_only && row != col) ? 0.0 : fma(a.alpha, acc[tri][reg], LF[row + col * K]);
             }
     if (kq == 0) {
 #pragma unroll
@@ -770,6 +771,14 @@ __device__ __forceinline__ void finish_single(const SampleArgs &a, int col_local
         const double2 g = *reinterpret_cast<const double2 *>(&sA[i * LD + 2 * (q * S + h)]);
         row[2 * q] = fma(a.alpha, g.x, lf[2 * q]);
         row[2 * q + 1] = fma(a.alpha, g.y, lf[2 * q + 1]);
+    }
+    if (a.diag_only) {                                             // wave-uniform
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+            const int j = 2 * (q * S + h);
+            row[2 * q] = (j == i) ? row[2 * q] : 0.0;
+            row[2 * q + 1] = (j + 1 == i) ? row[2 * q + 1] : 0.0;
+        }
     }
     row[M] = (h == 0) ? lmu + sb[i] : 0.0;
     row[M + 1] = 0.0;

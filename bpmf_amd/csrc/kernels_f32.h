@@ -55,6 +55,7 @@ struct SampleArgsW {
     const double *Lmu;
     const double *mu;
     const double *prop_lambda;  // propagated posterior: K x K per local column, or NULL (see SampleArgs)
+    uint32_t diag_only;         // BPMF_NO_COVARIANCE (see SampleArgs)
     unsigned long long *fail;
     double mean_rating;
     double alpha;
@@ -168,7 +169,7 @@ __device__ __forceinline__ bool wg_column(const SampleArgsW<T> &a, int col_local
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int gi = 16 * I + X::drow(kq, reg), gj = 16 * J + li;
-                    acc[G::tri(I, J) / NW][reg] = (T)fma(a.alpha, (double)acc[G::tri(I, J) / NW][reg], LF[gi + (size_t)gj * K]);
+                    acc[G::tri(I, J) / NW][reg] = (a.diag_only && gi != gj) ? (T)0 : (T)fma(a.alpha, (double)acc[G::tri(I, J) / NW][reg], LF[gi + (size_t)gj * K]);
                 }
             }
     if (W == 0) {

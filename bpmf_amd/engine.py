@@ -49,6 +49,10 @@ class HipEngine:
             self.lib.bpmf_hip_ctx_destroy(self.ctx)
             self.ctx = None
 
+    def set_no_covariance(self, on):
+        """The reference's BPMF_NO_COVARIANCE build as a switch: diagonal Lambda* only."""
+        _lib.check(self.lib.bpmf_hip_ctx_set_no_covariance(self.ctx, 1 if on else 0))
+
     def sync(self):
         _lib.check(self.lib.bpmf_hip_ctx_sync(self.ctx))
 

@@ -74,6 +74,9 @@ BPMF_API int bpmf_hip_supports(int K, int dtype);
  * context create its own non-blocking stream. */
 BPMF_API int bpmf_hip_ctx_create(int device, int K, void *stream, bpmf_hip_ctx **out);      /* fp64 */
 BPMF_API int bpmf_hip_ctx_create_ex(int device, int K, int dtype, void *stream, bpmf_hip_ctx **out);
+/* run-time form of the reference's BPMF_NO_COVARIANCE build (c++/sample.cpp:300-304): only the
+ * diagonal of Lambda* = LambdaF + alpha G enters the factorisation of every column */
+BPMF_API int bpmf_hip_ctx_set_no_covariance(bpmf_hip_ctx *ctx, int on);
 BPMF_API int bpmf_hip_ctx_destroy(bpmf_hip_ctx *ctx);
 BPMF_API int bpmf_hip_ctx_sync(bpmf_hip_ctx *ctx);
 BPMF_API void *bpmf_hip_ctx_stream(bpmf_hip_ctx *ctx);

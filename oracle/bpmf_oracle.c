@@ -359,7 +359,7 @@ static inline __attribute__((always_inline)) int
 sample_col(const int K, int64_t idx, const int64_t *colptr, const int32_t *rowidx, const double *vals,
            double mean_rating, double alpha, const double *other_items, int iter,
            const double *Lmu /* LambdaF*mu */, const double *LambdaF,
-           double *MM, double *L, double *rr /* out: the sample */)
+           double *MM, double *L, double *rr /* out: the sample */, int no_covariance)
 {
     urng_t u;
     urng_reset(&u, (uint32_t)((idx + 1) * (int64_t)K * ((int64_t)iter + 1)));   /* :266, truncated to uint32 (Q3) */
@@ -383,6 +383,11 @@ sample_col(const int K, int64_t idx, const int64_t *colptr, const int32_t *rowid
             AT(MM, i, j) = v; AT(MM, j, i) = vt;
         }
 
+    if (no_covariance)                                                            /* BPMF_NO_COVARIANCE, :300-304: keep the diagonal */
+        for (int j = 0; j < K; ++j)
+            for (int i = 0; i < K; ++i)
+                if (i != j) AT(MM, i, j) = 0.0;
+
     if (chol_lower(K, MM, L)) return 1;                                           /* :306-308 */
 
     for (int i = 0; i < K; ++i) {                                                 /* :321 L y = rr */
@@ -403,7 +408,7 @@ static inline __attribute__((always_inline)) int64_t
 sample_side_K(const int K, int64_t from, int64_t to, const int64_t *colptr, const int32_t *rowidx,
               const double *vals, double mean_rating, double alpha, const double *other_items,
               double *items, int iter, const double *mu, const double *LambdaF,
-              double *sum_out, double *prod_out, double *norm_out, int nthreads, const double *propLambda)
+              double *sum_out, double *prod_out, double *norm_out, int nthreads, const double *propLambda, int no_covariance)
 {
     int64_t failed = 0;
     double *Lmu = (double *)malloc(sizeof(double) * K);
@@ -447,7 +452,7 @@ sample_side_K(const int K, int64_t from, int64_t to, const int64_t *colptr, cons
                 }
                 Lm = Lmu_i;
             }
-            if (sample_col(K, i, colptr, rowidx, vals, mean_rating, alpha, other_items, iter, Lm, LF_i, MM, L, r)) {
+            if (sample_col(K, i, colptr, rowidx, vals, mean_rating, alpha, other_items, iter, Lm, LF_i, MM, L, r, no_covariance)) {
 #pragma omp critical
                 if (!failed || -(i + 1) > failed) failed = -(i + 1);
                 continue;
@@ -485,11 +490,11 @@ ORACLE_API int64_t bpmf_oracle_sample_side(int K, int64_t from, int64_t to, cons
                                            const double *mu, const double *LambdaF, double *sum_out,
                                            double *prod_out, double *norm_out, int nthreads)
 {
-#define DISPATCH(KK) case KK: return sample_side_K(KK, from, to, colptr, rowidx, vals, mean_rating, alpha, other_items, items, iter, mu, LambdaF, sum_out, prod_out, norm_out, nthreads, NULL)
+#define DISPATCH(KK) case KK: return sample_side_K(KK, from, to, colptr, rowidx, vals, mean_rating, alpha, other_items, items, iter, mu, LambdaF, sum_out, prod_out, norm_out, nthreads, NULL, 0)
     switch (K) {
         DISPATCH(8); DISPATCH(16); DISPATCH(32); DISPATCH(64); DISPATCH(128);
     default:
-        return sample_side_K(K, from, to, colptr, rowidx, vals, mean_rating, alpha, other_items, items, iter, mu, LambdaF, sum_out, prod_out, norm_out, nthreads, NULL);
+        return sample_side_K(K, from, to, colptr, rowidx, vals, mean_rating, alpha, other_items, items, iter, mu, LambdaF, sum_out, prod_out, norm_out, nthreads, NULL, 0);
     }
 #undef DISPATCH
 }
@@ -503,7 +508,19 @@ ORACLE_API int64_t bpmf_oracle_sample_side_prop(int K, int64_t from, int64_t to,
                                                 double *sum_out, double *prod_out, double *norm_out, int nthreads)
 {
     return sample_side_K(K, from, to, colptr, rowidx, vals, mean_rating, alpha, other_items, items, iter, mu, LambdaF, sum_out,
-                         prod_out, norm_out, nthreads, propLambda);
+                         prod_out, norm_out, nthreads, propLambda, 0);
+}
+
+/* the BPMF_NO_COVARIANCE build of the reference (c++/sample.cpp:300-304): only the diagonal of
+ * Lambda* is kept before the factorisation */
+ORACLE_API int64_t bpmf_oracle_sample_side_nocov(int K, int64_t from, int64_t to, const int64_t *colptr,
+                                                 const int32_t *rowidx, const double *vals, double mean_rating,
+                                                 double alpha, const double *other_items, double *items, int iter,
+                                                 const double *mu, const double *LambdaF,
+                                                 double *sum_out, double *prod_out, double *norm_out, int nthreads)
+{
+    return sample_side_K(K, from, to, colptr, rowidx, vals, mean_rating, alpha, other_items, items, iter, mu, LambdaF, sum_out,
+                         prod_out, norm_out, nthreads, NULL, 1);
 }
 
 

@@ -54,6 +54,8 @@ class Oracle:
             C.c_int, C.c_int64, C.c_int64, _i64p, _i32p, _f64p, C.c_double, C.c_double, _f64p, _f64p,
             C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_int]
         lib.bpmf_oracle_sample_side_prop.restype = C.c_int64
+        lib.bpmf_oracle_sample_side_nocov.argtypes = lib.bpmf_oracle_sample_side.argtypes
+        lib.bpmf_oracle_sample_side_nocov.restype = C.c_int64
         lib.bpmf_oracle_cov.argtypes = [C.c_int, C.c_int64, _f64p, _f64p, _f64p]
         lib.bpmf_oracle_predict.argtypes = [
             C.c_int, C.c_int64, C.c_int64, _i64p, _i32p, _f64p, _f64p, _f64p, C.c_double, C.c_int,
@@ -102,7 +104,7 @@ class Oracle:
 
     # -- sampling ------------------------------------------------------------
     def sample_side(self, K, csc, mean_rating, alpha, other_items, items, it, mu, LambdaF,
-                    from_=0, to=None, nthreads=1, prop_lambda=None):
+                    from_=0, to=None, nthreads=1, prop_lambda=None, no_covariance=False):
         """Samples columns [from_,to) of `items` in place ([N,K] C-order arrays =
         column-major K x N); returns (sum[K], prod[K,K], norm).  prop_lambda: [N, K, K] array of
         per-column prior precisions (the propagated posterior of -m / -l), each stored transposed,
@@ -120,9 +122,9 @@ class Oracle:
             if rc:
                 raise RuntimeError("Cholesky failed in column %d" % (-rc - 1))
             return s, prod, float(nrm[0])
-        rc = self.lib.bpmf_oracle_sample_side(
-            K, from_, to, colptr, rowidx, vals, float(mean_rating), float(alpha), other_items, items,
-            int(it), np.ascontiguousarray(mu, np.float64), LF.T, s, prod.T, nrm, nthreads)
+        fn = self.lib.bpmf_oracle_sample_side_nocov if no_covariance else self.lib.bpmf_oracle_sample_side
+        rc = fn(K, from_, to, colptr, rowidx, vals, float(mean_rating), float(alpha), other_items, items,
+                int(it), np.ascontiguousarray(mu, np.float64), LF.T, s, prod.T, nrm, nthreads)
         if rc:
             raise RuntimeError("Cholesky failed in column %d" % (-rc - 1))
         return s, prod, float(nrm[0])

@@ -364,3 +364,32 @@ def test_blocking_fallback_paths_give_the_same_chain():
         runs.append(pick(r.stdout))
     for j in runs[1:]:
         assert abs(j["rmse"] - runs[0]["rmse"]) < 1e-9 and abs(j["rmse_avg"] - runs[0]["rmse_avg"]) < 1e-9
+
+
+@pytest.mark.parametrize("K", [16, 32, 64])
+def test_no_covariance_variant(oracle, hip_engine_factory, K, sampler_mode):
+    """BPMF_NO_COVARIANCE (c++/sample.cpp:300-304) as a run-time switch: only the diagonal of
+    Lambda* is factorised."""
+    M, Mt, T, Tt, nu, nm = util.ml100k()
+    eng = hip_engine_factory(K)
+    rng = np.random.default_rng(500 + K)
+    V = 0.3 * rng.standard_normal((nm, K))
+    ncols = len(Mt[0]) - 1
+    A = rng.standard_normal((K, 3 * K)); cov = A @ A.T / (3 * K)
+    it, alpha = 2, 2.0
+    mu, LU, LF = oracle.hyper_sample(K, ncols, cov, it)
+    mean = util.mean_rating(Mt)
+    items_ref = np.zeros((ncols, K))
+    s_ref, p_ref, n_ref = oracle.sample_side(K, Mt, mean, alpha, V, items_ref, it, mu, LF, no_covariance=True)
+    me = eng.side_create(ncols, nm, *Mt, mean)
+    ot = eng.side_create(nm, ncols, np.zeros(nm + 1, np.int64), np.zeros(0, np.int32), np.zeros(0), 0.0)
+    eng.set_items(ot, V)
+    eng.set_no_covariance(True)
+    try:
+        s1, p1, n1 = eng.sample_side(me, ot, it, alpha, mu, LF)
+        items = eng.get_items(me)
+    finally:
+        eng.set_no_covariance(False)
+    assert rel_err(items, items_ref) < RTOL
+    assert rel_err(s1, s_ref) < 1e-8 and rel_err(p1, p_ref) < 1e-8
+    eng.side_destroy(me); eng.side_destroy(ot)
