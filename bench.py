@@ -243,6 +243,10 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
+    try:
+        eng.close()                      # sides, collector threads, streams, (RCCL communicator)
+    except Exception:
+        pass
     if comm is not None:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -75,7 +75,8 @@ class BpmfHipError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "libbpmf_hip.so")
+    # BPMF_HIP_LIBRARY: another build of the same library (kernel A/B comparisons in one GPU session)
+    return os.environ.get("BPMF_HIP_LIBRARY") or os.path.join(_HERE, "libbpmf_hip.so")
 
 
 def build_library():

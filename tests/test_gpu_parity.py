@@ -393,3 +393,31 @@ def test_no_covariance_variant(oracle, hip_engine_factory, K, sampler_mode):
     assert rel_err(items, items_ref) < RTOL
     assert rel_err(s1, s_ref) < 1e-8 and rel_err(p1, p_ref) < 1e-8
     eng.side_destroy(me); eng.side_destroy(ot)
+
+
+def test_stateful_path_reports_a_failed_factorisation_and_does_not_hang(hip_engine_factory):
+    """The asynchronous Sys::sample: a half-iteration whose factorisation fails (non-finite factors
+    on the other side) surfaces as BPMF_HIP_ECHOL at the next call that needs host state; samplers
+    queued behind the failing one still run to completion (their gate is opened regardless)."""
+    import bpmf_amd
+    K = 16
+    M, Mt, T, Tt, nu, nm = util.ml100k()
+    eng = hip_engine_factory(K)
+    movies = eng.side_create(nm, nu, *M, util.mean_rating(M))
+    users = eng.side_create(nu, nm, *Mt, util.mean_rating(M))
+    eng.sys_sample(movies, users, 2.0)                       # a healthy half-iteration first
+    eng.sys_state(movies)
+    bad = np.zeros((nu, K)); bad[::7] = np.nan
+    eng.set_items(users, bad)
+    eng.sys_sample(movies, users, 2.0)                       # fails on the device ...
+    with pytest.raises(bpmf_amd.BpmfHipError) as e:
+        eng.sys_sample(users, movies, 2.0)                   # ... one more half-iteration may be queued behind it
+        eng.sys_sample(movies, users, 2.0)
+        eng.sys_state(movies)                                # ... and is reported here at the latest
+    assert e.value.code == -4 and "Cholesky failed in column" in str(e.value)
+    try:
+        eng.sync()                                           # the half-iteration queued behind saw NaN factors: same error once more
+    except bpmf_amd.BpmfHipError as e2:
+        assert e2.code == -4
+    eng.sync()                                               # drained: nothing is left spinning
+    eng.side_destroy(movies); eng.side_destroy(users)
