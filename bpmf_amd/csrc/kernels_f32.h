@@ -30,7 +30,7 @@ template <> struct WgTraits<float> {
     typedef f4 acc_t;
     __device__ static __forceinline__ f4 mfma(float x, float y, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, c, 0, 0, 0); }
     __device__ static __forceinline__ int drow(int kq, int reg) { return 4 * kq + reg; }      // D[i = 4 (lane / 16) + reg][j = lane % 16]
-    __device__ static __forceinline__ float rsqrt_acc(float d) { return 1.0f / sqrtf(d); }
+    __device__ static __forceinline__ float rsqrt_acc(float d) { return __frsqrt_rn(d); }                // v_rsq_f32 (1 ulp)
     __device__ static __forceinline__ float bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
 };
 template <> struct WgTraits<double> {
@@ -302,18 +302,32 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? 2 : 3)) void k_sample_wg(Sample
     }
     __syncthreads();
 
-    // ---- R^T y = b (:321), y += z (:322), R x = y (:323): wave 0, rows (lane, lane + 64)
+    // ---- R^T y = b (:321), y += z (:322), R x = y (:323): wave 0, rows (lane, lane + 64).
+    // Sixteen steps (one block row of R) at a time: their R entries and 1/R(k,k) are loaded into
+    // registers first, so that the dependency chain of a step is readlane -> multiply -> fma only.
     if (wave == 0) {
         T y0 = bv[lane], y1 = (K > 64) ? bv[lane + 64] : (T)0;
         // forward: after y_k is known, b_j -= R(k, j) y_k for j > k (row k of R: contiguous)
-        for (int k = 0; k < K; ++k) {
-            const int s = k >> 4;
-            const T *row = R + G::roff(s) + (k & 15) * G::ld(s) - 16 * s;           // row[j] = R(k, j)
-            const T own = (k < 64) ? y0 : y1;
-            const T yk = X::bcast(own, k & 63) * dinv[k];
-            if (lane == (k & 63)) { if (k < 64) y0 = yk; else y1 = yk; }
-            if (lane > k) y0 = fma(-row[lane], yk, y0);
-            if (K > 64 && lane + 64 > k) y1 = fma(-row[lane + 64], yk, y1);
+        for (int s = 0; s < G::NT; ++s) {
+            const T *Rs = R + G::roff(s) - 16 * s;                   // Rs[r * ld + j] = R(16 s + r, j)
+            const int LDs = G::ld(s);
+            T r0[16], r1[16], di[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = 16 * s + r;
+                di[r] = dinv[k];
+                r0[r] = (lane > k) ? Rs[r * LDs + lane] : (T)0;
+                r1[r] = (K > 64 && lane + 64 > k) ? Rs[r * LDs + lane + 64] : (T)0;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = 16 * s + r;
+                const T own = (k < 64) ? y0 : y1;
+                const T yk = X::bcast(own, k & 63) * di[r];
+                if (lane == (k & 63)) { if (k < 64) y0 = yk; else y1 = yk; }
+                y0 = fma(-r0[r], yk, y0);
+                if (K > 64) y1 = fma(-r1[r], yk, y1);
+            }
         }
         y0 += (T)zs[lane];
         if (K > 64) y1 += (T)zs[lane + 64];
@@ -324,12 +338,24 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? 2 : 3)) void k_sample_wg(Sample
             base0 = G::roff(s0) + (lane & 15) * G::ld(s0) - 16 * s0;
             base1 = G::roff(s1) + (lane & 15) * G::ld(s1) - 16 * s1;
         }
-        for (int k = K - 1; k >= 0; --k) {
-            const T own = (k < 64) ? y0 : y1;
-            const T xk = X::bcast(own, k & 63) * dinv[k];
-            if (lane == (k & 63)) { if (k < 64) y0 = xk; else y1 = xk; }
-            if (lane < k) y0 = fma(-R[base0 + k], xk, y0);
-            if (K > 64 && lane + 64 < k) y1 = fma(-R[base1 + k], xk, y1);
+        for (int s = G::NT - 1; s >= 0; --s) {
+            T c0[16], c1[16], di[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = 16 * s + r;
+                di[r] = dinv[k];
+                c0[r] = (lane < k) ? R[base0 + k] : (T)0;            // R(lane, k)
+                c1[r] = (K > 64 && lane + 64 < k) ? R[base1 + k] : (T)0;
+            }
+#pragma unroll
+            for (int r = 15; r >= 0; --r) {
+                const int k = 16 * s + r;
+                const T own = (k < 64) ? y0 : y1;
+                const T xk = X::bcast(own, k & 63) * di[r];
+                if (lane == (k & 63)) { if (k < 64) y0 = xk; else y1 = xk; }
+                y0 = fma(-c0[r], xk, y0);
+                if (K > 64) y1 = fma(-c1[r], xk, y1);
+            }
         }
         T *dst = a.items + (size_t)idx * K;                                     // items().col(idx) = rr (:324)
         dst[lane] = y0;
