@@ -297,7 +297,7 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     // side (1M x 500K x 45M ratings: 3.5 / 5.3 ms vs 3.8 / 5.7 ms).  K = 64: persistent waves with
     // the 16x16x4 Gram (k_sample).
     const int mode_env = env_int("BPMF_HIP_MODE", -1);
-    s->mode = mode_env >= 0 ? mode_env : ((K <= 32 && nloc < 65536) ? 1 : 0);
+    s->mode = mode_env >= 0 ? mode_env : (K <= 32 ? 1 : 0);
     const bool f32 = s->ctx->dtype == BPMF_HIP_F32;
     if (f32) s->mode = 2;                                // one workgroup per column (k_sample_wg), no chunking
     else if (K == 64) {
@@ -307,7 +307,7 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
         // are latency-bound at 6 waves per CU), about equal on ML-1M.  No chunking: not for columns
         // far above 16 384 ratings.
         if (mode_env == 2) s->mode = 2;
-    } else if (s->mode == 2) s->mode = (K <= 32 && nloc < 65536) ? 1 : 0;      // (BPMF_HIP_MODE=2 exists for K = 64 only)
+    } else if (s->mode == 2) s->mode = K <= 32 ? 1 : 0;                        // (BPMF_HIP_MODE=2 exists for K = 64 only)
     const bool wg = s->mode == 2;
     int chunk = wg ? (1 << 30) : env_int("BPMF_HIP_CHUNK", 0);
     if (chunk <= 0) {
@@ -318,7 +318,7 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
         // bytes gathered per rating, so shorter chunks make the partials a first-order traffic term.
         int64_t c = s->mode == 1 ? (s->nnz * 2) / (simds * 3) : s->nnz / (simds * 8);
         c = (c + 63) / 64 * 64;
-        chunk = (int)std::min<int64_t>(std::max<int64_t>(c, 16 * K), 4096);
+        chunk = (int)std::min<int64_t>(std::max<int64_t>(c, 16 * K), 65536);   // (upper limit: 10M x 1M shards measured best with 64 K-rating chunks)
     }
     chunk = (chunk + 15) / 16 * 16;
 
