@@ -1105,8 +1105,8 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     // half-iteration's parameters.  S0: sampler, exchange.  S1: statistics -> pinned result blob.
     // (The previous statistics pass has finished reading the columns the sampler overwrites: the
     // gate only opens after its sums were seen.)
-    hipLaunchKernelGGL(bpmf::k_gate_stage, dim3(1), dim3(64), 0, s1, (const unsigned *)self->a_gate_dev, (unsigned)(iter + 1),
-                       (const double *)self->a_h_in_dev, self->a_d_in, (int)c->in_words);
+    hipLaunchKernelGGL(bpmf::k_gate_stage, dim3(c->in_words > 8192 ? 16 : 1), dim3(64), 0, s1, (const unsigned *)self->a_gate_dev,
+                       (unsigned)(iter + 1), (const double *)self->a_h_in_dev, self->a_d_in, (int)c->in_words);
     if (s1 != s0) {
         HIP_TRY(hipEventRecord(ev[3], s1));
         HIP_TRY(hipStreamWaitEvent(s0, ev[3], 0));
