@@ -83,6 +83,7 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommSplit) CommSplit = nullptr;       // optional (second communicator for the statistics streams)
 };
 
 Rccl *rccl()
@@ -98,7 +99,7 @@ Rccl *rccl()
         if (r.handle) {
 #define BPMF_SYM(f) r.f = reinterpret_cast<decltype(r.f)>(dlsym(r.handle, "nccl" #f))
             BPMF_SYM(GetUniqueId); BPMF_SYM(CommInitRank); BPMF_SYM(CommDestroy); BPMF_SYM(AllReduce);
-            BPMF_SYM(Broadcast); BPMF_SYM(GroupStart); BPMF_SYM(GroupEnd); BPMF_SYM(GetErrorString);
+            BPMF_SYM(Broadcast); BPMF_SYM(GroupStart); BPMF_SYM(GroupEnd); BPMF_SYM(GetErrorString); BPMF_SYM(CommSplit);
 #undef BPMF_SYM
             if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.Broadcast || !r.GroupStart || !r.GroupEnd)
                 r.handle = nullptr;
@@ -166,6 +167,10 @@ struct bpmf_hip_ctx {
     // multi-GPU: RCCL communicator (one rank per process / GPU) and a device staging blob for the
     // all-reduced sums: prod[K*K] | sum[K] | - | fail (u64) | se | se_avg | count
     ncclComm_t comm = nullptr;
+    // second communicator over the same ranks (ncclCommSplit): the all-reduce of a side's column
+    // statistics runs on the side's own stream, beside the other side's sampler and exchange, which
+    // two collectives on ONE communicator could not do.  NULL: everything on the main stream.
+    ncclComm_t comm2 = nullptr;
     int nranks = 1, rank = 0;
     double *d_red = nullptr;
     unsigned seq = 0;                    // value the next publishing kernel writes behind its results
@@ -200,6 +205,7 @@ struct bpmf_hip_side {
     double *a_h_out = nullptr, *a_h_out_dev = nullptr;
     unsigned *a_gate = nullptr, *a_gate_dev = nullptr;   // pinned word the host sets to iter + 1 when a_h_in holds that iteration's parameters
     unsigned *a_ticket = nullptr;                        // arrival counters of this side's k_colstats waves
+    double *a_d_red = nullptr;                           // multi-GPU: this side's device blob for the all-reduced sums
     unsigned a_seq = 0;
     hipEvent_t evs[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // (start, sampled, stats, staged) of the two half-iterations that may be in flight
     hipStream_t saux = nullptr;          // this side's statistics stream (high priority: its few blocks must not queue behind the other side's sampler)
@@ -467,6 +473,7 @@ extern "C" int bpmf_hip_ctx_destroy(bpmf_hip_ctx *c)
     if (c->d_ticket) (void)hipFree(c->d_ticket);
     if (c->d_zero) (void)hipFree(c->d_zero);
     if (c->d_red) (void)hipFree(c->d_red);
+    if (c->comm2 && rccl()) (void)rccl()->CommDestroy(c->comm2);
     if (c->comm && rccl()) (void)rccl()->CommDestroy(c->comm);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -567,6 +574,7 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
     for (auto &set : s->evs) for (hipEvent_t e : set) if (e) (void)hipEventDestroy(e);
     if (s->a_gate) (void)hipHostFree(s->a_gate);
     if (s->a_ticket) (void)hipFree(s->a_ticket);
+    if (s->a_d_red) (void)hipFree(s->a_d_red);
     delete s;
     return BPMF_HIP_OK;
 }
@@ -755,11 +763,14 @@ int launch_stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double
         // local sums into a device blob, all-reduce them (cov is then formed once from the GLOBAL
         // sums: SURVEY Q19) together with the failed-column word, publish to the host
         Rccl *R = rccl();
+        // on the side's own stream: its own reduction blob and the second communicator
+        const bool own = st != c->stream && c->comm2 && self->a_d_red;
+        double *red = own ? self->a_d_red : c->d_red;
         hipLaunchKernelGGL(k_colstats<K>, dim3(self->nstat_waves), dim3(64), 0, st,
                            (const double *)self->d_items, self->from, self->to, self->nstat_waves, self->d_stat_partials,
-                           failp, c->d_red, ticket, ticket + 8, 0u);
-        NCCL_TRY(R->AllReduce(c->d_red, c->d_red, (size_t)K * K + K + 1, ncclDouble, ncclSum, c->comm, st));   // prod | sum | failed-column word
-        hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, st, (const double *)c->d_red, out_host_dev, K * K + K + 1, flag, seq, K * K + K);
+                           failp, red, ticket, ticket + 8, 0u);
+        NCCL_TRY(R->AllReduce(red, red, (size_t)K * K + K + 1, ncclDouble, ncclSum, own ? c->comm2 : c->comm, st));   // prod | sum | failed-column word
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, st, (const double *)red, out_host_dev, K * K + K + 1, flag, seq, K * K + K);
     }
     return 0;
     }
@@ -921,6 +932,7 @@ int ensure_state(bpmf_hip_side *s)
     HIP_TRY(hipMalloc((void **)&s->a_d_in, c->in_words * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&s->a_ticket, 64));
     HIP_TRY(hipMemset(s->a_ticket, 0, 64));
+    HIP_TRY(hipMalloc((void **)&s->a_d_red, (c->out_words + 8) * sizeof(double)));
     static const unsigned evflags = env_int("BPMF_HIP_EVENT_FENCE", 0) ? 0u : hipEventDisableSystemFence;
     for (auto &set : s->evs) for (hipEvent_t &e : set) HIP_TRY(hipEventCreateWithFlags(&e, evflags));
     int lo = 0, hi = 0;                                              // numerically lowest = most urgent
@@ -1097,7 +1109,7 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     }
     self->iter = iter;
 
-    hipStream_t s0 = c->stream, s1 = c->comm ? c->stream : self->saux;   // one stream when RCCL is in play
+    hipStream_t s0 = c->stream, s1 = (c->comm && !c->comm2) ? c->stream : self->saux;   // one stream when there is one communicator only
     const unsigned seq = ++self->a_seq;
     const int evset = (int)(seq & 1u);
     hipEvent_t *ev = self->evs[evset];
@@ -1188,6 +1200,11 @@ extern "C" int bpmf_hip_ctx_comm_init(bpmf_hip_ctx *c, int nranks, int rank, con
     memcpy(&id, id128, sizeof id);
     NCCL_TRY(R->CommInitRank(&c->comm, nranks, id, rank));
     c->nranks = nranks; c->rank = rank;
+    if (R->CommSplit && env_int("BPMF_HIP_COMM_STREAMS", 2) >= 2) {
+        // every rank, same colour: a duplicate of the communicator.  Without it (old RCCL, or
+        // BPMF_HIP_COMM_STREAMS=1) the statistics pass stays on the main stream.
+        if (R->CommSplit(c->comm, 0, rank, &c->comm2, nullptr) != ncclSuccess) c->comm2 = nullptr;
+    }
     return BPMF_HIP_OK;
 }
 
