@@ -179,7 +179,9 @@ int main(int argc, char *argv[])
     }
     (void)k_given;
     if (fname.empty() || probename.empty()) { usage(); return 1; }
-    if (!bpmf_hip_supports_k(K)) die("unsupported number of latent dimensions " + std::to_string(K) + " (8, 16, 32, 64)");
+    // fp64 like the reference for 8..64 latent dimensions; 128 selects the fp32 large-K path of the library
+    const int dtype = (K == 128) ? BPMF_HIP_F32 : BPMF_HIP_F64;
+    if (!bpmf_hip_supports(K, dtype)) die("unsupported number of latent dimensions " + std::to_string(K) + " (8, 16, 32, 64; 128 in fp32)");
 
     std::ofstream redirected;
     if (redirect) redirected.open("bpmf_0.out");
@@ -204,7 +206,7 @@ int main(int argc, char *argv[])
     const double mean_m = msum / (double)M.nnz(), mean_u = usum / (double)Mt.nnz();
 
     bpmf_hip_ctx *ctx = nullptr;
-    check(bpmf_hip_ctx_create(0, K, nullptr, &ctx));
+    check(bpmf_hip_ctx_create_ex(0, K, dtype, nullptr, &ctx));
     bpmf_hip_side *movies = nullptr, *users = nullptr;
     bpmf_hip_test *test = nullptr;
     check(bpmf_hip_side_create(ctx, nmovies, nusers, 0, nmovies, M.colptr.data(), M.rowidx.data(), M.vals.data(), mean_m, &movies));

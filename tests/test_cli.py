@@ -122,3 +122,13 @@ def test_propagated_posterior_workflow(hip_engine_factory, tmp_path):
     assert r.returncode != 0 and "MU_FILE,LAMBDA_FILE" in r.stderr
     r = run(["-i", "1", "-d", str(K), "-n", train, "-p", test, "-m", "o1/U-mu.ddm,o1/U-Lambda.ddm"], tmp_path)
     assert r.returncode != 0 and "expected" in r.stderr
+
+
+@pytest.mark.gpu
+def test_k128_selects_the_fp32_path(tmp_path):
+    """-d 128: the fp32 large-K path of the library behind the same command line."""
+    r = run(["-i", "4", "-b", "1", "-d", "128", "-n", os.path.join(G, "ml100k-train.mtx.gz"), "-p", os.path.join(G, "ml100k-test.mtx.gz")], tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert "num_latent: 128" in r.stdout
+    final = float(re.search(r"Final Avg RMSE: (\S+)", r.stdout).group(1))
+    assert 0.9 < final < 1.3
