@@ -44,10 +44,12 @@ def algorithmic_flops(nnz, ncols, K):
 
 
 def profiled_traffic():
-    """HBM-side bytes per launch of the sampler from the committed rocprofv3 PMC pass
+    """HBM-side bytes per launch of the sampler from the committed rocprofv3 PMC passes
     (profiles/r*_pmc_sampler.txt: FETCH_SIZE and WRITE_SIZE in KB, separate --pmc passes of this
-    same workload).  Not a live measurement: counters need rocprofv3.  Uncalibrated for 8-byte
-    gathers (MI355X_MICROARCH.md: FETCH_SIZE halves wide coalesced reads only)."""
+    same workload).  Not a live measurement: counters need rocprofv3.  Correction as
+    MI355X_MICROARCH.md prescribes, calibrated on this kernel's own access pattern
+    (tools/probes/fetch_calib.hip: 1 GiB read once with the sampler's 16-byte gathers reports
+    0.50 GiB, 1 GiB written reports 1.00 GiB): traffic = 2 * FETCH_SIZE + WRITE_SIZE."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sampler.txt")))
     if not files:
@@ -59,7 +61,7 @@ def profiled_traffic():
             vals[f[1]] = float(f[3])
     if len(vals) != 2:
         return None
-    return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
 
 
 def cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies, budget_s=15.0):
