@@ -55,3 +55,59 @@ def test_ml1m_shape_half_iteration_properties(oracle, hip_engine_factory, ml1m):
     assert np.allclose(Xp[lo:hi], X[lo:hi], rtol=1e-11, atol=1e-13) and not np.any(Xp[:lo]) and not np.any(Xp[hi:])
     for sd in (me, ot, part):
         eng.side_destroy(sd)
+
+
+def _prior_only_check(eng, K, M, nrows, it, tol, nsample=256, seed=0):
+    """alpha = 0 removes the data term: Lambda* = LambdaF, b = LambdaF mu, hence
+    x_i = mu + L^-T z_i with L = chol(LambdaF) and z_i the K normals of stream (i+1)*K*(it+1) mod 2^32
+    -- a closed form for EVERY column that needs no oracle: (x_i - mu)^T L must be z_i."""
+    import bpmf_amd
+    rng = np.random.default_rng(seed)
+    ncols = len(M[0]) - 1
+    A = rng.standard_normal((K, 2 * K)); LF = A @ A.T / (2 * K) + np.eye(K)
+    mu = rng.standard_normal(K)
+    other = 0.3 * rng.standard_normal((nrows, K))
+    me = eng.side_create(ncols, nrows, *M, 3.0)
+    ot = eng.side_create(nrows, ncols, np.zeros(nrows + 1, np.int64), np.zeros(0, np.int32), np.zeros(0), 0.0)
+    eng.set_items(ot, other)
+    s, p, n = eng.sample_side(me, ot, it, 0.0, mu, LF)
+    X = eng.get_items(me)
+    eng.side_destroy(me); eng.side_destroy(ot)
+    assert np.all(np.isfinite(X))
+    Z = (X - mu) @ np.linalg.cholesky(LF)
+    # every column: standard normals (the whole matrix is ncols*K draws)
+    assert abs(Z.mean()) < 5.0 / np.sqrt(Z.size) + tol and abs(Z.var() - 1.0) < 0.02
+    # sampled columns: exactly the reference's stream (host implementation of the same Philox / polar draw)
+    pick = np.unique(np.concatenate([[0, 1, ncols - 1], rng.choice(ncols, nsample, replace=False)]))
+    for c in pick:
+        z = bpmf_amd.engine.randn_host(((int(c) + 1) * K * (it + 1)) % 2 ** 32, K)
+        assert np.abs(Z[c] - z).max() < tol, (c, np.abs(Z[c] - z).max())
+    # the reductions belong to these columns
+    assert np.allclose(s, X.sum(0), rtol=1e-9, atol=1e-6 * max(1.0, tol * 1e6))
+    return X
+
+
+def test_chembl_shape_k64_prior_only_closed_form(hip_engine_factory):
+    """BASELINE configs[2] size (483 500 x 5 775, ~1.02 M activities, K = 64): both sides."""
+    K = 64
+    M, Mt, T, Tt, nu, nm = util.synthetic(483500, 5775, 1_023_952, seed=42)
+    eng = hip_engine_factory(K)
+    _prior_only_check(eng, K, Mt, nm, 3, 1e-9)          # 483 500 compound columns, 1-3 activities each
+    _prior_only_check(eng, K, M, nu, 4, 1e-9, nsample=64)
+
+
+def test_ml1m_shape_k128_f32_prior_only_closed_form(hip_engine_factory, ml1m):
+    """BASELINE configs[4] size (ML-1M shape, K = 128, fp32): the closed form within fp32 tolerance."""
+    K = 128
+    M, Mt, T, Tt, nu, nm = ml1m
+    eng = hip_engine_factory(K, "f32")
+    _prior_only_check(eng, K, Mt, nm, 2, 2e-3, nsample=64)
+
+
+def test_large_side_k32_prior_only_closed_form(hip_engine_factory):
+    """10^6 columns on one side (the per-rank column count of the 10M x 1M config is 1.25 M): the
+    per-item sampler with a seven-digit grid."""
+    K = 32
+    M, Mt, T, Tt, nu, nm = util.synthetic(1_000_000, 20_000, 6_000_000, seed=7)
+    eng = hip_engine_factory(K)
+    _prior_only_check(eng, K, Mt, nm, 1, 1e-9, nsample=128)
