@@ -3,22 +3,27 @@
 // The path (c++/sample.cpp:248-336 + c++/mvnormal.cpp:18-47 of the reference),
 // re-designed for MI355X:
 //
-//   k_sample<K>      persistent single-wave workgroups pull (column, rating-chunk) work items
-//                    from per-XCD queues.  The K-vectors of the rated rows are gathered straight
-//                    into MFMA operand layout (16 lanes x 8 B = one 128-B line per 16 latent dims
-//                    per rating, 4 ratings per instruction) and the upper-triangular 16x16 tiles of
-//                    sum_j u_j u_j^T are accumulated with v_mfma_f64_16x16x4_f64; the K-vector
-//                    sum_j w_j u_j rides along on the VALU.  A column that fits one chunk is
-//                    finished by the same wave; chunks of a heavy column park their partial tiles
-//                    (write-through stores) and the wave drawing the last ticket sums them in
-//                    chunk order and finishes the column.
-//   finish_column<K> Lambda* = LambdaF + alpha*G through LDS into registers (S lanes per row),
+//   k_sample1<K>     (K <= 32, the default) one single-wave workgroup per work item = column or
+//                    chunk of a heavy column, cost-sorted, balanced by the hardware dispatcher.
+//                    gram_chunk44: the K-vectors of the rated rows are gathered straight into the
+//                    operand layout of v_mfma_f64_4x4x4_4b_f64 (16 ratings per instruction, one
+//                    accumulator register per upper 4x4 block of sum_j u_j u_j^T), one group of 16
+//                    ratings ahead of the MFMAs; sum_j w_j u_j rides along on the VALU.  Chunks of a
+//                    heavy column park their accumulators (write-through stores); the wave drawing
+//                    the last ticket sums them in chunk order and finishes the column.
+//   finish_single<K> Lambda* = LambdaF + alpha*G through LDS into registers (S lanes per row),
 //                    right-looking Cholesky two columns per step with the pivot block through
 //                    v_readlane and the scaled columns broadcast through LDS, fused forward
 //                    solve, Philox/polar normal draw, backward solve, coalesced 8*K-byte store.
-//   k_colstats<K>    sum x, sum x x^T of the fresh columns (again an MFMA Gram),
-//                    reduced in a fixed order so results are run-to-run identical.
-//   k_predict<K>     test-set dot products, running mean / M2, squared errors.
+//   k_sample<K>      (K = 64) persistent single-wave workgroups walk the static item list; Gram on
+//                    v_mfma_f64_16x16x4_f64 tiles (gram_chunk), C = 64/K columns factorised side by
+//                    side (deposit_column, finish_slots).
+//   k_colstats<K>    sum x, sum x x^T of the fresh columns (again an MFMA Gram); the last waves to
+//                    arrive add the partials in a fixed order (run-to-run identical) and publish.
+//   k_predict<K>     test-set dot products, running mean / M2, squared errors; last block publishes.
+//   k_gate_stage     polls the host's gate word, then stages the parameter blob (asynchronous path).
+// (kernels_f32.h: k_sample_wg, one workgroup per column with a blocked factorisation on MFMA tiles:
+//  K = 128 in fp32, K = 64 in fp64 behind BPMF_HIP_MODE=2.)
 //
 // Everything is fp64 like the reference (c++/bpmf.h:55-58).
 #pragma once
