@@ -27,6 +27,7 @@
 #include "../../include/bpmf_hip.h"
 #include "kernels.h"
 #include "kernels_f32.h"
+#include "kernels_q4.h"
 
 namespace {
 
@@ -297,13 +298,16 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
 {
     const int64_t nloc = s->to - s->from;
     const int K = s->ctx->K;
-    // Form of the sampler.  K <= 32: every work item gets its own single-wave workgroup and the
-    // hardware dispatcher balances them (k_sample1, Gram on the 4x4x4 MFMA shape) -- measured
-    // faster than the persistent form from 3 700 columns (ML-1M: 53 vs 79 us) to 10^6 columns per
-    // side (1M x 500K x 45M ratings: 3.5 / 5.3 ms vs 3.8 / 5.7 ms).  K = 64: persistent waves with
-    // the 16x16x4 Gram (k_sample).
+    // Form of the sampler.  K <= 32, up to ~20 000 columns per side: every work item gets its own
+    // single-wave workgroup and the hardware dispatcher balances them (k_sample1: Gram on the 4x4x4
+    // MFMA shape, factorisation on the VALU; ML-1M: 53 us against 79 us of the persistent form).
+    // More columns: four work items per wave with the factorisation on the MFMA as well (k_sample4:
+    // a third of the VALU work per column, but a quarter of the workgroups, which only pays when
+    // there are enough of them -- 24 000 x 14 800: even; 60 400 x 37 060: 349 / 382 us against
+    // 401 / 510 us; 1M x 500K x 45M ratings: 2.35 / 3.13 ms against 3.5 / 5.3 ms, 3.8 / 5.7 ms persistent).
+    // K = 64: persistent waves with the 16x16x4 Gram (k_sample).
     const int mode_env = env_int("BPMF_HIP_MODE", -1);
-    s->mode = mode_env >= 0 ? mode_env : (K <= 32 ? 1 : 0);
+    s->mode = mode_env >= 0 ? mode_env : (K <= 32 ? (nloc >= 20000 ? 3 : 1) : 0);
     const bool f32 = s->ctx->dtype == BPMF_HIP_F32;
     if (f32) s->mode = 2;                                // one workgroup per column (k_sample_wg), no chunking
     else if (K == 64) {
@@ -314,6 +318,7 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
         // far above 16 384 ratings.
         if (mode_env == 2) s->mode = 2;
     } else if (s->mode == 2) s->mode = K <= 32 ? 1 : 0;                        // (BPMF_HIP_MODE=2 exists for K = 64 only)
+    if (s->mode == 3 && K > 32) s->mode = 0;                                   // (BPMF_HIP_MODE=3, four columns per wave: K <= 32)
     const bool wg = s->mode == 2;
     int chunk = wg ? (1 << 30) : env_int("BPMF_HIP_CHUNK", 0);
     if (chunk <= 0) {
@@ -322,9 +327,12 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
         // mode 0: >= 8 work items per SIMD so the tail of the launch stays short.  Lower bound
         // 16 K: a chunk's partial tiles are ~1.3 K^2 doubles written and read back, against 8 K
         // bytes gathered per rating, so shorter chunks make the partials a first-order traffic term.
-        int64_t c = s->mode == 1 ? (s->nnz * 2) / (simds * 3) : s->nnz / (simds * 8);
+        int64_t c = (s->mode == 1 || s->mode == 3) ? (s->nnz * 2) / (simds * 3) : s->nnz / (simds * 8);
         c = (c + 63) / 64 * 64;
         chunk = (int)std::min<int64_t>(std::max<int64_t>(c, 16 * K), 65536);   // (upper limit: 10M x 1M shards measured best with 64 K-rating chunks)
+        // four columns per wave: a wave holds four items (and a chunk's partial is a quarter of the
+        // size), so the same work per wave means chunks of a quarter of the length
+        if (s->mode == 3) chunk = std::max(chunk / 4, 4 * K);
     }
     chunk = (chunk + 15) / 16 * 16;
 
@@ -706,6 +714,12 @@ int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, do
     a.mean_rating = self->mean_rating; a.alpha = alpha; a.iter_plus_1 = (uint32_t)(iter + 1);
     a.ablate = c->ablate;
     a.zero_row = c->d_zero;
+    if constexpr (K <= 32) {
+        if (self->nwork > 0 && self->mode == 3) {                    // four columns per wave (k_sample4)
+            launch(k_sample4<K>, dim3((self->nwork + 3) / 4), dim3(64), a);
+            return 0;
+        }
+    }
     if (self->nwork > 0 && self->mode == 1) {
         launch(k_sample1<K>, dim3(self->nwork), dim3(64), a);
     } else if (self->nwork > 0) {

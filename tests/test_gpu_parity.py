@@ -15,11 +15,12 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-9
 
 
-@pytest.fixture(params=[None, 0, 1, 2], ids=["auto", "persistent", "per-item", "workgroup"])
+@pytest.fixture(params=[None, 0, 1, 2, 3], ids=["auto", "persistent", "per-item", "workgroup", "four-columns"])
 def sampler_mode(request):
     """The forms of the sampler (BPMF_HIP_MODE, read when a side is created): 0 = persistent
     waves with C = 64/K columns factorised side by side, 1 = one work item per single-wave
-    workgroup, 2 = one four-wave workgroup per column (K = 64 only; other K fall back to auto)."""
+    workgroup, 2 = one four-wave workgroup per column (K = 64 only; other K fall back to auto),
+    3 = four columns per wave, factorisation on the 4x4x4 MFMA shape (K <= 32)."""
     import os
     old = os.environ.get("BPMF_HIP_MODE")
     if request.param is None:
