@@ -361,7 +361,13 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
             slots += nch;
         }
     }
-    std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.cost > b.cost; });
+    if (s->mode == 3) {
+        // four items share a wave and all run as many Gram steps as the longest of them: group by
+        // LENGTH (chunks of one column stay together), longest groups first
+        std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.len > b.len; });
+    } else {
+        std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.cost > b.cost; });
+    }
 
     const size_t nw = items.size();
     std::vector<int32_t> wcol(nw), wlen(nw), wmc(nw), wchunk(nw);
