@@ -107,7 +107,8 @@ def test_ml1m_shape_k128_f32_prior_only_closed_form(hip_engine_factory, ml1m):
 def test_large_side_k32_prior_only_closed_form(hip_engine_factory):
     """10^6 columns on one side (the per-rank column count of the 10M x 1M config is 1.25 M): the
     per-item sampler with a seven-digit grid."""
-    K = 32
     M, Mt, T, Tt, nu, nm = util.synthetic(1_000_000, 20_000, 6_000_000, seed=7)
-    eng = hip_engine_factory(K)
-    _prior_only_check(eng, K, Mt, nm, 1, 1e-9, nsample=128)
+    for K in (32, 16, 8):                                # >= 20 000 columns: four columns per wave (k_sample4)
+        eng = hip_engine_factory(K)
+        _prior_only_check(eng, K, Mt, nm, 1, 1e-9, nsample=128)
+        _prior_only_check(eng, K, M, nu, 2, 1e-9, nsample=32)
