@@ -98,8 +98,8 @@ def cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--K", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
