@@ -85,6 +85,8 @@ struct Rccl {
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclCommSplit) CommSplit = nullptr;       // optional (second communicator for the statistics streams)
+    decltype(&ncclSend) Send = nullptr;                 // optional (connectivity-aware exchange)
+    decltype(&ncclRecv) Recv = nullptr;
 };
 
 Rccl *rccl()
@@ -101,6 +103,7 @@ Rccl *rccl()
 #define BPMF_SYM(f) r.f = reinterpret_cast<decltype(r.f)>(dlsym(r.handle, "nccl" #f))
             BPMF_SYM(GetUniqueId); BPMF_SYM(CommInitRank); BPMF_SYM(CommDestroy); BPMF_SYM(AllReduce);
             BPMF_SYM(Broadcast); BPMF_SYM(GroupStart); BPMF_SYM(GroupEnd); BPMF_SYM(GetErrorString); BPMF_SYM(CommSplit);
+            BPMF_SYM(Send); BPMF_SYM(Recv);
 #undef BPMF_SYM
             if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.Broadcast || !r.GroupStart || !r.GroupEnd)
                 r.handle = nullptr;
@@ -197,6 +200,11 @@ struct bpmf_hip_side {
     int nstat_waves = 0;
     double *d_stat_partials = nullptr;
     std::vector<int64_t> bounds;         // multi-GPU: column range of every rank (nranks + 1 entries)
+    // connectivity-aware exchange (bpmf_hip_side_set_conn): per peer, the columns of this rank's range the
+    // peer reads (send) and the columns of the peer's range this rank reads (recv), as global column ids
+    std::vector<int64_t> conn_send_ptr, conn_recv_ptr;
+    int32_t *d_conn_send = nullptr, *d_conn_recv = nullptr;
+    double *d_conn_sbuf = nullptr, *d_conn_rbuf = nullptr;
     int64_t failed_column = -1;
     bool pending = false;
     float last_sample_ms = 0.f, last_reduce_ms = 0.f;
@@ -581,7 +589,8 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
     if (s->own_csc) { if (s->d_rowidx) (void)hipFree(s->d_rowidx); if (s->d_vals) (void)hipFree(s->d_vals); }
     if (s->own_items && s->d_items) (void)hipFree(s->d_items);
     if (s->d_prop) (void)hipFree(s->d_prop);
-    void *ptrs[] = {s->d_wi_col, s->d_wi_len, s->d_wi_mc, s->d_wi_chunk, s->d_wi_p0, s->d_mc_slot0, s->d_mc_nch, s->d_mc_count, s->d_partials, s->d_stat_partials, s->a_d_in};
+    void *ptrs[] = {s->d_wi_col, s->d_wi_len, s->d_wi_mc, s->d_wi_chunk, s->d_wi_p0, s->d_mc_slot0, s->d_mc_nch, s->d_mc_count, s->d_partials, s->d_stat_partials, s->a_d_in,
+                    s->d_conn_send, s->d_conn_recv, s->d_conn_sbuf, s->d_conn_rbuf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (s->a_h_in) (void)hipHostFree(s->a_h_in);
     if (s->a_h_out) (void)hipHostFree(s->a_h_out);
@@ -748,6 +757,29 @@ int launch_exchange(bpmf_hip_side *self, hipStream_t st)
     // every rank broadcasts the range it just sampled (= all-gather-v of disjoint, uneven
     // ranges), in place in the replicated factor matrix, on the sampler's stream
     Rccl *R = rccl();
+    if (!self->conn_send_ptr.empty()) {
+        // connectivity-aware form (c++/assign.cpp:204-241 conn_map + send_item, c++/sample.cpp:370): a column
+        // only travels to the ranks whose ratings / test entries reference it.  Pack the columns of
+        // every peer's list into one buffer, one grouped send / receive per peer, scatter what arrived.
+        const int64_t ns = self->conn_send_ptr.back(), nr = self->conn_recv_ptr.back();
+        constexpr int P = K / 2;                                   // 16-byte pieces per column
+        if (ns > 0)
+            hipLaunchKernelGGL(bpmf::k_pack_cols<K>, dim3((unsigned)((ns * P + 255) / 256)), dim3(256), 0, st,
+                               (const double *)self->d_items, (const int32_t *)self->d_conn_send, ns, self->d_conn_sbuf);
+        NCCL_TRY(R->GroupStart());
+        for (int r = 0; r < c->nranks; ++r) {
+            const int64_t s0 = self->conn_send_ptr[(size_t)r], s1 = self->conn_send_ptr[(size_t)r + 1];
+            const int64_t r0 = self->conn_recv_ptr[(size_t)r], r1 = self->conn_recv_ptr[(size_t)r + 1];
+            if (s1 > s0) NCCL_TRY(R->Send(self->d_conn_sbuf + (size_t)s0 * K, (size_t)(s1 - s0) * K, ncclDouble, r, c->comm, st));
+            if (r1 > r0) NCCL_TRY(R->Recv(self->d_conn_rbuf + (size_t)r0 * K, (size_t)(r1 - r0) * K, ncclDouble, r, c->comm, st));
+        }
+        NCCL_TRY(R->GroupEnd());
+        if (nr > 0)
+            hipLaunchKernelGGL(bpmf::k_unpack_cols<K>, dim3((unsigned)((nr * P + 255) / 256)), dim3(256), 0, st,
+                               (const double *)self->d_conn_rbuf, (const int32_t *)self->d_conn_recv, nr, self->d_items);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     NCCL_TRY(R->GroupStart());
     for (int r = 0; r < c->nranks; ++r) {
         const int64_t lo = self->bounds[(size_t)r], hi = self->bounds[(size_t)r + 1];
@@ -1238,6 +1270,66 @@ extern "C" int bpmf_hip_side_set_ranges(bpmf_hip_side *s, const int64_t *bounds)
     for (int r = 0; r < c->nranks; ++r)
         if (bounds[r + 1] < bounds[r]) return fail(BPMF_HIP_EINVAL, "side_set_ranges: ranges are not monotone");
     s->bounds.assign(bounds, bounds + c->nranks + 1);
+    return BPMF_HIP_OK;
+}
+
+extern "C" int bpmf_hip_side_set_conn(bpmf_hip_side *s, const int64_t *send_ptr, const int32_t *send_cols,
+                                      const int64_t *recv_ptr, const int32_t *recv_cols)
+{
+    if (!s) return fail(BPMF_HIP_EINVAL, "side_set_conn: NULL");
+    bpmf_hip_ctx *c = s->ctx;
+    if (!c->comm || s->bounds.empty()) return fail(BPMF_HIP_EINVAL, "side_set_conn: set the communicator and the ranges first");
+    if (c->dtype != BPMF_HIP_F64) return fail(BPMF_HIP_EINVAL, "side_set_conn: the fp32 path is single-GPU for now");
+    int rc;
+    if ((rc = settle_async(s))) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (void *p : {(void *)s->d_conn_send, (void *)s->d_conn_recv, (void *)s->d_conn_sbuf, (void *)s->d_conn_rbuf})
+        if (p) HIP_TRY(hipFree(p));
+    s->d_conn_send = s->d_conn_recv = nullptr; s->d_conn_sbuf = s->d_conn_rbuf = nullptr;
+    s->conn_send_ptr.clear(); s->conn_recv_ptr.clear();
+    if (!send_ptr && !recv_ptr) return BPMF_HIP_OK;                     // back to the all-gather form
+    if (!send_ptr || !recv_ptr) return fail(BPMF_HIP_EINVAL, "side_set_conn: both lists or none");
+    Rccl *R = rccl();
+    if (!R || !R->Send || !R->Recv) return fail(BPMF_HIP_ENODEV, "side_set_conn: this RCCL has no ncclSend / ncclRecv");
+    const int n = c->nranks;
+    if (send_ptr[0] != 0 || recv_ptr[0] != 0) return fail(BPMF_HIP_EINVAL, "side_set_conn: list offsets must start at 0");
+    for (int r = 0; r < n; ++r)
+        if (send_ptr[r + 1] < send_ptr[r] || recv_ptr[r + 1] < recv_ptr[r]) return fail(BPMF_HIP_EINVAL, "side_set_conn: list offsets are not monotone");
+    const int64_t ns = send_ptr[n], nr = recv_ptr[n];
+    if ((ns > 0 && !send_cols) || (nr > 0 && !recv_cols)) return fail(BPMF_HIP_EINVAL, "side_set_conn: NULL column list");
+    // what leaves must be this rank's to give, what arrives must land in the sender's range
+    for (int64_t i = 0; i < ns; ++i)
+        if (send_cols[i] < s->from || send_cols[i] >= s->to) return fail(BPMF_HIP_EINVAL, "side_set_conn: send list names a column outside this rank's range");
+    for (int r = 0; r < n; ++r)
+        for (int64_t i = recv_ptr[r]; i < recv_ptr[r + 1]; ++i)
+            if (recv_cols[i] < s->bounds[(size_t)r] || recv_cols[i] >= s->bounds[(size_t)r + 1])
+                return fail(BPMF_HIP_EINVAL, "side_set_conn: receive list names a column outside the sender's range");
+    if ((rc = dev_upload<int32_t>(&s->d_conn_send, send_cols, (size_t)std::max<int64_t>(ns, 1)))) return rc;
+    if ((rc = dev_upload<int32_t>(&s->d_conn_recv, recv_cols, (size_t)std::max<int64_t>(nr, 1)))) return rc;
+    if ((rc = dev_upload<double>(&s->d_conn_sbuf, nullptr, (size_t)std::max<int64_t>(ns, 1) * c->K))) return rc;
+    if ((rc = dev_upload<double>(&s->d_conn_rbuf, nullptr, (size_t)std::max<int64_t>(nr, 1) * c->K))) return rc;
+    s->conn_send_ptr.assign(send_ptr, send_ptr + n + 1);
+    s->conn_recv_ptr.assign(recv_ptr, recv_ptr + n + 1);
+    return BPMF_HIP_OK;
+}
+
+extern "C" int bpmf_hip_side_exchange(bpmf_hip_side *s)
+{
+    if (!s) return fail(BPMF_HIP_EINVAL, "side_exchange: NULL");
+    bpmf_hip_ctx *c = s->ctx;
+    if (!c->comm || s->bounds.empty()) return fail(BPMF_HIP_EINVAL, "side_exchange: set the communicator and the ranges first");
+    int rc;
+    if ((rc = settle_async(s))) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    switch (c->K) {
+#define BPMF_CASE(KK) case KK: rc = launch_exchange<KK>(s, c->stream); break;
+        BPMF_CASE(8) BPMF_CASE(16) BPMF_CASE(32) BPMF_CASE(64) BPMF_CASE(128)
+#undef BPMF_CASE
+        default: return fail(BPMF_HIP_EINVAL, "unsupported K");
+    }
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return BPMF_HIP_OK;
 }
 

@@ -1240,6 +1240,35 @@ __global__ __launch_bounds__(256) void k_predict(const int32_t *__restrict__ tco
     }
 }
 
+// Connectivity-aware exchange: the columns a peer reads are packed into one contiguous buffer
+// (and scattered back on the receiving side), one 16-byte piece per thread -- a column is K / 2
+// consecutive pieces, so a wave moves whole 128-byte lines on both sides.
+template <int K>
+__global__ __launch_bounds__(256) void k_pack_cols(const double *__restrict__ items, const int32_t *__restrict__ cols, int64_t n,
+                                                   double *__restrict__ buf)
+{
+    typedef double dd2 __attribute__((ext_vector_type(2)));
+    constexpr int P = K / 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * P) return;
+    const int64_t c = i / P;
+    const int piece = (int)(i % P);
+    reinterpret_cast<dd2 *>(buf)[i] = reinterpret_cast<const dd2 *>(items + (size_t)cols[c] * K)[piece];
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void k_unpack_cols(const double *__restrict__ buf, const int32_t *__restrict__ cols, int64_t n,
+                                                     double *__restrict__ items)
+{
+    typedef double dd2 __attribute__((ext_vector_type(2)));
+    constexpr int P = K / 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * P) return;
+    const int64_t c = i / P;
+    const int piece = (int)(i % P);
+    reinterpret_cast<dd2 *>(items + (size_t)cols[c] * K)[piece] = reinterpret_cast<const dd2 *>(buf)[i];
+}
+
 // hp.mu / hp.LambdaF blob: pinned host memory -> device memory (replaces a hipMemcpyAsync;
 // the sampler re-reads LambdaF per column, so it must sit behind the L2)
 __global__ __launch_bounds__(256) void k_stage(const double *__restrict__ src_host, double *__restrict__ dst, int n)

@@ -71,6 +71,19 @@ class HipEngine:
         b = np.ascontiguousarray(bounds, np.int64)
         _lib.check(self.lib.bpmf_hip_side_set_ranges(side.handle, _ptr(b)))
 
+    def side_set_conn(self, side, send_ptr=None, send_cols=None, recv_ptr=None, recv_cols=None):
+        """Connectivity-aware exchange lists (include/bpmf_hip.h); all None: back to the all-gather form."""
+        if send_ptr is None:
+            _lib.check(self.lib.bpmf_hip_side_set_conn(side.handle, None, None, None, None))
+            return
+        sp = np.ascontiguousarray(send_ptr, np.int64); sc = np.ascontiguousarray(send_cols, np.int32)
+        rp = np.ascontiguousarray(recv_ptr, np.int64); rc = np.ascontiguousarray(recv_cols, np.int32)
+        _lib.check(self.lib.bpmf_hip_side_set_conn(side.handle, _ptr(sp), _ptr(sc) if len(sc) else None,
+                                                   _ptr(rp), _ptr(rc) if len(rc) else None))
+
+    def side_exchange(self, side):
+        _lib.check(self.lib.bpmf_hip_side_exchange(side.handle))
+
     # -- sides ----------------------------------------------------------------
     def side_create(self, ncols, nrows, colptr, rowidx, vals, mean_rating, col_from=0, col_to=None):
         col_to = ncols if col_to is None else col_to

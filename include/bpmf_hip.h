@@ -96,6 +96,22 @@ BPMF_API int bpmf_hip_comm_unique_id(void *id128);
 BPMF_API int bpmf_hip_ctx_comm_init(bpmf_hip_ctx *ctx, int nranks, int rank, const void *id128);
 BPMF_API int bpmf_hip_side_set_ranges(bpmf_hip_side *side, const int64_t *bounds);
 
+/* Connectivity-aware exchange.  Replaces Sys::update_conn's conn_map and the
+ * per-item sends it steers (c++/assign.cpp:204-241; send_item at c++/sample.cpp:370,
+ * c++/mpi_isendirecv.h:222-250, c++/bpmf_gaspi.h:140-172: `if (!conn(i, k)) continue`): a fresh column travels only to the ranks whose stored
+ * ratings or test entries reference it, instead of to everyone.  After _side_set_ranges, give the
+ * side, per peer rank r (offsets *_ptr[nranks+1], CSR style; global column ids, int32):
+ *   send_cols[send_ptr[r] .. send_ptr[r+1])  columns of THIS rank's range that rank r reads,
+ *   recv_cols[recv_ptr[r] .. recv_ptr[r+1])  columns of rank r's range that THIS rank reads
+ * (the two must mirror each other across ranks: r's receive list from q == q's send list to r, same
+ * order).  The exchange then packs, does one grouped ncclSend / ncclRecv per peer, and scatters;
+ * columns nobody asked for stay stale in the replica (they are never read on this rank).  Both
+ * pointers NULL: back to the all-gather form.  bpmf_hip_side_exchange runs the side's exchange on
+ * its own (blocking), e.g. to replicate factors written with _side_set_items. */
+BPMF_API int bpmf_hip_side_set_conn(bpmf_hip_side *side, const int64_t *send_ptr, const int32_t *send_cols,
+                                    const int64_t *recv_ptr, const int32_t *recv_cols);
+BPMF_API int bpmf_hip_side_exchange(bpmf_hip_side *side);
+
 /* ---- one side (= one Sys) ---------------------------------------------------
  * Replaces Sys::Sys + alloc_and_init + Sys::init (c++/sample.cpp:112-137,179-226,
  * c++/nocomm.h:29-33).  The factor matrix has `ncols` columns (all of them,

@@ -46,6 +46,36 @@ def test_sharded_equals_single_process(oracle, tmp_path, dataset, K, nsims, burn
         assert abs(float(r["final"]) - ref["final_rmse_avg"]) < 1e-9
 
 
+def test_connectivity_aware_exchange(oracle, tmp_path):
+    """SURVEY 8f rank 2 (c++/assign.cpp:204-241): on a two-community matrix a column only travels to
+    the rank that reads it.  Every rank must still own exact samples and report the global RMSE;
+    replica columns nobody on the rank reads are left untouched (zero, the initial state)."""
+    from bpmf_amd import synth
+    from bpmf_amd.dist import connectivity, conn_lists
+    K, nsims, burnin, world = 8, 3, 1, 2
+    res = run_job(tmp_path, "blocks", K, nsims, burnin, world)
+    M, Mt, T, Tt, nu, nm = util.blocks()
+    ref = oracle.gibbs(K, M, Mt, T, Tt, nsims=nsims, burnin=burnin)
+    bm = synth.balanced_ranges(M[0], world); bu = synth.balanced_ranges(Mt[0], world)
+    need_u = connectivity(M, bm, T); need_m = connectivity(Mt, bu)
+    for rank, r in enumerate(res):
+        assert r["conn_used"].all()
+        assert list(r["dom_m"]) == [bm[rank], bm[rank + 1]] and list(r["dom_u"]) == [bu[rank], bu[rank + 1]]
+        assert np.allclose(r["rmse"], ref["rmse"], atol=1e-9) and np.allclose(r["rmse_avg"], ref["rmse_avg"], atol=1e-9)
+        assert np.allclose(r["norm_u"], ref["norm_u"], rtol=1e-10) and np.allclose(r["norm_m"], ref["norm_m"], rtol=1e-10)
+        for X, Xref, dom, need in ((r["U"], ref["U"], r["dom_u"], need_u[rank]), (r["V"], ref["V"], r["dom_m"], need_m[rank])):
+            held = np.zeros(len(X), bool); held[dom[0]:dom[1]] = True; held[need] = True
+            assert np.allclose(X[held], Xref[held], rtol=1e-9, atol=1e-11)          # owned or read here: current
+            assert (~held).sum() > len(X) // 4 and np.all(X[~held] == 0.0)          # never shipped
+    # the lists mirror each other: what q sends to r is what r expects from q, in the same order
+    for need, bounds in ((need_u, bu), (need_m, bm)):
+        L = [conn_lists(need, bounds, r) for r in range(world)]
+        for r in range(world):
+            assert L[r][0][r + 1] == L[r][0][r] and L[r][2][r + 1] == L[r][2][r]      # nothing to self
+            for q in range(world):
+                assert np.array_equal(L[q][1][L[q][0][r]:L[q][0][r + 1]], L[r][3][L[r][2][q]:L[r][2][q + 1]])
+
+
 def test_balanced_ranges_cover_and_balance():
     from bpmf_amd import synth
     M, Mt, T, Tt, nu, nm = util.ml100k()

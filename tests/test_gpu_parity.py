@@ -315,6 +315,19 @@ def test_sharded_path_over_rccl_single_rank(tmp_path):
     assert ja["value"] > 0 and ja["n_gpus"] == 1
 
 
+@pytest.mark.parametrize("K", [32, 64])
+def test_connectivity_exchange_loopback(K):
+    """bpmf_hip_side_set_conn / bpmf_hip_side_exchange over a one-rank RCCL
+    communicator: tests/_conn_worker.py (own process: the communicator is per process)."""
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_conn_worker.py"), str(K)], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0 and "CONN-OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
 @pytest.mark.parametrize("K", [16, 32, 64])
 def test_propagated_posterior_priors(oracle, hip_engine_factory, K, sampler_mode):
     """-m / -l of the reference (c++/sample.cpp:157-174,272-277): every column has its own prior

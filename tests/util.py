@@ -43,3 +43,26 @@ def synthetic(nusers, nmovies, nnz, seed=42, test_frac=0.1, heavy=None, rating_l
 
 def mean_rating(M):
     return float(np.sum(M[2])) / len(M[2])
+
+
+def blocks(nusers=240, nmovies=160, per_user=12, cross=6, seed=7):
+    """Two communities: the first half of the users rates the first half of the movies, the second
+    half the second, plus `cross` ratings across -- the shape where a column is read by few ranks
+    (c++/assign.cpp:204-241).  Same return layout as synth.ratings()."""
+    rng = np.random.default_rng(seed)
+    rows, cols = [], []
+    hu, hm = nusers // 2, nmovies // 2
+    for u in range(nusers):
+        base = 0 if u < hu else hm
+        for m in rng.choice(hm if u < hu else nmovies - hm, size=per_user, replace=False):
+            rows.append(u); cols.append(base + int(m))
+    for _ in range(cross):
+        u = int(rng.integers(0, nusers)); m = int(rng.integers(0, nmovies))
+        rows.append(u); cols.append(m)
+    key = np.unique(np.asarray(rows, np.int64) * nmovies + np.asarray(cols, np.int64))
+    rows, cols = key // nmovies, key % nmovies
+    vals = rng.integers(1, 6, size=len(rows)).astype(np.float64)
+    is_test = rng.random(len(rows)) < 0.1
+    M = sp.coo_matrix((vals[~is_test], (rows[~is_test], cols[~is_test])), shape=(nusers, nmovies)).tocsc()
+    T = sp.coo_matrix((vals[is_test], (rows[is_test], cols[is_test])), shape=(nusers, nmovies)).tocsc()
+    return csc_arrays(M), csc_arrays(M.T), csc_arrays(T), csc_arrays(T.T), nusers, nmovies
