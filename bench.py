@@ -173,13 +173,13 @@ def main():
             step()
     else:
         # the same K iterations, software-pipelined the way the `bpmf` executable runs them: the RMSE
-        # of iteration i is collected after the first half of iteration i+1 has been enqueued (the
-        # device runs them in program order; the host round trip of the evaluation is hidden)
+        # of iteration i is collected after iteration i+1 has been enqueued (the evaluation runs on
+        # its own stream beside those samplers, which write the other copy of the factors)
         for i in range(args.steps):
             movies.sample(users)
+            users.sample(movies)
             if i > 0:
                 movies.predict_finish()
-            users.sample(movies)
             movies.predict_launch(users)
         movies.predict_finish()
     fence()

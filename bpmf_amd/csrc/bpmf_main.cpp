@@ -265,22 +265,23 @@ int main(int argc, char *argv[])
     if (!aggregate && !verbose) {
         // Plain sampling run: the loop of c++/bpmf.cpp:180-198 software-pipelined by one half-iteration.
         // The library only enqueues in bpmf_hip_sys_sample; the line of iteration i-1 (its RMSE sums
-        // and norms) is collected after the first half of iteration i has been queued, so the device
+        // and norms) is collected after iteration i has been queued, so the device
         // never waits for the host's printing.  The per-iteration rate is the time between two lines.
         double mark = tick(), norm_m = 0.0, norm_u = 0.0;
         for (int i = 0; i < nsims; ++i) {
             if (i > 0) check(bpmf_hip_sys_state(movies, nullptr, &norm_m, nullptr, nullptr, nullptr, nullptr));   // of iteration i-1
             check(bpmf_hip_sys_sample(movies, users, alpha));   // movies.sample(users)
+            if (i > 0) check(bpmf_hip_sys_state(users, nullptr, &norm_u, nullptr, nullptr, nullptr, nullptr));    // of iteration i-1
+            check(bpmf_hip_sys_sample(users, movies, alpha));   // users.sample(movies)
             if (i > 0) {
+                // the evaluation of iteration i-1 ran beside the two samplers just queued
                 check(bpmf_hip_predict_finish(test, &se, &se_avg, &num_predict));
                 rmse = std::sqrt(se / (double)num_predict);
                 rmse_avg = std::sqrt(se_avg / (double)num_predict);
-                check(bpmf_hip_sys_state(users, nullptr, &norm_u, nullptr, nullptr, nullptr, nullptr));
                 const double now = tick();
                 print_line(i - 1, rmse, rmse_avg, norm_u, norm_m, now - mark);
                 mark = now;
             }
-            check(bpmf_hip_sys_sample(users, movies, alpha));   // users.sample(movies)
             iter = i;
             check(bpmf_hip_predict_launch(test, movies, users, (iter < burnin) ? 0 : (iter - burnin)));
         }

@@ -124,6 +124,7 @@ Rccl *rccl()
 
 extern "C" void bpmf_hip_set_error_(const char *msg) { g_err = msg; }
 static int settle_async(struct bpmf_hip_side *s);      // waits until the worker is done with `s`; returns its deferred error
+static void flush_deferred(struct bpmf_hip_test *t);   // enqueues an evaluation whose launch was put off
 
 struct bpmf_hip_side;
 // host-side timeline for BPMF_HIP_TRACE=1: (time, tag, side) records, printed when the context dies
@@ -189,6 +190,13 @@ struct bpmf_hip_side {
     double mean_rating = 0.0;
     int32_t *d_rowidx = nullptr; double *d_vals = nullptr; bool own_csc = true;
     double *d_items = nullptr; bool own_items = true;
+    // Second copy of the factor matrix: a sampler writes the copy that is NOT current and the two swap
+    // roles behind it, so that an evaluation of the previous iteration (k_predict on its own stream)
+    // can still read the factors the sampler replaces.  Only while the library owns the storage, the
+    // raw pointer was never handed out, and this rank's launches rewrite or receive every column.
+    double *d_items_alt = nullptr; bool items_exposed = false; int cur_buf = 0;
+    struct Reader { struct bpmf_hip_test *t = nullptr; unsigned seq = 0; } readers[2];   // last evaluation that read buffer 0 / 1
+    struct bpmf_hip_test *deferred_eval = nullptr;      // evaluation waiting for this side's next gate kernel (flush_deferred)
     double *d_prop = nullptr;            // propagated posterior (-m / -l): K x K prior precision per local column, or NULL
     // schedule
     int nwork = 0, nmulti = 0, nslots = 0, mode = 0;
@@ -251,8 +259,13 @@ struct bpmf_hip_test {
     int64_t global_nnz = -1;             // multi-GPU: test ratings over all ranks (all-reduced once)
     double *h_res = nullptr, *h_res_dev = nullptr;       // pinned: se | se_avg | flag
     unsigned *d_ticket = nullptr;                        // arrival counter of k_predict's blocks
-    unsigned seq = 0;
+    unsigned seq = 0, done_seq = 0;
     bool launched = false;
+    hipEvent_t ev_in = nullptr, ev_done[2] = {nullptr, nullptr};
+    hipStream_t pstream = nullptr;       // where the launch in flight was enqueued (the main stream, or the other side's)
+    // requested, not yet enqueued (flush_deferred): the factor copies it reads, captured at the request
+    bool deferred = false, cancelled = false; int def_n = 0; struct bpmf_hip_side *def_other = nullptr;
+    const void *def_self_items = nullptr, *def_other_items = nullptr;
 };
 
 namespace {
@@ -509,6 +522,7 @@ extern "C" int bpmf_hip_ctx_sync(bpmf_hip_ctx *c)
     { std::lock_guard<std::mutex> lk(c->launch_mutex); sides = c->sides; }
     int rc = 0;
     for (bpmf_hip_side *s : sides) { const int r = settle_async(s); if (r && !rc) rc = r; }
+    for (bpmf_hip_side *s : sides) flush_deferred(s->deferred_eval);
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (bpmf_hip_side *s : sides) HIP_TRY(hipStreamSynchronize(s->saux));
     return rc;
@@ -550,6 +564,12 @@ static int side_create_common(bpmf_hip_ctx *ctx, int64_t ncols, int64_t nrows, i
     if (e != hipSuccess) { bpmf_hip_side_destroy(s); return fail(BPMF_HIP_ENOMEM, "side_create: factor matrix allocation failed"); }
     e = hipMemset(s->d_items, 0, words * esz);                      // items().setZero(), c++/sample.cpp:185
     if (e != hipSuccess) { bpmf_hip_side_destroy(s); return fail(BPMF_HIP_ENODEV, "side_create: memset failed"); }
+    if (env_int("BPMF_HIP_DBUF", 1) != 0 && hipMalloc((void **)&s->d_items_alt, words * esz) == hipSuccess) {
+        if (hipMemset(s->d_items_alt, 0, words * esz) != hipSuccess) { (void)hipFree(s->d_items_alt); s->d_items_alt = nullptr; }
+    } else {
+        (void)hipGetLastError();                                    // no second copy: samplers write in place
+        s->d_items_alt = nullptr;
+    }
     if ((rc = build_schedule(s, colptr))) { bpmf_hip_side_destroy(s); return rc; }
     *out = s;
     return BPMF_HIP_OK;
@@ -579,6 +599,12 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
         s->worker.join();
     }
     (void)hipSetDevice(s->ctx->device);
+    {   // an evaluation over this side's test matrix that was never enqueued dies with the side
+        std::lock_guard<std::mutex> lk(s->ctx->launch_mutex);
+        for (bpmf_hip_side *sd : s->ctx->sides)
+            if (sd->deferred_eval && sd->deferred_eval->side == s) { sd->deferred_eval->deferred = false; sd->deferred_eval->cancelled = true; sd->deferred_eval = nullptr; }
+    }
+    flush_deferred(s->deferred_eval);                               // (it would go to this side's stream)
     (void)hipStreamSynchronize(s->ctx->stream);
     if (s->saux) {
         (void)hipStreamSynchronize(s->saux); (void)hipStreamDestroy(s->saux);
@@ -588,6 +614,7 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
     }
     if (s->own_csc) { if (s->d_rowidx) (void)hipFree(s->d_rowidx); if (s->d_vals) (void)hipFree(s->d_vals); }
     if (s->own_items && s->d_items) (void)hipFree(s->d_items);
+    if (s->d_items_alt) (void)hipFree(s->d_items_alt);
     if (s->d_prop) (void)hipFree(s->d_prop);
     void *ptrs[] = {s->d_wi_col, s->d_wi_len, s->d_wi_mc, s->d_wi_chunk, s->d_wi_p0, s->d_mc_slot0, s->d_mc_nch, s->d_mc_count, s->d_partials, s->d_stat_partials, s->a_d_in,
                     s->d_conn_send, s->d_conn_recv, s->d_conn_sbuf, s->d_conn_rbuf};
@@ -621,7 +648,25 @@ extern "C" int bpmf_hip_side_set_prop_posterior(bpmf_hip_side *s, const double *
     return BPMF_HIP_OK;
 }
 
-extern "C" double *bpmf_hip_side_items_dev(bpmf_hip_side *s) { return (s && s->ctx->dtype == BPMF_HIP_F64) ? s->d_items : nullptr; }
+// the caller is about to use the raw pointer: from here on the samplers write in place
+static int drop_second_copy(bpmf_hip_side *s)
+{
+    s->items_exposed = true;
+    if (!s->d_items_alt) return 0;
+    (void)settle_async(s);
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(s->d_items_alt);
+    s->d_items_alt = nullptr;
+    return 0;
+}
+
+extern "C" double *bpmf_hip_side_items_dev(bpmf_hip_side *s)
+{
+    if (!s || s->ctx->dtype != BPMF_HIP_F64) return nullptr;
+    if (drop_second_copy(s)) return nullptr;
+    return s->d_items;
+}
 
 extern "C" int bpmf_hip_side_bind_items(bpmf_hip_side *s, double *items_dev)
 {
@@ -631,6 +676,7 @@ extern "C" int bpmf_hip_side_bind_items(bpmf_hip_side *s, double *items_dev)
     (void)settle_async(s);
     HIP_TRY(hipStreamSynchronize(s->ctx->stream));
     if (s->saux) HIP_TRY(hipStreamSynchronize(s->saux));
+    { const int rc = drop_second_copy(s); if (rc) return rc; }
     if (s->own_items && s->d_items) (void)hipFree(s->d_items);
     s->d_items = items_dev; s->own_items = false;
     return BPMF_HIP_OK;
@@ -657,8 +703,7 @@ extern "C" int bpmf_hip_side_set_items(bpmf_hip_side *s, const double *h)
     if (!s || !h) return fail(BPMF_HIP_EINVAL, "set_items: NULL");
     HIP_TRY(hipSetDevice(s->ctx->device));
     { const int rc = settle_async(s); if (rc) return rc; }
-    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
-    if (s->saux) HIP_TRY(hipStreamSynchronize(s->saux));
+    HIP_TRY(hipDeviceSynchronize());                                // (an evaluation on its own stream may still read the factors)
     const size_t words = (size_t)s->ctx->K * s->ncols;
     if (s->ctx->dtype == BPMF_HIP_F32) {
         std::vector<float> tmp(words);
@@ -682,8 +727,8 @@ template <int K>
 // ev_start / ev_stop (optional): recorded by the dispatch packet of the sampler itself
 // (hipExtLaunchKernel) instead of by marker packets before and after it -- every marker is a few
 // microseconds on the stream between two samplers.
-int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double alpha, double *d_in, hipStream_t st,
-                   hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr)
+int launch_sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *other, int iter, double alpha, double *d_in, hipStream_t st,
+                        hipEvent_t ev_start, hipEvent_t ev_stop)
 {
     using namespace bpmf;
     bpmf_hip_ctx *c = self->ctx;
@@ -697,7 +742,7 @@ int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, do
         SampleArgsW<T> f;
         f.rowidx = self->d_rowidx; f.vals = self->d_vals;
         f.wi_col = self->d_wi_col; f.wi_p0 = self->d_wi_p0; f.wi_len = self->d_wi_len;
-        f.other_items = reinterpret_cast<const T *>(other->d_items); f.items = reinterpret_cast<T *>(self->d_items);
+        f.other_items = reinterpret_cast<const T *>(other->d_items); f.items = reinterpret_cast<T *>(out_items);
         f.col_from = self->from;
         f.LambdaF = d_in; f.Lmu = d_in + (size_t)K * K;
         f.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
@@ -722,7 +767,7 @@ int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, do
     a.wi_col = self->d_wi_col; a.wi_p0 = self->d_wi_p0; a.wi_len = self->d_wi_len; a.wi_mc = self->d_wi_mc; a.wi_chunk = self->d_wi_chunk;
     a.mc_slot0 = self->d_mc_slot0; a.mc_nchunks = self->d_mc_nch; a.mc_count = self->d_mc_count;
     a.partials = self->d_partials; a.nwork = self->nwork;
-    a.other_items = other->d_items; a.items = self->d_items; a.col_from = self->from;
+    a.other_items = other->d_items; a.items = out_items; a.col_from = self->from;
     a.LambdaF = d_in; a.Lmu = d_in + (size_t)K * K;
     a.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
     a.mu = d_in + (size_t)K * K + K + 2; a.prop_lambda = self->d_prop; a.diag_only = c->diag_only;
@@ -745,6 +790,35 @@ int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, do
     }
     return 0;
     }
+}
+
+// may this side's samplers write the second copy of the factors?  Every column of the new copy must
+// be produced by this launch or arrive through the exchange that follows it.
+inline bool second_copy_usable(const bpmf_hip_side *s)
+{
+    if (!s->d_items_alt || !s->own_items || s->items_exposed || s->nwork <= 0) return false;
+    const bool dist = s->ctx->comm != nullptr && !s->bounds.empty();
+    return dist || (s->from == 0 && s->to == s->ncols);
+}
+
+template <int K>
+int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double alpha, double *d_in, hipStream_t st,
+                   hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr)
+{
+    if (!second_copy_usable(self)) return launch_sampler_into<K>(self, self->d_items, other, iter, alpha, d_in, st, ev_start, ev_stop);
+    // the copy about to be overwritten may still be read by an evaluation that has not been collected
+    const int tgt = self->cur_buf ^ 1;
+    bpmf_hip_side::Reader &rd = self->readers[tgt];
+    if (rd.t) {
+        if (rd.t->deferred && rd.seq == rd.t->seq + 1) flush_deferred(rd.t);      // (the one that reads this copy, not a later one)
+        if (rd.t->done_seq < rd.seq) HIP_TRY(hipStreamWaitEvent(st, rd.t->ev_done[rd.seq & 1u], 0));
+    }
+    rd.t = nullptr;
+    const int rc = launch_sampler_into<K>(self, self->d_items_alt, other, iter, alpha, d_in, st, ev_start, ev_stop);
+    if (rc) return rc;
+    std::swap(self->d_items, self->d_items_alt);                    // everything enqueued from here on sees the new factors
+    self->cur_buf = tgt;
+    return 0;
 }
 
 template <int K>
@@ -1175,6 +1249,9 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
         HIP_TRY(hipEventRecord(ev[3], s1));
         HIP_TRY(hipStreamWaitEvent(s0, ev[3], 0));
     }
+    // an evaluation of the previous iteration that was put off until here: behind this gate (nothing
+    // the next sampler needs waits for it), ahead of this half-iteration's statistics pass
+    flush_deferred(self->deferred_eval);
     // kernel times come from events around every n-th launch of the side (BPMF_HIP_TIMING_EVERY,
     // default 4; 1 = every launch; 0 = never): the start marker costs a few microseconds on S0
     static const int every = env_int("BPMF_HIP_TIMING_EVERY", 4);
@@ -1376,15 +1453,49 @@ extern "C" int bpmf_hip_test_create(bpmf_hip_side *side, const int64_t *tcolptr,
         bpmf_hip_test_destroy(t);
         return rc;
     }
+    // events for an evaluation that runs beside the samplers of the next iteration (launch_predict)
+    if (env_int("BPMF_HIP_DBUF", 1) != 0) {
+        bool ok = hipEventCreateWithFlags(&t->ev_in, hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
+        for (auto &e : t->ev_done) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            if (t->ev_in) { (void)hipEventDestroy(t->ev_in); t->ev_in = nullptr; }
+        }
+    }
     *out = t;
     return BPMF_HIP_OK;
+}
+
+// the stream an evaluation was enqueued on, if it still exists (it belongs to a side)
+static hipStream_t live_pstream(bpmf_hip_test *t)
+{
+    bpmf_hip_ctx *c = t->side->ctx;
+    if (!t->pstream || t->pstream == c->stream) return c->stream;
+    std::lock_guard<std::mutex> lk(c->launch_mutex);
+    for (bpmf_hip_side *sd : c->sides) if (sd->saux == t->pstream) return t->pstream;
+    return c->stream;
 }
 
 extern "C" int bpmf_hip_test_destroy(bpmf_hip_test *t)
 {
     if (!t) return BPMF_HIP_OK;
-    (void)hipSetDevice(t->side->ctx->device);
-    (void)hipStreamSynchronize(t->side->ctx->stream);
+    bpmf_hip_ctx *c = t->side->ctx;
+    (void)hipSetDevice(c->device);
+    if (t->deferred) {                                              // never enqueued: nothing to wait for
+        t->deferred = false;
+        std::lock_guard<std::mutex> lk(c->launch_mutex);
+        for (bpmf_hip_side *sd : c->sides) if (sd->deferred_eval == t) sd->deferred_eval = nullptr;
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(live_pstream(t));
+    {   // no side may wait for this evaluation any more
+        std::lock_guard<std::mutex> lk(c->launch_mutex);
+        for (bpmf_hip_side *sd : c->sides)
+            for (auto &rd : sd->readers) if (rd.t == t) rd.t = nullptr;
+        for (auto &rd : t->side->readers) if (rd.t == t) rd.t = nullptr;
+    }
+    if (t->ev_in) (void)hipEventDestroy(t->ev_in);
+    for (hipEvent_t e : t->ev_done) if (e) (void)hipEventDestroy(e);
     void *ptrs[] = {t->d_tcol, t->d_trow, t->d_tval, t->d_pavg, t->d_pm2, t->d_partial, t->d_ticket};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (t->h_res) (void)hipHostFree(t->h_res);
@@ -1393,25 +1504,30 @@ extern "C" int bpmf_hip_test_destroy(bpmf_hip_test *t)
 }
 
 namespace {
+// k_predict on stream `ps` over explicit factor pointers.  in_order: on the main stream behind the
+// samplers.  Otherwise (`beside`): behind ev_in (everything that was on the main stream when the
+// evaluation was requested), with ev_done recorded after it for launch_sampler's hazard check.
 template <int K>
-void launch_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const bpmf_hip_side *other, int n)
+void launch_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items, const void *other_items, int n,
+                    hipStream_t ps, bool beside)
 {
     bpmf_hip_ctx *c = self->ctx;
     unsigned *flag = reinterpret_cast<unsigned *>(t->h_res_dev + 2);
     const bool dist = c->comm && !self->bounds.empty();
+    t->pstream = ps;
+    if (beside) (void)hipStreamWaitEvent(ps, t->ev_in, 0);
     // se | se_avg of this rank's test ratings: straight to the host, or -> all-reduce -> host
     double *red = c->d_red + c->out_words;          // 2 spare words behind the sampler's blob
     if constexpr (K == 128) {
-        hipLaunchKernelGGL(bpmf::k_predict_f32<K>, dim3((unsigned)t->nblocks), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(bpmf::k_predict_f32<K>, dim3((unsigned)t->nblocks), dim3(256), 0, ps,
                            (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz,
-                           reinterpret_cast<const float *>(self->d_items), reinterpret_cast<const float *>(other->d_items), self->from,
+                           reinterpret_cast<const float *>(self_items), reinterpret_cast<const float *>(other_items), self->from,
                            self->mean_rating, n, t->d_pavg, t->d_pm2, t->d_partial, t->h_res_dev, t->d_ticket, flag, ++t->seq);
         (void)red; (void)dist;
-        return;
     } else {
-    hipLaunchKernelGGL(bpmf::k_predict<K>, dim3((unsigned)t->nblocks), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(bpmf::k_predict<K>, dim3((unsigned)t->nblocks), dim3(256), 0, ps,
                        (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz,
-                       (const double *)self->d_items, (const double *)other->d_items, self->from, self->mean_rating, n,
+                       (const double *)self_items, (const double *)other_items, self->from, self->mean_rating, n,
                        t->d_pavg, t->d_pm2, t->d_partial, dist ? red : t->h_res_dev, t->d_ticket,
                        dist ? t->d_ticket + 8 : flag, dist ? 0u : ++t->seq);
     if (dist) {
@@ -1419,26 +1535,70 @@ void launch_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const bpmf_hip_
         hipLaunchKernelGGL(bpmf::k_publish, dim3(1), dim3(256), 0, c->stream, (const double *)red, t->h_res_dev, 2, flag, ++t->seq, -1);
     }
     }
+    if (beside) (void)hipEventRecord(t->ev_done[t->seq & 1u], ps);
+}
+
+void dispatch_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items, const void *other_items, int n,
+                      hipStream_t ps, bool beside)
+{
+    switch (self->ctx->K) {
+    case 8: launch_predict<8>(t, self, self_items, other_items, n, ps, beside); break;
+    case 16: launch_predict<16>(t, self, self_items, other_items, n, ps, beside); break;
+    case 32: launch_predict<32>(t, self, self_items, other_items, n, ps, beside); break;
+    case 64: launch_predict<64>(t, self, self_items, other_items, n, ps, beside); break;
+    case 128: launch_predict<128>(t, self, self_items, other_items, n, ps, beside); break;
+    default: break;
+    }
 }
 }  // namespace
 
-extern "C" int bpmf_hip_predict_launch(bpmf_hip_test *t, const bpmf_hip_side *self, const bpmf_hip_side *other, int n)
+// An evaluation that was requested while both sides keep two copies of their factors is enqueued
+// LATER: on the other side's statistics stream, right behind the gate kernel of that side's next
+// half-iteration (bpmf_hip_sys_sample), so that it runs beside the samplers that follow instead of
+// between them -- they write the other copies.  (Enqueued at once it would sit in front of that
+// gate kernel and hold up the sampler behind it; a stream of its own shares a hardware queue with
+// one of the other four, and behind a gate kernel that polls the host everything on that queue
+// stalls: 0.13 -> 0.34 ms per iteration.)  Whoever needs it earlier flushes it: predict_finish,
+// a sampler about to overwrite a copy it reads, test_get, the destructors.
+static void flush_deferred(bpmf_hip_test *t)
 {
-    if (!t || !self || !other) return fail(BPMF_HIP_EINVAL, "predict: NULL argument");
+    if (!t || !t->deferred) return;
+    t->deferred = false;
+    bpmf_hip_side *o = t->def_other;
+    if (o && o->deferred_eval == t) o->deferred_eval = nullptr;
+    (void)hipSetDevice(t->side->ctx->device);
+    dispatch_predict(t, t->side, t->def_self_items, t->def_other_items, t->def_n, o->saux, true);
+    trace("predict: enqueued", t->side, t->def_n);
+}
+
+extern "C" int bpmf_hip_predict_launch(bpmf_hip_test *t, const bpmf_hip_side *self, const bpmf_hip_side *other_c, int n)
+{
+    if (!t || !self || !other_c) return fail(BPMF_HIP_EINVAL, "predict: NULL argument");
     if (t->side != self) return fail(BPMF_HIP_EINVAL, "predict: test matrix belongs to another side");
     if (n < 0) return fail(BPMF_HIP_EINVAL, "predict: n < 0");
     if (t->launched) return fail(BPMF_HIP_EINVAL, "predict_launch: previous launch not finished");
     bpmf_hip_ctx *c = self->ctx;
+    bpmf_hip_side *other = const_cast<bpmf_hip_side *>(other_c);
     HIP_TRY(hipSetDevice(c->device));
-    if (t->nnz == 0 && !(c->comm && !self->bounds.empty())) { t->launched = true; return BPMF_HIP_OK; }
-    switch (c->K) {
-    case 8: launch_predict<8>(t, self, other, n); break;
-    case 16: launch_predict<16>(t, self, other, n); break;
-    case 32: launch_predict<32>(t, self, other, n); break;
-    case 64: launch_predict<64>(t, self, other, n); break;
-    case 128: launch_predict<128>(t, self, other, n); break;
-    default: return fail(BPMF_HIP_EINVAL, "predict: unsupported K");
+    const bool dist = c->comm && !self->bounds.empty();
+    if (t->nnz == 0 && !dist) { t->launched = true; return BPMF_HIP_OK; }
+    if (c->K != 8 && c->K != 16 && c->K != 32 && c->K != 64 && c->K != 128) return fail(BPMF_HIP_EINVAL, "predict: unsupported K");
+    // (the all-reduce of the sharded form shares the main communicator: that form stays in order)
+    const bool beside = t->ev_in && !dist && other->saux && !other->deferred_eval && second_copy_usable(self) && second_copy_usable(other);
+    if (beside) {
+        HIP_TRY(hipEventRecord(t->ev_in, c->stream));               // the samplers this evaluation is about
+        t->deferred = true; t->def_n = n; t->def_other = other;
+        t->def_self_items = self->d_items; t->def_other_items = other->d_items;
+        other->deferred_eval = t;
+        bpmf_hip_side *sm = t->side;
+        sm->readers[sm->cur_buf].t = t; sm->readers[sm->cur_buf].seq = t->seq + 1;
+        other->readers[other->cur_buf].t = t; other->readers[other->cur_buf].seq = t->seq + 1;
+        t->pstream = other->saux;
+        t->launched = true;
+        trace("predict: deferred", self, n);
+        return BPMF_HIP_OK;
     }
+    dispatch_predict(t, self, self->d_items, other->d_items, n, c->stream, false);
     HIP_TRY(hipGetLastError());
     t->launched = true;
     trace("predict: enqueued", self, n);
@@ -1449,7 +1609,9 @@ extern "C" int bpmf_hip_predict_finish(bpmf_hip_test *t, double *se, double *se_
 {
     if (!t || !se || !se_avg || !count) return fail(BPMF_HIP_EINVAL, "predict_finish: NULL argument");
     if (!t->launched) return fail(BPMF_HIP_EINVAL, "predict_finish: nothing launched");
+    flush_deferred(t);
     t->launched = false;
+    if (t->cancelled) { t->cancelled = false; return fail(BPMF_HIP_EINVAL, "predict_finish: the side of this test matrix was destroyed before the evaluation ran"); }
     bpmf_hip_side *self = t->side;
     bpmf_hip_ctx *c = self->ctx;
     HIP_TRY(hipSetDevice(c->device));
@@ -1466,10 +1628,11 @@ extern "C" int bpmf_hip_predict_finish(bpmf_hip_test *t, double *se, double *se_
             if ((spins & 0xFFFu) == 0xFFFu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > spin_limit_s()) break;
         }
         if (!seen) {
-            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipStreamSynchronize(live_pstream(t)));
             if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != t->seq) return fail(BPMF_HIP_ENODEV, "device did not publish its results");
         }
     }
+    t->done_seq = t->seq;                                           // every block has read its factors
     trace("predict: sums landed", self, 0);
     *se = t->h_res[0];
     *se_avg = t->h_res[1];
@@ -1502,6 +1665,8 @@ extern "C" int bpmf_hip_test_get(bpmf_hip_test *t, double *pavg, double *pm2)
     if (!t) return fail(BPMF_HIP_EINVAL, "test_get: NULL");
     HIP_TRY(hipSetDevice(t->side->ctx->device));
     HIP_TRY(hipStreamSynchronize(t->side->ctx->stream));
+    flush_deferred(t);
+    HIP_TRY(hipStreamSynchronize(live_pstream(t)));
     if (pavg) HIP_TRY(hipMemcpy(pavg, t->d_pavg, (size_t)t->nnz * sizeof(double), hipMemcpyDeviceToHost));
     if (pm2) HIP_TRY(hipMemcpy(pm2, t->d_pm2, (size_t)t->nnz * sizeof(double), hipMemcpyDeviceToHost));
     return BPMF_HIP_OK;

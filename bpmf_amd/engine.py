@@ -42,6 +42,10 @@ class HipEngine:
     # -- lifetime -----------------------------------------------------------
     def close(self):
         if getattr(self, "ctx", None):
+            for t in getattr(self, "_tests", []):
+                if t[0]:
+                    self.lib.bpmf_hip_test_destroy(t[0])
+                    t[0] = None
             for s in self._sides:
                 if s.handle:
                     self.lib.bpmf_hip_side_destroy(s.handle)
@@ -111,6 +115,9 @@ class HipEngine:
         return s
 
     def side_destroy(self, side):
+        for t in getattr(self, "_tests", []):                      # test matrices go before the side they sit on
+            if t[0] and t[2] is side:
+                self.test_destroy(t)
         if side.handle:
             _lib.check(self.lib.bpmf_hip_side_destroy(side.handle))
             side.handle = None
@@ -197,7 +204,16 @@ class HipEngine:
         tvals = np.ascontiguousarray(tvals, np.float64)
         h = C.c_void_p()
         _lib.check(self.lib.bpmf_hip_test_create(side.handle, _ptr(tcolptr), _ptr(trowidx), _ptr(tvals), C.byref(h)))
-        return (h, int(tcolptr[-1]))
+        t = [h, int(tcolptr[-1]), side]
+        if not hasattr(self, "_tests"):
+            self._tests = []
+        self._tests.append(t)
+        return t
+
+    def test_destroy(self, test):
+        if test[0]:
+            _lib.check(self.lib.bpmf_hip_test_destroy(test[0]))
+            test[0] = None
 
     def predict(self, test, side, other, n):
         se = C.c_double(); sea = C.c_double(); cnt = C.c_int64()

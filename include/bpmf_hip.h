@@ -140,7 +140,9 @@ BPMF_API int bpmf_hip_side_destroy(bpmf_hip_side *side);
 /* items(): device address of the K x ncols factor matrix (c++/bpmf.h:193-194);
  * bind_items makes the side use caller-owned device storage instead (so a
  * torch tensor / RCCL buffer can be exchanged in place; replaces the
- * backend's malloc in alloc_and_init, c++/nocomm.h:31). */
+ * backend's malloc in alloc_and_init, c++/nocomm.h:31).  Either call pins the
+ * factors to ONE address: the side gives up its second copy (see
+ * bpmf_hip_predict_launch) and its samplers write in place from then on. */
 BPMF_API double *bpmf_hip_side_items_dev(bpmf_hip_side *side);
 BPMF_API int bpmf_hip_side_bind_items(bpmf_hip_side *side, double *items_dev);
 /* host <-> device copies of the whole K x ncols matrix (the -v / -o dumps,
@@ -201,9 +203,12 @@ BPMF_API int bpmf_hip_test_create(bpmf_hip_side *side, const int64_t *tcolptr, c
 BPMF_API int bpmf_hip_test_destroy(bpmf_hip_test *test);
 BPMF_API int bpmf_hip_predict(bpmf_hip_test *test, const bpmf_hip_side *self, const bpmf_hip_side *other, int n,
                      double *se, double *se_avg, int64_t *count);
-/* the same in two halves: _launch enqueues the kernels behind the samplers, _finish waits for the
- * two sums.  A caller may enqueue the next half-iteration in between (it is ordered behind the
- * prediction kernels on the device), which hides the host round trip of the RMSE evaluation. */
+/* the same in two halves: _launch requests the evaluation of the factors as they are after the
+ * samplers enqueued so far, _finish waits for the two sums.  A caller may enqueue the next
+ * iteration in between (one evaluation per test matrix may be outstanding).  While both sides
+ * keep two copies of their factors (library-owned storage, raw pointer never requested) those
+ * samplers do not wait for the evaluation: they write the other copies, and the kernel is enqueued
+ * beside them.  Otherwise it runs in order on the main stream.  Same results either way. */
 BPMF_API int bpmf_hip_predict_launch(bpmf_hip_test *test, const bpmf_hip_side *self, const bpmf_hip_side *other, int n);
 BPMF_API int bpmf_hip_predict_finish(bpmf_hip_test *test, double *se, double *se_avg, int64_t *count);
 /* Pavg / Pm2 in the nnz order of the slice passed to _test_create (Pavg.sdm /

@@ -228,6 +228,49 @@ def test_pipelined_predict_is_the_same_chain(hip_engine_factory):
         movies.predict_finish()                       # nothing launched
 
 
+@pytest.mark.parametrize("K", [16, 32])
+def test_evaluation_beside_the_samplers_is_the_same_chain(hip_engine_factory, monkeypatch, K):
+    """Two copies of every factor matrix (samplers write the copy that is not current) let the
+    evaluation of iteration i run beside the samplers of iteration i + 1; its launch is put off to
+    the other side's next half-iteration.  Odd call orders must flush it in time: a side sampled
+    twice in a row (the second launch overwrites a copy the evaluation reads), predict_finish with
+    nothing in between, a raw-pointer request in mid-run (drops the second copy), a test matrix
+    destroyed with its evaluation still waiting.  Everything must equal the in-place run
+    (BPMF_HIP_DBUF=0) bit for bit."""
+    from bpmf_amd.sys import Sys
+    M, Mt, T, Tt, nu, nm = util.ml100k()
+    eng = hip_engine_factory(K)
+
+    def run(dbuf):
+        monkeypatch.setenv("BPMF_HIP_DBUF", dbuf)                  # read when the sides / test matrices are created
+        Sys.nsims, Sys.burnin, Sys.alpha = 9, 2, 2.0
+        movies = Sys("movs", eng, M, nm, nu, T=T)
+        users = Sys("users", eng, Mt, nu, nm)
+        trace = []
+        for i in range(9):
+            movies.sample(users)
+            if i == 3:
+                movies.sample(users)                                # (the evaluation of iteration 2 reads the copy this writes)
+            users.sample(movies)
+            if i == 6:
+                assert eng.items_dev_ptr(users.side)                # raw pointer: users go back to one copy
+            if i > 0:
+                movies.predict_finish(); trace.append((movies.rmse, movies.rmse_avg))
+            movies.predict_launch(users)
+            if i == 4:
+                movies.predict_finish(); trace.append((movies.rmse, movies.rmse_avg))   # nothing in between
+                movies.predict_launch(users)
+        # leave the last evaluation waiting: destroying the test matrix must cope
+        U, V = users.items().copy(), movies.items().copy()
+        eng.test_destroy(movies.test); movies.test = None
+        eng.side_destroy(movies.side); eng.side_destroy(users.side)
+        return np.asarray(trace), U, V
+
+    t0, U0, V0 = run("0")
+    t1, U1, V1 = run("1")
+    assert np.array_equal(t0, t1) and np.array_equal(U0, U1) and np.array_equal(V0, V1)
+
+
 def test_posterior_moments_of_one_column(hip_engine_factory):
     """Statistical check that does not involve the oracle: many draws of the same column
     (different iter => different streams) have mean Lambda*^-1 b and covariance Lambda*^-1."""

@@ -12,8 +12,8 @@ for rep in range(60):
     movies = Sys("movs", eng, M, nm, nu, T=T); users = Sys("users", eng, Mt, nu, nm)
     for i in range(30):
         movies.sample(users)
-        if i > 0: movies.predict_finish()
         users.sample(movies)
+        if i > 0: movies.predict_finish()
         movies.predict_launch(users)
     movies.predict_finish()
     eng.close()
@@ -24,8 +24,8 @@ t0 = time.time()
 n = 30000
 for i in range(n):
     movies.sample(users)
-    if i > 0: movies.predict_finish()
     users.sample(movies)
+    if i > 0: movies.predict_finish()
     movies.predict_launch(users)
 movies.predict_finish(); eng.sync()
 dt = time.time() - t0
