@@ -157,6 +157,10 @@ struct bpmf_hip_ctx {
     int K = 0;
     int dtype = BPMF_HIP_F64;            // arithmetic of the column loop and storage of the factors (BPMF_HIP_F32: K = 128)
     hipStream_t stream = nullptr;        // S0: samplers, exchange, predict
+    hipEvent_t last_sampler_done = nullptr;   // stop event of the newest thing on S0 when that is a stateful sampler (+ exchange), else NULL
+    // fused stateful path: the side whose newest half-iteration still has its statistics to run (they
+    // ride in the next k_sample1 launch; flush_pending_stats launches them alone if none comes)
+    struct bpmf_hip_side *pending_stats = nullptr; unsigned pending_seq = 0; int pending_evset = 0;
     std::vector<bpmf_hip_side *> sides;  // stateful sides with a statistics stream of their own (for ctx_sync)
     bool own_stream = false;
     int num_cu = 256;
@@ -220,6 +224,12 @@ struct bpmf_hip_side {
     // asynchronous (stateful) path: own parameter / result blobs, gate word, events
     double *a_h_in = nullptr, *a_h_in_dev = nullptr, *a_d_in = nullptr;
     double *a_h_out = nullptr, *a_h_out_dev = nullptr;
+    bpmf::FusedArgs cur_fused{};         // gate + statistics riders of the k_sample1 launch being enqueued (fused stateful path)
+    // the event behind which this side's statistics of the job with event set 0 / 1 are complete, once they
+    // have been enqueued (inside the next sampler launch, or as a kernel of their own): the collector's blocking wait
+    std::atomic<hipEvent_t> stats_ev[2] = {{nullptr}, {nullptr}};
+    unsigned *a_dflag = nullptr;         // device word k_gate_stage sets when the parameters are staged (in-kernel gate of the sampler)
+    const unsigned *cur_gate_flag = nullptr; unsigned cur_gate_want = 0;   // what the launch being enqueued polls (NULL: ordered by the queue)
     unsigned *a_gate = nullptr, *a_gate_dev = nullptr;   // pinned word the host sets to iter + 1 when a_h_in holds that iteration's parameters
     unsigned *a_ticket = nullptr;                        // arrival counters of this side's k_colstats waves
     double *a_d_red = nullptr;                           // multi-GPU: this side's device blob for the all-reduced sums
@@ -228,7 +238,9 @@ struct bpmf_hip_side {
     hipStream_t saux = nullptr;          // this side's statistics stream (high priority: its few blocks must not queue behind the other side's sampler)
     // host worker of this side: collects its sums when they land, forms cov, draws its next
     // hyper-parameters and releases the gate of its next sampler, all while the GPU samples the other side
-    struct Job { int iter; unsigned seq; int evset; bool timed; };
+    struct Job { int iter; unsigned seq; int evset; bool timed; hipEvent_t prev_stop; };
+    hipEvent_t last_stop = nullptr;      // stop event of this side's newest sampler (diagnostic: boundary to the next launch)
+    double tot_gap_ms = 0.0; int64_t n_gap = 0;
     std::thread worker;
     std::mutex wm;
     std::condition_variable wcv;
@@ -261,7 +273,7 @@ struct bpmf_hip_test {
     unsigned *d_ticket = nullptr;                        // arrival counter of k_predict's blocks
     unsigned seq = 0, done_seq = 0;
     bool launched = false;
-    hipEvent_t ev_in = nullptr, ev_done[2] = {nullptr, nullptr};
+    hipEvent_t ev_in = nullptr, ev_done[2] = {nullptr, nullptr}, in_ev = nullptr;
     hipStream_t pstream = nullptr;       // where the launch in flight was enqueued (the main stream, or the other side's)
     // requested, not yet enqueued (flush_deferred): the factor copies it reads, captured at the request
     bool deferred = false, cancelled = false; int def_n = 0; struct bpmf_hip_side *def_other = nullptr;
@@ -599,6 +611,9 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
         s->worker.join();
     }
     (void)hipSetDevice(s->ctx->device);
+    if (g_trace_on && s->n_gap > 0)
+        fprintf(stderr, "[bpmf_hip] side %04x: previous sampler's end -> this sampler's start: %.2f us (mean of %lld timed launches)\n",
+                (unsigned)((uintptr_t)s >> 4) & 0xFFFF, s->tot_gap_ms / (double)s->n_gap * 1e3, (long long)s->n_gap);
     {   // an evaluation over this side's test matrix that was never enqueued dies with the side
         std::lock_guard<std::mutex> lk(s->ctx->launch_mutex);
         for (bpmf_hip_side *sd : s->ctx->sides)
@@ -624,6 +639,7 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
     for (auto &set : s->evs) for (hipEvent_t e : set) if (e) (void)hipEventDestroy(e);
     if (s->a_gate) (void)hipHostFree(s->a_gate);
     if (s->a_ticket) (void)hipFree(s->a_ticket);
+    if (s->a_dflag) (void)hipFree(s->a_dflag);
     if (s->a_d_red) (void)hipFree(s->a_d_red);
     delete s;
     return BPMF_HIP_OK;
@@ -773,6 +789,7 @@ int launch_sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_s
     a.mu = d_in + (size_t)K * K + K + 2; a.prop_lambda = self->d_prop; a.diag_only = c->diag_only;
     a.mean_rating = self->mean_rating; a.alpha = alpha; a.iter_plus_1 = (uint32_t)(iter + 1);
     a.ablate = c->ablate;
+    a.gate_flag = self->cur_gate_flag; a.gate_want = self->cur_gate_want;
     a.zero_row = c->d_zero;
     if constexpr (K <= 32) {
         if (self->nwork > 0 && self->mode == 3) {                    // four columns per wave (k_sample4)
@@ -781,7 +798,10 @@ int launch_sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_s
         }
     }
     if (self->nwork > 0 && self->mode == 1) {
-        launch(k_sample1<K>, dim3(self->nwork), dim3(64), a);
+        const FusedArgs &f = self->cur_fused;                        // (all zero outside the fused stateful path)
+        const dim3 grid((unsigned)(self->nwork + (f.gate_host ? 1 : 0) + f.nstat));
+        if (ev_start || ev_stop) hipExtLaunchKernelGGL(k_sample1<K>, grid, dim3(64), 0, st, ev_start, ev_stop, 0, a, f);
+        else hipLaunchKernelGGL(k_sample1<K>, grid, dim3(64), 0, st, a, f);
     } else if (self->nwork > 0) {
         // persistent waves: as many single-wave workgroups as the chip holds at this kernel's occupancy
         const int resident = c->num_cu * 4 * Geo<K>::WPS;
@@ -949,6 +969,7 @@ extern "C" int bpmf_hip_sample_side_launch(bpmf_hip_side *self, const bpmf_hip_s
     hipLaunchKernelGGL(bpmf::k_stage, dim3((unsigned)((c->in_words + 255) / 256)), dim3(256), 0, c->stream,
                        (const double *)c->h_in_dev, c->d_in, (int)c->in_words);
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    c->last_sampler_done = nullptr;
     int rc = BPMF_DISPATCH_K(K, launch_sampler<KK>(self, other, iter, alpha, c->d_in, c->stream));
     if (rc) return rc;
     rc = BPMF_DISPATCH_K(K, launch_exchange<KK>(self, c->stream));
@@ -1058,6 +1079,8 @@ int ensure_state(bpmf_hip_side *s)
     HIP_TRY(hipMalloc((void **)&s->a_d_in, c->in_words * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&s->a_ticket, 64));
     HIP_TRY(hipMemset(s->a_ticket, 0, 64));
+    HIP_TRY(hipMalloc((void **)&s->a_dflag, 64));
+    HIP_TRY(hipMemset(s->a_dflag, 0, 64));
     HIP_TRY(hipMalloc((void **)&s->a_d_red, (c->out_words + 8) * sizeof(double)));
     static const unsigned evflags = env_int("BPMF_HIP_EVENT_FENCE", 0) ? 0u : hipEventDisableSystemFence;
     for (auto &set : s->evs) for (hipEvent_t &e : set) HIP_TRY(hipEventCreateWithFlags(&e, evflags));
@@ -1126,7 +1149,16 @@ void collect(bpmf_hip_side *s, const bpmf_hip_side::Job &job)
     int rc = 0;
     std::string msg;
     if (!seen) {                                                      // long kernel or an error: blocking wait
-        (void)hipEventSynchronize(ev[2]);                             // (not the stream: our own next gate may be queued on it)
+        // (an event, not the stream: our own next gate may be queued on it.)  The statistics may not
+        // be enqueued yet: in the fused form they ride in the next sampler launch of the context
+        const auto tw = std::chrono::steady_clock::now();
+        for (;;) {
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == job.seq) break;
+            hipEvent_t sev = s->stats_ev[job.evset].load(std::memory_order_acquire);
+            if (sev) { (void)hipEventSynchronize(sev); break; }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count() > 60.0) break;
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != job.seq) { rc = BPMF_HIP_ENODEV; msg = "device did not publish its results"; }
     }
     if (!rc) {
@@ -1151,10 +1183,14 @@ void collect(bpmf_hip_side *s, const bpmf_hip_side::Job &job)
     if (!rc) s->nx_iter = job.iter + 1;
     {   // kernel times of this launch (its events are complete: the flag is published behind them)
         float a = 0.f, b = 0.f;
-        if (job.timed && hipEventSynchronize(ev[2]) == hipSuccess && hipEventElapsedTime(&a, ev[0], ev[1]) == hipSuccess) {
-            (void)hipEventElapsedTime(&b, ev[1], ev[2]);
+        const bool own_stats = s->stats_ev[job.evset].load(std::memory_order_acquire) == ev[2];   // else: inside another launch
+        if (job.timed && hipEventSynchronize(own_stats ? ev[2] : ev[1]) == hipSuccess && hipEventElapsedTime(&a, ev[0], ev[1]) == hipSuccess) {
+            if (own_stats) (void)hipEventElapsedTime(&b, ev[1], ev[2]);
             s->last_sample_ms = a; s->last_reduce_ms = b; s->timing_valid = true;
             s->tot_sample_ms += a; s->tot_reduce_ms += b; s->n_launches++;
+            float g = 0.f;                                         // end of the other side's sampler -> start of this one
+            if (job.prev_stop && hipEventElapsedTime(&g, job.prev_stop, ev[0]) == hipSuccess) { s->tot_gap_ms += g; s->n_gap++; }
+            else (void)hipGetLastError();
         }
     }
     if (rc && !s->async_rc) { s->async_rc = rc; s->async_msg = msg; }
@@ -1186,13 +1222,41 @@ void post_collect(bpmf_hip_side *s, const bpmf_hip_side::Job &job)
     s->wcv.notify_all();
 }
 
+// fused stateful path: the statistics of the newest half-iteration ride in the NEXT sampler launch;
+// when somebody needs them and no launch has come, they run as a kernel of their own on the side's stream
+int flush_pending_stats(bpmf_hip_ctx *c)
+{
+    bpmf_hip_side *P = c->pending_stats;
+    if (!P) return 0;
+    c->pending_stats = nullptr;
+    const int K = c->K;
+    HIP_TRY(hipSetDevice(c->device));
+    hipEvent_t *ev = P->evs[c->pending_evset];
+    HIP_TRY(hipStreamWaitEvent(P->saux, ev[1], 0));                  // (ev[1]: recorded with / behind P's sampler)
+    unsigned *flag = reinterpret_cast<unsigned *>(P->a_h_out_dev + c->out_words - 1);
+    const int rc = BPMF_DISPATCH_K(K, launch_stats<KK>(P, P->saux, P->a_d_in, P->a_h_out_dev, flag, c->pending_seq, P->a_ticket));
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ev[2], P->saux));
+    P->stats_ev[c->pending_evset].store(ev[2], std::memory_order_release);
+    trace("statistics flushed (no launch to ride in)", P, P->iter);
+    return 0;
+}
+
 // waits until at most `depth` half-iterations of the side are uncollected; returns a deferred error
 int wait_async(bpmf_hip_side *s, int depth)
 {
+    if (depth == 0 && s->ctx->pending_stats == s) {                   // (main thread: nobody else enqueues)
+        const int rc = flush_pending_stats(s->ctx);
+        if (rc) return rc;
+    }
     {
         std::unique_lock<std::mutex> lk(s->wm);
         s->wcv.wait(lk, [s, depth] { return s->in_flight <= depth; });
         if (!s->async_rc) return 0;
+    }
+    if (s->ctx->pending_stats == s) (void)flush_pending_stats(s->ctx);   // the chain ends here: no launch will carry them
+    {
+        std::unique_lock<std::mutex> lk(s->wm);
         s->wcv.wait(lk, [s] { return s->in_flight == 0; });           // an error ends the chain: drain it
     }
     const int rc = s->async_rc;
@@ -1239,38 +1303,80 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     const unsigned seq = ++self->a_seq;
     const int evset = (int)(seq & 1u);
     hipEvent_t *ev = self->evs[evset];
-    // S1 (behind the statistics of the previous half-iteration): gate + staging of this
-    // half-iteration's parameters.  S0: sampler, exchange.  S1: statistics -> pinned result blob.
-    // (The previous statistics pass has finished reading the columns the sampler overwrites: the
-    // gate only opens after its sums were seen.)
-    hipLaunchKernelGGL(bpmf::k_gate_stage, dim3(c->in_words > 8192 ? 16 : 1), dim3(64), 0, s1, (const unsigned *)self->a_gate_dev,
-                       (unsigned)(iter + 1), (const double *)self->a_h_in_dev, self->a_d_in, (int)c->in_words);
-    if (s1 != s0) {
-        HIP_TRY(hipEventRecord(ev[3], s1));
-        HIP_TRY(hipStreamWaitEvent(s0, ev[3], 0));
+    // Fused form (single GPU, K <= 32 in fp64, one item per workgroup): ONE launch on S0 per
+    // half-iteration carries the gate + staging of its own parameters (workgroup 0) and the column
+    // statistics of the previous launch's side (the next workgroups) -- see FusedArgs in kernels.h.
+    // Otherwise: S1 (behind the statistics of the previous half-iteration): gate + staging kernel;
+    // S0: sampler, exchange; S1: statistics -> pinned result blob.  (The previous statistics pass
+    // has finished reading the columns the sampler overwrites: the gate only opens after its sums
+    // were seen.)
+    const bool dist = c->comm != nullptr && !self->bounds.empty();
+    const bool fused = s1 != s0 && !dist && c->in_words <= 8192 && K <= 32 && self->mode == 1 && self->nwork > 0 &&
+                       c->dtype == BPMF_HIP_F64 && env_int("BPMF_HIP_FUSED", 1) != 0;
+    bpmf::FusedArgs fz{};
+    bpmf_hip_side *P = c->pending_stats;
+    // statistics waiting for a carrier: they ride here, unless this launch cannot take them, or would
+    // overwrite in place the very columns they read (the same side twice in a row without a second copy)
+    bool carry = fused && P != nullptr;
+    if (carry && P == self && !second_copy_usable(self)) carry = false;
+    if (P && !carry) { if ((rc = flush_pending_stats(c))) return rc; }
+    if (fused) {
+        fz.gate_host = self->a_gate_dev; fz.gate_want = (unsigned)(iter + 1); fz.src_host = self->a_h_in_dev;
+        fz.dst = self->a_d_in; fz.n = (int)c->in_words; fz.dflag = self->a_dflag; fz.dval = seq;
+        if (carry) {
+            fz.nstat = P->nstat_waves; fz.st_items = P->d_items; fz.st_c0 = P->from; fz.st_c1 = P->to;
+            fz.st_partials = P->d_stat_partials;
+            fz.st_fail = (const unsigned long long *)(P->a_d_in + (size_t)K * K + K);
+            fz.st_out = P->a_h_out_dev; fz.st_ticket = P->a_ticket;
+            fz.st_flag = reinterpret_cast<unsigned *>(P->a_h_out_dev + c->out_words - 1); fz.st_seq = c->pending_seq;
+        }
+    } else {
+        hipLaunchKernelGGL(bpmf::k_gate_stage, dim3(c->in_words > 8192 ? 16 : 1), dim3(64), 0, s1, (const unsigned *)self->a_gate_dev,
+                           (unsigned)(iter + 1), (const double *)self->a_h_in_dev, self->a_d_in, (int)c->in_words);
+        if (s1 != s0) {
+            HIP_TRY(hipEventRecord(ev[3], s1));
+            HIP_TRY(hipStreamWaitEvent(s0, ev[3], 0));
+        }
     }
-    // an evaluation of the previous iteration that was put off until here: behind this gate (nothing
-    // the next sampler needs waits for it), ahead of this half-iteration's statistics pass
+    // an evaluation of the previous iteration that was put off until here: beside the samplers that
+    // follow (on S1: in the unfused form behind this gate kernel -- nothing the next sampler needs
+    // waits for it -- and ahead of this half-iteration's statistics pass)
     flush_deferred(self->deferred_eval);
     // kernel times come from events around every n-th launch of the side (BPMF_HIP_TIMING_EVERY,
-    // default 4; 1 = every launch; 0 = never): the start marker costs a few microseconds on S0
-    static const int every = env_int("BPMF_HIP_TIMING_EVERY", 4);
+    // default 8; 1 = every launch; 0 = never): the start marker costs a few microseconds on S0
+    static const int every = env_int("BPMF_HIP_TIMING_EVERY", 8);
     const bool timed = every > 0 && seq % (unsigned)every == 0;
     const bool ride = s1 != s0 && self->nwork > 0 && env_int("BPMF_HIP_EXT_EVENTS", 1) != 0;   // events on the sampler's own packet
     if (timed && !ride) HIP_TRY(hipEventRecord(ev[0], s0));
+    self->cur_fused = fz;
+    self->cur_gate_flag = fused ? self->a_dflag : nullptr; self->cur_gate_want = seq;
     rc = BPMF_DISPATCH_K(K, launch_sampler<KK>(self, other, iter, alpha, self->a_d_in, s0, (ride && timed) ? ev[0] : nullptr,
                                                ride ? ev[1] : nullptr));
+    self->cur_gate_flag = nullptr;
+    self->cur_fused = bpmf::FusedArgs{};
     if (!rc) rc = BPMF_DISPATCH_K(K, launch_exchange<KK>(self, s0));
     if (rc) return rc;
     if (!ride) HIP_TRY(hipEventRecord(ev[1], s0));
-    if (s1 != s0) HIP_TRY(hipStreamWaitEvent(s1, ev[1], 0));
-    unsigned *flag = reinterpret_cast<unsigned *>(self->a_h_out_dev + c->out_words - 1);
-    rc = BPMF_DISPATCH_K(K, launch_stats<KK>(self, s1, self->a_d_in, self->a_h_out_dev, flag, seq, self->a_ticket));
-    if (rc) return rc;
-    HIP_TRY(hipEventRecord(ev[2], s1));
+    c->last_sampler_done = (env_int("BPMF_HIP_EVAL_MARKER", 0) == 0) ? ev[1] : nullptr;   // an evaluation requested next waits for this: no marker of its own on S0
+    if (carry) {                                                      // P's statistics are inside this launch: complete behind ev[1]
+        P->stats_ev[c->pending_evset].store(ev[1], std::memory_order_release);
+        c->pending_stats = nullptr;
+    }
+    self->stats_ev[evset].store(nullptr, std::memory_order_release);
+    if (fused) {
+        c->pending_stats = self; c->pending_seq = seq; c->pending_evset = evset;     // ride in the next launch
+    } else {
+        if (s1 != s0) HIP_TRY(hipStreamWaitEvent(s1, ev[1], 0));
+        unsigned *flag = reinterpret_cast<unsigned *>(self->a_h_out_dev + c->out_words - 1);
+        rc = BPMF_DISPATCH_K(K, launch_stats<KK>(self, s1, self->a_d_in, self->a_h_out_dev, flag, seq, self->a_ticket));
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(ev[2], s1));
+        self->stats_ev[evset].store(ev[2], std::memory_order_release);
+    }
     HIP_TRY(hipGetLastError());
     self->timing_valid = false;
-    post_collect(self, {iter, seq, evset, timed});
+    self->last_stop = ev[1];
+    post_collect(self, {iter, seq, evset, timed, (timed && ride) ? other->last_stop : nullptr});
     trace("sys_sample: enqueued", self, iter);
     return BPMF_HIP_OK;
 }
@@ -1399,6 +1505,7 @@ extern "C" int bpmf_hip_side_exchange(bpmf_hip_side *s)
     int rc;
     if ((rc = settle_async(s))) return rc;
     HIP_TRY(hipSetDevice(c->device));
+    c->last_sampler_done = nullptr;
     switch (c->K) {
 #define BPMF_CASE(KK) case KK: rc = launch_exchange<KK>(s, c->stream); break;
         BPMF_CASE(8) BPMF_CASE(16) BPMF_CASE(32) BPMF_CASE(64) BPMF_CASE(128)
@@ -1515,7 +1622,7 @@ void launch_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *sel
     unsigned *flag = reinterpret_cast<unsigned *>(t->h_res_dev + 2);
     const bool dist = c->comm && !self->bounds.empty();
     t->pstream = ps;
-    if (beside) (void)hipStreamWaitEvent(ps, t->ev_in, 0);
+    if (beside) (void)hipStreamWaitEvent(ps, t->in_ev, 0);
     // se | se_avg of this rank's test ratings: straight to the host, or -> all-reduce -> host
     double *red = c->d_red + c->out_words;          // 2 spare words behind the sampler's blob
     if constexpr (K == 128) {
@@ -1586,7 +1693,10 @@ extern "C" int bpmf_hip_predict_launch(bpmf_hip_test *t, const bpmf_hip_side *se
     // (the all-reduce of the sharded form shares the main communicator: that form stays in order)
     const bool beside = t->ev_in && !dist && other->saux && !other->deferred_eval && second_copy_usable(self) && second_copy_usable(other);
     if (beside) {
-        HIP_TRY(hipEventRecord(t->ev_in, c->stream));               // the samplers this evaluation is about
+        // the samplers this evaluation is about: the stop event of the newest one if nothing else
+        // went to the main stream since, else a marker (a packet between two samplers)
+        if (c->last_sampler_done) t->in_ev = c->last_sampler_done;
+        else { HIP_TRY(hipEventRecord(t->ev_in, c->stream)); t->in_ev = t->ev_in; }
         t->deferred = true; t->def_n = n; t->def_other = other;
         t->def_self_items = self->d_items; t->def_other_items = other->d_items;
         other->deferred_eval = t;
@@ -1598,6 +1708,7 @@ extern "C" int bpmf_hip_predict_launch(bpmf_hip_test *t, const bpmf_hip_side *se
         trace("predict: deferred", self, n);
         return BPMF_HIP_OK;
     }
+    c->last_sampler_done = nullptr;
     dispatch_predict(t, self, self->d_items, other->d_items, n, c->stream, false);
     HIP_TRY(hipGetLastError());
     t->launched = true;

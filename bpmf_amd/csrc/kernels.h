@@ -149,6 +149,10 @@ struct SampleArgs {
     double mean_rating;
     double alpha;
     uint32_t iter_plus_1;
+    // in-kernel gate (NULL: the launch itself was ordered behind the staging kernel): the word
+    // k_gate_stage sets to `gate_want` once LambdaF | Lmu | fail | mu are in device memory
+    const unsigned *gate_flag;
+    unsigned gate_want;
     uint32_t ablate;            // profiling only (BPMF_HIP_ABLATE): 1 = skip the factorisation, 2 = skip the Gram, 4 = gather from 64 hot rows only
 };
 
@@ -170,6 +174,26 @@ template <int K>
 __device__ __forceinline__ uint32_t sample_counter(int64_t idx, uint32_t iter_plus_1)
 {
     return (uint32_t)((uint64_t)(idx + 1) * (uint64_t)K * (uint64_t)iter_plus_1);
+}
+
+// The hyper-parameters of this half-iteration may still be on their way (the host's Normal-Wishart
+// draw -> pinned memory -> k_gate_stage -> device memory) when the launch starts: a workgroup only
+// needs them after its Gram, so it waits HERE, not the launch at the queue (a cross-queue barrier
+// packet ahead of the dispatch costs ~5 us of command-processor time per launch even when it has
+// long been satisfied: tools/probes/boundary2.hip).  k_gate_stage writes the blob through to
+// memory (device-scope relaxed atomic stores + s_waitcnt) before it sets the word; nothing in this
+// launch has touched the blob before it sees the word, and the caches were invalidated when the
+// launch began, so plain loads behind the wait read the new values.  Gives up after ~2 s of wall
+// clock (then the host side reports the stale gate).
+__device__ __forceinline__ void wait_params(const SampleArgs &a)
+{
+    if (a.gate_flag == nullptr) return;
+    const unsigned long long t0 = wall_clock64();
+    while ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.gate_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != a.gate_want) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > 200000000ull) break;
+    }
+    asm volatile("" ::: "memory");
 }
 
 template <int NMAX>
@@ -879,12 +903,46 @@ __device__ __forceinline__ void finish_single(const SampleArgs &a, int col_local
 // one wave alone (finish_single: S lanes per row, lowest latency per column), which is what a
 // matrix with only a few thousand columns per side needs.
 // ---------------------------------------------------------------------------
+// What else one k_sample1 launch carries besides its work items (the stateful single-GPU path):
+// one workgroup per half-iteration that is not on any queue but this one.
+//   * workgroup 0, if gate_host: the gate + staging of THIS launch's parameters (k_gate_stage's
+//     job): polls the word the host sets when the Normal-Wishart draw is in pinned memory, copies
+//     the blob to device memory, sets dflag; the item workgroups wait for dflag after their Gram
+//     (wait_params).  Being the first workgroup of the launch it is always resident: no other
+//     queue has to get a kernel scheduled beside a launch that fills the chip.
+//   * the next nstat workgroups: the column statistics of the PREVIOUS launch's side (k_colstats'
+//     job: that side's sampler is the previous kernel on this queue, so its columns are complete);
+//     the host thread of that side spins on their result while this launch samples.
+// A cross-queue dependency costs ~6.5 us of command-processor latency per hop even when it is
+// satisfied long before (tools/probes/boundary2.hip): with both jobs inside the launch, two
+// samplers follow each other on one queue in ~2 us instead of 8-11.
+struct FusedArgs {
+    const unsigned *gate_host; unsigned gate_want; const double *src_host; double *dst; int n; unsigned *dflag; unsigned dval;
+    int nstat; const double *st_items; int64_t st_c0, st_c1; double *st_partials; const unsigned long long *st_fail;
+    double *st_out; unsigned *st_ticket; unsigned *st_flag; unsigned st_seq;
+};
 template <int K>
-__global__ __launch_bounds__(64, Geo1<K>::WPS) void k_sample1(SampleArgs a)
+__device__ __forceinline__ void colstats_body(int w, const double *__restrict__ items, int64_t c0, int64_t c1, int nwaves,
+                                              double *partials, const unsigned long long *__restrict__ fail_in,
+                                              double *__restrict__ out, unsigned *ticket, unsigned *flag, unsigned seq);
+__device__ __forceinline__ void gate_stage_body(int block, int nblocks, const unsigned *gate_host, unsigned want, const double *src_host,
+                                                double *__restrict__ dst, int n, unsigned *dflag, unsigned dval);
+
+template <int K>
+__global__ __launch_bounds__(64, Geo1<K>::WPS) void k_sample1(SampleArgs a, FusedArgs f)
 {
     __shared__ __attribute__((aligned(16))) double lds[Geo1<K>::LDS_WORDS];
     const int lane = threadIdx.x;
-    const int w = blockIdx.x;
+    int bid = blockIdx.x;
+    if (f.gate_host) {
+        if (bid == 0) { gate_stage_body(0, 1, f.gate_host, f.gate_want, f.src_host, f.dst, f.n, f.dflag, f.dval); return; }
+        --bid;
+    }
+    if (bid < f.nstat) {
+        colstats_body<K>(bid, f.st_items, f.st_c0, f.st_c1, f.nstat, f.st_partials, f.st_fail, f.st_out, f.st_ticket, f.st_flag, f.st_seq);
+        return;
+    }
+    const int w = bid - f.nstat;
     const int col = a.wi_col[w];
     const int64_t p0 = a.wi_p0[w];
     const int len = a.wi_len[w];
@@ -948,6 +1006,7 @@ __global__ __launch_bounds__(64, Geo1<K>::WPS) void k_sample1(SampleArgs a)
                 for (int t2 = 0; t2 < NG; ++t2) rr[t2] += tmp[NB + t2];
             }
         }
+        wait_params(a);
         finish_single<K>(a, col, lds, lane, mc < 0,
                          [&](double *sA, double *sb, int LD, int ln) { assemble44<K>(acc, rr, sA, sb, LD, ln); });
     } else {
@@ -999,6 +1058,7 @@ __global__ __launch_bounds__(64, Geo1<K>::WPS) void k_sample1(SampleArgs a)
                 for (int t2 = 0; t2 < NT; ++t2) r[t2] += __hip_atomic_load(&pc[NTRI * 256 + t2 * 16 + (lane & 15)], BPMF_RLX_AGENT);
             }
         }
+        wait_params(a);
         finish_single<K>(a, col, lds, lane, mc < 0,
                          [&](double *sA, double *sb, int LD, int ln) { assemble16<K>(acc, r, sA, sb, LD, ln); });
     }
@@ -1040,14 +1100,13 @@ __device__ __forceinline__ void publish_when_last(unsigned *ticket, unsigned nbl
 }
 
 template <int K>
-__global__ __launch_bounds__(64) void k_colstats(const double *__restrict__ items, int64_t c0, int64_t c1, int nwaves,
-                                                 double *partials, const unsigned long long *__restrict__ fail_in,
-                                                 double *__restrict__ out, unsigned *ticket, unsigned *flag, unsigned seq)
+__device__ __forceinline__ void colstats_body(int w, const double *__restrict__ items, int64_t c0, int64_t c1, int nwaves,
+                                              double *partials, const unsigned long long *__restrict__ fail_in,
+                                              double *__restrict__ out, unsigned *ticket, unsigned *flag, unsigned seq)
 {
     constexpr int NT = Geo<K>::NT, NTRI = Geo<K>::NTRI, PART = Geo<K>::PART;
     constexpr int NSLICE = (K * K + K + 15) / 16;
     const int lane = threadIdx.x, kq = lane >> 4, li = lane & 15;
-    const int w = blockIdx.x;
     const int64_t n = c1 - c0;
     const int64_t per = (((n + nwaves - 1) / nwaves) + 3) & ~(int64_t)3;
     const int64_t b = c0 + w * per;
@@ -1159,6 +1218,14 @@ __global__ __launch_bounds__(64) void k_colstats(const double *__restrict__ item
         __hip_atomic_store(&reinterpret_cast<unsigned long long *>(out)[K * K + K + 1], fw, BPMF_RLX_SYSTEM);
     }
     publish_when_last(ticket + 1, (unsigned)nfin, flag, seq, ticket);
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void k_colstats(const double *__restrict__ items, int64_t c0, int64_t c1, int nwaves,
+                                                 double *partials, const unsigned long long *__restrict__ fail_in,
+                                                 double *__restrict__ out, unsigned *ticket, unsigned *flag, unsigned seq)
+{
+    colstats_body<K>((int)blockIdx.x, items, c0, c1, nwaves, partials, fail_in, out, ticket, flag, seq);
 }
 
 // ---------------------------------------------------------------------------
@@ -1282,8 +1349,8 @@ __global__ __launch_bounds__(256) void k_stage(const double *__restrict__ src_ho
 // until the host has stored `want` there (release; after it wrote the parameter blob), then the
 // block copies the blob into device memory.  The poll gives up after ~20 s of wall clock (host
 // gone): the sampler then runs on stale parameters and the host side reports the error.
-__global__ __launch_bounds__(64) void k_gate_stage(const unsigned *gate_host, unsigned want, const double *src_host,
-                                                   double *__restrict__ dst, int n)
+__device__ __forceinline__ void gate_stage_body(int block, int nblocks, const unsigned *gate_host, unsigned want, const double *src_host,
+                                                double *__restrict__ dst, int n, unsigned *dflag, unsigned dval)
 {
     const int lane = threadIdx.x;
     if (lane == 0) {
@@ -1301,7 +1368,7 @@ __global__ __launch_bounds__(64) void k_gate_stage(const unsigned *gate_host, un
     d2 *out = reinterpret_cast<d2 *>(dst);
     const int n2 = n >> 1;
     // (big blobs, K = 128: several blocks, each polls the gate and copies every gridDim.x-th slab)
-    for (int base = (int)blockIdx.x * 256; base < n2; base += 256 * (int)gridDim.x) {
+    for (int base = block * 256; base < n2; base += 256 * nblocks) {
         d2 v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1311,9 +1378,27 @@ __global__ __launch_bounds__(64) void k_gate_stage(const unsigned *gate_host, un
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = base + u * 64 + lane;
-            if (i < n2) out[i] = v[u];
+            if (i < n2) {
+                if (dflag) {                                          // readers poll dflag inside a running launch: write through
+                    __hip_atomic_store(dst + 2 * i, v[u].x, BPMF_RLX_AGENT);
+                    __hip_atomic_store(dst + 2 * i + 1, v[u].y, BPMF_RLX_AGENT);
+                } else {
+                    out[i] = v[u];
+                }
+            }
         }
     }
+    if (dflag) {                                                      // (one block in this form)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (lane == 0) __hip_atomic_store(dflag, dval, BPMF_RLX_AGENT);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_gate_stage(const unsigned *gate_host, unsigned want, const double *src_host,
+                                                   double *__restrict__ dst, int n, unsigned *dflag = nullptr, unsigned dval = 0)
+{
+    gate_stage_body((int)blockIdx.x, (int)gridDim.x, gate_host, want, src_host, dst, n, dflag, dval);
 }
 
 // multi-GPU: the all-reduced sums sit in device memory; copy them to the pinned result blob and

@@ -271,6 +271,48 @@ def test_evaluation_beside_the_samplers_is_the_same_chain(hip_engine_factory, mo
     assert np.array_equal(t0, t1) and np.array_equal(U0, U1) and np.array_equal(V0, V1)
 
 
+@pytest.mark.parametrize("K", [16, 32])
+def test_fused_launch_is_the_same_chain(hip_engine_factory, monkeypatch, K):
+    """The fused form of the stateful path (one k_sample1 launch carries its own gate + staging
+    workgroup and the column statistics of the previous launch's side) against the unfused one
+    (gate kernel and statistics kernel on the side's stream): same hyper-parameters, same samples,
+    same norms, bit for bit -- also when the statistics find no launch to ride in (state read
+    straight after a sample), when one side is sampled twice in a row, and when a stateless launch
+    comes in between."""
+    from bpmf_amd.sys import Sys
+    M, Mt, T, Tt, nu, nm = util.ml100k()
+    eng = hip_engine_factory(K)
+
+    def run(fused):
+        monkeypatch.setenv("BPMF_HIP_FUSED", fused)
+        Sys.nsims, Sys.burnin, Sys.alpha = 8, 2, 2.0
+        movies = Sys("movs", eng, M, nm, nu, T=T)
+        users = Sys("users", eng, Mt, nu, nm)
+        out = []
+        for i in range(8):
+            movies.sample(users)
+            if i == 2:
+                out.append(eng.sys_state(movies.side)[1])              # norm: needs this launch's statistics NOW
+            if i == 4:
+                movies.sample(users)                                    # carries its own previous statistics
+            users.sample(movies)
+            if i == 5:
+                eng.sample_side(users.side, movies.side, 99, 2.0, np.zeros(K), np.eye(K))   # stateless launch in between
+            movies.predict(users)
+            out += [movies.rmse, movies.rmse_avg]
+        st_m, st_u = eng.sys_state(movies.side), eng.sys_state(users.side)
+        out += [st_m[1], st_u[1]]
+        U, V = users.items().copy(), movies.items().copy()
+        cov = np.asarray(st_u[2]).copy()
+        eng.side_destroy(movies.side); eng.side_destroy(users.side)
+        return np.asarray(out), U, V, cov
+
+    a = run("0")
+    b = run("1")
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
 def test_posterior_moments_of_one_column(hip_engine_factory):
     """Statistical check that does not involve the oracle: many draws of the same column
     (different iter => different streams) have mean Lambda*^-1 b and covariance Lambda*^-1."""
