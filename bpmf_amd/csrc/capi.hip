@@ -18,7 +18,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <deque>
+#include <limits>
 #include <new>
 #include <numeric>
 #include <string>
@@ -28,6 +30,7 @@
 #include "kernels.h"
 #include "kernels_f32.h"
 #include "kernels_q4.h"
+#include "kernels_lr.h"
 
 namespace {
 
@@ -204,6 +207,11 @@ struct bpmf_hip_side {
     double *d_prop = nullptr;            // propagated posterior (-m / -l): K x K prior precision per local column, or NULL
     // schedule
     int nwork = 0, nmulti = 0, nslots = 0, mode = 0;
+    // K = 64: columns with a handful of ratings take the low-rank form (k_sample_lr), the rest the regular
+    // one -- lr_n light items + hv_nwork others (the full list above stays for per-column priors etc.)
+    int lr_n = 0, hv_nwork = 0;
+    int32_t *d_lr_col = nullptr, *d_lr_len = nullptr; int64_t *d_lr_p0 = nullptr;
+    int32_t *d_hv_col = nullptr, *d_hv_len = nullptr, *d_hv_mc = nullptr, *d_hv_chunk = nullptr; int64_t *d_hv_p0 = nullptr;
     int32_t *d_wi_col = nullptr, *d_wi_len = nullptr, *d_wi_mc = nullptr, *d_wi_chunk = nullptr;
     int64_t *d_wi_p0 = nullptr;
     int32_t *d_mc_slot0 = nullptr, *d_mc_nch = nullptr;
@@ -409,6 +417,24 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
 
     s->nwork = (int)nw; s->nmulti = (int)mc_slot0.size(); s->nslots = slots;
     int rc;
+    if (K == 64 && !f32 && s->mode == 0) {
+        // Low-rank form for the columns with at most BPMF_HIP_LOWRANK_MAX ratings (default 6; 0: off):
+        // worth a second launch when they are at least half of the side (ChEMBL-shaped compounds)
+        const int nlr = env_int("BPMF_HIP_LOWRANK_MAX", 6);
+        std::vector<int32_t> lc, ll, hc, hl, hm, hk; std::vector<int64_t> lp, hp;
+        for (const Item &it : items) {
+            if (it.mc < 0 && it.len <= nlr) { lc.push_back(it.col); ll.push_back(it.len); lp.push_back(it.p0); }
+            else { hc.push_back(it.col); hl.push_back(it.len); hm.push_back(it.mc); hk.push_back(it.chunk); hp.push_back(it.p0); }
+        }
+        if (nlr > 0 && (int64_t)lc.size() * 2 >= nloc && !lc.empty()) {
+            s->lr_n = (int)lc.size(); s->hv_nwork = (int)hc.size();
+            if ((rc = dev_upload(&s->d_lr_col, lc.data(), lc.size())) || (rc = dev_upload(&s->d_lr_len, ll.data(), ll.size())) ||
+                (rc = dev_upload(&s->d_lr_p0, lp.data(), lp.size())) || (rc = dev_upload(&s->d_hv_col, hc.data(), hc.size())) ||
+                (rc = dev_upload(&s->d_hv_len, hl.data(), hl.size())) || (rc = dev_upload(&s->d_hv_mc, hm.data(), hm.size())) ||
+                (rc = dev_upload(&s->d_hv_chunk, hk.data(), hk.size())) || (rc = dev_upload(&s->d_hv_p0, hp.data(), hp.size())))
+                return rc;
+        }
+    }
     if ((rc = dev_upload(&s->d_wi_col, wcol.data(), nw))) return rc;
     if ((rc = dev_upload(&s->d_wi_len, wlen.data(), nw))) return rc;
     if ((rc = dev_upload(&s->d_wi_mc, wmc.data(), nw))) return rc;
@@ -482,6 +508,7 @@ static int ctx_create_impl(int device, int K, int dtype, void *stream, bpmf_hip_
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     c->in_words = (size_t)K * K + K + 2 + K;                           // LambdaF | Lmu | fail | pad | mu (even: staged as 16-byte words)
+    if (K == 64 && dtype == BPMF_HIP_F64) c->in_words += (size_t)K * K;   // | chol(LambdaF).matrixU(), row-major (k_sample_lr)
     c->out_words = (size_t)K * K + K + 1 + 1 + 2 + 1;
     HIP_TRY(hipHostMalloc((void **)&c->h_in, c->in_words * sizeof(double), hipHostMallocMapped));
     HIP_TRY(hipHostMalloc((void **)&c->h_out, c->out_words * sizeof(double), hipHostMallocMapped));
@@ -632,6 +659,7 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
     if (s->d_items_alt) (void)hipFree(s->d_items_alt);
     if (s->d_prop) (void)hipFree(s->d_prop);
     void *ptrs[] = {s->d_wi_col, s->d_wi_len, s->d_wi_mc, s->d_wi_chunk, s->d_wi_p0, s->d_mc_slot0, s->d_mc_nch, s->d_mc_count, s->d_partials, s->d_stat_partials, s->a_d_in,
+                    s->d_lr_col, s->d_lr_len, s->d_lr_p0, s->d_hv_col, s->d_hv_len, s->d_hv_mc, s->d_hv_chunk, s->d_hv_p0,
                     s->d_conn_send, s->d_conn_recv, s->d_conn_sbuf, s->d_conn_rbuf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (s->a_h_in) (void)hipHostFree(s->a_h_in);
@@ -805,6 +833,27 @@ int launch_sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_s
     } else if (self->nwork > 0) {
         // persistent waves: as many single-wave workgroups as the chip holds at this kernel's occupancy
         const int resident = c->num_cu * 4 * Geo<K>::WPS;
+        if constexpr (K == 64) {
+            if (self->lr_n > 0 && !self->d_prop && !c->diag_only && !c->ablate) {
+                // light columns: rank-n update of the shared factor of LambdaF (k_sample_lr); the others as usual
+                if (self->hv_nwork > 0) {
+                    a.wi_col = self->d_hv_col; a.wi_p0 = self->d_hv_p0; a.wi_len = self->d_hv_len; a.wi_mc = self->d_hv_mc;
+                    a.wi_chunk = self->d_hv_chunk; a.nwork = self->hv_nwork;
+                    const int grid = std::min(self->hv_nwork, env_int("BPMF_HIP_GRID", resident));
+                    if (ev_start) hipExtLaunchKernelGGL(k_sample<K>, dim3(grid), dim3(64), 0, st, ev_start, nullptr, 0, a);
+                    else hipLaunchKernelGGL(k_sample<K>, dim3(grid), dim3(64), 0, st, a);
+                }
+                LrArgs l;
+                l.rowidx = self->d_rowidx; l.vals = self->d_vals; l.col = self->d_lr_col; l.p0 = self->d_lr_p0; l.len = self->d_lr_len;
+                l.nitems = self->lr_n; l.other_items = other->d_items; l.items = out_items; l.col_from = self->from;
+                l.R0 = d_in + (size_t)K * K + K + 2 + K; l.Lmu = a.Lmu; l.fail = a.fail;
+                l.mean_rating = self->mean_rating; l.alpha = alpha; l.sqrt_alpha = std::sqrt(alpha); l.iter_plus_1 = (uint32_t)(iter + 1);
+                hipEvent_t e0 = self->hv_nwork > 0 ? nullptr : ev_start;
+                if (e0 || ev_stop) hipExtLaunchKernelGGL(k_sample_lr<K>, dim3(self->lr_n), dim3(64), 0, st, e0, ev_stop, 0, l);
+                else hipLaunchKernelGGL(k_sample_lr<K>, dim3(self->lr_n), dim3(64), 0, st, l);
+                return 0;
+            }
+        }
         const int grid = std::min(self->nwork, env_int("BPMF_HIP_GRID", resident));
         launch(k_sample<K>, dim3(grid), dim3(64), a);
     }
@@ -935,7 +984,7 @@ int launch_stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double
     }()
 
 // parameter blob of one half-iteration: LambdaF | LambdaF*mu | "no column failed"
-void fill_blob(int K, const double *mu, const double *LambdaF, double *h_in)
+void fill_blob(int K, const double *mu, const double *LambdaF, double *h_in, bool with_factor)
 {
     // rr = hp_LambdaF * hp.mu is the same for every column (c++/sample.cpp:285)
     memcpy(h_in, LambdaF, sizeof(double) * K * K);
@@ -948,6 +997,23 @@ void fill_blob(int K, const double *mu, const double *LambdaF, double *h_in)
     memcpy(&h_in[(size_t)K * K + K], &nofail, sizeof(nofail));
     h_in[(size_t)K * K + K + 1] = 0.0;
     memcpy(&h_in[(size_t)K * K + K + 2], mu, sizeof(double) * K);       // hp.mu itself: the propagated-posterior columns need it
+    if (with_factor) {
+        // R0 = chol(LambdaF).matrixU(), row-major with zeros below the diagonal: the factor every
+        // light column updates (k_sample_lr).  Not positive definite: NaN, which reaches the samples
+        // and is reported as "Cholesky failed" like the reference's own LLT (c++/sample.cpp:306-308).
+        double *R = h_in + (size_t)K * K + K + 2 + K;
+        bool ok = true;
+        for (int i = 0; i < K && ok; ++i) {
+            for (int j = 0; j < K; ++j) R[(size_t)i * K + j] = 0.0;
+            for (int j = i; j < K; ++j) {
+                double v = LambdaF[(size_t)j * K + i];
+                for (int k = 0; k < i; ++k) v -= R[(size_t)k * K + i] * R[(size_t)k * K + j];
+                if (j == i) { if (!(v > 0.0)) { ok = false; break; } R[(size_t)i * K + i] = std::sqrt(v); }
+                else R[(size_t)i * K + j] = v / R[(size_t)i * K + i];
+            }
+        }
+        if (!ok) for (size_t q = 0; q < (size_t)K * K; ++q) R[q] = std::numeric_limits<double>::quiet_NaN();
+    }
 }
 
 }  // namespace
@@ -965,7 +1031,7 @@ extern "C" int bpmf_hip_sample_side_launch(bpmf_hip_side *self, const bpmf_hip_s
     HIP_TRY(hipSetDevice(c->device));
     { const int rs = settle_async(self); if (rs) return rs; }
     if (self->saux) HIP_TRY(hipStreamSynchronize(self->saux));
-    fill_blob(K, mu, LambdaF, c->h_in);
+    fill_blob(K, mu, LambdaF, c->h_in, K == 64 && c->dtype == BPMF_HIP_F64);
     hipLaunchKernelGGL(bpmf::k_stage, dim3((unsigned)((c->in_words + 255) / 256)), dim3(256), 0, c->stream,
                        (const double *)c->h_in_dev, c->d_in, (int)c->in_words);
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
@@ -1109,7 +1175,7 @@ int draw_and_release(bpmf_hip_side *s, int iter, double *mu, double *LU, double 
         if (!rc) s->rd_iter = iter;
     }
     if (!rc) rc = bpmf_hyper_finish(K, s->ncols, s->cov.data(), nullptr, s->rd_au.data(), s->rd_z.data(), mu, LU, LF);
-    if (!rc) fill_blob(K, mu, LF, s->a_h_in);
+    if (!rc) fill_blob(K, mu, LF, s->a_h_in, K == 64 && s->ctx->dtype == BPMF_HIP_F64);
     // the gate is opened even after an error: a sampler may already be queued behind it and must
     // not be left spinning (its results are never looked at: the error is reported first)
     __atomic_store_n(s->a_gate, (unsigned)(iter + 1), __ATOMIC_RELEASE);

@@ -86,6 +86,29 @@ def test_tiny_first_half_iterations(oracle, hip_engine_factory, K, sampler_mode)
     check_half_iteration(*half_iteration_pair(oracle, eng, K, Mt, nm, V, 2))
 
 
+def test_low_rank_columns(oracle, hip_engine_factory, monkeypatch):
+    """K = 64, a ChEMBL-shaped side (thousands of columns with 0..6 ratings, a few heavy ones): the
+    light columns update the shared factor of LambdaF by one rotation sweep per rating (k_sample_lr)
+    instead of factorising Lambda*; same Cholesky factor, hence the reference's sample for the same
+    normals.  Checked against the oracle, and against the regular path (BPMF_HIP_LOWRANK_MAX=0)."""
+    K = 64
+    rng = np.random.default_rng(64)
+    ncols, nrows = 3000, 150
+    counts = rng.choice([0, 1, 2, 3, 4, 6, 40], size=ncols, p=[0.05, 0.3, 0.3, 0.15, 0.1, 0.05, 0.05])
+    colptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    rowidx = np.concatenate([np.sort(rng.choice(nrows, size=c, replace=False)) for c in counts]).astype(np.int32)
+    vals = rng.normal(6.0, 1.3, size=len(rowidx))
+    M = (colptr, rowidx, vals)
+    U = 0.4 * rng.standard_normal((nrows, K))
+    A = rng.standard_normal((K, 3 * K)); cov = A @ A.T / (3 * K)
+    eng = hip_engine_factory(K)
+    hip, ref = half_iteration_pair(oracle, eng, K, M, nrows, U, 4, cov=cov)
+    check_half_iteration(hip, ref)
+    monkeypatch.setenv("BPMF_HIP_LOWRANK_MAX", "0")
+    reg, _ = half_iteration_pair(oracle, eng, K, M, nrows, U, 4, cov=cov)
+    assert rel_err(hip[0], reg[0]) < RTOL
+
+
 @pytest.mark.parametrize("K", [16, 32, 64])
 def test_ml100k_half_iterations(oracle, hip_engine_factory, K, sampler_mode):
     M, Mt, T, Tt, nu, nm = util.ml100k()
