@@ -85,7 +85,6 @@ __global__ __launch_bounds__(64, 3) void k_sample_lr(LrArgs a)
             // (lane k's x is now ~1e-17 |x_k| instead of 0 and leaks that much into the LOWER triangle of the
             //  later rows; nothing reads it: the solves below touch R[i][j] with i <= j only.  Zeroing it
             //  with a `lane == k` select would keep 64 loop-invariant compare masks -- 128 SGPRs -- alive.)
-            __builtin_amdgcn_sched_barrier(0);                        // (the scheduler would hoist all 64 diagonal broadcasts: 128 SGPRs)
         }
     }
 
@@ -97,20 +96,19 @@ __global__ __launch_bounds__(64, 3) void k_sample_lr(LrArgs a)
     const double invd = rs * rs;                                      // 1 / R[lane][lane]; NaN for a non-positive pivot
 
     // ---- forward solve R^T y = b (:321): lane k accumulates sum_{i<k} R[i][k] y_i from its own column
-    double acc = 0.0, y = 0.0;
+    // (lane k stops accumulating at step k: (b - acc) * invd is then its y for good -- no per-step capture,
+    //  which the compiler turns into 64 live candidates)
+    double acc = 0.0;
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-        const double cand = (b - acc) * invd;                         // final in lane i at step i
-        y = (lane == i) ? cand : y;
-        const double yi = readlane_d(cand, i);
-        acc = fma(r[i], yi, acc);
-        __builtin_amdgcn_sched_barrier(0);
+        const double yi = readlane_d((b - acc) * invd, i);            // y_i: final in lane i at step i
+        acc = (i < lane) ? fma(r[i], yi, acc) : acc;
     }
+    const double y = (b - acc) * invd;
     __syncthreads();                                                  // the normals are in LDS
     double wk = y + sz[lane];                                         // :322
 
     // ---- backward solve R x = w (:323): rows of R through LDS, 16 columns at a time
-    double xs = 0.0;
 #pragma unroll
     for (int jb = K / 16 - 1; jb >= 0; --jb) {
         __syncthreads();
@@ -124,14 +122,12 @@ __global__ __launch_bounds__(64, 3) void k_sample_lr(LrArgs a)
 #pragma unroll
         for (int jj = 15; jj >= 0; --jj) {
             const int j = 16 * jb + jj;
-            const double cand = wk * invd;                            // final in lane j at this step
-            xs = (lane == j) ? cand : xs;
-            const double xj = readlane_d(cand, j);
+            const double xj = readlane_d(wk * invd, j);               // x_j: lane j's w no longer changes from here on
             const double Rkj = tile[lane * TLD + jj];                 // R[lane][j] (rows >= 16 (jb + 1): not written, not used)
             wk = (lane < j) ? fma(-Rkj, xj, wk) : wk;
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
+    const double xs = wk * invd;
 
     // ---- items().col(idx) = rr (:324); a failed factorisation (:308) shows as a non-finite sample
     a.items[(size_t)(a.col_from + col) * K + lane] = xs;
