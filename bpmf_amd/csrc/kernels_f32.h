@@ -271,7 +271,7 @@ __device__ __forceinline__ bool wg_column(const SampleArgsW<T> &a, int col_local
 }
 
 template <int K, typename T, int NW>
-__global__ __launch_bounds__(64 * NW, (NW == 1 ? 2 : 3)) void k_sample_wg(SampleArgsW<T> a)
+__global__ __launch_bounds__(64 * NW, 2) void k_sample_wg(SampleArgsW<T> a)
 {
     using G = GeoF<K>;
     using X = WgTraits<T>;
