@@ -692,11 +692,25 @@ extern "C" int bpmf_hip_side_set_prop_posterior(bpmf_hip_side *s, const double *
     return BPMF_HIP_OK;
 }
 
+// evaluations that were requested but not enqueued yet and read this side's factors: enqueue them now
+// (before the factors are replaced from outside, or a copy they captured goes away)
+static void flush_evals_touching(bpmf_hip_side *s)
+{
+    std::vector<bpmf_hip_test *> pend;
+    {
+        std::lock_guard<std::mutex> lk(s->ctx->launch_mutex);
+        for (bpmf_hip_side *sd : s->ctx->sides)
+            if (sd->deferred_eval && (sd->deferred_eval->side == s || sd->deferred_eval->def_other == s)) pend.push_back(sd->deferred_eval);
+    }
+    for (bpmf_hip_test *t : pend) flush_deferred(t);
+}
+
 // the caller is about to use the raw pointer: from here on the samplers write in place
 static int drop_second_copy(bpmf_hip_side *s)
 {
     s->items_exposed = true;
     if (!s->d_items_alt) return 0;
+    flush_evals_touching(s);                                        // (one may have captured the copy about to be freed)
     (void)settle_async(s);
     HIP_TRY(hipSetDevice(s->ctx->device));
     HIP_TRY(hipDeviceSynchronize());
@@ -747,7 +761,8 @@ extern "C" int bpmf_hip_side_set_items(bpmf_hip_side *s, const double *h)
     if (!s || !h) return fail(BPMF_HIP_EINVAL, "set_items: NULL");
     HIP_TRY(hipSetDevice(s->ctx->device));
     { const int rc = settle_async(s); if (rc) return rc; }
-    HIP_TRY(hipDeviceSynchronize());                                // (an evaluation on its own stream may still read the factors)
+    flush_evals_touching(s);
+    HIP_TRY(hipDeviceSynchronize());                                // (an evaluation beside the samplers may still read the factors)
     const size_t words = (size_t)s->ctx->K * s->ncols;
     if (s->ctx->dtype == BPMF_HIP_F32) {
         std::vector<float> tmp(words);
