@@ -109,6 +109,52 @@ bool cholesky_lower(int K, const double *S_in, double *L_out)
     return true;
 }
 
+// K >= 128 (the fp32 large-K configuration): chol(X^-1).matrixU() WITHOUT the inverse.  X is
+// symmetric positive definite; with its "reverse" Cholesky factorisation X = Ux Ux^T (Ux upper
+// triangular, positive diagonal) X^-1 = Ux^-T Ux^-1 = R^T R with R = Ux^-1 upper triangular and
+// positive on the diagonal -- the unique Cholesky factor the reference obtains as
+// inverse().llt().matrixU() (c++/mvnormal.cpp:78,124).  ~K^3/2 multiply-adds instead of ~2 K^3:
+// at K = 128 the host draw drops from ~630 us to ~250 us, which matters because a side's
+// sampler -> statistics -> draw -> next sampler loop (not the sum of the two samplers) bounds the
+// iteration there.  Different operation order than the reference's LU + LLT, hence kept to the
+// configuration whose tolerance is the fp32 one (tests/test_gpu_f32.py); K <= 64 follows the
+// reference's order.  Writes the LOWER factor L (T_c = L L^T, L = R^T) column-major like cholesky_lower.
+bool inverse_factor_spd(int K, const double *X_in, double *L_out)
+{
+    // (buffers are kept per thread: a K x K double vector is exactly glibc's mmap threshold at K = 128,
+    //  i.e. an mmap, 32 page faults and an munmap per call and vector)
+    static thread_local std::vector<double> ux;
+    ux.assign(X_in, X_in + (size_t)K * K);
+    Mat U{ux.data(), K};
+    for (int c = K - 1; c >= 0; --c) {                   // right-looking from the last column: contiguous inner loops
+        double *uc = &U(0, c);
+        const double d = uc[c];
+        if (!(d > 0.0)) return false;
+        const double sd = std::sqrt(d);
+        uc[c] = sd;
+        for (int r = 0; r < c; ++r) uc[r] /= sd;
+        for (int j = 0; j < c; ++j) {                     // X(0..j, j) -= Ux(0..j, c) Ux(j, c)
+            double *uj = &U(0, j);
+            const double f = uc[j];
+            for (int r = 0; r <= j; ++r) uj[r] -= uc[r] * f;
+        }
+    }
+    std::memset(L_out, 0, sizeof(double) * K * K);
+    static thread_local std::vector<double> x;
+    x.assign(K, 0.0);
+    for (int c = 0; c < K; ++c) {                         // column c of R = Ux^-1: Ux x = e_c, x_r = 0 for r > c
+        for (int r = 0; r < c; ++r) x[r] = 0.0;
+        x[c] = 1.0;
+        for (int j = c; j >= 0; --j) {
+            const double *uj = &U(0, j);
+            const double xj = (x[j] /= uj[j]);
+            for (int r = 0; r < j; ++r) x[r] -= uj[r] * xj;
+        }
+        for (int r = 0; r <= c; ++r) L_out[(size_t)r * K + c] = x[r];   // L(c, r) = R(r, c)
+    }
+    return true;
+}
+
 }  // namespace
 
 extern "C" void bpmf_hip_set_error_(const char *msg);   // capi.cpp
@@ -149,7 +195,8 @@ extern "C" int bpmf_hyper_finish(int K, int64_t N, const double *cov, const doub
     const size_t KK = (size_t)K * K;
     // fixed prior (c++/bpmf.h:80-96): mu0 = 0, kappa = b0 = 2, T = WI = I, nu = df = K
     const double kappa = 2.0, dN = (double)N;
-    std::vector<double> mu_m(K), mu_c(K), X(KK), Tc(KK), R(KK), z(z_in, z_in + K);
+    static thread_local std::vector<double> mu_m, mu_c, X, Tc, R, z, W;
+    mu_m.assign(K, 0.0); mu_c.assign(K, 0.0); X.resize(KK); Tc.resize(KK); R.resize(KK); z.assign(z_in, z_in + K); W.resize(KK);
     for (int i = 0; i < K; ++i) {
         const double um = Um ? Um[i] : 0.0;
         mu_m[i] = 0.0 - um;
@@ -160,6 +207,12 @@ extern "C" int bpmf_hyper_finish(int K, int64_t N, const double *cov, const doub
     for (int j = 0; j < K; ++j)
         for (int i = 0; i < K; ++i)
             X[(size_t)j * K + i] = ((i == j ? 1.0 : 0.0) + dN * cov[(size_t)j * K + i]) + kappa_m * (mu_m[i] * mu_m[j]);
+    if (K >= 128) {
+        if (!inverse_factor_spd(K, X.data(), R.data())) {
+            bpmf_hip_set_error_("bpmf_hyper_sample: posterior scale matrix not positive definite");
+            return BPMF_HIP_ENUM;
+        }
+    } else {
     if (!invert(K, X.data(), Tc.data())) {
         bpmf_hip_set_error_("bpmf_hyper_sample: singular posterior scale matrix");
         return BPMF_HIP_ENUM;
@@ -169,18 +222,20 @@ extern "C" int bpmf_hyper_finish(int K, int64_t N, const double *cov, const doub
         bpmf_hip_set_error_("bpmf_hyper_sample: posterior scale matrix not positive definite");
         return BPMF_HIP_ENUM;
     }
+    }
     Mat U{LambdaU, K}, F{LambdaF, K};
-    {   // U(i,j) = sum_{k=i..j} au(i,k) * matrixU(k,j), matrixU(k,j) = R(j,k); transposed copies make both factors contiguous in k
-        std::vector<double> aut(KK), rt(KK);
-        for (int k = 0; k < K; ++k)
-            for (int i = 0; i < K; ++i) { aut[(size_t)i * K + k] = au[(size_t)k * K + i]; rt[(size_t)i * K + k] = R[(size_t)k * K + i]; }
-        for (int j = 0; j < K; ++j)
-            for (int i = 0; i < K; ++i) {
-                double s = 0.0;
-                const double *a = &aut[(size_t)i * K], *r = &rt[(size_t)j * K];
-                for (int k = i; k <= j; ++k) s += a[k] * r[k];
-                U(i, j) = s;
-            }
+    // U(i,j) = sum_{k=i..j} au(i,k) * matrixU(k,j), matrixU(k,j) = R(j,k).  Written as column updates
+    // U(0..k, j) += au(0..k, k) * R(j,k), k ascending: every entry still adds its terms in the order
+    // k = i, i+1, ..., j (bit-identical to the dot-product form) but the inner loop runs down a
+    // contiguous column and vectorises without re-association.
+    std::memset(LambdaU, 0, sizeof(double) * KK);
+    for (int j = 0; j < K; ++j) {
+        double *uj = &U(0, j);
+        for (int k = 0; k <= j; ++k) {
+            const double f = R[(size_t)k * K + j];
+            const double *ak = au + (size_t)k * K;
+            for (int i = 0; i <= k; ++i) uj[i] += ak[i] * f;
+        }
     }
     // MvNormalChol_prec (c++/mvnormal.cpp:56-61)
     for (int i = K - 1; i >= 0; --i) {
@@ -190,13 +245,20 @@ extern "C" int bpmf_hyper_finish(int K, int64_t N, const double *cov, const doub
     }
     const double sk = std::sqrt(kappa_c);
     for (int i = 0; i < K; ++i) mu[i] = z[i] / sk + mu_c[i];
-    for (int j = 0; j < K; ++j)                           // LambdaF = LambdaU^T LambdaU (c++/bpmf.h:101)
-        for (int i = 0; i < K; ++i) {
-            double s = 0.0;
-            const int m = i < j ? i : j;
-            for (int k = 0; k <= m; ++k) s += U(k, i) * U(k, j);
-            F(i, j) = s;
+    {   // LambdaF = LambdaU^T LambdaU (c++/bpmf.h:101): F(i,j) = sum_{k <= min(i,j)} U(k,i) U(k,j), again as
+        // column updates F(k.., j) += W(k.., k) * U(k,j) with W = U^T (row k of U made contiguous), k ascending
+        for (int c = 0; c < K; ++c)
+            for (int r = 0; r < K; ++r) W[(size_t)r * K + c] = U(r, c);      // W(c, r) = U(r, c): column r of W = row r of U
+        std::memset(LambdaF, 0, sizeof(double) * KK);
+        for (int j = 0; j < K; ++j) {
+            double *fj = &F(0, j);
+            for (int k = 0; k <= j; ++k) {
+                const double f = U(k, j);
+                const double *wk = &W[(size_t)k * K];
+                for (int i = k; i < K; ++i) fj[i] += wk[i] * f;
+            }
         }
+    }
     return BPMF_HIP_OK;
 }
 
