@@ -423,6 +423,43 @@ def test_sharded_path_over_rccl_single_rank(tmp_path):
     assert ja["value"] > 0 and ja["n_gpus"] == 1
 
 
+@pytest.mark.parametrize("dataset,K", [("ml100k", 16), ("blocks", 32)])
+def test_two_ranks_share_one_gpu(oracle, tmp_path, dataset, K):
+    """Two processes, both driving the HIP kernels on cuda:0, joined by gloo (RCCL refuses two ranks on
+    one device): the sharded path with REAL kernels on REAL shards -- nnz-balanced column ranges, CSC
+    slices, shard-local launches (col_from / col_to), exchange of the fresh ranges, all-reduced sums
+    and RMSE -- must reproduce the single-process chain.  "blocks": the connectivity-aware exchange."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "res")
+    nsims, burnin = 4, 1
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dist_gpu_worker.py"), dataset, str(K),
+                                       str(nsims), str(burnin), out], env=env, cwd=ROOT, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        _, err = p.communicate(timeout=600)
+        assert p.returncode == 0, err[-3000:]
+    res = [np.load(out + ".rank%d.npz" % r) for r in range(2)]
+    M, Mt, T, Tt, nu, nm = util.ml100k() if dataset == "ml100k" else util.blocks()
+    ref = oracle.gibbs(K, M, Mt, T, Tt, nsims=nsims, burnin=burnin)
+    for r in res:
+        assert np.allclose(r["rmse"], ref["rmse"], atol=1e-7) and np.allclose(r["rmse_avg"], ref["rmse_avg"], atol=1e-7)
+        assert np.allclose(r["norm_u"], ref["norm_u"], rtol=1e-8) and np.allclose(r["norm_m"], ref["norm_m"], rtol=1e-8)
+        if dataset == "blocks":
+            assert r["conn_used"].all()
+            for X, Xref, dom in ((r["U"], ref["U"], r["dom_u"]), (r["V"], ref["V"], r["dom_m"])):
+                assert rel_err(X[dom[0]:dom[1]], Xref[dom[0]:dom[1]]) < 1e-7        # what the rank owns
+        else:
+            assert rel_err(r["U"], ref["U"]) < 1e-7 and rel_err(r["V"], ref["V"]) < 1e-7
+            assert np.array_equal(r["U"], res[0]["U"]) and np.array_equal(r["V"], res[0]["V"])
+
+
 @pytest.mark.parametrize("K", [32, 64])
 def test_connectivity_exchange_loopback(K):
     """bpmf_hip_side_set_conn / bpmf_hip_side_exchange over a one-rank RCCL
