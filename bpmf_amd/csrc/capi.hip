@@ -210,6 +210,7 @@ struct bpmf_hip_side {
     // K = 64: columns with a handful of ratings take the low-rank form (k_sample_lr), the rest the regular
     // one -- lr_n light items + hv_nwork others (the full list above stays for per-column priors etc.)
     int lr_n = 0, hv_nwork = 0;
+    int lr_class[5] = {0, 0, 0, 0, 0};     // light items sorted by sweep width: class c (1..4 ratings per sweep) is [lr_class[c-1], lr_class[c])
     int32_t *d_lr_col = nullptr, *d_lr_len = nullptr; int64_t *d_lr_p0 = nullptr;
     int32_t *d_hv_col = nullptr, *d_hv_len = nullptr, *d_hv_mc = nullptr, *d_hv_chunk = nullptr; int64_t *d_hv_p0 = nullptr;
     int32_t *d_wi_col = nullptr, *d_wi_len = nullptr, *d_wi_mc = nullptr, *d_wi_chunk = nullptr;
@@ -420,12 +421,17 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     if (K == 64 && !f32 && s->mode == 0) {
         // Low-rank form for the columns with at most BPMF_HIP_LOWRANK_MAX ratings (default 6; 0: off):
         // worth a second launch when they are at least half of the side (ChEMBL-shaped compounds)
-        const int nlr = env_int("BPMF_HIP_LOWRANK_MAX", 6);
+        const int nlr = std::min(env_int("BPMF_HIP_LOWRANK_MAX", 12), 32);
+        // sweep width of a light column: 1 | 2 | 3 (3, 5, 6, 9 ratings) | 4 (4, 7, 8, 10, 11, 12); none: with width 1
+        auto width = [](int n) { return n <= 1 ? 1 : n == 2 ? 2 : (n == 3 || n == 5 || n == 6 || n == 9) ? 3 : 4; };
         std::vector<int32_t> lc, ll, hc, hl, hm, hk; std::vector<int64_t> lp, hp;
-        for (const Item &it : items) {
-            if (it.mc < 0 && it.len <= nlr) { lc.push_back(it.col); ll.push_back(it.len); lp.push_back(it.p0); }
-            else { hc.push_back(it.col); hl.push_back(it.len); hm.push_back(it.mc); hk.push_back(it.chunk); hp.push_back(it.p0); }
+        for (int cls = 1; cls <= 4; ++cls) {
+            for (const Item &it : items)
+                if (it.mc < 0 && it.len <= nlr && width(it.len) == cls) { lc.push_back(it.col); ll.push_back(it.len); lp.push_back(it.p0); }
+            s->lr_class[cls] = (int)lc.size();
         }
+        for (const Item &it : items)
+            if (!(it.mc < 0 && it.len <= nlr)) { hc.push_back(it.col); hl.push_back(it.len); hm.push_back(it.mc); hk.push_back(it.chunk); hp.push_back(it.p0); }
         if (nlr > 0 && (int64_t)lc.size() * 2 >= nloc && !lc.empty()) {
             s->lr_n = (int)lc.size(); s->hv_nwork = (int)hc.size();
             if ((rc = dev_upload(&s->d_lr_col, lc.data(), lc.size())) || (rc = dev_upload(&s->d_lr_len, ll.data(), ll.size())) ||
@@ -508,7 +514,7 @@ static int ctx_create_impl(int device, int K, int dtype, void *stream, bpmf_hip_
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     c->in_words = (size_t)K * K + K + 2 + K;                           // LambdaF | Lmu | fail | pad | mu (even: staged as 16-byte words)
-    if (K == 64 && dtype == BPMF_HIP_F64) c->in_words += (size_t)K * K;   // | chol(LambdaF).matrixU(), row-major (k_sample_lr)
+    if (K == 64 && dtype == BPMF_HIP_F64) c->in_words += 2 * (size_t)K * K + K;   // | R0 = chol(LambdaF).matrixU() row-major | (R0^-1)^T | R0^-T LambdaF mu (k_sample_lr)
     c->out_words = (size_t)K * K + K + 1 + 1 + 2 + 1;
     HIP_TRY(hipHostMalloc((void **)&c->h_in, c->in_words * sizeof(double), hipHostMallocMapped));
     HIP_TRY(hipHostMalloc((void **)&c->h_out, c->out_words * sizeof(double), hipHostMallocMapped));
@@ -861,11 +867,25 @@ int launch_sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_s
                 LrArgs l;
                 l.rowidx = self->d_rowidx; l.vals = self->d_vals; l.col = self->d_lr_col; l.p0 = self->d_lr_p0; l.len = self->d_lr_len;
                 l.nitems = self->lr_n; l.other_items = other->d_items; l.items = out_items; l.col_from = self->from;
-                l.R0 = d_in + (size_t)K * K + K + 2 + K; l.Lmu = a.Lmu; l.fail = a.fail;
+                l.R0 = d_in + (size_t)K * K + K + 2 + K; l.S0t = l.R0 + (size_t)K * K; l.y0 = l.S0t + (size_t)K * K;
+                l.Lmu = a.Lmu; l.fail = a.fail;
                 l.mean_rating = self->mean_rating; l.alpha = alpha; l.sqrt_alpha = std::sqrt(alpha); l.iter_plus_1 = (uint32_t)(iter + 1);
-                hipEvent_t e0 = self->hv_nwork > 0 ? nullptr : ev_start;
-                if (e0 || ev_stop) hipExtLaunchKernelGGL(k_sample_lr<K>, dim3(self->lr_n), dim3(64), 0, st, e0, ev_stop, 0, l);
-                else hipLaunchKernelGGL(k_sample_lr<K>, dim3(self->lr_n), dim3(64), 0, st, l);
+                // one launch per sweep width (the events ride on the first / last launch of the side)
+                int first = 0, last = 0;
+                for (int cls = 1; cls <= 4; ++cls) if (self->lr_class[cls] > self->lr_class[cls - 1]) { if (!first) first = cls; last = cls; }
+                for (int cls = 1; cls <= 4; ++cls) {
+                    const int n0 = self->lr_class[cls - 1], n1 = self->lr_class[cls];
+                    if (n1 <= n0) continue;
+                    LrArgs lc = l;
+                    lc.col = l.col + n0; lc.p0 = l.p0 + n0; lc.len = l.len + n0; lc.nitems = n1 - n0;
+                    hipEvent_t e0 = (cls == first && self->hv_nwork == 0) ? ev_start : nullptr, e1 = (cls == last) ? ev_stop : nullptr;
+                    auto go = [&](auto kernel) {
+                        if (e0 || e1) hipExtLaunchKernelGGL(kernel, dim3(n1 - n0), dim3(64), 0, st, e0, e1, 0, lc);
+                        else hipLaunchKernelGGL(kernel, dim3(n1 - n0), dim3(64), 0, st, lc);
+                    };
+                    if (cls == 1) go(k_sample_lr<K, 1>); else if (cls == 2) go(k_sample_lr<K, 2>);
+                    else if (cls == 3) go(k_sample_lr<K, 3>); else go(k_sample_lr<K, 4>);
+                }
                 return 0;
             }
         }
@@ -1027,7 +1047,31 @@ void fill_blob(int K, const double *mu, const double *LambdaF, double *h_in, boo
                 else R[(size_t)i * K + j] = v / R[(size_t)i * K + i];
             }
         }
-        if (!ok) for (size_t q = 0; q < (size_t)K * K; ++q) R[q] = std::numeric_limits<double>::quiet_NaN();
+        double *S0t = R + (size_t)K * K, *y0 = S0t + (size_t)K * K;
+        if (!ok) {
+            for (size_t q = 0; q < 2 * (size_t)K * K + K; ++q) R[q] = std::numeric_limits<double>::quiet_NaN();
+        } else {
+            // S = R0^-1 (upper), stored transposed (S0t[j*K + i] = S[i][j]); y0 = R0^-T (LambdaF mu): what the
+            // columns WITHOUT ratings need (x = S (y0 + z))
+            for (size_t q = 0; q < (size_t)K * K; ++q) S0t[q] = 0.0;
+            std::vector<double> x(K);
+            for (int c = 0; c < K; ++c) {                  // column c of S: R0 x = e_c
+                for (int r = 0; r <= c; ++r) x[r] = 0.0;
+                x[c] = 1.0;
+                for (int j = c; j >= 0; --j) {
+                    double v = x[j];
+                    for (int m = j + 1; m <= c; ++m) v -= R[(size_t)j * K + m] * x[m];
+                    x[j] = v / R[(size_t)j * K + j];
+                }
+                for (int r = 0; r <= c; ++r) S0t[(size_t)c * K + r] = x[r];
+            }
+            const double *Lmu = h_in + (size_t)K * K;
+            for (int k = 0; k < K; ++k) {                  // R0^T y = Lmu
+                double v = Lmu[k];
+                for (int i = 0; i < k; ++i) v -= R[(size_t)i * K + k] * y0[i];
+                y0[k] = v / R[(size_t)k * K + k];
+            }
+        }
     }
 }
 

@@ -1,18 +1,20 @@
-// k_sample_lr<K>: the column update for columns with only a few ratings, K = 64.
+// k_sample_lr<K, NB>: the column update for columns with only a few ratings, K = 64.
 //
 // A column with n ratings has  Lambda* = LambdaF + alpha sum_r u_r u_r^T  (c++/sample.cpp:248-258,297-298):
 // a rank-n update of a matrix that is the SAME for every column of the half-iteration.  The
-// host ships R0 = chol(LambdaF).matrixU() with the parameters; the wave applies n rank-one updates
-// to it (Givens form: R^T R + x x^T = R'^T R', R' upper triangular with positive diagonal, i.e.
-// THE Cholesky factor the reference computes at :306, up to rounding), then solves as the reference
-// does: x = R'^-1 (R'^-T b + z) (:321-323).  O(n K^2) instead of K^3 / 3: on a ChEMBL-shaped side
-// (483 500 compounds, ~2 activities each) the full factorisation is >95 % of the work.
+// host ships R0 = chol(LambdaF).matrixU() with the parameters; the wave applies the update to it in
+// sweeps over NB <= 4 ratings (lr_update_block: one Householder reflector per row; R stays upper
+// triangular with a positive diagonal, i.e. THE Cholesky factor the reference computes at :306, up
+// to rounding), then solves as the reference does: x = R'^-1 (R'^-T b + z) (:321-323).  O(n K^2)
+// instead of K^3 / 3: on a ChEMBL-shaped side (483 500 compounds, ~2 activities each) the full
+// factorisation is >95 % of the work.
 //
 // One wave per column, lane j owns COLUMN j of R in registers (r[i] = R[i][j], zero below the
-// diagonal).  Update step k broadcasts R[k][k] and x[k] (v_readlane), forms the rotation once per
-// wave, and every lane rotates its (R[k][j], x[j]) pair.  The forward solve R^T y = b is
-// lane-local (lane k needs column k); the backward solve R x = w needs ROWS: the columns pass
-// through LDS 16 at a time (a K x 17 tile, conflict-free both ways).
+// diagonal).  Update step k broadcasts R[k][k] and the x_m[k] (v_readlane), forms the reflector once
+// per wave, and every lane updates its (R[k][j], x_m[j]).  The forward solve R^T y = b is lane-local
+// (lane k needs column k); the backward solve R x = w needs ROWS: the columns pass through LDS 16
+// at a time (a K x 17 tile, conflict-free both ways).  Columns without ratings skip all of that:
+// x = R0^-1 (y0 + z) with R0^-1 and y0 = R0^-T LambdaF mu from the host.
 #pragma once
 #include "kernels.h"
 
@@ -24,6 +26,8 @@ struct LrArgs {
     int nitems;
     const double *other_items; double *items; int64_t col_from;
     const double *R0;          // K x K, row-major upper factor of LambdaF (zeros below the diagonal)
+    const double *S0t;         // K x K: S0t[j * K + i] = (R0^-1)[i][j] -- columns without ratings: x = R0^-1 (y0 + z)
+    const double *y0;          // K: R0^-T (LambdaF mu), the forward solve every such column would repeat
     const double *Lmu;         // LambdaF * mu
     unsigned long long *fail;
     double mean_rating, alpha, sqrt_alpha;
@@ -37,7 +41,62 @@ __device__ __forceinline__ double readlane_d(double v, int lane)
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
-template <int K>
+__device__ __forceinline__ double rcp_nr(double d)
+{
+    double y = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-d, y, 1.0);
+    return fma(y, e, y);
+}
+
+// R^T R += sum_{m < NB} x_m x_m^T for NB ratings at once: step k annihilates x_0[k] .. x_{NB-1}[k] against
+// R[k][k] with ONE Householder reflector (v = a + |a| e_1 for a = (R[k][k], x_0[k], ...), row k negated
+// afterwards so that its diagonal stays positive: no cancellation, same R as NB Givens sweeps up to
+// rounding).  With sigma = |a|, v1 = R[k][k] + sigma, beta = 1 / (sigma v1), t_j = v1 R[k][j] + sum_m x_m[k] x_m[j]:
+//     R'[k][j] = t_j / sigma - R[k][j],     x_m'[j] = x_m[j] - (x_m[k] beta) t_j.
+// Per step 2 NB + 2 instructions per lane and 4 NB + 17 wave-uniform ones (one 1/sqrt, one reciprocal)
+// instead of NB x (4 + 18) for NB separate rotations.
+template <int K, int NB>
+__device__ __forceinline__ void lr_update_block(double (&r)[K], double &b, const LrArgs &a, int64_t p, int navail, int lane)
+{
+    double x[NB];
+#pragma unroll
+    for (int m = 0; m < NB; ++m) {                                     // (slots past the column's last rating: a zero vector)
+        const bool ok = m < navail;                                   // wave-uniform
+        const int row = ok ? a.rowidx[p + m] : 0;
+        const double u = ok ? a.other_items[(size_t)row * K + lane] : 0.0;
+        const double wv = ok ? (a.vals[p + m] - a.mean_rating) * a.alpha : 0.0;  // c++/sample.cpp:256
+        b = fma(u, wv, b);
+        x[m] = u * a.sqrt_alpha;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const double Rkk = readlane_d(r[k], k);
+        double xk[NB];
+        double s2 = Rkk * Rkk;
+#pragma unroll
+        for (int m = 0; m < NB; ++m) { xk[m] = readlane_d(x[m], k); s2 = fma(xk[m], xk[m], s2); }
+        const double inv = rsqrt_nr(s2);                              // 1 / sigma
+        const double v1 = fma(s2, inv, Rkk);                          // R[k][k] + sigma
+        const double beta = inv * rcp_nr(v1);
+        const double rk = r[k];
+        double t = v1 * rk;
+#pragma unroll
+        for (int m = 0; m < NB; ++m) t = fma(xk[m], x[m], t);
+        r[k] = fma(inv, t, -rk);
+#pragma unroll
+        for (int m = 0; m < NB; ++m) x[m] = fma(-(xk[m] * beta), t, x[m]);
+        // (lane k's x_m is now ~1e-17 |x_m[k]| instead of 0 and leaks that much into the LOWER triangle of the
+        //  later rows; nothing reads it: the solves below touch R[i][j] with i <= j only.  Zeroing it
+        //  with a `lane == k` select would keep 64 loop-invariant compare masks -- 128 SGPRs -- alive.)
+    }
+}
+
+// NB = ratings per sweep: one instantiation per class of columns (the host sorts the light columns by
+// their number of ratings: 1 | 2 | 3, 5, 6, 9 | 4, 7, 8, 10, 11, 12; a switch between sweep widths inside
+// one kernel makes the register allocator spill ~400 registers)
+template <int K, int NB>
 __global__ __launch_bounds__(64, 3) void k_sample_lr(LrArgs a)
 {
     static_assert(K == 64, "one lane per column of R");
@@ -50,43 +109,36 @@ __global__ __launch_bounds__(64, 3) void k_sample_lr(LrArgs a)
     const int64_t p0 = a.p0[w];
     const int len = a.len[w];
 
-    // the first ratings' operands are requested before the normal draw
-    const int row0 = len > 0 ? a.rowidx[p0] : 0;
-    double u_next = len > 0 ? a.other_items[(size_t)row0 * K + lane] : 0.0;
-    double wv_next = len > 0 ? (a.vals[p0] - a.mean_rating) * a.alpha : 0.0;   // c++/sample.cpp:256
-
     // (the normal draw first: its Philox / log / sqrt temporaries are dead before R occupies 128 registers)
     draw_normals<K>(sample_counter<K>(a.col_from + col, a.iter_plus_1), K, sz, lane);
     __builtin_amdgcn_sched_barrier(0);
+
+    if (len == 0) {
+        // no ratings (a third of a ChEMBL-shaped side): Lambda* = LambdaF, so the factor, its inverse and the
+        // forward solve are the same for all of them and come from the host: x = R0^-1 (y0 + z), one
+        // triangular matrix-vector product (lane i = row i of R0^-1, w_j broadcast)
+        __syncthreads();
+        const double wv = a.y0[lane] + sz[lane];
+        double x0 = 0.0, x1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < K; j += 2) {
+            x0 = fma(a.S0t[(size_t)j * K + lane], readlane_d(wv, j), x0);
+            x1 = fma(a.S0t[(size_t)(j + 1) * K + lane], readlane_d(wv, j + 1), x1);
+        }
+        const double xs0 = x0 + x1;
+        a.items[(size_t)(a.col_from + col) * K + lane] = xs0;
+        const bool bad0 = !(fabs(xs0) <= 1.79769313486231570815e+308);
+        if (__any(bad0)) { if (lane == 0) atomicMin(a.fail, (unsigned long long)(a.col_from + col)); }
+        return;
+    }
 
     double r[K];
 #pragma unroll
     for (int i = 0; i < K; ++i) r[i] = a.R0[(size_t)i * K + lane];
     double b = a.Lmu[lane];                                            // rr = LambdaF mu (:285)
 
-    // ---- n rank-one updates of R (R^T R += alpha u u^T) and of the rhs (:251-256)
-    for (int t = 0; t < len; ++t) {
-        const double u = u_next, wv = wv_next;
-        if (t + 1 < len) {                                             // wave-uniform
-            const int row = a.rowidx[p0 + t + 1];
-            u_next = a.other_items[(size_t)row * K + lane];
-            wv_next = (a.vals[p0 + t + 1] - a.mean_rating) * a.alpha;
-        }
-        b = fma(u, wv, b);
-        double x = u * a.sqrt_alpha;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const double Rkk = readlane_d(r[k], k), xk = readlane_d(x, k);
-            const double inv = rsqrt_nr(fma(xk, xk, Rkk * Rkk));      // 1 / hypot: the rotation (c, s) = (Rkk, xk) / hypot
-            const double c = Rkk * inv, s = xk * inv;
-            const double rk = r[k];
-            r[k] = fma(c, rk, s * x);                                 // lanes j < k: both terms are zero
-            x = fma(c, x, -(s * rk));
-            // (lane k's x is now ~1e-17 |x_k| instead of 0 and leaks that much into the LOWER triangle of the
-            //  later rows; nothing reads it: the solves below touch R[i][j] with i <= j only.  Zeroing it
-            //  with a `lane == k` select would keep 64 loop-invariant compare masks -- 128 SGPRs -- alive.)
-        }
-    }
+    // ---- rank-n update of R (R^T R += alpha sum u u^T) and of the rhs (:251-256), NB ratings per sweep
+    for (int t = 0; t < len; t += NB) lr_update_block<K, NB>(r, b, a, p0 + t, len - t, lane);
 
     // ---- my diagonal entry and its reciprocal
     double dg = 0.0;

@@ -87,14 +87,16 @@ def test_tiny_first_half_iterations(oracle, hip_engine_factory, K, sampler_mode)
 
 
 def test_low_rank_columns(oracle, hip_engine_factory, monkeypatch):
-    """K = 64, a ChEMBL-shaped side (thousands of columns with 0..6 ratings, a few heavy ones): the
-    light columns update the shared factor of LambdaF by one rotation sweep per rating (k_sample_lr)
+    """K = 64, a ChEMBL-shaped side (thousands of columns with 0..12 ratings, a few heavy ones): the
+    light columns update the shared factor of LambdaF by reflector sweeps over 1..4 ratings (k_sample_lr)
     instead of factorising Lambda*; same Cholesky factor, hence the reference's sample for the same
     normals.  Checked against the oracle, and against the regular path (BPMF_HIP_LOWRANK_MAX=0)."""
     K = 64
     rng = np.random.default_rng(64)
     ncols, nrows = 3000, 150
-    counts = rng.choice([0, 1, 2, 3, 4, 6, 40], size=ncols, p=[0.05, 0.3, 0.3, 0.15, 0.1, 0.05, 0.05])
+    # (every count up to 12 -- the sweeps take 1..4 ratings at a time, the last one padded -- and some heavy columns)
+    counts = rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 40], size=ncols,
+                        p=[0.06, 0.2, 0.2, 0.1, 0.08, 0.05, 0.05, 0.04, 0.04, 0.03, 0.03, 0.03, 0.03, 0.03, 0.03])
     colptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     rowidx = np.concatenate([np.sort(rng.choice(nrows, size=c, replace=False)) for c in counts]).astype(np.int32)
     vals = rng.normal(6.0, 1.3, size=len(rowidx))
