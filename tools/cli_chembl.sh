@@ -10,4 +10,4 @@ os.makedirs("/tmp/chembl", exist_ok=True)
 io.write_sparse("/tmp/chembl/train.sdm", nu, nm, M)
 io.write_sparse("/tmp/chembl/test.sdm", nu, nm, T)
 PY
-bpmf_amd/bpmf -n /tmp/chembl/train.sdm -p /tmp/chembl/test.sdm -i ${1:-12} -b 5 -k 64 2>&1 | tail -${2:-8}
+bpmf_amd/bpmf -n /tmp/chembl/train.sdm -p /tmp/chembl/test.sdm -i ${1:-12} -b 5 -d 64 2>&1 | tail -${2:-8}

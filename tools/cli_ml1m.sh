@@ -10,4 +10,4 @@ os.makedirs("/tmp/ml1m", exist_ok=True)
 io.write_sparse("/tmp/ml1m/train.sdm", nu, nm, M)      # rows = users, one column per movie
 io.write_sparse("/tmp/ml1m/test.sdm", nu, nm, T)
 PY
-bpmf_amd/bpmf -n /tmp/ml1m/train.sdm -p /tmp/ml1m/test.sdm -i ${1:-12} -b 5 -k 32 2>&1 | tail -${2:-18}
+bpmf_amd/bpmf -n /tmp/ml1m/train.sdm -p /tmp/ml1m/test.sdm -i ${1:-12} -b 5 -d 32 2>&1 | tail -${2:-18}
