@@ -292,6 +292,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sample_wg(SampleArgsW<T> a)
     bool bad;
     if constexpr (NW == 1) {
         bad = wg_column<K, T, 1, 0>(a, col, p0, len, R, dinv, bv, tid);
+    } else if constexpr (NW == 2) {
+        if (wave == 0) bad = wg_column<K, T, 2, 0>(a, col, p0, len, R, dinv, bv, tid);
+        else bad = wg_column<K, T, 2, 1>(a, col, p0, len, R, dinv, bv, tid);
     } else {
         switch (wave) {
         case 0: bad = wg_column<K, T, 4, 0>(a, col, p0, len, R, dinv, bv, tid); break;
