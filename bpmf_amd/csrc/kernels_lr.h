@@ -187,4 +187,129 @@ __global__ __launch_bounds__(64, 3) void k_sample_lr(LrArgs a)
     if (__any(bad)) { if (lane == 0) atomicMin(a.fail, (unsigned long long)(a.col_from + col)); }
 }
 
+
+// ---------------------------------------------------------------------------
+// k_sample_pf<K, NCAP>: the same update in PRODUCT FORM, for columns with at most NCAP <= 6 ratings.
+//
+// With x_1 = sqrt(alpha) u_1 and p_1 = R0^-T x_1:  Lambda* = R0^T (I + p_1 p_1^T) R0, and the Cholesky
+// factor of a rank-one update of the identity is known in closed form: I + p p^T = C^T C with
+//     C[k][k] = sqrt(s_{k+1} / s_k),   C[k][j] = p_k p_j / sqrt(s_k s_{k+1})  (j > k),   s_k = 1 + sum_{i<k} p_i^2.
+// So R' = C_n ... C_1 R0 (upper triangular, positive diagonal: the reference's factor) never has to be
+// formed: with p_m = C_{m-1}^-T ... C_1^-T R0^-T x_m,
+//     x = R0^-1 C_1^-1 ... C_n^-1 ( C_n^-T ... C_1^-T (y0 + sum_m kappa_m R0^-T x_m) + z ),
+// and a solve with C or C^T collapses to ONE prefix (suffix) sum across the wave:
+//     C^T t = c :  t_j = (c_j - p_j B_j / s_j) sqrt(s_j / s_{j+1}),        B_j = sum_{k<j} p_k c_k
+//     C  v = w :  v_k = (w_k - p_k sqrt(s_{k+1} / s_k) F_k) sqrt(s_k / s_{k+1}),   F_k = sum_{j>k} g_j w_j,  g = p / sqrt(s s')
+// R0^-1 (host side, like R0 itself) sits in LDS once per workgroup, padded to K + 1 so that rows and
+// columns are both conflict-free; eight waves walk the light columns of the side.  A column costs
+// n + 1 matrix-vector products with R0^-1 (256 instructions each) and n (n - 1) / 2 + 3 n scans
+// (~35 each) instead of ~25-43 instructions x 64 steps per sweep plus two triangular solves.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double wave_incl_prefix(double v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = __shfl_up(v, d);
+        v += (lane >= d) ? o : 0.0;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_incl_suffix(double v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = __shfl_down(v, d);
+        v += (lane + d < 64) ? o : 0.0;
+    }
+    return v;
+}
+
+struct PfFactor { double p, is, rs, irs; };                        // p_j, 1 / s_j, sqrt(s_j / s_{j+1}), sqrt(s_{j+1} / s_j)
+
+__device__ __forceinline__ PfFactor pf_make(double p, int lane)
+{
+    PfFactor f;
+    const double p2 = p * p;
+    const double s = 1.0 + (wave_incl_prefix(p2, lane) - p2);          // s_j = 1 + sum_{i<j} p_i^2
+    const double sn = s + p2;
+    const double rsq_s = rsqrt_nr(s), rsq_sn = rsqrt_nr(sn);
+    f.p = p;
+    f.is = rsq_s * rsq_s;
+    f.rs = (s * rsq_s) * rsq_sn;
+    f.irs = rsq_s * (sn * rsq_sn);
+    return f;
+}
+__device__ __forceinline__ double pf_solve_t(const PfFactor &f, double c, int lane)     // C^T t = c
+{
+    const double pc = f.p * c;
+    const double B = wave_incl_prefix(pc, lane) - pc;
+    return (c - f.p * B * f.is) * f.rs;
+}
+__device__ __forceinline__ double pf_solve(const PfFactor &f, double w, int lane)       // C v = w
+{
+    const double gw = (f.p * f.rs * f.is) * w;
+    const double F = wave_incl_suffix(gw, lane) - gw;
+    return (w - (f.p * f.irs) * F) * f.rs;
+}
+
+template <int K, int NCAP>
+__global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
+{
+    static_assert(K == 64, "one lane per latent index");
+    constexpr int LD = K + 1, NW = 8;
+    __shared__ double S0[K * LD];                                     // S0[i * LD + j] = (R0^-1)[i][j]
+    __shared__ double sz[NW][K];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int q = tid; q < K * K; q += 64 * NW) {                       // a.S0t[j * K + i] = (R0^-1)[i][j]
+        const int j = q / K, i = q % K;
+        S0[i * LD + j] = a.S0t[q];
+    }
+    const double y0 = a.y0[lane];
+    __syncthreads();
+
+    for (int w = (int)blockIdx.x * NW + wave; w < a.nitems; w += (int)gridDim.x * NW) {
+        const int col = a.col[w];
+        const int64_t p0 = a.p0[w];
+        const int len = a.len[w];
+        draw_normals<K>(sample_counter<K>(a.col_from + col, a.iter_plus_1), K, sz[wave], lane);
+
+        PfFactor f[NCAP];
+        double c = y0;                                                // R0^-T b = y0 + sum_m kappa_m R0^-T x_m
+#pragma unroll
+        for (int m = 0; m < NCAP; ++m) {
+            if (m < len) {                                            // wave-uniform
+                const int row = a.rowidx[p0 + m];
+                const double u = a.other_items[(size_t)row * K + lane];
+                const double wv = (a.vals[p0 + m] - a.mean_rating) * a.alpha;                       // c++/sample.cpp:256
+                double q = 0.0;                                       // q = R0^-T u: q_j = sum_i S0[i][j] u_i
+#pragma unroll
+                for (int i = 0; i < K; ++i) q = fma(S0[i * LD + lane], readlane_d(u, i), q);
+                c = fma(wv, q, c);                                    // R0^-T b = y0 + sum_m wv_m R0^-T u_m
+                q *= a.sqrt_alpha;                                    // R0^-T x_m, x_m = sqrt(alpha) u_m
+#pragma unroll
+                for (int k = 0; k < m; ++k) q = pf_solve_t(f[k], q, lane);      // p_m = C_{m-1}^-T ... C_1^-T q
+                f[m] = pf_make(q, lane);
+            }
+        }
+        double t = c;
+#pragma unroll
+        for (int m = 0; m < NCAP; ++m)
+            if (m < len) t = pf_solve_t(f[m], t, lane);
+        double v = t + sz[wave][lane];                                // :322 (same wave wrote the normals)
+#pragma unroll
+        for (int m = NCAP - 1; m >= 0; --m)
+            if (m < len) v = pf_solve(f[m], v, lane);
+        double x0 = 0.0, x1 = 0.0;                                    // x = R0^-1 v: x_i = sum_j S0[i][j] v_j
+#pragma unroll
+        for (int j = 0; j < K; j += 2) {
+            x0 = fma(S0[lane * LD + j], readlane_d(v, j), x0);
+            x1 = fma(S0[lane * LD + j + 1], readlane_d(v, j + 1), x1);
+        }
+        const double xs = x0 + x1;
+        a.items[(size_t)(a.col_from + col) * K + lane] = xs;
+        const bool bad = !(fabs(xs) <= 1.79769313486231570815e+308);
+        if (__any(bad)) { if (lane == 0) atomicMin(a.fail, (unsigned long long)(a.col_from + col)); }
+    }
+}
+
 }  // namespace bpmf
