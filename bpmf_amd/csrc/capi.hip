@@ -211,7 +211,7 @@ struct bpmf_hip_side {
     // one -- lr_n light items + hv_nwork others (the full list above stays for per-column priors etc.)
     int lr_n = 0, hv_nwork = 0;
     int lr_class[5] = {0, 0, 0, 0, 0};     // light items sorted by sweep width: class c (1..4 ratings per sweep) is [lr_class[c-1], lr_class[c])
-    int pf_class[3] = {0, 0, 0};           // ahead of them: product-form items (k_sample_pf), <= 2 ratings [pf_class[0], pf_class[1]), 3..6 [pf_class[1], pf_class[2])
+    int pf_class[4] = {0, 0, 0, 0};        // ahead of them: product-form items (k_sample_pf): <= 2 ratings, 3..6, 7..12 -- class c is [pf_class[c], pf_class[c+1])
     int32_t *d_lr_col = nullptr, *d_lr_len = nullptr; int64_t *d_lr_p0 = nullptr;
     int32_t *d_hv_col = nullptr, *d_hv_len = nullptr, *d_hv_mc = nullptr, *d_hv_chunk = nullptr; int64_t *d_hv_p0 = nullptr;
     int32_t *d_wi_col = nullptr, *d_wi_len = nullptr, *d_wi_mc = nullptr, *d_wi_chunk = nullptr;
@@ -427,18 +427,20 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
         auto width = [](int n) { return n <= 1 ? 1 : n == 2 ? 2 : (n == 3 || n == 5 || n == 6 || n == 9) ? 3 : 4; };
         std::vector<int32_t> lc, ll, hc, hl, hm, hk; std::vector<int64_t> lp, hp;
         // up to 6 ratings: product form (k_sample_pf), sorted by their number so that the waves of a workgroup stay in step
-        const int pfmax = env_int("BPMF_HIP_PF", 1) ? std::min(nlr, 6) : -1;
-        for (int n = 0; n <= pfmax; ++n) {
+        const int pfmax = std::min(nlr, std::min(env_int("BPMF_HIP_PF", 12), 12));            // (0: product form off)
+        for (int n = 0; n <= pfmax && pfmax > 0; ++n) {
             for (const Item &it : items)
                 if (it.mc < 0 && it.len == n) { lc.push_back(it.col); ll.push_back(it.len); lp.push_back(it.p0); }
             if (n == 2) s->pf_class[1] = (int)lc.size();
+            if (n == 6) s->pf_class[2] = (int)lc.size();
         }
-        if (pfmax >= 0 && pfmax < 2) s->pf_class[1] = (int)lc.size();
-        s->pf_class[2] = (int)lc.size();
+        if (pfmax < 2) s->pf_class[1] = (int)lc.size();
+        if (pfmax < 6) s->pf_class[2] = (int)lc.size();
+        s->pf_class[3] = (int)lc.size();
         s->lr_class[0] = (int)lc.size();
         for (int cls = 1; cls <= 4; ++cls) {
             for (const Item &it : items)
-                if (it.mc < 0 && it.len > pfmax && it.len <= nlr && width(it.len) == cls) { lc.push_back(it.col); ll.push_back(it.len); lp.push_back(it.p0); }
+                if (it.mc < 0 && (pfmax <= 0 || it.len > pfmax) && it.len <= nlr && width(it.len) == cls) { lc.push_back(it.col); ll.push_back(it.len); lp.push_back(it.p0); }
             s->lr_class[cls] = (int)lc.size();
         }
         for (const Item &it : items)
@@ -892,12 +894,14 @@ int launch_sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_s
                 int first = 0, last = 0;
                 for (int cls = 1; cls <= 4; ++cls) if (self->lr_class[cls] > self->lr_class[cls - 1]) { if (!first) first = cls; last = cls; }
                 bool started = self->hv_nwork > 0;
-                for (int pc = 0; pc < 2; ++pc) {
+                int last_pf = -1;
+                for (int pc = 0; pc < 3; ++pc) if (self->pf_class[pc + 1] > self->pf_class[pc]) last_pf = pc;
+                for (int pc = 0; pc < 3; ++pc) {
                     const int n0 = self->pf_class[pc], n1 = self->pf_class[pc + 1];
                     if (n1 <= n0) continue;
                     LrArgs lc = l;
                     lc.col = l.col + n0; lc.p0 = l.p0 + n0; lc.len = l.len + n0; lc.nitems = n1 - n0;
-                    const bool is_last = last == 0 && (pc == 1 || self->pf_class[2] == self->pf_class[1]);
+                    const bool is_last = last == 0 && pc == last_pf;
                     hipEvent_t e0 = started ? nullptr : ev_start, e1 = is_last ? ev_stop : nullptr;
                     started = true;
                     const int grid = std::max(1, std::min((n1 - n0 + 7) / 8, c->num_cu * 4));
@@ -905,7 +909,7 @@ int launch_sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_s
                         if (e0 || e1) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(512), 0, st, e0, e1, 0, lc);
                         else hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), 0, st, lc);
                     };
-                    if (pc == 0) go(k_sample_pf<K, 2>); else go(k_sample_pf<K, 6>);
+                    if (pc == 0) go(k_sample_pf<K, 2>); else if (pc == 1) go(k_sample_pf<K, 6>); else go(k_sample_pf<K, 12>);
                 }
                 for (int cls = 1; cls <= 4; ++cls) {
                     const int n0 = self->lr_class[cls - 1], n1 = self->lr_class[cls];

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64, 3) void k_sample_lr(LrArgs a)
 
 
 // ---------------------------------------------------------------------------
-// k_sample_pf<K, NCAP>: the same update in PRODUCT FORM, for columns with at most NCAP <= 6 ratings.
+// k_sample_pf<K, NCAP>: the same update in PRODUCT FORM, for columns with at most NCAP <= 12 ratings.
 //
 // With x_1 = sqrt(alpha) u_1 and p_1 = R0^-T x_1:  Lambda* = R0^T (I + p_1 p_1^T) R0, and the Cholesky
 // factor of a rank-one update of the identity is known in closed form: I + p p^T = C^T C with
