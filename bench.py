@@ -225,7 +225,7 @@ def main():
                    "parallelism": "columns of U and V sharded over %d GPU(s)" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": profiled_traffic() if (world == 1 and K == 32) else None,
-                     "kernel": ("k_sample_wg<%d>" if dtype == "f32" else ("k_sample1<%d>" if K <= 32 else "k_sample<%d>")) % K,
+                     "kernel": ("k_sample_wg<%d>" if dtype == "f32" else "k_sample1<%d>") % K,
                      "launch_ms": launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_launch,
                      "fp64_tflops": flops_launch / launch_s / 1e12 if launch_s > 0 else 0.0,
                      "fp64_frac": (flops_launch / launch_s / 1e12) / FP64_PEAK_TFLOPS if launch_s > 0 else 0.0,

@@ -348,9 +348,11 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     // a third of the VALU work per column, but a quarter of the workgroups, which only pays when
     // there are enough of them -- 24 000 x 14 800: even; 60 400 x 37 060: 349 / 382 us against
     // 401 / 510 us; 1M x 500K x 45M ratings: 2.35 / 3.13 ms against 3.5 / 5.3 ms, 3.8 / 5.7 ms persistent).
-    // K = 64: persistent waves with the 16x16x4 Gram (k_sample).
+    // K = 64: one item per workgroup as well (k_sample1<64>, 16x16x4 Gram, one wave per SIMD): 0.63 against
+    // 0.77 ms per iteration on the ML-1M shape, 4.4 / 6.0 ms at 60 400 x 37 060 x 10 M, 13.5 / 16.5 ms at
+    // 300 000 x 100 000 x 20 M, 2.15 / 2.45 ms ChEMBL-shaped -- the persistent form (k_sample) is BPMF_HIP_MODE=0.
     const int mode_env = env_int("BPMF_HIP_MODE", -1);
-    s->mode = mode_env >= 0 ? mode_env : (K <= 32 ? (nloc >= 20000 ? 3 : 1) : 0);
+    s->mode = mode_env >= 0 ? mode_env : (K <= 32 ? (nloc >= 20000 ? 3 : 1) : 1);
     const bool f32 = s->ctx->dtype == BPMF_HIP_F32;
     if (f32) s->mode = 2;                                // one workgroup per column (k_sample_wg), no chunking
     else if (K == 64) {
@@ -419,7 +421,7 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
 
     s->nwork = (int)nw; s->nmulti = (int)mc_slot0.size(); s->nslots = slots;
     int rc;
-    if (K == 64 && !f32 && s->mode == 0) {
+    if (K == 64 && !f32 && (s->mode == 0 || s->mode == 1)) {
         // Low-rank form for the columns with at most BPMF_HIP_LOWRANK_MAX ratings (default 6; 0: off):
         // worth a second launch when they are at least half of the side (ChEMBL-shaped compounds)
         const int nlr = std::min(env_int("BPMF_HIP_LOWRANK_MAX", 12), 32);
@@ -864,6 +866,67 @@ int launch_sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_s
             return 0;
         }
     }
+    if constexpr (K == 64) {
+        if (self->lr_n > 0 && !self->d_prop && !c->diag_only && !c->ablate) {
+            // light columns: rank-n update of the shared factor of LambdaF (k_sample_lr); the others as usual
+            if (self->hv_nwork > 0) {
+                a.wi_col = self->d_hv_col; a.wi_p0 = self->d_hv_p0; a.wi_len = self->d_hv_len; a.wi_mc = self->d_hv_mc;
+                a.wi_chunk = self->d_hv_chunk; a.nwork = self->hv_nwork;
+                if (self->mode == 1) {
+                    const FusedArgs f0{};
+                    if (ev_start) hipExtLaunchKernelGGL(k_sample1<K>, dim3(self->hv_nwork), dim3(64), 0, st, ev_start, nullptr, 0, a, f0);
+                    else hipLaunchKernelGGL(k_sample1<K>, dim3(self->hv_nwork), dim3(64), 0, st, a, f0);
+                } else {
+                    const int grid = std::min(self->hv_nwork, env_int("BPMF_HIP_GRID", c->num_cu * 4 * Geo<K>::WPS));
+                    if (ev_start) hipExtLaunchKernelGGL(k_sample<K>, dim3(grid), dim3(64), 0, st, ev_start, nullptr, 0, a);
+                    else hipLaunchKernelGGL(k_sample<K>, dim3(grid), dim3(64), 0, st, a);
+                }
+            }
+            LrArgs l;
+            l.rowidx = self->d_rowidx; l.vals = self->d_vals; l.col = self->d_lr_col; l.p0 = self->d_lr_p0; l.len = self->d_lr_len;
+            l.nitems = self->lr_n; l.other_items = other->d_items; l.items = out_items; l.col_from = self->from;
+            l.R0 = d_in + (size_t)K * K + K + 2 + K; l.S0t = l.R0 + (size_t)K * K; l.y0 = l.S0t + (size_t)K * K;
+            l.Lmu = a.Lmu; l.fail = a.fail;
+            l.mean_rating = self->mean_rating; l.alpha = alpha; l.sqrt_alpha = std::sqrt(alpha); l.iter_plus_1 = (uint32_t)(iter + 1);
+            // product form for the columns with <= 6 ratings: two instantiations (<= 2, <= 6), persistent workgroups
+            // of eight waves with R0^-1 in LDS; then one launch per sweep width for the rest (the events ride on
+            // the first / last launch of the side)
+            int first = 0, last = 0;
+            for (int cls = 1; cls <= 4; ++cls) if (self->lr_class[cls] > self->lr_class[cls - 1]) { if (!first) first = cls; last = cls; }
+            bool started = self->hv_nwork > 0;
+            int last_pf = -1;
+            for (int pc = 0; pc < 3; ++pc) if (self->pf_class[pc + 1] > self->pf_class[pc]) last_pf = pc;
+            for (int pc = 0; pc < 3; ++pc) {
+                const int n0 = self->pf_class[pc], n1 = self->pf_class[pc + 1];
+                if (n1 <= n0) continue;
+                LrArgs lc = l;
+                lc.col = l.col + n0; lc.p0 = l.p0 + n0; lc.len = l.len + n0; lc.nitems = n1 - n0;
+                const bool is_last = last == 0 && pc == last_pf;
+                hipEvent_t e0 = started ? nullptr : ev_start, e1 = is_last ? ev_stop : nullptr;
+                started = true;
+                const int grid = std::max(1, std::min((n1 - n0 + 7) / 8, c->num_cu * 4));
+                auto go = [&](auto kernel) {
+                    if (e0 || e1) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(512), 0, st, e0, e1, 0, lc);
+                    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), 0, st, lc);
+                };
+                if (pc == 0) go(k_sample_pf<K, 2>); else if (pc == 1) go(k_sample_pf<K, 6>); else go(k_sample_pf<K, 12>);
+            }
+            for (int cls = 1; cls <= 4; ++cls) {
+                const int n0 = self->lr_class[cls - 1], n1 = self->lr_class[cls];
+                if (n1 <= n0) continue;
+                LrArgs lc = l;
+                lc.col = l.col + n0; lc.p0 = l.p0 + n0; lc.len = l.len + n0; lc.nitems = n1 - n0;
+                hipEvent_t e0 = (cls == first && !started) ? ev_start : nullptr, e1 = (cls == last) ? ev_stop : nullptr;
+                auto go = [&](auto kernel) {
+                    if (e0 || e1) hipExtLaunchKernelGGL(kernel, dim3(n1 - n0), dim3(64), 0, st, e0, e1, 0, lc);
+                    else hipLaunchKernelGGL(kernel, dim3(n1 - n0), dim3(64), 0, st, lc);
+                };
+                if (cls == 1) go(k_sample_lr<K, 1>); else if (cls == 2) go(k_sample_lr<K, 2>);
+                else if (cls == 3) go(k_sample_lr<K, 3>); else go(k_sample_lr<K, 4>);
+            }
+            return 0;
+        }
+    }
     if (self->nwork > 0 && self->mode == 1) {
         const FusedArgs &f = self->cur_fused;                        // (all zero outside the fused stateful path)
         const dim3 grid((unsigned)(self->nwork + (f.gate_host ? 1 : 0) + f.nstat));
@@ -872,61 +935,6 @@ int launch_sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_s
     } else if (self->nwork > 0) {
         // persistent waves: as many single-wave workgroups as the chip holds at this kernel's occupancy
         const int resident = c->num_cu * 4 * Geo<K>::WPS;
-        if constexpr (K == 64) {
-            if (self->lr_n > 0 && !self->d_prop && !c->diag_only && !c->ablate) {
-                // light columns: rank-n update of the shared factor of LambdaF (k_sample_lr); the others as usual
-                if (self->hv_nwork > 0) {
-                    a.wi_col = self->d_hv_col; a.wi_p0 = self->d_hv_p0; a.wi_len = self->d_hv_len; a.wi_mc = self->d_hv_mc;
-                    a.wi_chunk = self->d_hv_chunk; a.nwork = self->hv_nwork;
-                    const int grid = std::min(self->hv_nwork, env_int("BPMF_HIP_GRID", resident));
-                    if (ev_start) hipExtLaunchKernelGGL(k_sample<K>, dim3(grid), dim3(64), 0, st, ev_start, nullptr, 0, a);
-                    else hipLaunchKernelGGL(k_sample<K>, dim3(grid), dim3(64), 0, st, a);
-                }
-                LrArgs l;
-                l.rowidx = self->d_rowidx; l.vals = self->d_vals; l.col = self->d_lr_col; l.p0 = self->d_lr_p0; l.len = self->d_lr_len;
-                l.nitems = self->lr_n; l.other_items = other->d_items; l.items = out_items; l.col_from = self->from;
-                l.R0 = d_in + (size_t)K * K + K + 2 + K; l.S0t = l.R0 + (size_t)K * K; l.y0 = l.S0t + (size_t)K * K;
-                l.Lmu = a.Lmu; l.fail = a.fail;
-                l.mean_rating = self->mean_rating; l.alpha = alpha; l.sqrt_alpha = std::sqrt(alpha); l.iter_plus_1 = (uint32_t)(iter + 1);
-                // product form for the columns with <= 6 ratings: two instantiations (<= 2, <= 6), persistent workgroups
-                // of eight waves with R0^-1 in LDS; then one launch per sweep width for the rest (the events ride on
-                // the first / last launch of the side)
-                int first = 0, last = 0;
-                for (int cls = 1; cls <= 4; ++cls) if (self->lr_class[cls] > self->lr_class[cls - 1]) { if (!first) first = cls; last = cls; }
-                bool started = self->hv_nwork > 0;
-                int last_pf = -1;
-                for (int pc = 0; pc < 3; ++pc) if (self->pf_class[pc + 1] > self->pf_class[pc]) last_pf = pc;
-                for (int pc = 0; pc < 3; ++pc) {
-                    const int n0 = self->pf_class[pc], n1 = self->pf_class[pc + 1];
-                    if (n1 <= n0) continue;
-                    LrArgs lc = l;
-                    lc.col = l.col + n0; lc.p0 = l.p0 + n0; lc.len = l.len + n0; lc.nitems = n1 - n0;
-                    const bool is_last = last == 0 && pc == last_pf;
-                    hipEvent_t e0 = started ? nullptr : ev_start, e1 = is_last ? ev_stop : nullptr;
-                    started = true;
-                    const int grid = std::max(1, std::min((n1 - n0 + 7) / 8, c->num_cu * 4));
-                    auto go = [&](auto kernel) {
-                        if (e0 || e1) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(512), 0, st, e0, e1, 0, lc);
-                        else hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), 0, st, lc);
-                    };
-                    if (pc == 0) go(k_sample_pf<K, 2>); else if (pc == 1) go(k_sample_pf<K, 6>); else go(k_sample_pf<K, 12>);
-                }
-                for (int cls = 1; cls <= 4; ++cls) {
-                    const int n0 = self->lr_class[cls - 1], n1 = self->lr_class[cls];
-                    if (n1 <= n0) continue;
-                    LrArgs lc = l;
-                    lc.col = l.col + n0; lc.p0 = l.p0 + n0; lc.len = l.len + n0; lc.nitems = n1 - n0;
-                    hipEvent_t e0 = (cls == first && !started) ? ev_start : nullptr, e1 = (cls == last) ? ev_stop : nullptr;
-                    auto go = [&](auto kernel) {
-                        if (e0 || e1) hipExtLaunchKernelGGL(kernel, dim3(n1 - n0), dim3(64), 0, st, e0, e1, 0, lc);
-                        else hipLaunchKernelGGL(kernel, dim3(n1 - n0), dim3(64), 0, st, lc);
-                    };
-                    if (cls == 1) go(k_sample_lr<K, 1>); else if (cls == 2) go(k_sample_lr<K, 2>);
-                    else if (cls == 3) go(k_sample_lr<K, 3>); else go(k_sample_lr<K, 4>);
-                }
-                return 0;
-            }
-        }
         const int grid = std::min(self->nwork, env_int("BPMF_HIP_GRID", resident));
         launch(k_sample<K>, dim3(grid), dim3(64), a);
     }
