@@ -707,8 +707,14 @@ struct Geo1 {
     static constexpr int QN = NP / S;
     static constexpr int M = 2 * QN;
     static constexpr int FLD = K + 2;
+    // K = 64: a full K x (K + 2) matrix is 34 KB of LDS per single-wave workgroup, i.e. ONE wave per SIMD.
+    // Only the lower triangle is kept there (row j: entries 0 .. j, padded to an even count so that the
+    // 16-byte accesses of the factorisation stay aligned): 19 KB, two waves per SIMD.
+    static constexpr bool PACKED = K == 64;
+    __host__ __device__ static constexpr int roff_c(int j) { return (j & 1) ? ((j + 1) * (j + 1)) / 2 : (j * (j + 2)) / 2; }
+    static constexpr int AWORDS = PACKED ? roff_c(K) : K * FLD;
     static constexpr int LANES = K * S;
-    static constexpr int LDS_WORDS = K * FLD + 4 * K + 2;
+    static constexpr int LDS_WORDS = AWORDS + 4 * K + 2;
     // waves per SIMD k_sample1 is compiled for: the 4x4x4 Gram of K = 32 keeps 36 + 8 accumulators
     // and two operand sets in registers (<= 168 VGPRs)
     static constexpr int WPS = K == 32 ? 3 : (K < 32 ? 4 : 2);
@@ -744,8 +750,12 @@ __device__ __forceinline__ void assemble16(const d4 (&acc)[Geo<K>::NTRI], const 
             for (int reg = 0; reg < 4; ++reg) {
                 const int gi = I * 16 + kq + 4 * reg, gj = J * 16 + li;
                 if (gi < K && gj < K) {
-                    sA[gi * LD + gj] = acc[tri][reg];
-                    if (I != J) sA[gj * LD + gi] = acc[tri][reg];
+                    if constexpr (Geo1<K>::PACKED) {                 // lower triangle only: G(gi, gj) -> row max, column min
+                        if (gi <= gj) sA[Geo1<K>::roff_c(0) + ((gj & 1) ? ((gj + 1) * (gj + 1)) / 2 : (gj * (gj + 2)) / 2) + gi] = acc[tri][reg];
+                    } else {
+                        sA[gi * LD + gj] = acc[tri][reg];
+                        if (I != J) sA[gj * LD + gi] = acc[tri][reg];
+                    }
                 }
             }
     if (kq == 0) {
@@ -765,7 +775,12 @@ __device__ __forceinline__ void finish_single(const SampleArgs &a, int col_local
     // The caller runs this inside its persistent work loop: make the lane id opaque here so that
     // LLVM does not hoist every per-step address and lane mask out of that loop (and spill them).
     asm volatile("" : "+v"(lane));
-    double *sA = lds, *sb = lds + K * LD, *sz = sb + K, *sdummy = sz + K, *szero = sdummy + 2 * K;
+    double *sA = lds, *sb = lds + G::AWORDS, *sz = sb + K, *sdummy = sz + K, *szero = sdummy + 2 * K;
+    // start of row j of the LDS matrix (full rows of LD words, or the packed lower triangle)
+    auto roff = [](int j) -> int {
+        if constexpr (G::PACKED) return (j & 1) ? ((j + 1) * (j + 1)) >> 1 : (j * (j + 2)) >> 1;
+        else return j * G::FLD;
+    };
     const int64_t idx = a.col_from + col_local;
 
     // z ~ N(0, I) from stream (idx+1)*K*(iter+1) truncated to 32 bits (c++/sample.cpp:266, c++/bpmf.h:67)
@@ -775,12 +790,16 @@ __device__ __forceinline__ void finish_single(const SampleArgs &a, int col_local
     const int h = l / K, i = l % K;
     // this lane's entries of LambdaF and LambdaF*mu: issued before the LDS round trip below
     const double *LF = a.prop_lambda ? a.prop_lambda + (size_t)col_local * K * K : a.LambdaF;
-    double lf[M];
+    // (K = 64: a row is 128 registers already; its LambdaF entries are read when they are used instead)
+    constexpr bool PRELOAD = K <= 32;
+    double lf[PRELOAD ? M : 2];
+    if constexpr (PRELOAD) {
 #pragma unroll
-    for (int q = 0; q < QN; ++q) {
-        const int j = 2 * (q * S + h);
-        lf[2 * q] = LF[i + j * K];
-        lf[2 * q + 1] = LF[i + (j + 1) * K];
+        for (int q = 0; q < QN; ++q) {
+            const int j = 2 * (q * S + h);
+            lf[2 * q] = LF[i + j * K];
+            lf[2 * q + 1] = LF[i + (j + 1) * K];
+        }
     }
     double lmu = a.Lmu[i];
     if (a.prop_lambda) {                                           // wave-uniform: rr = Lambda_i * hp.mu (:285)
@@ -790,16 +809,29 @@ __device__ __forceinline__ void finish_single(const SampleArgs &a, int col_local
 
     // G -> LDS, mirrored (c++/sample.cpp:297); rhs sums -> LDS
     assemble(sA, sb, LD, lane);
-    if (lane == 0) szero[0] = 0.0;
+    if (lane < 2) szero[lane] = 0.0;
     __syncthreads();
 
     // Lambda* = LambdaF + alpha * G (:298); b = LambdaF*mu + rr (:285,:256)
     double row[M + 2];
 #pragma unroll
     for (int q = 0; q < QN; ++q) {
-        const double2 g = *reinterpret_cast<const double2 *>(&sA[i * LD + 2 * (q * S + h)]);
-        row[2 * q] = fma(a.alpha, g.x, lf[2 * q]);
-        row[2 * q + 1] = fma(a.alpha, g.y, lf[2 * q + 1]);
+        double2 g;
+        if constexpr (G::PACKED) {                                 // G(i, j): row max(i, j), column min(i, j)
+            const int j = 2 * (q * S + h);
+            g.x = sA[(j <= i) ? roff(i) + j : roff(j) + i];
+            g.y = sA[(j + 1 <= i) ? roff(i) + j + 1 : roff(j + 1) + i];
+        } else {
+            g = *reinterpret_cast<const double2 *>(&sA[i * LD + 2 * (q * S + h)]);
+        }
+        if constexpr (PRELOAD) {
+            row[2 * q] = fma(a.alpha, g.x, lf[2 * q]);
+            row[2 * q + 1] = fma(a.alpha, g.y, lf[2 * q + 1]);
+        } else {
+            const int j = 2 * (q * S + h);
+            row[2 * q] = fma(a.alpha, g.x, LF[i + j * K]);
+            row[2 * q + 1] = fma(a.alpha, g.y, LF[i + (j + 1) * K]);
+        }
     }
     if (a.diag_only) {                                             // wave-uniform
 #pragma unroll
@@ -840,15 +872,15 @@ __device__ __forceinline__ void finish_single(const SampleArgs &a, int col_local
         double2 lp;
         lp.x = row[2 * qk] * dinv0;
         lp.y = fma(-lp.x, l10, row[2 * qk + 1]) * dinv1;
-        double *dst = (h == hk) ? &sA[i * LD + k] : &sdummy[2 * i];
+        double *dst = (h == hk && (!G::PACKED || i >= k)) ? &sA[roff(i) + k] : &sdummy[2 * i];   // (packed: rows above k have no such entries)
         *reinterpret_cast<double2 *>(dst) = lp;
         __syncthreads();
-        const double2 L = *reinterpret_cast<const double2 *>(&sA[i * LD + k]);     // L(i,k), L(i,k+1)
+        const double2 L = *reinterpret_cast<const double2 *>((!G::PACKED || i >= k) ? &sA[roff(i) + k] : szero);   // L(i,k), L(i,k+1)
         row[M] = fma(-L.y, yk1, fma(-L.x, yk, row[M]));            // rhs column: b_i -= L(i,k) y_k + L(i,k+1) y_k+1
         if constexpr (S > 1) {                                     // pairs of this slot owned by higher h are still to come
             const int j0 = 2 * (qk * S + h);
-            const double2 A0 = *reinterpret_cast<const double2 *>(&sA[j0 * LD + k]);
-            const double2 A1 = *reinterpret_cast<const double2 *>(&sA[(j0 + 1) * LD + k]);
+            const double2 A0 = *reinterpret_cast<const double2 *>(&sA[roff(j0) + k]);
+            const double2 A1 = *reinterpret_cast<const double2 *>(&sA[roff(j0 + 1) + k]);
             const double u0 = fma(-L.y, A0.y, fma(-L.x, A0.x, row[2 * qk]));
             const double u1 = fma(-L.y, A1.y, fma(-L.x, A1.x, row[2 * qk + 1]));
             row[2 * qk] = (h > hk) ? u0 : row[2 * qk];
@@ -857,8 +889,8 @@ __device__ __forceinline__ void finish_single(const SampleArgs &a, int col_local
 #pragma unroll
         for (int q = qk + 1; q < QN; ++q) {
             const int j0 = 2 * (q * S + h);
-            const double2 A0 = *reinterpret_cast<const double2 *>(&sA[j0 * LD + k]);
-            const double2 A1 = *reinterpret_cast<const double2 *>(&sA[(j0 + 1) * LD + k]);
+            const double2 A0 = *reinterpret_cast<const double2 *>(&sA[roff(j0) + k]);
+            const double2 A1 = *reinterpret_cast<const double2 *>(&sA[roff(j0 + 1) + k]);
             row[2 * q] = fma(-L.y, A0.y, fma(-L.x, A0.x, row[2 * q]));
             row[2 * q + 1] = fma(-L.y, A1.y, fma(-L.x, A1.x, row[2 * q + 1]));
         }
@@ -872,13 +904,13 @@ __device__ __forceinline__ void finish_single(const SampleArgs &a, int col_local
     //   u_i = rr_i - sum_{k>i} L(k,i) x_k,  x_i = u_i / L(i,i)
     // the L(k,i) a lane needs are fetched eight steps at a time (LDS latency once per batch)
     double bi = yi + zi;
-    const double my_dinv = 1.0 / sA[i * LD + i];
+    const double my_dinv = 1.0 / sA[roff(i) + i];
     constexpr int BB = K < 8 ? K : 8;
 #pragma unroll
     for (int kb = K - BB; kb >= 0; kb -= BB) {
         double lv[BB];
 #pragma unroll
-        for (int t = 0; t < BB; ++t) lv[t] = *((i < kb + t) ? &sA[(kb + t) * LD + i] : szero);
+        for (int t = 0; t < BB; ++t) lv[t] = *((i < kb + t) ? &sA[roff(kb + t) + i] : szero);
 #pragma unroll
         for (int t = BB - 1; t >= 0; --t) {
             const int k = kb + t;
@@ -956,7 +988,7 @@ __global__ __launch_bounds__(64, Geo1<K>::WPS) void k_sample1(SampleArgs a, Fuse
     // whole column in one item: its normals do not depend on the Gram -- draw them first so that
     // the Philox / log / sqrt chain is off the critical path between the last MFMA and the factorisation
     if (mc < 0 && !(a.ablate & 1u))
-        draw_normals<K>(sample_counter<K>(a.col_from + col, a.iter_plus_1), K, lds + K * Geo1<K>::FLD + K, lane);
+        draw_normals<K>(sample_counter<K>(a.col_from + col, a.iter_plus_1), K, lds + Geo1<K>::AWORDS + K, lane);
 
     if constexpr (K <= 32) {
         // Gram on the 4x4x4 MFMA shape: NB block accumulators + NG rhs sums per lane
