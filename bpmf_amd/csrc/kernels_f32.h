@@ -67,10 +67,10 @@ struct GeoF {
     static constexpr int NT = K / 16;                    // 16-wide tiles per dimension
     static constexpr int NTRI = NT * (NT + 1) / 2;
     // R (upper, Lambda* = R^T R) lives in LDS by block rows: block row s is 16 x (K - 16 s) floats
-    // with a row stride of K - 16 s + 8 (two-way bank conflicts at most for the MFMA operand reads)
+    // with a row stride of K - 16 s + 4: 40 960 B of LDS per K = 128 fp32 workgroup, i.e. four per CU (+ 8: 43 008 B, three per CU, 5 % slower although its operand reads conflict less)
     __host__ __device__ static constexpr int width(int s) { return K - 16 * s; }
-    __host__ __device__ static constexpr int ld(int s) { return width(s) + 8; }
-    __host__ __device__ static constexpr int roff(int s) { return 16 * s * (K + 8) - 128 * s * (s - 1); }   // 16 * sum_{t<s} ld(t)
+    __host__ __device__ static constexpr int ld(int s) { return width(s) + 4; }
+    __host__ __device__ static constexpr int roff(int s) { return 16 * s * (K + 4) - 128 * s * (s - 1); }   // 16 * sum_{t<s} ld(t)
     static constexpr int RWORDS = roff(NT);
     template <typename T> static constexpr size_t lds_bytes() { return (size_t)K * 8 + (size_t)RWORDS * sizeof(T) + 2 * K * sizeof(T); }
     // row-major upper index of tile (I, J), I <= J; with NW waves its owner is wave tri % NW, slot tri / NW
