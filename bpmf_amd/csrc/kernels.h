@@ -218,6 +218,33 @@ __device__ __forceinline__ void draw_normals(uint32_t counter, int n, double *ou
     }
 }
 
+// The same stream when more than one round of 64 attempts is certain (n = 64 needs ~82): the rounds
+// only park (y, r2) of the accepted attempts by rank; log / sqrt / divide -- a third of a round --
+// run once at the end, one lane per normal.  Same expression on the same inputs: bit-identical.
+template <int NMAX>
+__device__ __forceinline__ void draw_normals_deferred(uint32_t counter, int n, double *out_lds, double *r2_lds, int lane)
+{
+    int produced = 0;
+    uint32_t base = 0;
+    while (produced < n) {                                         // wave-uniform
+        const Philox4 b = stream_block(counter, base + (uint32_t)lane);
+        const double x = 2.0 * canonical53(b.w[3], b.w[2]) - 1.0;   // URNG order: w3, w2, w1, w0
+        const double y = 2.0 * canonical53(b.w[1], b.w[0]) - 1.0;
+        const double r2 = polar_r2(x, y);
+        const bool acc = !(r2 > 1.0 || r2 == 0.0);
+        const unsigned long long m = __ballot(acc);
+        const int rank = produced + __popcll(m & ((1ull << lane) - 1ull));
+        if (acc && rank < n) { out_lds[rank] = y; r2_lds[rank] = r2; }
+        produced += __popcll(m);
+        base += 64u;
+    }
+    for (int i = lane; i < n; i += 64) {
+        const double r2 = r2_lds[i];
+        const double mult = sqrt(-2 * log(r2) / r2);
+        out_lds[i] = out_lds[i] * mult;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Gram accumulation over one chunk of a column's ratings.
 // ---------------------------------------------------------------------------

@@ -259,6 +259,7 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
     constexpr int LD = K + 1, NW = 8;
     __shared__ double S0[K * LD];                                     // S0[i * LD + j] = (R0^-1)[i][j]
     __shared__ double sz[NW][K];
+    __shared__ double sr[NW][K];                                      // r2 of the accepted polar attempts (draw_normals_deferred)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int q = tid; q < K * K; q += 64 * NW) {                       // a.S0t[j * K + i] = (R0^-1)[i][j]
         const int j = q / K, i = q % K;
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
         const int col = a.col[w];
         const int64_t p0 = a.p0[w];
         const int len = a.len[w];
-        draw_normals<K>(sample_counter<K>(a.col_from + col, a.iter_plus_1), K, sz[wave], lane);
+        draw_normals_deferred<K>(sample_counter<K>(a.col_from + col, a.iter_plus_1), K, sz[wave], sr[wave], lane);
 
         PfFactor f[NCAP];
         double c = y0;                                                // R0^-T b = y0 + sum_m kappa_m R0^-T x_m
