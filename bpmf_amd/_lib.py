@@ -83,7 +83,7 @@ def library_path():
 
 def build_library():
     """hipcc --offload-arch=gfx950 build of the in-tree extension (bpmf_amd/csrc/Makefile)."""
-    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+    subprocess.check_call(["make", "-s", "-j%d" % max(1, min(os.cpu_count() or 1, 10)), "-C", os.path.join(_HERE, "csrc")])
 
 
 def exported_signatures():

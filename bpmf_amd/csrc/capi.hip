@@ -4,93 +4,14 @@
 // static work schedule of a side once (columns sorted by cost, heavy columns
 // cut into nnz chunks), upload hp.mu / hp.LambdaF per half-iteration, launch
 // the kernels on one stream and bring the K*K+K+1 reduction words back.
-#include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
 #include <dlfcn.h>
-#include <rccl/rccl.h>      // types and prototypes only: the library is dlopen'ed on first use
 
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <condition_variable>
-#include <mutex>
-#include <thread>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <cmath>
-#include <deque>
-#include <limits>
-#include <new>
-#include <numeric>
-#include <string>
-#include <vector>
-
-#include "../../include/bpmf_hip.h"
-#include "kernels.h"
-#include "kernels_f32.h"
-#include "kernels_q4.h"
-#include "kernels_lr.h"
+#include "launch.h"
 
 namespace {
-
 thread_local std::string g_err;
-
-int fail(int code, const std::string &msg)
-{
-    g_err = msg;
-    return code;
 }
-
-#define HIP_TRY(expr)                                                                                  \
-    do {                                                                                               \
-        hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess)                                                                          \
-            return fail(e_ == hipErrorOutOfMemory ? BPMF_HIP_ENOMEM : BPMF_HIP_ENODEV,                 \
-                        std::string(#expr) + ": " + hipGetErrorString(e_));                            \
-    } while (0)
-
-template <typename T>
-int dev_upload(T **dst, const T *src, size_t n)
-{
-    *dst = nullptr;
-    if (n == 0) n = 1;
-    HIP_TRY(hipMalloc((void **)dst, n * sizeof(T)));
-    if (src) HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
-    return 0;
-}
-
-int env_int(const char *name, int dflt);
-// how long a host thread spins on a result word before it falls back to a blocking wait on the
-// event behind the kernels (BPMF_HIP_SPIN_MS, default 50; 0 = always block: used by the tests)
-double spin_limit_s()
-{
-    static const double v = env_int("BPMF_HIP_SPIN_MS", 50) * 1e-3;
-    return v;
-}
-
-int env_int(const char *name, int dflt)
-{
-    const char *s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
-}
-
-// RCCL entry points, resolved at run time: single-GPU users never load the library, and inside a
-// torch process the already-loaded librccl.so.1 is reused (one communicator runtime per process).
-struct Rccl {
-    void *handle = nullptr;
-    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
-    decltype(&ncclCommInitRank) CommInitRank = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclAllReduce) AllReduce = nullptr;
-    decltype(&ncclBroadcast) Broadcast = nullptr;
-    decltype(&ncclGroupStart) GroupStart = nullptr;
-    decltype(&ncclGroupEnd) GroupEnd = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
-    decltype(&ncclCommSplit) CommSplit = nullptr;       // optional (second communicator for the statistics streams)
-    decltype(&ncclSend) Send = nullptr;                 // optional (connectivity-aware exchange)
-    decltype(&ncclRecv) Recv = nullptr;
-};
+extern "C" void bpmf_hip_set_error_(const char *msg) { g_err = msg; }
 
 Rccl *rccl()
 {
@@ -115,17 +36,7 @@ Rccl *rccl()
     return r.handle ? &r : nullptr;
 }
 
-#define NCCL_TRY(expr)                                                                                 \
-    do {                                                                                               \
-        ncclResult_t r_ = (expr);                                                                      \
-        if (r_ != ncclSuccess)                                                                         \
-            return fail(BPMF_HIP_ENODEV, std::string(#expr) + ": " +                                   \
-                        (rccl() && rccl()->GetErrorString ? rccl()->GetErrorString(r_) : "RCCL error")); \
-    } while (0)
 
-}  // namespace
-
-extern "C" void bpmf_hip_set_error_(const char *msg) { g_err = msg; }
 static int settle_async(struct bpmf_hip_side *s);      // waits until the worker is done with `s`; returns its deferred error
 static void flush_deferred(struct bpmf_hip_test *t);   // enqueues an evaluation whose launch was put off
 
@@ -155,163 +66,7 @@ void trace_dump()
 struct TraceAtExit { ~TraceAtExit() { if (g_trace_on) trace_dump(); } } g_trace_at_exit;
 }  // namespace
 
-struct bpmf_hip_ctx {
-    int device = 0;
-    int K = 0;
-    int dtype = BPMF_HIP_F64;            // arithmetic of the column loop and storage of the factors (BPMF_HIP_F32: K = 128)
-    hipStream_t stream = nullptr;        // S0: samplers, exchange, predict
-    hipEvent_t last_sampler_done = nullptr;   // stop event of the newest thing on S0 when that is a stateful sampler (+ exchange), else NULL
-    // fused stateful path: the side whose newest half-iteration still has its statistics to run (they
-    // ride in the next k_sample1 launch; flush_pending_stats launches them alone if none comes)
-    struct bpmf_hip_side *pending_stats = nullptr; unsigned pending_seq = 0; int pending_evset = 0;
-    std::vector<bpmf_hip_side *> sides;  // stateful sides with a statistics stream of their own (for ctx_sync)
-    bool own_stream = false;
-    int num_cu = 256;
-    unsigned ablate = 0;
-    unsigned diag_only = 0;              // BPMF_NO_COVARIANCE variant (bpmf_hip_ctx_set_no_covariance)
-    // per-call parameter blob: LambdaF[K*K] | Lmu[K] | fail (u64); pinned host copy + device copy
-    double *h_in = nullptr, *h_in_dev = nullptr, *d_in = nullptr;
-    // result blob in pinned host memory the kernels write directly (zero-copy):
-    // prod[K*K] | sum[K] | - | fail (u64) | se | se_avg | flag (u32)
-    double *h_out = nullptr, *h_out_dev = nullptr;
-    size_t in_words = 0, out_words = 0;
-    std::mutex launch_mutex;             // kernel launches come from the caller's thread and from the sides' workers
-    // multi-GPU: RCCL communicator (one rank per process / GPU) and a device staging blob for the
-    // all-reduced sums: prod[K*K] | sum[K] | - | fail (u64) | se | se_avg | count
-    ncclComm_t comm = nullptr;
-    // second communicator over the same ranks (ncclCommSplit): the all-reduce of a side's column
-    // statistics runs on the side's own stream, beside the other side's sampler and exchange, which
-    // two collectives on ONE communicator could not do.  NULL: everything on the main stream.
-    ncclComm_t comm2 = nullptr;
-    int nranks = 1, rank = 0;
-    double *d_red = nullptr;
-    unsigned seq = 0;                    // value the next publishing kernel writes behind its results
-    unsigned *d_ticket = nullptr;        // arrival counters of k_colstats' waves (stateless path)
-    double *d_zero = nullptr;            // K zeros: the row padding slots of a ragged rating group gather from
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-};
-
-struct bpmf_hip_side {
-    bpmf_hip_ctx *ctx = nullptr;
-    int64_t ncols = 0, nrows = 0, from = 0, to = 0, nnz = 0;
-    double mean_rating = 0.0;
-    int32_t *d_rowidx = nullptr; double *d_vals = nullptr; bool own_csc = true;
-    double *d_items = nullptr; bool own_items = true;
-    // Second copy of the factor matrix: a sampler writes the copy that is NOT current and the two swap
-    // roles behind it, so that an evaluation of the previous iteration (k_predict on its own stream)
-    // can still read the factors the sampler replaces.  Only while the library owns the storage, the
-    // raw pointer was never handed out, and this rank's launches rewrite or receive every column.
-    double *d_items_alt = nullptr; bool items_exposed = false; int cur_buf = 0;
-    struct Reader { struct bpmf_hip_test *t = nullptr; unsigned seq = 0; } readers[2];   // last evaluation that read buffer 0 / 1
-    struct bpmf_hip_test *deferred_eval = nullptr;      // evaluation waiting for this side's next gate kernel (flush_deferred)
-    double *d_prop = nullptr;            // propagated posterior (-m / -l): K x K prior precision per local column, or NULL
-    // schedule
-    int nwork = 0, nmulti = 0, nslots = 0, mode = 0;
-    // K = 64: columns with a handful of ratings take the low-rank form (k_sample_lr), the rest the regular
-    // one -- lr_n light items + hv_nwork others (the full list above stays for per-column priors etc.)
-    int lr_n = 0, hv_nwork = 0;
-    int lr_class[5] = {0, 0, 0, 0, 0};     // light items sorted by sweep width: class c (1..4 ratings per sweep) is [lr_class[c-1], lr_class[c])
-    int pf_class[4] = {0, 0, 0, 0};        // ahead of them: product-form items (k_sample_pf): <= 2 ratings, 3..6, 7..12 -- class c is [pf_class[c], pf_class[c+1])
-    int32_t *d_lr_col = nullptr, *d_lr_len = nullptr; int64_t *d_lr_p0 = nullptr;
-    int32_t *d_hv_col = nullptr, *d_hv_len = nullptr, *d_hv_mc = nullptr, *d_hv_chunk = nullptr; int64_t *d_hv_p0 = nullptr;
-    int32_t *d_wi_col = nullptr, *d_wi_len = nullptr, *d_wi_mc = nullptr, *d_wi_chunk = nullptr;
-    int64_t *d_wi_p0 = nullptr;
-    int32_t *d_mc_slot0 = nullptr, *d_mc_nch = nullptr;
-    unsigned *d_mc_count = nullptr;
-    double *d_partials = nullptr;
-    int nstat_waves = 0;
-    double *d_stat_partials = nullptr;
-    std::vector<int64_t> bounds;         // multi-GPU: column range of every rank (nranks + 1 entries)
-    // connectivity-aware exchange (bpmf_hip_side_set_conn): per peer, the columns of this rank's range the
-    // peer reads (send) and the columns of the peer's range this rank reads (recv), as global column ids
-    std::vector<int64_t> conn_send_ptr, conn_recv_ptr;
-    int32_t *d_conn_send = nullptr, *d_conn_recv = nullptr;
-    double *d_conn_sbuf = nullptr, *d_conn_rbuf = nullptr;
-    int64_t failed_column = -1;
-    bool pending = false;
-    float last_sample_ms = 0.f, last_reduce_ms = 0.f;
-    bool timing_valid = true;
-    // asynchronous (stateful) path: own parameter / result blobs, gate word, events
-    double *a_h_in = nullptr, *a_h_in_dev = nullptr, *a_d_in = nullptr;
-    double *a_h_out = nullptr, *a_h_out_dev = nullptr;
-    bpmf::FusedArgs cur_fused{};         // gate + statistics riders of the k_sample1 launch being enqueued (fused stateful path)
-    // the event behind which this side's statistics of the job with event set 0 / 1 are complete, once they
-    // have been enqueued (inside the next sampler launch, or as a kernel of their own): the collector's blocking wait
-    std::atomic<hipEvent_t> stats_ev[2] = {{nullptr}, {nullptr}};
-    unsigned *a_dflag = nullptr;         // device word k_gate_stage sets when the parameters are staged (in-kernel gate of the sampler)
-    const unsigned *cur_gate_flag = nullptr; unsigned cur_gate_want = 0;   // what the launch being enqueued polls (NULL: ordered by the queue)
-    unsigned *a_gate = nullptr, *a_gate_dev = nullptr;   // pinned word the host sets to iter + 1 when a_h_in holds that iteration's parameters
-    unsigned *a_ticket = nullptr;                        // arrival counters of this side's k_colstats waves
-    double *a_d_red = nullptr;                           // multi-GPU: this side's device blob for the all-reduced sums
-    unsigned a_seq = 0;
-    hipEvent_t evs[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};   // (start, sampled, stats, staged) of the two half-iterations that may be in flight
-    hipStream_t saux = nullptr;          // this side's statistics stream (high priority: its few blocks must not queue behind the other side's sampler)
-    // host worker of this side: collects its sums when they land, forms cov, draws its next
-    // hyper-parameters and releases the gate of its next sampler, all while the GPU samples the other side
-    struct Job { int iter; unsigned seq; int evset; bool timed; hipEvent_t prev_stop; };
-    hipEvent_t last_stop = nullptr;      // stop event of this side's newest sampler (diagnostic: boundary to the next launch)
-    double tot_gap_ms = 0.0; int64_t n_gap = 0;
-    std::thread worker;
-    std::mutex wm;
-    std::condition_variable wcv;
-    std::deque<Job> jobs;
-    int in_flight = 0;                   // half-iterations enqueued and not collected yet (at most 2)
-    bool wstop = false;
-    int async_rc = 0;                    // deferred error of a half-iteration (e.g. Cholesky failed)
-    std::string async_msg;
-    int gate_iter = -2;                  // iteration whose parameters the gate has been opened for
-    double tot_sample_ms = 0.0, tot_reduce_ms = 0.0;
-    long long n_launches = 0;
-    // state of the reference's Sys (c++/bpmf.h:139,221-226) for bpmf_hip_sys_sample
-    int iter = -1;
-    double norm = 0.0;
-    std::vector<double> cov, hp_mu, hp_LambdaU, hp_LambdaF;      // current
-    std::vector<double> nx_mu, nx_LambdaU, nx_LambdaF;           // pre-drawn for iteration nx_iter
-    int nx_iter = -2;
-    std::vector<double> rd_au, rd_z;                             // cov-independent random part, drawn for iteration rd_iter
-    int rd_iter = -2;
-};
-
-struct bpmf_hip_test {
-    bpmf_hip_side *side = nullptr;
-    int64_t nnz = 0;
-    int32_t *d_tcol = nullptr, *d_trow = nullptr;
-    double *d_tval = nullptr, *d_pavg = nullptr, *d_pm2 = nullptr, *d_partial = nullptr;
-    int64_t nblocks = 0;
-    int64_t global_nnz = -1;             // multi-GPU: test ratings over all ranks (all-reduced once)
-    double *h_res = nullptr, *h_res_dev = nullptr;       // pinned: se | se_avg | flag
-    unsigned *d_ticket = nullptr;                        // arrival counter of k_predict's blocks
-    unsigned seq = 0, done_seq = 0;
-    bool launched = false;
-    hipEvent_t ev_in = nullptr, ev_done[2] = {nullptr, nullptr}, in_ev = nullptr;
-    hipStream_t pstream = nullptr;       // where the launch in flight was enqueued (the main stream, or the other side's)
-    // requested, not yet enqueued (flush_deferred): the factor copies it reads, captured at the request
-    bool deferred = false, cancelled = false; int def_n = 0; struct bpmf_hip_side *def_other = nullptr;
-    const void *def_self_items = nullptr, *def_other_items = nullptr;
-};
-
 namespace {
-
-// doubles in the partial of one chunk of a heavy column: the larger of the two accumulator layouts
-// (16x16x4 tiles of k_sample, 4x4x4 blocks of k_sample1 for K <= 32)
-template <int K>
-size_t part_words()
-{
-    size_t w = (size_t)bpmf::Geo<K>::PART;
-    if constexpr (K <= 32) w = std::max(w, (size_t)bpmf::Geo44<K>::PART);
-    return w;
-}
-
-size_t part_words_rt(int K)
-{
-    switch (K) {
-    case 8: return part_words<8>();
-    case 16: return part_words<16>();
-    case 32: return part_words<32>();
-    case 64: return part_words<64>();
-    }
-    return 0;
-}
 
 // The kernels write their few result words straight into pinned host memory; the last block
 // of the last kernel then publishes a sequence number and the host thread spins on it.  This replaces
@@ -795,167 +550,15 @@ extern "C" int bpmf_hip_side_set_items(bpmf_hip_side *s, const double *h)
     return BPMF_HIP_OK;
 }
 
-// ---------------------------------------------------------------------------
 namespace {
 
-// The device work of one half-iteration, in three pieces that the synchronous (stateless) and
-// the asynchronous (stateful) paths put on their streams:
-//   launch_sampler: the per-column update, reading the parameter blob `d_in`
-//   launch_exchange: multi-GPU only, in-place broadcast of every rank's fresh column range
-//   launch_stats: sum x / sum x x^T of this rank's columns (+ all-reduce), published to `out_host_dev`
-template <int K>
-// ev_start / ev_stop (optional): recorded by the dispatch packet of the sampler itself
-// (hipExtLaunchKernel) instead of by marker packets before and after it -- every marker is a few
-// microseconds on the stream between two samplers.
-int launch_sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *other, int iter, double alpha, double *d_in, hipStream_t st,
-                        hipEvent_t ev_start, hipEvent_t ev_stop)
-{
-    using namespace bpmf;
-    bpmf_hip_ctx *c = self->ctx;
-    auto launch = [&](auto kernel, dim3 grid, dim3 block, auto args) {
-        if (ev_start || ev_stop) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, ev_start, ev_stop, 0, args);
-        else hipLaunchKernelGGL(kernel, grid, block, 0, st, args);
-    };
-    // one workgroup per column (k_sample_wg): the fp32 large-K path, and K = 64 in fp64
-    auto launch_wg = [&](auto zero) {
-        typedef decltype(zero) T;
-        SampleArgsW<T> f;
-        f.rowidx = self->d_rowidx; f.vals = self->d_vals;
-        f.wi_col = self->d_wi_col; f.wi_p0 = self->d_wi_p0; f.wi_len = self->d_wi_len;
-        f.other_items = reinterpret_cast<const T *>(other->d_items); f.items = reinterpret_cast<T *>(out_items);
-        f.col_from = self->from;
-        f.LambdaF = d_in; f.Lmu = d_in + (size_t)K * K;
-        f.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
-        f.mu = d_in + (size_t)K * K + K + 2; f.prop_lambda = self->d_prop; f.diag_only = c->diag_only;
-        f.mean_rating = self->mean_rating; f.alpha = alpha; f.iter_plus_1 = (uint32_t)(iter + 1);
-        // four waves per column at K = 128; one wave owning all tiles at K = 64 (no idle waves in the
-        // serial phases of the factorisation: the column-dominated shapes are what K = 64 is run on)
-        if (self->nwork > 0) {
-            if constexpr (K == 128) {
-                // two waves per column (18 tiles each) by default: three columns in flight per CU instead of two,
-                // and one idle wave instead of three through the serial phases (0.66 -> 0.58 ms per launch)
-                if (env_int("BPMF_HIP_WG_WAVES", 2) == 4) launch(k_sample_wg<K, T, 4>, dim3(self->nwork), dim3(256), f);
-                else launch(k_sample_wg<K, T, 2>, dim3(self->nwork), dim3(128), f);
-            }
-            else launch(k_sample_wg<K, T, 1>, dim3(self->nwork), dim3(64), f);
-        }
-    };
-    if constexpr (K == 128) {
-        launch_wg(0.0f);
-        return 0;
-    } else {
-    if constexpr (K == 64) {
-        if (self->mode == 2) { launch_wg(0.0); return 0; }
-    }
-    SampleArgs a;
-    a.rowidx = self->d_rowidx; a.vals = self->d_vals;
-    a.wi_col = self->d_wi_col; a.wi_p0 = self->d_wi_p0; a.wi_len = self->d_wi_len; a.wi_mc = self->d_wi_mc; a.wi_chunk = self->d_wi_chunk;
-    a.mc_slot0 = self->d_mc_slot0; a.mc_nchunks = self->d_mc_nch; a.mc_count = self->d_mc_count;
-    a.partials = self->d_partials; a.nwork = self->nwork;
-    a.other_items = other->d_items; a.items = out_items; a.col_from = self->from;
-    a.LambdaF = d_in; a.Lmu = d_in + (size_t)K * K;
-    a.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
-    a.mu = d_in + (size_t)K * K + K + 2; a.prop_lambda = self->d_prop; a.diag_only = c->diag_only;
-    a.mean_rating = self->mean_rating; a.alpha = alpha; a.iter_plus_1 = (uint32_t)(iter + 1);
-    a.ablate = c->ablate;
-    a.gate_flag = self->cur_gate_flag; a.gate_want = self->cur_gate_want;
-    a.zero_row = c->d_zero;
-    if constexpr (K <= 32) {
-        if (self->nwork > 0 && self->mode == 3) {                    // four columns per wave (k_sample4)
-            launch(k_sample4<K>, dim3((self->nwork + 3) / 4), dim3(64), a);
-            return 0;
-        }
-    }
-    if constexpr (K == 64) {
-        if (self->lr_n > 0 && !self->d_prop && !c->diag_only && !c->ablate) {
-            // light columns: rank-n update of the shared factor of LambdaF (k_sample_lr); the others as usual
-            if (self->hv_nwork > 0) {
-                a.wi_col = self->d_hv_col; a.wi_p0 = self->d_hv_p0; a.wi_len = self->d_hv_len; a.wi_mc = self->d_hv_mc;
-                a.wi_chunk = self->d_hv_chunk; a.nwork = self->hv_nwork;
-                if (self->mode == 1) {
-                    const FusedArgs f0{};
-                    if (ev_start) hipExtLaunchKernelGGL(k_sample1<K>, dim3(self->hv_nwork), dim3(64), 0, st, ev_start, nullptr, 0, a, f0);
-                    else hipLaunchKernelGGL(k_sample1<K>, dim3(self->hv_nwork), dim3(64), 0, st, a, f0);
-                } else {
-                    const int grid = std::min(self->hv_nwork, env_int("BPMF_HIP_GRID", c->num_cu * 4 * Geo<K>::WPS));
-                    if (ev_start) hipExtLaunchKernelGGL(k_sample<K>, dim3(grid), dim3(64), 0, st, ev_start, nullptr, 0, a);
-                    else hipLaunchKernelGGL(k_sample<K>, dim3(grid), dim3(64), 0, st, a);
-                }
-            }
-            LrArgs l;
-            l.rowidx = self->d_rowidx; l.vals = self->d_vals; l.col = self->d_lr_col; l.p0 = self->d_lr_p0; l.len = self->d_lr_len;
-            l.nitems = self->lr_n; l.other_items = other->d_items; l.items = out_items; l.col_from = self->from;
-            l.R0 = d_in + (size_t)K * K + K + 2 + K; l.S0t = l.R0 + (size_t)K * K; l.y0 = l.S0t + (size_t)K * K;
-            l.Lmu = a.Lmu; l.fail = a.fail;
-            l.mean_rating = self->mean_rating; l.alpha = alpha; l.sqrt_alpha = std::sqrt(alpha); l.iter_plus_1 = (uint32_t)(iter + 1);
-            // product form for the columns with <= 6 ratings: two instantiations (<= 2, <= 6), persistent workgroups
-            // of eight waves with R0^-1 in LDS; then one launch per sweep width for the rest (the events ride on
-            // the first / last launch of the side)
-            int first = 0, last = 0;
-            for (int cls = 1; cls <= 4; ++cls) if (self->lr_class[cls] > self->lr_class[cls - 1]) { if (!first) first = cls; last = cls; }
-            bool started = self->hv_nwork > 0;
-            int last_pf = -1;
-            for (int pc = 0; pc < 3; ++pc) if (self->pf_class[pc + 1] > self->pf_class[pc]) last_pf = pc;
-            for (int pc = 0; pc < 3; ++pc) {
-                const int n0 = self->pf_class[pc], n1 = self->pf_class[pc + 1];
-                if (n1 <= n0) continue;
-                LrArgs lc = l;
-                lc.col = l.col + n0; lc.p0 = l.p0 + n0; lc.len = l.len + n0; lc.nitems = n1 - n0;
-                const bool is_last = last == 0 && pc == last_pf;
-                hipEvent_t e0 = started ? nullptr : ev_start, e1 = is_last ? ev_stop : nullptr;
-                started = true;
-                const int grid = std::max(1, std::min((n1 - n0 + 7) / 8, c->num_cu * 4));
-                auto go = [&](auto kernel) {
-                    if (e0 || e1) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(512), 0, st, e0, e1, 0, lc);
-                    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), 0, st, lc);
-                };
-                if (pc == 0) go(k_sample_pf<K, 2>); else if (pc == 1) go(k_sample_pf<K, 6>); else go(k_sample_pf<K, 12>);
-            }
-            for (int cls = 1; cls <= 4; ++cls) {
-                const int n0 = self->lr_class[cls - 1], n1 = self->lr_class[cls];
-                if (n1 <= n0) continue;
-                LrArgs lc = l;
-                lc.col = l.col + n0; lc.p0 = l.p0 + n0; lc.len = l.len + n0; lc.nitems = n1 - n0;
-                hipEvent_t e0 = (cls == first && !started) ? ev_start : nullptr, e1 = (cls == last) ? ev_stop : nullptr;
-                auto go = [&](auto kernel) {
-                    if (e0 || e1) hipExtLaunchKernelGGL(kernel, dim3(n1 - n0), dim3(64), 0, st, e0, e1, 0, lc);
-                    else hipLaunchKernelGGL(kernel, dim3(n1 - n0), dim3(64), 0, st, lc);
-                };
-                if (cls == 1) go(k_sample_lr<K, 1>); else if (cls == 2) go(k_sample_lr<K, 2>);
-                else if (cls == 3) go(k_sample_lr<K, 3>); else go(k_sample_lr<K, 4>);
-            }
-            return 0;
-        }
-    }
-    if (self->nwork > 0 && self->mode == 1) {
-        const FusedArgs &f = self->cur_fused;                        // (all zero outside the fused stateful path)
-        const dim3 grid((unsigned)(self->nwork + (f.gate_host ? 1 : 0) + f.nstat));
-        if (ev_start || ev_stop) hipExtLaunchKernelGGL(k_sample1<K>, grid, dim3(64), 0, st, ev_start, ev_stop, 0, a, f);
-        else hipLaunchKernelGGL(k_sample1<K>, grid, dim3(64), 0, st, a, f);
-    } else if (self->nwork > 0) {
-        // persistent waves: as many single-wave workgroups as the chip holds at this kernel's occupancy
-        const int resident = c->num_cu * 4 * Geo<K>::WPS;
-        const int grid = std::min(self->nwork, env_int("BPMF_HIP_GRID", resident));
-        launch(k_sample<K>, dim3(grid), dim3(64), a);
-    }
-    return 0;
-    }
-}
-
-// may this side's samplers write the second copy of the factors?  Every column of the new copy must
-// be produced by this launch or arrive through the exchange that follows it.
-inline bool second_copy_usable(const bpmf_hip_side *s)
-{
-    if (!s->d_items_alt || !s->own_items || s->items_exposed || s->nwork <= 0) return false;
-    const bool dist = s->ctx->comm != nullptr && !s->bounds.empty();
-    return dist || (s->from == 0 && s->to == s->ncols);
-}
+using bpmf_launch::sampler_into;
 
 template <int K>
 int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double alpha, double *d_in, hipStream_t st,
                    hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr)
 {
-    if (!second_copy_usable(self)) return launch_sampler_into<K>(self, self->d_items, other, iter, alpha, d_in, st, ev_start, ev_stop);
+    if (!second_copy_usable(self)) return sampler_into<K>(self, self->d_items, other, iter, alpha, d_in, st, ev_start, ev_stop);
     // the copy about to be overwritten may still be read by an evaluation that has not been collected
     const int tgt = self->cur_buf ^ 1;
     bpmf_hip_side::Reader &rd = self->readers[tgt];
@@ -964,92 +567,11 @@ int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, do
         if (rd.t->done_seq < rd.seq) HIP_TRY(hipStreamWaitEvent(st, rd.t->ev_done[rd.seq & 1u], 0));
     }
     rd.t = nullptr;
-    const int rc = launch_sampler_into<K>(self, self->d_items_alt, other, iter, alpha, d_in, st, ev_start, ev_stop);
+    const int rc = sampler_into<K>(self, self->d_items_alt, other, iter, alpha, d_in, st, ev_start, ev_stop);
     if (rc) return rc;
     std::swap(self->d_items, self->d_items_alt);                    // everything enqueued from here on sees the new factors
     self->cur_buf = tgt;
     return 0;
-}
-
-template <int K>
-int launch_exchange(bpmf_hip_side *self, hipStream_t st)
-{
-    bpmf_hip_ctx *c = self->ctx;
-    if (!(c->comm != nullptr && !self->bounds.empty())) return 0;
-    if constexpr (K == 128) return fail(BPMF_HIP_EINVAL, "the fp32 path is single-GPU for now");
-    else {
-    // every rank broadcasts the range it just sampled (= all-gather-v of disjoint, uneven
-    // ranges), in place in the replicated factor matrix, on the sampler's stream
-    Rccl *R = rccl();
-    if (!self->conn_send_ptr.empty()) {
-        // connectivity-aware form (c++/assign.cpp:204-241 conn_map + send_item, c++/sample.cpp:370): a column
-        // only travels to the ranks whose ratings / test entries reference it.  Pack the columns of
-        // every peer's list into one buffer, one grouped send / receive per peer, scatter what arrived.
-        const int64_t ns = self->conn_send_ptr.back(), nr = self->conn_recv_ptr.back();
-        constexpr int P = K / 2;                                   // 16-byte pieces per column
-        if (ns > 0)
-            hipLaunchKernelGGL(bpmf::k_pack_cols<K>, dim3((unsigned)((ns * P + 255) / 256)), dim3(256), 0, st,
-                               (const double *)self->d_items, (const int32_t *)self->d_conn_send, ns, self->d_conn_sbuf);
-        NCCL_TRY(R->GroupStart());
-        for (int r = 0; r < c->nranks; ++r) {
-            const int64_t s0 = self->conn_send_ptr[(size_t)r], s1 = self->conn_send_ptr[(size_t)r + 1];
-            const int64_t r0 = self->conn_recv_ptr[(size_t)r], r1 = self->conn_recv_ptr[(size_t)r + 1];
-            if (s1 > s0) NCCL_TRY(R->Send(self->d_conn_sbuf + (size_t)s0 * K, (size_t)(s1 - s0) * K, ncclDouble, r, c->comm, st));
-            if (r1 > r0) NCCL_TRY(R->Recv(self->d_conn_rbuf + (size_t)r0 * K, (size_t)(r1 - r0) * K, ncclDouble, r, c->comm, st));
-        }
-        NCCL_TRY(R->GroupEnd());
-        if (nr > 0)
-            hipLaunchKernelGGL(bpmf::k_unpack_cols<K>, dim3((unsigned)((nr * P + 255) / 256)), dim3(256), 0, st,
-                               (const double *)self->d_conn_rbuf, (const int32_t *)self->d_conn_recv, nr, self->d_items);
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
-    NCCL_TRY(R->GroupStart());
-    for (int r = 0; r < c->nranks; ++r) {
-        const int64_t lo = self->bounds[(size_t)r], hi = self->bounds[(size_t)r + 1];
-        if (hi > lo) {
-            double *p = self->d_items + (size_t)lo * K;
-            NCCL_TRY(R->Broadcast(p, p, (size_t)(hi - lo) * K, ncclDouble, r, c->comm, st));
-        }
-    }
-    NCCL_TRY(R->GroupEnd());
-    return 0;
-    }
-}
-
-template <int K>
-int launch_stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_host_dev, unsigned *flag, unsigned seq, unsigned *ticket)
-{
-    using namespace bpmf;
-    bpmf_hip_ctx *c = self->ctx;
-    const unsigned long long *failp = (const unsigned long long *)(d_in + (size_t)K * K + K);
-    if constexpr (K == 128) {                           // fp32 factors, fp64 sums (single GPU)
-        if (c->comm != nullptr && !self->bounds.empty()) return fail(BPMF_HIP_EINVAL, "the fp32 path is single-GPU for now");
-        hipLaunchKernelGGL(k_colstats_f32<K>, dim3(self->nstat_waves), dim3(256), 0, st, reinterpret_cast<const float *>(self->d_items),
-                           self->from, self->to, self->nstat_waves, self->d_stat_partials);
-        hipLaunchKernelGGL(k_colstats_f32_final<K>, dim3((K * K + K + 255) / 256), dim3(256), 0, st,
-                           (const double *)self->d_stat_partials, self->nstat_waves, failp, out_host_dev, ticket, flag, seq);
-        return 0;
-    } else {
-    if (!(c->comm != nullptr && !self->bounds.empty())) {
-        hipLaunchKernelGGL(k_colstats<K>, dim3(self->nstat_waves), dim3(64), 0, st,
-                           (const double *)self->d_items, self->from, self->to, self->nstat_waves, self->d_stat_partials,
-                           failp, out_host_dev, ticket, flag, seq);
-    } else {
-        // local sums into a device blob, all-reduce them (cov is then formed once from the GLOBAL
-        // sums: SURVEY Q19) together with the failed-column word, publish to the host
-        Rccl *R = rccl();
-        // on the side's own stream: its own reduction blob and the second communicator
-        const bool own = st != c->stream && c->comm2 && self->a_d_red;
-        double *red = own ? self->a_d_red : c->d_red;
-        hipLaunchKernelGGL(k_colstats<K>, dim3(self->nstat_waves), dim3(64), 0, st,
-                           (const double *)self->d_items, self->from, self->to, self->nstat_waves, self->d_stat_partials,
-                           failp, red, ticket, ticket + 8, 0u);
-        NCCL_TRY(R->AllReduce(red, red, (size_t)K * K + K + 1, ncclDouble, ncclSum, own ? c->comm2 : c->comm, st));   // prod | sum | failed-column word
-        hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, st, (const double *)red, out_host_dev, K * K + K + 1, flag, seq, K * K + K);
-    }
-    return 0;
-    }
 }
 
 #define BPMF_DISPATCH_K(K_, CALL)                                                    \
@@ -1137,17 +659,16 @@ extern "C" int bpmf_hip_sample_side_launch(bpmf_hip_side *self, const bpmf_hip_s
     { const int rs = settle_async(self); if (rs) return rs; }
     if (self->saux) HIP_TRY(hipStreamSynchronize(self->saux));
     fill_blob(K, mu, LambdaF, c->h_in, K == 64 && c->dtype == BPMF_HIP_F64);
-    hipLaunchKernelGGL(bpmf::k_stage, dim3((unsigned)((c->in_words + 255) / 256)), dim3(256), 0, c->stream,
-                       (const double *)c->h_in_dev, c->d_in, (int)c->in_words);
+    bpmf_launch::stage(c->h_in_dev, c->d_in, (int)c->in_words, c->stream);
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     c->last_sampler_done = nullptr;
     int rc = BPMF_DISPATCH_K(K, launch_sampler<KK>(self, other, iter, alpha, c->d_in, c->stream));
     if (rc) return rc;
-    rc = BPMF_DISPATCH_K(K, launch_exchange<KK>(self, c->stream));
+    rc = BPMF_DISPATCH_K(K, bpmf_launch::exchange<KK>(self, c->stream));
     if (rc) return rc;
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     unsigned *flag = reinterpret_cast<unsigned *>(c->h_out_dev + c->out_words - 1);
-    rc = BPMF_DISPATCH_K(K, launch_stats<KK>(self, c->stream, c->d_in, c->h_out_dev, flag, ++c->seq, c->d_ticket));
+    rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK>(self, c->stream, c->d_in, c->h_out_dev, flag, ++c->seq, c->d_ticket));
     if (rc) return rc;
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     // prod | sum | - | fail word land in the pinned result blob; the last wave of k_colstats
@@ -1166,6 +687,7 @@ extern "C" int bpmf_hip_sample_side_finish(bpmf_hip_side *self, double *sum_out,
     HIP_TRY(hipSetDevice(c->device));
     self->pending = false;
     { const int rcw = wait_host(c); if (rcw) return rcw; }
+    { std::string m; if (check_timeout(c->h_out, K, &m)) return fail(BPMF_HIP_ENODEV, m); }
     memcpy(prod_out, c->h_out, sizeof(double) * K * K);
     memcpy(sum_out, c->h_out + (size_t)K * K, sizeof(double) * K);
     {   // sum |x|^2 = trace(sum x x^T)
@@ -1283,6 +805,10 @@ int draw_and_release(bpmf_hip_side *s, int iter, double *mu, double *LU, double 
     if (!rc) fill_blob(K, mu, LF, s->a_h_in, K == 64 && s->ctx->dtype == BPMF_HIP_F64);
     // the gate is opened even after an error: a sampler may already be queued behind it and must
     // not be left spinning (its results are never looked at: the error is reported first)
+    {   // test hook: a host worker that is descheduled for a while (SIGSTOP, debugger, oversubscription)
+        static const int stall_ms = env_int("BPMF_HIP_TEST_STALL_WORKER_MS", 0);
+        if (stall_ms > 0 && iter > 0) std::this_thread::sleep_for(std::chrono::milliseconds(stall_ms));
+    }
     __atomic_store_n(s->a_gate, (unsigned)(iter + 1), __ATOMIC_RELEASE);
     s->gate_iter = iter;
     return rc;
@@ -1332,6 +858,7 @@ void collect(bpmf_hip_side *s, const bpmf_hip_side::Job &job)
         }
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != job.seq) { rc = BPMF_HIP_ENODEV; msg = "device did not publish its results"; }
     }
+    if (!rc) rc = check_timeout(s->a_h_out, K, &msg);     // a bounded in-kernel wait gave up: the sums are not to be used
     if (!rc) {
         const double *prod = s->a_h_out, *sum = s->a_h_out + (size_t)K * K;
         unsigned long long f;
@@ -1405,7 +932,7 @@ int flush_pending_stats(bpmf_hip_ctx *c)
     hipEvent_t *ev = P->evs[c->pending_evset];
     HIP_TRY(hipStreamWaitEvent(P->saux, ev[1], 0));                  // (ev[1]: recorded with / behind P's sampler)
     unsigned *flag = reinterpret_cast<unsigned *>(P->a_h_out_dev + c->out_words - 1);
-    const int rc = BPMF_DISPATCH_K(K, launch_stats<KK>(P, P->saux, P->a_d_in, P->a_h_out_dev, flag, c->pending_seq, P->a_ticket));
+    const int rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK>(P, P->saux, P->a_d_in, P->a_h_out_dev, flag, c->pending_seq, P->a_ticket));
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ev[2], P->saux));
     P->stats_ev[c->pending_evset].store(ev[2], std::memory_order_release);
@@ -1500,10 +1027,11 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
             fz.st_fail = (const unsigned long long *)(P->a_d_in + (size_t)K * K + K);
             fz.st_out = P->a_h_out_dev; fz.st_ticket = P->a_ticket;
             fz.st_flag = reinterpret_cast<unsigned *>(P->a_h_out_dev + c->out_words - 1); fz.st_seq = c->pending_seq;
+            fz.st_tmo = tmo_word(P->a_h_out_dev, K);
         }
     } else {
-        hipLaunchKernelGGL(bpmf::k_gate_stage, dim3(c->in_words > 8192 ? 16 : 1), dim3(64), 0, s1, (const unsigned *)self->a_gate_dev,
-                           (unsigned)(iter + 1), (const double *)self->a_h_in_dev, self->a_d_in, (int)c->in_words);
+        bpmf_launch::gate_stage(c->in_words > 8192 ? 16 : 1, self->a_gate_dev, (unsigned)(iter + 1), self->a_h_in_dev, self->a_d_in, (int)c->in_words,
+                                tmo_word(self->a_h_out_dev, K), wait_ticks(), s1);
         if (s1 != s0) {
             HIP_TRY(hipEventRecord(ev[3], s1));
             HIP_TRY(hipStreamWaitEvent(s0, ev[3], 0));
@@ -1525,7 +1053,7 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
                                                ride ? ev[1] : nullptr));
     self->cur_gate_flag = nullptr;
     self->cur_fused = bpmf::FusedArgs{};
-    if (!rc) rc = BPMF_DISPATCH_K(K, launch_exchange<KK>(self, s0));
+    if (!rc) rc = BPMF_DISPATCH_K(K, bpmf_launch::exchange<KK>(self, s0));
     if (rc) return rc;
     if (!ride) HIP_TRY(hipEventRecord(ev[1], s0));
     c->last_sampler_done = (env_int("BPMF_HIP_EVAL_MARKER", 0) == 0) ? ev[1] : nullptr;   // an evaluation requested next waits for this: no marker of its own on S0
@@ -1539,7 +1067,7 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     } else {
         if (s1 != s0) HIP_TRY(hipStreamWaitEvent(s1, ev[1], 0));
         unsigned *flag = reinterpret_cast<unsigned *>(self->a_h_out_dev + c->out_words - 1);
-        rc = BPMF_DISPATCH_K(K, launch_stats<KK>(self, s1, self->a_d_in, self->a_h_out_dev, flag, seq, self->a_ticket));
+        rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK>(self, s1, self->a_d_in, self->a_h_out_dev, flag, seq, self->a_ticket));
         if (rc) return rc;
         HIP_TRY(hipEventRecord(ev[2], s1));
         self->stats_ev[evset].store(ev[2], std::memory_order_release);
@@ -1678,7 +1206,7 @@ extern "C" int bpmf_hip_side_exchange(bpmf_hip_side *s)
     HIP_TRY(hipSetDevice(c->device));
     c->last_sampler_done = nullptr;
     switch (c->K) {
-#define BPMF_CASE(KK) case KK: rc = launch_exchange<KK>(s, c->stream); break;
+#define BPMF_CASE(KK) case KK: rc = bpmf_launch::exchange<KK>(s, c->stream); break;
         BPMF_CASE(8) BPMF_CASE(16) BPMF_CASE(32) BPMF_CASE(64) BPMF_CASE(128)
 #undef BPMF_CASE
         default: return fail(BPMF_HIP_EINVAL, "unsupported K");
@@ -1780,51 +1308,16 @@ extern "C" int bpmf_hip_test_destroy(bpmf_hip_test *t)
     delete t;
     return BPMF_HIP_OK;
 }
-
 namespace {
-// k_predict on stream `ps` over explicit factor pointers.  in_order: on the main stream behind the
-// samplers.  Otherwise (`beside`): behind ev_in (everything that was on the main stream when the
-// evaluation was requested), with ev_done recorded after it for launch_sampler's hazard check.
-template <int K>
-void launch_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items, const void *other_items, int n,
-                    hipStream_t ps, bool beside)
-{
-    bpmf_hip_ctx *c = self->ctx;
-    unsigned *flag = reinterpret_cast<unsigned *>(t->h_res_dev + 2);
-    const bool dist = c->comm && !self->bounds.empty();
-    t->pstream = ps;
-    if (beside) (void)hipStreamWaitEvent(ps, t->in_ev, 0);
-    // se | se_avg of this rank's test ratings: straight to the host, or -> all-reduce -> host
-    double *red = c->d_red + c->out_words;          // 2 spare words behind the sampler's blob
-    if constexpr (K == 128) {
-        hipLaunchKernelGGL(bpmf::k_predict_f32<K>, dim3((unsigned)t->nblocks), dim3(256), 0, ps,
-                           (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz,
-                           reinterpret_cast<const float *>(self_items), reinterpret_cast<const float *>(other_items), self->from,
-                           self->mean_rating, n, t->d_pavg, t->d_pm2, t->d_partial, t->h_res_dev, t->d_ticket, flag, ++t->seq);
-        (void)red; (void)dist;
-    } else {
-    hipLaunchKernelGGL(bpmf::k_predict<K>, dim3((unsigned)t->nblocks), dim3(256), 0, ps,
-                       (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz,
-                       (const double *)self_items, (const double *)other_items, self->from, self->mean_rating, n,
-                       t->d_pavg, t->d_pm2, t->d_partial, dist ? red : t->h_res_dev, t->d_ticket,
-                       dist ? t->d_ticket + 8 : flag, dist ? 0u : ++t->seq);
-    if (dist) {
-        if (rccl()->AllReduce(red, red, 2, ncclDouble, ncclSum, c->comm, c->stream) != ncclSuccess) return;
-        hipLaunchKernelGGL(bpmf::k_publish, dim3(1), dim3(256), 0, c->stream, (const double *)red, t->h_res_dev, 2, flag, ++t->seq, -1);
-    }
-    }
-    if (beside) (void)hipEventRecord(t->ev_done[t->seq & 1u], ps);
-}
-
 void dispatch_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items, const void *other_items, int n,
                       hipStream_t ps, bool beside)
 {
     switch (self->ctx->K) {
-    case 8: launch_predict<8>(t, self, self_items, other_items, n, ps, beside); break;
-    case 16: launch_predict<16>(t, self, self_items, other_items, n, ps, beside); break;
-    case 32: launch_predict<32>(t, self, self_items, other_items, n, ps, beside); break;
-    case 64: launch_predict<64>(t, self, self_items, other_items, n, ps, beside); break;
-    case 128: launch_predict<128>(t, self, self_items, other_items, n, ps, beside); break;
+    case 8: bpmf_launch::predict<8>(t, self, self_items, other_items, n, ps, beside); break;
+    case 16: bpmf_launch::predict<16>(t, self, self_items, other_items, n, ps, beside); break;
+    case 32: bpmf_launch::predict<32>(t, self, self_items, other_items, n, ps, beside); break;
+    case 64: bpmf_launch::predict<64>(t, self, self_items, other_items, n, ps, beside); break;
+    case 128: bpmf_launch::predict<128>(t, self, self_items, other_items, n, ps, beside); break;
     default: break;
     }
 }
@@ -1960,10 +1453,11 @@ extern "C" int bpmf_hip_randn_stream(bpmf_hip_ctx *c, uint32_t counter, int n, d
     HIP_TRY(hipSetDevice(c->device));
     double *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, 128 * sizeof(double)));
-    hipLaunchKernelGGL(bpmf::k_randn_probe, dim3(1), dim3(64), 0, c->stream, counter, n, d);
+    bpmf_launch::randn_probe(counter, n, d, c->stream);
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(out, d, n * sizeof(double), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(BPMF_HIP_ENODEV, std::string("randn_stream: ") + hipGetErrorString(e));
     return BPMF_HIP_OK;
 }
+

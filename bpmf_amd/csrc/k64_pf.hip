@@ -1,0 +1,23 @@
+// k64_pf.hip -- K = 64, product form for columns with <= 12 ratings (see launch.h)
+#include "launch.h"
+#include "kernels_lr.h"
+
+namespace bpmf_launch {
+
+template <typename Kern, typename Args>
+static void go(Kern kernel, int grid, int block, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const Args &a)
+{
+    if (e0 || e1) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, st, e0, e1, 0, a);
+    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, st, a);
+}
+
+void k64_pf(int cls, int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::LrArgs &a)
+{
+    switch (cls) {
+    case 0: go(bpmf::k_sample_pf<64, 2>, grid, 512, st, e0, e1, a); break;
+    case 1: go(bpmf::k_sample_pf<64, 6>, grid, 512, st, e0, e1, a); break;
+    default: go(bpmf::k_sample_pf<64, 12>, grid, 512, st, e0, e1, a); break;
+    }
+}
+
+}  // namespace bpmf_launch

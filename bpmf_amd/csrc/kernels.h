@@ -31,29 +31,11 @@
 #include <stdint.h>
 
 #include "philox.h"
+#include "args.h"
 
 namespace bpmf {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
-
-// offset of row i in the packed lower-triangular row-major storage of L: row i keeps its
-// i+1 entries padded to an even count (so that a pair of columns 2p, 2p+1 is 16-byte aligned)
-__host__ __device__ constexpr int tri_off(int i) { return 2 * ((i >> 1) + 1) * ((i >> 1) + (i & 1)); }
-
-template <int K>
-struct Geo {
-    static constexpr int NT = (K + 15) / 16;             // 16-wide tiles per dimension (K=8 is zero-padded)
-    static constexpr int NTRI = NT * (NT + 1) / 2;        // upper-triangular tiles incl. diagonal
-    static constexpr int PART = NTRI * 256 + NT * 16;     // doubles in one partial: tiles in accumulator layout + rhs
-    // waves per SIMD the sampler is compiled for (bounds the VGPR budget: 512 / WPS)
-    static constexpr int WPS = K <= 32 ? 4 : 2;
-    // factorisation: one lane per row of Lambda*, C = 64/K columns side by side in one wave
-    static constexpr int C = 64 / K;
-    static constexpr int NP = K / 2;                      // column pairs = steps of the factorisation
-    static constexpr int PLEN = tri_off(K);               // packed L: 544 doubles at K=32
-    static constexpr int SLOT = PLEN + 2 * K;             // per column: L | rhs, later y [K] | normals [K]
-    static constexpr int LDS_WORDS = C * SLOT + 2 * C;    // + the global column id of each slot
-};
 
 // v_mfma_f64_16x16x4_f64 operand / result layout (lane l, kq = l>>4, li = l&15):
 //   A[i=li][k=kq], B[k=kq][j=li]  one double each;  D[i = kq + 4*reg][j = li], reg 0..3.
@@ -72,21 +54,6 @@ __device__ __forceinline__ double mfma44(double a, double b, double c)
 {
     return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
-
-// Gram of the one-column-per-wave sampler (K <= 32) on the 4x4x4 shape.  The four blocks of an
-// instruction take four DIFFERENT ratings each (16 ratings per instruction) and the same 4x4
-// block (g, g') of the Gram; lane (k, b, x) feeds rating slot s = 4 k + b with the latent index
-// idx(g, x) = 8 (g / 2) + 2 x + (g & 1)  (so that one 16-byte load per lane brings the operands of
-// two groups).  The NB = NG (NG + 1) / 2 upper blocks are NB accumulator registers per lane, each
-// holding the contribution of the lane's b; the four b are added once per column (DPP row rotates).
-template <int K>
-struct Geo44 {
-    static constexpr int NG = K / 4;                      // groups of 4 latent indices
-    static constexpr int NB = NG * (NG + 1) / 2;          // upper blocks incl. diagonal
-    static constexpr int NL = K / 8;                      // 16-byte loads per lane and 16 ratings
-    static constexpr int PART = (NB + NG) * 64;           // doubles in one partial of a chunked column
-    __host__ __device__ static constexpr int idx(int g, int x) { return 8 * (g >> 1) + 2 * x + (g & 1); }
-};
 
 // 1/sqrt(d) to ~1 ulp: v_rsq_f64 (2^-23 relative) + one third-order (Halley) correction,
 // y = y0 (1 + e/2 + 3e^2/8) with e = 1 - d y0^2, error ~ e^3: 6 dependent instructions
@@ -117,44 +84,6 @@ __device__ __forceinline__ double bcast(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
-struct SampleArgs {
-    // ratings of this rank's columns
-    const int32_t *rowidx;
-    const double *vals;
-    // static schedule of the side: work item = (column, chunk of its ratings)
-    const int32_t *wi_col;      // local column
-    const int64_t *wi_p0;       // first rating of the chunk
-    const int32_t *wi_len;      // ratings in the chunk
-    const int32_t *wi_mc;       // heavy column index the chunk belongs to, or -1 (whole column)
-    const int32_t *wi_chunk;    // ordinal of the chunk inside its column
-    const int32_t *mc_slot0;    // heavy columns: first partial slot, number of chunks
-    const int32_t *mc_nchunks;
-    unsigned *mc_count;         // arrival counters of the heavy columns (zero between launches)
-    double *partials;
-    int nwork;
-    // factors
-    const double *other_items;  // K x nrows
-    const double *zero_row;     // K zeros (gather target of the padding slots of a ragged group of ratings)
-    double *items;              // K x ncols
-    int64_t col_from;           // global id of local column 0
-    // per-call
-    const double *LambdaF;      // K x K col-major (device)
-    const double *Lmu;          // LambdaF * mu (device)
-    const double *mu;           // hp.mu (device)
-    // propagated posterior (-m / -l, c++/sample.cpp:152-174,272-277): one K x K col-major prior
-    // precision per LOCAL column replaces LambdaF; rr = Lambda_i * hp.mu keeps the global mu (Q2)
-    const double *prop_lambda;
-    uint32_t diag_only;         // BPMF_NO_COVARIANCE build of the reference (c++/sample.cpp:300-304): keep only the diagonal of Lambda*
-    unsigned long long *fail;   // min global column id whose factorisation failed
-    double mean_rating;
-    double alpha;
-    uint32_t iter_plus_1;
-    // in-kernel gate (NULL: the launch itself was ordered behind the staging kernel): the word
-    // k_gate_stage sets to `gate_want` once LambdaF | Lmu | fail | mu are in device memory
-    const unsigned *gate_flag;
-    unsigned gate_want;
-    uint32_t ablate;            // profiling only (BPMF_HIP_ABLATE): 1 = skip the factorisation, 2 = skip the Gram, 4 = gather from 64 hot rows only
-};
 
 // ---------------------------------------------------------------------------
 // K normals of the reference's per-column stream, in stream order.
@@ -183,15 +112,28 @@ __device__ __forceinline__ uint32_t sample_counter(int64_t idx, uint32_t iter_pl
 // long been satisfied: tools/probes/boundary2.hip).  k_gate_stage writes the blob through to
 // memory (device-scope relaxed atomic stores + s_waitcnt) before it sets the word; nothing in this
 // launch has touched the blob before it sees the word, and the caches were invalidated when the
-// launch began, so plain loads behind the wait read the new values.  Gives up after ~2 s of wall
-// clock (then the host side reports the stale gate).
+// launch began, so plain loads behind the wait read the new values.  Bounded: the gate workgroup
+// itself gives up on the host after `wait_ticks` (and then still sets the word), so a workgroup here
+// only runs into ITS limit (1.5 x that) when the gate workgroup never ran; either way the side's
+// sticky time-out word is set and the host reports BPMF_HIP_ENODEV instead of using the results.
+#define BPMF_RLX_SYSTEM_ __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
+enum { BPMF_TMO_GATE = 1, BPMF_TMO_PARAMS = 2, BPMF_TMO_STATS = 3 };
+__device__ __forceinline__ void flag_timeout(unsigned long long *tmo, unsigned long long what)
+{
+    if (tmo) __hip_atomic_store(tmo, what, BPMF_RLX_SYSTEM_);
+}
+
 __device__ __forceinline__ void wait_params(const SampleArgs &a)
 {
     if (a.gate_flag == nullptr) return;
     const unsigned long long t0 = wall_clock64();
+    const unsigned long long limit = a.wait_ticks + (a.wait_ticks >> 1);
     while ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.gate_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != a.gate_want) {
         __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > 200000000ull) break;
+        if (wall_clock64() - t0 > limit) {
+            if (threadIdx.x == 0) flag_timeout(a.tmo, BPMF_TMO_PARAMS);
+            break;
+        }
     }
     asm volatile("" ::: "memory");
 }
@@ -975,17 +917,14 @@ __device__ __forceinline__ void finish_single(const SampleArgs &a, int col_local
 // A cross-queue dependency costs ~6.5 us of command-processor latency per hop even when it is
 // satisfied long before (tools/probes/boundary2.hip): with both jobs inside the launch, two
 // samplers follow each other on one queue in ~2 us instead of 8-11.
-struct FusedArgs {
-    const unsigned *gate_host; unsigned gate_want; const double *src_host; double *dst; int n; unsigned *dflag; unsigned dval;
-    int nstat; const double *st_items; int64_t st_c0, st_c1; double *st_partials; const unsigned long long *st_fail;
-    double *st_out; unsigned *st_ticket; unsigned *st_flag; unsigned st_seq;
-};
 template <int K>
 __device__ __forceinline__ void colstats_body(int w, const double *__restrict__ items, int64_t c0, int64_t c1, int nwaves,
                                               double *partials, const unsigned long long *__restrict__ fail_in,
-                                              double *__restrict__ out, unsigned *ticket, unsigned *flag, unsigned seq);
+                                              double *__restrict__ out, unsigned *ticket, unsigned *flag, unsigned seq,
+                                              unsigned long long *tmo, unsigned long long wait_ticks);
 __device__ __forceinline__ void gate_stage_body(int block, int nblocks, const unsigned *gate_host, unsigned want, const double *src_host,
-                                                double *__restrict__ dst, int n, unsigned *dflag, unsigned dval);
+                                                double *__restrict__ dst, int n, unsigned *dflag, unsigned dval,
+                                                unsigned long long *tmo, unsigned long long wait_ticks);
 
 template <int K>
 __global__ __launch_bounds__(64, Geo1<K>::WPS) void k_sample1(SampleArgs a, FusedArgs f)
@@ -994,11 +933,12 @@ __global__ __launch_bounds__(64, Geo1<K>::WPS) void k_sample1(SampleArgs a, Fuse
     const int lane = threadIdx.x;
     int bid = blockIdx.x;
     if (f.gate_host) {
-        if (bid == 0) { gate_stage_body(0, 1, f.gate_host, f.gate_want, f.src_host, f.dst, f.n, f.dflag, f.dval); return; }
+        if (bid == 0) { gate_stage_body(0, 1, f.gate_host, f.gate_want, f.src_host, f.dst, f.n, f.dflag, f.dval, a.tmo, a.wait_ticks); return; }
         --bid;
     }
     if (bid < f.nstat) {
-        colstats_body<K>(bid, f.st_items, f.st_c0, f.st_c1, f.nstat, f.st_partials, f.st_fail, f.st_out, f.st_ticket, f.st_flag, f.st_seq);
+        colstats_body<K>(bid, f.st_items, f.st_c0, f.st_c1, f.nstat, f.st_partials, f.st_fail, f.st_out, f.st_ticket, f.st_flag, f.st_seq,
+                         f.st_tmo, a.wait_ticks);
         return;
     }
     const int w = bid - f.nstat;
@@ -1161,7 +1101,8 @@ __device__ __forceinline__ void publish_when_last(unsigned *ticket, unsigned nbl
 template <int K>
 __device__ __forceinline__ void colstats_body(int w, const double *__restrict__ items, int64_t c0, int64_t c1, int nwaves,
                                               double *partials, const unsigned long long *__restrict__ fail_in,
-                                              double *__restrict__ out, unsigned *ticket, unsigned *flag, unsigned seq)
+                                              double *__restrict__ out, unsigned *ticket, unsigned *flag, unsigned seq,
+                                              unsigned long long *tmo, unsigned long long wait_ticks)
 {
     constexpr int NT = Geo<K>::NT, NTRI = Geo<K>::NTRI, PART = Geo<K>::PART;
     constexpr int NSLICE = (K * K + K + 15) / 16;
@@ -1225,9 +1166,17 @@ __device__ __forceinline__ void colstats_body(int w, const double *__restrict__ 
     if ((int)tk < nwaves - nfin) return;
     const int f = (int)tk - (nwaves - nfin);                          // finisher 0 .. nfin-1
     // every wave takes its ticket before it waits, so the count reaches nwaves as soon as all
-    // waves have run (those not yet resident get the slots the samplers' workgroups free)
-    if (lane == 0)
-        while (__hip_atomic_load(ticket, BPMF_RLX_AGENT) < (unsigned)nwaves) __builtin_amdgcn_s_sleep(1);
+    // waves have run (those not yet resident get the slots the samplers' workgroups free): at most
+    // NSLICE <= 66 (K = 32) / 260 (K = 64) waves ever wait, fewer than the wave slots of a single XCD.
+    // Bounded all the same (a co-tenant holding every other slot): the sums published after a
+    // time-out are incomplete, the sticky word says so and the host discards them.
+    if (lane == 0) {
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(ticket, BPMF_RLX_AGENT) < (unsigned)nwaves) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wait_ticks && wall_clock64() - t0 > wait_ticks) { flag_timeout(tmo, BPMF_TMO_STATS); break; }
+        }
+    }
     __syncthreads();
 
     const int o = lane & 15, grp = lane >> 4;
@@ -1282,9 +1231,10 @@ __device__ __forceinline__ void colstats_body(int w, const double *__restrict__ 
 template <int K>
 __global__ __launch_bounds__(64) void k_colstats(const double *__restrict__ items, int64_t c0, int64_t c1, int nwaves,
                                                  double *partials, const unsigned long long *__restrict__ fail_in,
-                                                 double *__restrict__ out, unsigned *ticket, unsigned *flag, unsigned seq)
+                                                 double *__restrict__ out, unsigned *ticket, unsigned *flag, unsigned seq,
+                                                 unsigned long long *tmo, unsigned long long wait_ticks)
 {
-    colstats_body<K>((int)blockIdx.x, items, c0, c1, nwaves, partials, fail_in, out, ticket, flag, seq);
+    colstats_body<K>((int)blockIdx.x, items, c0, c1, nwaves, partials, fail_in, out, ticket, flag, seq, tmo, wait_ticks);
 }
 
 // ---------------------------------------------------------------------------
@@ -1395,28 +1345,24 @@ __global__ __launch_bounds__(256) void k_unpack_cols(const double *__restrict__ 
     reinterpret_cast<dd2 *>(items + (size_t)cols[c] * K)[piece] = reinterpret_cast<const dd2 *>(buf)[i];
 }
 
-// hp.mu / hp.LambdaF blob: pinned host memory -> device memory (replaces a hipMemcpyAsync;
-// the sampler re-reads LambdaF per column, so it must sit behind the L2)
-__global__ __launch_bounds__(256) void k_stage(const double *__restrict__ src_host, double *__restrict__ dst, int n)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[i] = src_host[i];
-}
 
 // Gate + staging of the stateful path.  The kernel is queued ahead of a sampler whose
 // hyper-parameters the host may still be computing: one lane polls a word in pinned host memory
 // until the host has stored `want` there (release; after it wrote the parameter blob), then the
-// block copies the blob into device memory.  The poll gives up after ~20 s of wall clock (host
-// gone): the sampler then runs on stale parameters and the host side reports the error.
+// block copies the blob into device memory.  The poll gives up after `wait_ticks` of wall clock
+// (default 20 s; host gone or descheduled): it then sets the side's sticky time-out word, the sampler
+// behind it runs on whatever the blob holds, and the host side discards that half-iteration with
+// BPMF_HIP_ENODEV "device wait timed out" (collect() in capi.hip).
 __device__ __forceinline__ void gate_stage_body(int block, int nblocks, const unsigned *gate_host, unsigned want, const double *src_host,
-                                                double *__restrict__ dst, int n, unsigned *dflag, unsigned dval)
+                                                double *__restrict__ dst, int n, unsigned *dflag, unsigned dval,
+                                                unsigned long long *tmo, unsigned long long wait_ticks)
 {
     const int lane = threadIdx.x;
     if (lane == 0) {
         const unsigned long long t0 = wall_clock64();                 // 100 MHz
         while (__hip_atomic_load(gate_host, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != want) {
             __builtin_amdgcn_s_sleep(4);
-            if (wall_clock64() - t0 > 2000000000ull) break;
+            if (wall_clock64() - t0 > wait_ticks) { flag_timeout(tmo, BPMF_TMO_GATE); break; }
         }
     }
     __syncthreads();
@@ -1454,38 +1400,6 @@ __device__ __forceinline__ void gate_stage_body(int block, int nblocks, const un
     }
 }
 
-__global__ __launch_bounds__(64) void k_gate_stage(const unsigned *gate_host, unsigned want, const double *src_host,
-                                                   double *__restrict__ dst, int n, unsigned *dflag = nullptr, unsigned dval = 0)
-{
-    gate_stage_body((int)blockIdx.x, (int)gridDim.x, gate_host, want, src_host, dst, n, dflag, dval);
-}
 
-// multi-GPU: the all-reduced sums sit in device memory; copy them to the pinned result blob and
-// publish the sequence number behind them.  fail_at >= 0: src[fail_at] is the summed "failed
-// column + 1" word of k_colstats (0 = no rank failed; with several failing ranks the id is only a
-// witness that something failed) and becomes the u64 word behind it.
-__global__ __launch_bounds__(256) void k_publish(const double *__restrict__ src, double *__restrict__ dst_host, int n,
-                                                 unsigned *flag_host, unsigned seq, int fail_at)
-{
-    for (int i = threadIdx.x; i < n; i += 256) dst_host[i] = src[i];
-    if (fail_at >= 0 && threadIdx.x == 0) {
-        const double d = src[fail_at];
-        reinterpret_cast<unsigned long long *>(dst_host)[fail_at + 1] = (d == 0.0) ? ~0ull : (unsigned long long)(d - 1.0);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence_system();
-        __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
-// test probe: the first n normals of stream `counter`
-__global__ __launch_bounds__(64) void k_randn_probe(uint32_t counter, int n, double *out)
-{
-    __shared__ double z[128];
-    draw_normals<128>(counter, n, z, threadIdx.x);
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 64) out[i] = z[i];
-}
 
 }  // namespace bpmf

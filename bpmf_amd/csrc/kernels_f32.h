@@ -41,26 +41,6 @@ template <> struct WgTraits<double> {
     __device__ static __forceinline__ double bcast(double v, int l) { return ::bpmf::bcast(v, l); }
 };
 
-template <typename T>
-struct SampleArgsW {
-    const int32_t *rowidx;
-    const double *vals;
-    const int32_t *wi_col;      // work item -> local column (cost-sorted; no chunking on this path)
-    const int64_t *wi_p0;
-    const int32_t *wi_len;
-    const T *other_items;       // K x nrows
-    T *items;                   // K x ncols
-    int64_t col_from;
-    const double *LambdaF;      // K x K col-major (device, fp64)
-    const double *Lmu;
-    const double *mu;
-    const double *prop_lambda;  // propagated posterior: K x K per local column, or NULL (see SampleArgs)
-    uint32_t diag_only;         // BPMF_NO_COVARIANCE (see SampleArgs)
-    unsigned long long *fail;
-    double mean_rating;
-    double alpha;
-    uint32_t iter_plus_1;
-};
 
 template <int K>
 struct GeoF {

@@ -20,19 +20,6 @@
 
 namespace bpmf {
 
-struct LrArgs {
-    const int32_t *rowidx; const double *vals;
-    const int32_t *col; const int64_t *p0; const int32_t *len;   // light work items (len <= NLR)
-    int nitems;
-    const double *other_items; double *items; int64_t col_from;
-    const double *R0;          // K x K, row-major upper factor of LambdaF (zeros below the diagonal)
-    const double *S0t;         // K x K: S0t[j * K + i] = (R0^-1)[i][j] -- columns without ratings: x = R0^-1 (y0 + z)
-    const double *y0;          // K: R0^-T (LambdaF mu), the forward solve every such column would repeat
-    const double *Lmu;         // LambdaF * mu
-    unsigned long long *fail;
-    double mean_rating, alpha, sqrt_alpha;
-    uint32_t iter_plus_1;
-};
 
 __device__ __forceinline__ double readlane_d(double v, int lane)
 {

@@ -1,0 +1,36 @@
+// launch.h -- what capi.hip needs from the translation units that hold the kernels.  The templates
+// are defined in launch_impl.h and explicitly instantiated one K per file (k8.hip ... k128.hip), so
+// that the five instantiations of the sampler compile side by side (make -j).
+#pragma once
+#include "state.h"
+
+namespace bpmf_launch {
+
+// the per-column update of `self` into `out_items`, reading the parameter blob `d_in`
+template <int K>
+int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *other, int iter, double alpha, double *d_in, hipStream_t st,
+                 hipEvent_t ev_start, hipEvent_t ev_stop);
+// multi-GPU: in-place broadcast / packed send-receive of every rank's fresh column range
+template <int K>
+int exchange(bpmf_hip_side *self, hipStream_t st);
+// sum x / sum x x^T of this rank's columns (+ all-reduce), published to `out_host_dev`
+template <int K>
+int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_host_dev, unsigned *flag, unsigned seq, unsigned *ticket);
+template <int K>
+void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items, const void *other_items, int n, hipStream_t ps, bool beside);
+
+// K = 64: every kernel family but k_sample1 sits in a unit of its own (k64_*.hip) -- the instantiations
+// of this size take minutes to compile.  e0 / e1: events riding on the dispatch packet, or NULL.
+void k64_persistent(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a);
+void k64_wg(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgsW<double> &a);
+void k64_lr(int width, int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::LrArgs &a);     // sweep width 1..4
+void k64_pf(int cls, int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::LrArgs &a);       // class 0..2: <= 2 | 6 | 12 ratings
+
+// kernels that do not depend on K (kcommon.hip)
+void stage(const double *src_host_dev, double *dst, int n, hipStream_t st);
+void gate_stage(int nblocks, const unsigned *gate_host_dev, unsigned want, const double *src_host_dev, double *dst, int n,
+                unsigned long long *tmo, unsigned long long ticks, hipStream_t st);
+void publish(const double *src, double *dst_host_dev, int n, unsigned *flag_host_dev, unsigned seq, int fail_at, hipStream_t st);
+void randn_probe(uint32_t counter, int n, double *out_dev, hipStream_t st);
+
+}  // namespace bpmf_launch

@@ -1,0 +1,270 @@
+// launch_impl.h -- definitions of launch.h's templates: which kernel of kernels*.h runs for which
+// form of a side, and with what arguments.  Included by the per-K units only.
+#pragma once
+#include "launch.h"
+#include "kernels.h"
+#include "kernels_f32.h"
+#include "kernels_q4.h"
+
+namespace bpmf_launch {
+
+
+// The device work of one half-iteration, in three pieces that the synchronous (stateless) and
+// the asynchronous (stateful) paths put on their streams:
+//   launch_sampler: the per-column update, reading the parameter blob `d_in`
+//   launch_exchange: multi-GPU only, in-place broadcast of every rank's fresh column range
+//   launch_stats: sum x / sum x x^T of this rank's columns (+ all-reduce), published to `out_host_dev`
+template <int K>
+// ev_start / ev_stop (optional): recorded by the dispatch packet of the sampler itself
+// (hipExtLaunchKernel) instead of by marker packets before and after it -- every marker is a few
+// microseconds on the stream between two samplers.
+int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *other, int iter, double alpha, double *d_in, hipStream_t st,
+                        hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    using namespace bpmf;
+    bpmf_hip_ctx *c = self->ctx;
+    auto launch = [&](auto kernel, dim3 grid, dim3 block, auto args) {
+        if (ev_start || ev_stop) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, ev_start, ev_stop, 0, args);
+        else hipLaunchKernelGGL(kernel, grid, block, 0, st, args);
+    };
+    // one workgroup per column (k_sample_wg): the fp32 large-K path, and K = 64 in fp64
+    auto launch_wg = [&](auto zero) {
+        typedef decltype(zero) T;
+        SampleArgsW<T> f;
+        f.rowidx = self->d_rowidx; f.vals = self->d_vals;
+        f.wi_col = self->d_wi_col; f.wi_p0 = self->d_wi_p0; f.wi_len = self->d_wi_len;
+        f.other_items = reinterpret_cast<const T *>(other->d_items); f.items = reinterpret_cast<T *>(out_items);
+        f.col_from = self->from;
+        f.LambdaF = d_in; f.Lmu = d_in + (size_t)K * K;
+        f.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
+        f.mu = d_in + (size_t)K * K + K + 2; f.prop_lambda = self->d_prop; f.diag_only = c->diag_only;
+        f.mean_rating = self->mean_rating; f.alpha = alpha; f.iter_plus_1 = (uint32_t)(iter + 1);
+        // four waves per column at K = 128; one wave owning all tiles at K = 64 (no idle waves in the
+        // serial phases of the factorisation: the column-dominated shapes are what K = 64 is run on)
+        if (self->nwork > 0) {
+            if constexpr (K == 128) {
+                // two waves per column (18 tiles each) by default: three columns in flight per CU instead of two,
+                // and one idle wave instead of three through the serial phases (0.66 -> 0.58 ms per launch)
+                if (env_int("BPMF_HIP_WG_WAVES", 2) == 4) launch(k_sample_wg<K, T, 4>, dim3(self->nwork), dim3(256), f);
+                else launch(k_sample_wg<K, T, 2>, dim3(self->nwork), dim3(128), f);
+            }
+            else if constexpr (K == 64) k64_wg(self->nwork, st, ev_start, ev_stop, f);
+        }
+    };
+    if constexpr (K == 128) {
+        launch_wg(0.0f);
+        return 0;
+    } else {
+    if constexpr (K == 64) {
+        if (self->mode == 2) { launch_wg(0.0); return 0; }
+    }
+    SampleArgs a;
+    a.rowidx = self->d_rowidx; a.vals = self->d_vals;
+    a.wi_col = self->d_wi_col; a.wi_p0 = self->d_wi_p0; a.wi_len = self->d_wi_len; a.wi_mc = self->d_wi_mc; a.wi_chunk = self->d_wi_chunk;
+    a.mc_slot0 = self->d_mc_slot0; a.mc_nchunks = self->d_mc_nch; a.mc_count = self->d_mc_count;
+    a.partials = self->d_partials; a.nwork = self->nwork;
+    a.other_items = other->d_items; a.items = out_items; a.col_from = self->from;
+    a.LambdaF = d_in; a.Lmu = d_in + (size_t)K * K;
+    a.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
+    a.mu = d_in + (size_t)K * K + K + 2; a.prop_lambda = self->d_prop; a.diag_only = c->diag_only;
+    a.mean_rating = self->mean_rating; a.alpha = alpha; a.iter_plus_1 = (uint32_t)(iter + 1);
+    a.ablate = c->ablate;
+    a.gate_flag = self->cur_gate_flag; a.gate_want = self->cur_gate_want;
+    a.tmo = self->cur_gate_flag ? tmo_word(self->a_h_out_dev, K) : nullptr; a.wait_ticks = wait_ticks();
+    a.zero_row = c->d_zero;
+    if constexpr (K <= 32) {
+        if (self->nwork > 0 && self->mode == 3) {                    // four columns per wave (k_sample4)
+            launch(k_sample4<K>, dim3((self->nwork + 3) / 4), dim3(64), a);
+            return 0;
+        }
+    }
+    if constexpr (K == 64) {
+        if (self->lr_n > 0 && !self->d_prop && !c->diag_only && !c->ablate) {
+            // light columns: rank-n update of the shared factor of LambdaF (k_sample_lr); the others as usual
+            if (self->hv_nwork > 0) {
+                a.wi_col = self->d_hv_col; a.wi_p0 = self->d_hv_p0; a.wi_len = self->d_hv_len; a.wi_mc = self->d_hv_mc;
+                a.wi_chunk = self->d_hv_chunk; a.nwork = self->hv_nwork;
+                if (self->mode == 1) {
+                    const FusedArgs f0{};
+                    if (ev_start) hipExtLaunchKernelGGL(k_sample1<K>, dim3(self->hv_nwork), dim3(64), 0, st, ev_start, nullptr, 0, a, f0);
+                    else hipLaunchKernelGGL(k_sample1<K>, dim3(self->hv_nwork), dim3(64), 0, st, a, f0);
+                } else {
+                    const int grid = std::min(self->hv_nwork, env_int("BPMF_HIP_GRID", c->num_cu * 4 * Geo<K>::WPS));
+                    k64_persistent(grid, st, ev_start, nullptr, a);
+                }
+            }
+            LrArgs l;
+            l.rowidx = self->d_rowidx; l.vals = self->d_vals; l.col = self->d_lr_col; l.p0 = self->d_lr_p0; l.len = self->d_lr_len;
+            l.nitems = self->lr_n; l.other_items = other->d_items; l.items = out_items; l.col_from = self->from;
+            l.R0 = d_in + (size_t)K * K + K + 2 + K; l.S0t = l.R0 + (size_t)K * K; l.y0 = l.S0t + (size_t)K * K;
+            l.Lmu = a.Lmu; l.fail = a.fail;
+            l.mean_rating = self->mean_rating; l.alpha = alpha; l.sqrt_alpha = std::sqrt(alpha); l.iter_plus_1 = (uint32_t)(iter + 1);
+            // product form for the columns with <= 6 ratings: two instantiations (<= 2, <= 6), persistent workgroups
+            // of eight waves with R0^-1 in LDS; then one launch per sweep width for the rest (the events ride on
+            // the first / last launch of the side)
+            int first = 0, last = 0;
+            for (int cls = 1; cls <= 4; ++cls) if (self->lr_class[cls] > self->lr_class[cls - 1]) { if (!first) first = cls; last = cls; }
+            bool started = self->hv_nwork > 0;
+            int last_pf = -1;
+            for (int pc = 0; pc < 3; ++pc) if (self->pf_class[pc + 1] > self->pf_class[pc]) last_pf = pc;
+            for (int pc = 0; pc < 3; ++pc) {
+                const int n0 = self->pf_class[pc], n1 = self->pf_class[pc + 1];
+                if (n1 <= n0) continue;
+                LrArgs lc = l;
+                lc.col = l.col + n0; lc.p0 = l.p0 + n0; lc.len = l.len + n0; lc.nitems = n1 - n0;
+                const bool is_last = last == 0 && pc == last_pf;
+                hipEvent_t e0 = started ? nullptr : ev_start, e1 = is_last ? ev_stop : nullptr;
+                started = true;
+                const int grid = std::max(1, std::min((n1 - n0 + 7) / 8, c->num_cu * 4));
+                k64_pf(pc, grid, st, e0, e1, lc);
+            }
+            for (int cls = 1; cls <= 4; ++cls) {
+                const int n0 = self->lr_class[cls - 1], n1 = self->lr_class[cls];
+                if (n1 <= n0) continue;
+                LrArgs lc = l;
+                lc.col = l.col + n0; lc.p0 = l.p0 + n0; lc.len = l.len + n0; lc.nitems = n1 - n0;
+                hipEvent_t e0 = (cls == first && !started) ? ev_start : nullptr, e1 = (cls == last) ? ev_stop : nullptr;
+                k64_lr(cls, n1 - n0, st, e0, e1, lc);
+            }
+            return 0;
+        }
+    }
+    if (self->nwork > 0 && self->mode == 1) {
+        const FusedArgs &f = self->cur_fused;                        // (all zero outside the fused stateful path)
+        const dim3 grid((unsigned)(self->nwork + (f.gate_host ? 1 : 0) + f.nstat));
+        if (ev_start || ev_stop) hipExtLaunchKernelGGL(k_sample1<K>, grid, dim3(64), 0, st, ev_start, ev_stop, 0, a, f);
+        else hipLaunchKernelGGL(k_sample1<K>, grid, dim3(64), 0, st, a, f);
+    } else if (self->nwork > 0) {
+        // persistent waves: as many single-wave workgroups as the chip holds at this kernel's occupancy
+        const int resident = c->num_cu * 4 * Geo<K>::WPS;
+        const int grid = std::min(self->nwork, env_int("BPMF_HIP_GRID", resident));
+        if constexpr (K == 64) k64_persistent(grid, st, ev_start, ev_stop, a);
+        else launch(k_sample<K>, dim3(grid), dim3(64), a);
+    }
+    return 0;
+    }
+}
+
+template <int K>
+int exchange(bpmf_hip_side *self, hipStream_t st)
+{
+    bpmf_hip_ctx *c = self->ctx;
+    if (!(c->comm != nullptr && !self->bounds.empty())) return 0;
+    if constexpr (K == 128) return fail(BPMF_HIP_EINVAL, "the fp32 path is single-GPU for now");
+    else {
+    // every rank broadcasts the range it just sampled (= all-gather-v of disjoint, uneven
+    // ranges), in place in the replicated factor matrix, on the sampler's stream
+    Rccl *R = rccl();
+    if (!self->conn_send_ptr.empty()) {
+        // connectivity-aware form (c++/assign.cpp:204-241 conn_map + send_item, c++/sample.cpp:370): a column
+        // only travels to the ranks whose ratings / test entries reference it.  Pack the columns of
+        // every peer's list into one buffer, one grouped send / receive per peer, scatter what arrived.
+        const int64_t ns = self->conn_send_ptr.back(), nr = self->conn_recv_ptr.back();
+        constexpr int P = K / 2;                                   // 16-byte pieces per column
+        if (ns > 0)
+            hipLaunchKernelGGL(bpmf::k_pack_cols<K>, dim3((unsigned)((ns * P + 255) / 256)), dim3(256), 0, st,
+                               (const double *)self->d_items, (const int32_t *)self->d_conn_send, ns, self->d_conn_sbuf);
+        NCCL_TRY(R->GroupStart());
+        for (int r = 0; r < c->nranks; ++r) {
+            const int64_t s0 = self->conn_send_ptr[(size_t)r], s1 = self->conn_send_ptr[(size_t)r + 1];
+            const int64_t r0 = self->conn_recv_ptr[(size_t)r], r1 = self->conn_recv_ptr[(size_t)r + 1];
+            if (s1 > s0) NCCL_TRY(R->Send(self->d_conn_sbuf + (size_t)s0 * K, (size_t)(s1 - s0) * K, ncclDouble, r, c->comm, st));
+            if (r1 > r0) NCCL_TRY(R->Recv(self->d_conn_rbuf + (size_t)r0 * K, (size_t)(r1 - r0) * K, ncclDouble, r, c->comm, st));
+        }
+        NCCL_TRY(R->GroupEnd());
+        if (nr > 0)
+            hipLaunchKernelGGL(bpmf::k_unpack_cols<K>, dim3((unsigned)((nr * P + 255) / 256)), dim3(256), 0, st,
+                               (const double *)self->d_conn_rbuf, (const int32_t *)self->d_conn_recv, nr, self->d_items);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    NCCL_TRY(R->GroupStart());
+    for (int r = 0; r < c->nranks; ++r) {
+        const int64_t lo = self->bounds[(size_t)r], hi = self->bounds[(size_t)r + 1];
+        if (hi > lo) {
+            double *p = self->d_items + (size_t)lo * K;
+            NCCL_TRY(R->Broadcast(p, p, (size_t)(hi - lo) * K, ncclDouble, r, c->comm, st));
+        }
+    }
+    NCCL_TRY(R->GroupEnd());
+    return 0;
+    }
+}
+
+template <int K>
+int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_host_dev, unsigned *flag, unsigned seq, unsigned *ticket)
+{
+    using namespace bpmf;
+    bpmf_hip_ctx *c = self->ctx;
+    const unsigned long long *failp = (const unsigned long long *)(d_in + (size_t)K * K + K);
+    if constexpr (K == 128) {                           // fp32 factors, fp64 sums (single GPU)
+        if (c->comm != nullptr && !self->bounds.empty()) return fail(BPMF_HIP_EINVAL, "the fp32 path is single-GPU for now");
+        hipLaunchKernelGGL(k_colstats_f32<K>, dim3(self->nstat_waves), dim3(256), 0, st, reinterpret_cast<const float *>(self->d_items),
+                           self->from, self->to, self->nstat_waves, self->d_stat_partials);
+        hipLaunchKernelGGL(k_colstats_f32_final<K>, dim3((K * K + K + 255) / 256), dim3(256), 0, st,
+                           (const double *)self->d_stat_partials, self->nstat_waves, failp, out_host_dev, ticket, flag, seq);
+        return 0;
+    } else {
+    if (!(c->comm != nullptr && !self->bounds.empty())) {
+        hipLaunchKernelGGL(k_colstats<K>, dim3(self->nstat_waves), dim3(64), 0, st,
+                           (const double *)self->d_items, self->from, self->to, self->nstat_waves, self->d_stat_partials,
+                           failp, out_host_dev, ticket, flag, seq, tmo_word(out_host_dev, K), wait_ticks());
+    } else {
+        // local sums into a device blob, all-reduce them (cov is then formed once from the GLOBAL
+        // sums: SURVEY Q19) together with the failed-column word, publish to the host
+        Rccl *R = rccl();
+        // on the side's own stream: its own reduction blob and the second communicator
+        const bool own = st != c->stream && c->comm2 && self->a_d_red;
+        double *red = own ? self->a_d_red : c->d_red;
+        hipLaunchKernelGGL(k_colstats<K>, dim3(self->nstat_waves), dim3(64), 0, st,
+                           (const double *)self->d_items, self->from, self->to, self->nstat_waves, self->d_stat_partials,
+                           failp, red, ticket, ticket + 8, 0u, tmo_word(out_host_dev, K), wait_ticks());
+        NCCL_TRY(R->AllReduce(red, red, (size_t)K * K + K + 1, ncclDouble, ncclSum, own ? c->comm2 : c->comm, st));   // prod | sum | failed-column word
+        publish(red, out_host_dev, K * K + K + 1, flag, seq, K * K + K, st);
+    }
+    return 0;
+    }
+}
+
+// k_predict on stream `ps` over explicit factor pointers.  in_order: on the main stream behind the
+// samplers.  Otherwise (`beside`): behind ev_in (everything that was on the main stream when the
+// evaluation was requested), with ev_done recorded after it for launch_sampler's hazard check.
+template <int K>
+void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items, const void *other_items, int n,
+                    hipStream_t ps, bool beside)
+{
+    bpmf_hip_ctx *c = self->ctx;
+    unsigned *flag = reinterpret_cast<unsigned *>(t->h_res_dev + 2);
+    const bool dist = c->comm && !self->bounds.empty();
+    t->pstream = ps;
+    if (beside) (void)hipStreamWaitEvent(ps, t->in_ev, 0);
+    // se | se_avg of this rank's test ratings: straight to the host, or -> all-reduce -> host
+    double *red = c->d_red + c->out_words;          // 2 spare words behind the sampler's blob
+    if constexpr (K == 128) {
+        hipLaunchKernelGGL(bpmf::k_predict_f32<K>, dim3((unsigned)t->nblocks), dim3(256), 0, ps,
+                           (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz,
+                           reinterpret_cast<const float *>(self_items), reinterpret_cast<const float *>(other_items), self->from,
+                           self->mean_rating, n, t->d_pavg, t->d_pm2, t->d_partial, t->h_res_dev, t->d_ticket, flag, ++t->seq);
+        (void)red; (void)dist;
+    } else {
+    hipLaunchKernelGGL(bpmf::k_predict<K>, dim3((unsigned)t->nblocks), dim3(256), 0, ps,
+                       (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz,
+                       (const double *)self_items, (const double *)other_items, self->from, self->mean_rating, n,
+                       t->d_pavg, t->d_pm2, t->d_partial, dist ? red : t->h_res_dev, t->d_ticket,
+                       dist ? t->d_ticket + 8 : flag, dist ? 0u : ++t->seq);
+    if (dist) {
+        if (rccl()->AllReduce(red, red, 2, ncclDouble, ncclSum, c->comm, c->stream) != ncclSuccess) return;
+        publish(red, t->h_res_dev, 2, flag, ++t->seq, -1, c->stream);
+    }
+    }
+    if (beside) (void)hipEventRecord(t->ev_done[t->seq & 1u], ps);
+}
+
+}  // namespace bpmf_launch
+
+#define BPMF_INSTANTIATE_K(KK)                                                                                                   \
+    template int bpmf_launch::sampler_into<KK>(bpmf_hip_side *, double *, const bpmf_hip_side *, int, double, double *, hipStream_t, \
+                                               hipEvent_t, hipEvent_t);                                                          \
+    template int bpmf_launch::exchange<KK>(bpmf_hip_side *, hipStream_t);                                                        \
+    template int bpmf_launch::stats<KK>(bpmf_hip_side *, hipStream_t, const double *, double *, unsigned *, unsigned, unsigned *); \
+    template void bpmf_launch::predict<KK>(bpmf_hip_test *, const bpmf_hip_side *, const void *, const void *, int, hipStream_t, bool);
