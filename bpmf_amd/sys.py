@@ -61,11 +61,16 @@ class Sys:
         self.comm = comm
         colptr, rowidx, vals = M
         self.local_nnz = int(colptr[-1])
+        on_device = hasattr(rowidx, "data_ptr")           # torch tensors on the GPU (a matrix generated there): adopted, not copied
         if mean_rating is None:                           # Sys::init, c++/sample.cpp:183 (single rank)
-            mean_rating = float(np.sum(vals)) / max(self.local_nnz, 1)
+            mean_rating = float(vals.sum()) / max(self.local_nnz, 1)
         self.mean_rating = float(mean_rating)
-        self.side = engine.side_create(self._num, self.nrows, colptr, rowidx, vals, self.mean_rating,
-                                       self.dom[0], self.dom[1])
+        if on_device:
+            self.side = engine.side_create_dev(self._num, self.nrows, colptr, rowidx.data_ptr(), vals.data_ptr(), self.mean_rating,
+                                               self.dom[0], self.dom[1], keep=(rowidx, vals))
+        else:
+            self.side = engine.side_create(self._num, self.nrows, colptr, rowidx, vals, self.mean_rating,
+                                           self.dom[0], self.dom[1])
         self.test = None
         self.T_nnz = 0
         if T is not None:

@@ -404,6 +404,17 @@ sample_col(const int K, int64_t idx, const int64_t *colptr, const int32_t *rowid
     return 0;
 }
 
+/* per-thread work buffers (MM | L | r | Lmu_i), kept across calls: the column loop of a half-iteration
+ * is only milliseconds long on a many-core host, so nothing is allocated inside the parallel region */
+static __thread double *tl_buf = NULL;
+static __thread size_t tl_cap = 0;
+static double *thread_buffers(int K)
+{
+    const size_t need = 2 * (size_t)K * K + 2 * (size_t)K;
+    if (tl_cap < need) { free(tl_buf); tl_buf = (double *)malloc(sizeof(double) * need); tl_cap = tl_buf ? need : 0; }
+    return tl_buf;
+}
+
 static inline __attribute__((always_inline)) int64_t
 sample_side_K(const int K, int64_t from, int64_t to, const int64_t *colptr, const int32_t *rowidx,
               const double *vals, double mean_rating, double alpha, const double *other_items,
@@ -425,17 +436,20 @@ sample_side_K(const int K, int64_t from, int64_t to, const int64_t *colptr, cons
     const size_t per = (size_t)K * K + K + 1;
     double *part = (double *)calloc(per * nt, sizeof(double));        /* thread_vector<>, thread_vector.h:62-130 */
 
-#pragma omp parallel num_threads(nt)
+    /* proc_bind(spread): with OMP_PLACES=cores (bench.py's cpu_baseline leg sets it) the threads are
+     * spread over the physical cores of both sockets and stay there, so a thread's slice of `items`
+     * and its partial sums are first-touched on its own NUMA node */
+#pragma omp parallel num_threads(nt) proc_bind(spread)
     {
 #ifdef _OPENMP
         const int tid = omp_get_thread_num();
 #else
         const int tid = 0;
 #endif
-        double *MM = (double *)malloc(sizeof(double) * K * K);
-        double *L = (double *)malloc(sizeof(double) * K * K);
-        double *r = (double *)malloc(sizeof(double) * K);
-        double *Lmu_i = (double *)malloc(sizeof(double) * K);
+        double *MM = thread_buffers(K);
+        double *L = MM + (size_t)K * K;
+        double *r = L + (size_t)K * K;
+        double *Lmu_i = r + K;
         double *pp = part + per * tid, *ps = pp + (size_t)K * K, *pn = ps + K;
 #pragma omp for schedule(guided)
         for (int64_t i = from; i < to; ++i) {                          /* c++/sample.cpp:352-372 */
@@ -466,7 +480,6 @@ sample_side_K(const int K, int64_t from, int64_t to, const int64_t *colptr, cons
             *pn += nn;
             memcpy(items + (size_t)i * K, r, sizeof(double) * K);      /* :324 */
         }
-        free(MM); free(L); free(r); free(Lmu_i);
     }
     for (size_t q = 0; q < per; ++q) {                                  /* combine(): thread-id order */
         double s = 0.0;

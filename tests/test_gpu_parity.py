@@ -403,7 +403,7 @@ def test_sharded_path_over_rccl_single_rank(tmp_path):
     from tests.conftest import ROOT
     env = dict(os.environ, BPMF_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1",
                LOCAL_RANK="0")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-strong", "--repeats", "1", "--prewarm-ms", "0"]
     a = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert a.returncode == 0, a.stderr[-2000:]
     t = subprocess.run(cmd, env=dict(env, BPMF_DIST="torch", MASTER_PORT="29534"), cwd=ROOT, stdout=subprocess.PIPE,
@@ -413,7 +413,7 @@ def test_sharded_path_over_rccl_single_rank(tmp_path):
     o = subprocess.run(cmd, env=dict(env, BPMF_HIP_COMM_STREAMS="1", MASTER_PORT="29535"), cwd=ROOT, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=900)
     assert o.returncode == 0, o.stderr[-2000:]
-    b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
+    b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-strong", "--repeats", "1", "--prewarm-ms", "0"],
                        cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert b.returncode == 0, b.stderr[-2000:]
     pick = lambda out: json.loads([l for l in out.splitlines() if l.startswith('{"metric"')][-1])
@@ -519,7 +519,7 @@ def test_blocking_fallback_paths_give_the_same_chain():
     import subprocess
     import sys
     from tests.conftest import ROOT
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-strong", "--repeats", "1", "--prewarm-ms", "0"]
     pick = lambda out: json.loads([l for l in out.splitlines() if l.startswith('{"metric"')][-1])
     runs = []
     for extra in ({}, {"BPMF_HIP_SPIN_MS": "0"},

@@ -51,9 +51,15 @@ sys.path.insert(0, %r)
 import bpmf_amd
 from tests import util
 M, Mt, T, Tt, nu, nm = util.ml100k()
+from bpmf_amd.sys import Sys
 eng = bpmf_amd.HipEngine(32)
+movies = Sys("movs", eng, M, nm, nu, T=T); users = Sys("users", eng, Mt, nu, nm)
 try:
-    bpmf_amd.gibbs(eng, M, Mt, T, nu, nm, nsims=4, burnin=0)
+    # the pipelined loop of bench.py / the bpmf executable: the next half-iteration of a side is enqueued
+    # while its host worker still owes the hyper-parameters -- the sampler's gate workgroup waits for them
+    for i in range(4):
+        movies.sample(users); users.sample(movies)
+    movies.refresh(); users.refresh()
 except RuntimeError as e:
     print("raised:", e)
     sys.exit(0 if "device wait timed out" in str(e) else 3)
