@@ -21,6 +21,7 @@ import sys
 import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:] = [p for p in sys.path if os.path.abspath(p or ".") != HERE]      # (else `oracle` would resolve to oracle/oracle.py)
 sys.path.insert(0, os.path.dirname(HERE))
 
 import numpy as np  # noqa: E402
