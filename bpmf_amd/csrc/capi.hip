@@ -107,18 +107,18 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     // 0.77 ms per iteration on the ML-1M shape, 4.4 / 6.0 ms at 60 400 x 37 060 x 10 M, 13.5 / 16.5 ms at
     // 300 000 x 100 000 x 20 M, 2.15 / 2.45 ms ChEMBL-shaped -- the persistent form (k_sample) is BPMF_HIP_MODE=0.
     const int mode_env = env_int("BPMF_HIP_MODE", -1);
-    s->mode = mode_env >= 0 ? mode_env : (K <= 32 ? (nloc >= 20000 ? 3 : 1) : 1);
     const bool f32 = s->ctx->dtype == BPMF_HIP_F32;
-    if (f32) s->mode = 2;                                // one workgroup per column (k_sample_wg), no chunking
-    else if (K == 64) {
-        // K = 64 with the blocked factorisation on f64 MFMA tiles (one wave owning all ten tiles) is
-        // opt-in (BPMF_HIP_MODE=2): measured 12.8 ms against 10.5 ms of the persistent form on the
-        // column-dominated ChEMBL shape (the serial phases -- diagonal blocks, triangular solves --
-        // are latency-bound at 6 waves per CU), about equal on ML-1M.  No chunking: not for columns
-        // far above 16 384 ratings.
-        if (mode_env == 2) s->mode = 2;
-    } else if (s->mode == 2) s->mode = K <= 32 ? 1 : 0;                        // (BPMF_HIP_MODE=2 exists for K = 64 only)
-    if (s->mode == 3 && K > 32) s->mode = 0;                                   // (BPMF_HIP_MODE=3, four columns per wave: K <= 32)
+    // K >= 64: the slab form (mode 4, kernels_slab.h: one wave per item, factorisation on the 4x4x4 f64 MFMA).
+    // The earlier forms stay selectable for A/B runs: K = 64: 0 persistent, 1 per item with the lane-per-row
+    // factorisation, 2 one workgroup per column; K = 128: 2 (workgroup per column, fp32 16x16 blocked factorisation).
+    s->mode = mode_env >= 0 ? mode_env : (K <= 32 ? (nloc >= 20000 ? 3 : 1) : 4);
+    // K = 128: the slab form measured slower than the workgroup form (one wave per SIMD cannot hide the gather
+    // latency of a 36-tile Gram, and its 120 KB of straight-line code thrash the instruction cache): opt-in
+    if (f32) s->mode = (mode_env == 4) ? 4 : 2;
+    else if (K == 64) { if (s->mode == 3) s->mode = 4; }
+    else {
+        if (s->mode == 2 || s->mode == 4) s->mode = 1;                             // (BPMF_HIP_MODE=2 / 4 exist for K >= 64 only)
+    }
     const bool wg = s->mode == 2;
     int chunk = wg ? (1 << 30) : env_int("BPMF_HIP_CHUNK", 0);
     if (chunk <= 0) {
@@ -127,9 +127,13 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
         // mode 0: >= 8 work items per SIMD so the tail of the launch stays short.  Lower bound
         // 16 K: a chunk's partial tiles are ~1.3 K^2 doubles written and read back, against 8 K
         // bytes gathered per rating, so shorter chunks make the partials a first-order traffic term.
-        int64_t c = (s->mode == 1 || s->mode == 3) ? (s->nnz * 2) / (simds * 3) : s->nnz / (simds * 8);
+        int64_t c = (s->mode == 0) ? s->nnz / (simds * 8) : (s->nnz * 2) / (simds * 3);
         c = (c + 63) / 64 * 64;
-        chunk = (int)std::min<int64_t>(std::max<int64_t>(c, 16 * K), 65536);   // (upper limit: 10M x 1M shards measured best with 64 K-rating chunks)
+        // slab form: ONE wave walks an item, and a rating costs 36 (K = 128) / 10 (K = 64) tile MFMAs per 4
+        // ratings: a launch lasts (average load of a wave slot) + (longest item), so items must stay short (ML-1M shape,
+        // K = 64: 512-rating chunks 0.208 ms per launch, 256: 0.179)
+        const int64_t lo = s->mode == 4 ? 256 : 16 * K;
+        chunk = (int)std::min<int64_t>(std::max<int64_t>(c, lo), 65536);   // (upper limit: 10M x 1M shards measured best with 64 K-rating chunks)
         // four columns per wave: a wave holds four items (and a chunk's partial is a quarter of the
         // size), so the same work per wave means chunks of a quarter of the length
         if (s->mode == 3) chunk = std::max(chunk / 4, 4 * K);
@@ -176,7 +180,7 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
 
     s->nwork = (int)nw; s->nmulti = (int)mc_slot0.size(); s->nslots = slots;
     int rc;
-    if (K == 64 && !f32 && (s->mode == 0 || s->mode == 1)) {
+    if (K == 64 && !f32 && (s->mode == 0 || s->mode == 1 || s->mode == 4)) {
         // Low-rank form for the columns with at most BPMF_HIP_LOWRANK_MAX ratings (default 6; 0: off):
         // worth a second launch when they are at least half of the side (ChEMBL-shaped compounds)
         const int nlr = std::min(env_int("BPMF_HIP_LOWRANK_MAX", 12), 32);
@@ -226,6 +230,7 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
         // column statistics: <= 128 workgroups, each writing one partial of K*K + K doubles
         s->nstat_waves = (int)std::max<int64_t>(1, std::min<int64_t>((nloc + 15) / 16, 128));
         if ((rc = dev_upload<double>(&s->d_stat_partials, nullptr, (size_t)s->nstat_waves * ((size_t)K * K + K)))) return rc;
+        if ((rc = dev_upload<double>(&s->d_partials, nullptr, (size_t)slots * part_words_rt(K)))) return rc;     // chunks of heavy columns (slab form)
         return 0;
     }
     const size_t pw = part_words_rt(K);
@@ -658,7 +663,7 @@ extern "C" int bpmf_hip_sample_side_launch(bpmf_hip_side *self, const bpmf_hip_s
     HIP_TRY(hipSetDevice(c->device));
     { const int rs = settle_async(self); if (rs) return rs; }
     if (self->saux) HIP_TRY(hipStreamSynchronize(self->saux));
-    fill_blob(K, mu, LambdaF, c->h_in, K == 64 && c->dtype == BPMF_HIP_F64);
+    fill_blob(K, mu, LambdaF, c->h_in, K == 64 && c->dtype == BPMF_HIP_F64 && self->lr_n > 0);
     bpmf_launch::stage(c->h_in_dev, c->d_in, (int)c->in_words, c->stream);
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     c->last_sampler_done = nullptr;
@@ -802,7 +807,7 @@ int draw_and_release(bpmf_hip_side *s, int iter, double *mu, double *LU, double 
         if (!rc) s->rd_iter = iter;
     }
     if (!rc) rc = bpmf_hyper_finish(K, s->ncols, s->cov.data(), nullptr, s->rd_au.data(), s->rd_z.data(), mu, LU, LF);
-    if (!rc) fill_blob(K, mu, LF, s->a_h_in, K == 64 && s->ctx->dtype == BPMF_HIP_F64);
+    if (!rc) fill_blob(K, mu, LF, s->a_h_in, K == 64 && s->ctx->dtype == BPMF_HIP_F64 && s->lr_n > 0);   // (R0, R0^-1: only the low-rank forms read them)
     // the gate is opened even after an error: a sampler may already be queued behind it and must
     // not be left spinning (its results are never looked at: the error is reported first)
     {   // test hook: a host worker that is descheduled for a while (SIGSTOP, debugger, oversubscription)
@@ -879,6 +884,10 @@ void collect(bpmf_hip_side *s, const bpmf_hip_side::Job &job)
     trace("collect: gate of the next half-iteration opened", s, job.iter);
     if (!rc && rd) { rc = rd; msg = g_err; }
     if (!rc) s->nx_iter = job.iter + 1;
+    // the gate is open: NOW, while the device samples the other side and then this one, draw the random part
+    // of the draw after next (it depends on nothing but the counter).  At the head of collect() it sat between
+    // "sampler enqueued" and "sums landed": at K = 64 it takes longer than the sampler itself
+    if (!rc && bpmf_hyper_draws(K, s->ncols, (uint32_t)(job.iter + 2), s->rd_au.data(), s->rd_z.data()) == 0) s->rd_iter = job.iter + 2;
     {   // kernel times of this launch (its events are complete: the flag is published behind them)
         float a = 0.f, b = 0.f;
         const bool own_stats = s->stats_ev[job.evset].load(std::memory_order_acquire) == ev[2];   // else: inside another launch

@@ -1,0 +1,13 @@
+// k64_slab.hip -- K = 64 fp64: one wave per column, slab Cholesky on the 4x4x4 f64 MFMA (the default form) (see launch.h)
+#include "launch.h"
+#include "kernels_slab.h"
+
+namespace bpmf_launch {
+
+void k64_slab(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a)
+{
+    if (e0 || e1) hipExtLaunchKernelGGL((bpmf::k_sample_slab<64, double>), dim3(grid), dim3(64), 0, st, e0, e1, 0, a);
+    else hipLaunchKernelGGL((bpmf::k_sample_slab<64, double>), dim3(grid), dim3(64), 0, st, a);
+}
+
+}  // namespace bpmf_launch

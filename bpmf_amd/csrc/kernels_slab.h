@@ -1,0 +1,487 @@
+// kernels_slab.h -- k_sample_slab<K, T>: the column update for K = 64 (fp64 factors) and K = 128
+// (fp32 factors), one wave per work item, the whole factorisation on v_mfma_f64_4x4x4_4b_f64.
+//
+// Reference: Sys::sample(long idx, Sys&) + computeMuLambda, c++/sample.cpp:248-336.
+//
+// Why: at K >= 64 a column spent ~60 k cycles (K = 64, finish_single: one lane per row, ~10 % lane
+// efficiency) or ~60 us (K = 128: 128 sequential 16-wide pivots, one-thread-per-column panel solves)
+// in a factorisation that is only K^3 / 3 flops.  Here Lambda* lives in registers as 4-row SLABS:
+//
+//     slab (I, q), lane l  <->  Lambda*[4 I + (l >> 4)][16 q + (l & 15)]          I < K/4, q >= I/4
+//
+// which is at the same time (a) the accumulator layout of v_mfma_f64_16x16x4_f64 -- register `reg` of
+// the 16x16 Gram tile (TI, TJ) IS slab (4 TI + reg, TJ), so the Gram hands its registers over as
+// they are -- and (b) four 4x4 blocks (I, 4 q + b), b = 0..3, in the result layout of the 4x4x4
+// shape.  Blocked right-looking Cholesky Lambda* = R^T R with 4x4 blocks (the scheme of k_sample4,
+// kernels_q4.h, with the four blocks of an instruction now four block COLUMNS of one matrix):
+//   * the 4x4 diagonal block arrives through v_readlane, is factored and inverted redundantly by
+//     every lane (four 1/sqrt);
+//   * panel  R_sJ = W^T A_sJ : one MFMA per slab of block row s;
+//   * the block row is published to LDS (4 x K doubles); the A operand of the trailing update
+//     A_IJ -= R_sI^T R_sJ is read back from there already in operand layout (one 8-byte LDS read per
+//     row block I, broadcast over b), the B operand is the slab register as it is;
+//   * the rhs rides along as one more block column (forward solve, c++/sample.cpp:321);
+//   * backward solve (:323): the blocks of R are needed untransposed (one cross-lane permute per slab),
+//     the four blocks of an instruction are four column blocks of the SAME row, their partial sums
+//     are added with two DPP row rotates.
+// Natural 4-index blocks: R is THE Cholesky factor of the reference's Lambda* in the reference's
+// order, so x = R^-1 (R^-T b + z) is the reference's sample for the same z.
+// K = 128 keeps factors and Gram in fp32 (v_mfma_f32_16x16x4_f32) as the "fp32 large-K path" is defined
+// (BASELINE configs[4]); the 36 tiles are widened into fp64 slabs once per column and factorised in fp64.
+// Heavy columns are cut into chunks like everywhere else (partials in tile layout, last arriver adds).
+#pragma once
+#include "kernels.h"
+#include "kernels_f32.h"
+
+namespace bpmf {
+
+template <int K>
+struct GeoS {
+    static constexpr int NG = K / 4;                      // 4-row blocks
+    static constexpr int NQ = K / 16;                     // 16-column slabs per row block
+    static constexpr int NT = K / 16;
+    static constexpr int NTRI = NT * (NT + 1) / 2;
+    __host__ __device__ static constexpr int roff(int I) { int n = 0; for (int t = 0; t < I; ++t) n += NQ - (t >> 2); return n; }
+    static constexpr int NREG = roff(NG);                 // slabs kept: q >= I / 4
+    __host__ __device__ static constexpr int reg(int I, int q) { return roff(I) + q - (I >> 2); }
+    static constexpr int LDR = K + 2;                     // row stride of the published block row (doubles)
+    // LDS: z [K] | rhs [K] | block row [4][LDR] | inverted diagonal blocks [NG][16] | (fp32 path) one 16 x 17 tile
+    static constexpr int LDS_WORDS = 2 * K + 4 * LDR + 16 * NG + (K == 128 ? 16 * 17 / 2 + 8 : 0);
+    // doubles in the partial of one chunk of a heavy column (tile layout)
+    static constexpr int PART = K == 128 ? (NTRI * 256 + NT * 16) / 2 : NREG * 64 + NT * 16;
+    static constexpr int WPS = K == 64 ? 2 : 1;
+};
+
+// W = R_ss^-1 of a 4x4 SPD block given by its 10 upper entries (wave-uniform values): returns the
+// operand registers of k_sample4's scheme -- WA: lane (k, b, i) holds W[k][i] (A operand "W^T"),
+// WB: lane (k, b, i) holds W[i][k] (A operand "W").
+__device__ __forceinline__ void factor_block44(double d00, double d01, double d02, double d03, double d11, double d12, double d13,
+                                               double d22, double d23, double d33, int kq, int x, double &WA, double &WB)
+{
+    const double i0 = rsqrt_nr(d00);
+    const double R01 = d01 * i0, R02 = d02 * i0, R03 = d03 * i0;
+    const double e11 = fma(-R01, R01, d11);
+    const double i1 = rsqrt_nr(e11);
+    const double R12 = fma(-R01, R02, d12) * i1, R13 = fma(-R01, R03, d13) * i1;
+    const double e22 = fma(-R12, R12, fma(-R02, R02, d22));
+    const double i2 = rsqrt_nr(e22);
+    const double R23 = fma(-R12, R13, fma(-R02, R03, d23)) * i2;
+    const double e33 = fma(-R23, R23, fma(-R13, R13, fma(-R03, R03, d33)));
+    const double i3 = rsqrt_nr(e33);
+    const double W01 = -i0 * R01 * i1, W12 = -i1 * R12 * i2, W23 = -i2 * R23 * i3;
+    const double W02 = -i0 * fma(R01, W12, R02 * i2);
+    const double W13 = -i1 * fma(R12, W23, R13 * i3);
+    const double W03 = -i0 * fma(R01, W13, fma(R02, W23, R03 * i3));
+    auto pick = [&](int p, int q) -> double {
+        double v = 0.0;
+        v = (p == 0 && q == 0) ? i0 : v; v = (p == 1 && q == 1) ? i1 : v; v = (p == 2 && q == 2) ? i2 : v; v = (p == 3 && q == 3) ? i3 : v;
+        v = (p == 0 && q == 1) ? W01 : v; v = (p == 0 && q == 2) ? W02 : v; v = (p == 0 && q == 3) ? W03 : v;
+        v = (p == 1 && q == 2) ? W12 : v; v = (p == 1 && q == 3) ? W13 : v; v = (p == 2 && q == 3) ? W23 : v;
+        return v;
+    };
+    WA = pick(kq, x);
+    WB = pick(x, kq);
+}
+
+// value of quad b' of every row of 16 lanes, in all four quads of the row (ds_swizzle, bit mode: no LDS memory)
+template <int BQ>
+__device__ __forceinline__ double quad_splat(double v)
+{
+    constexpr int PAT = 0x13 | (BQ << 7);                            // lane' = (lane & 0b10011) | (BQ << 2), per group of 32 lanes
+    const long long w = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_ds_swizzle((int)w, PAT), hi = __builtin_amdgcn_ds_swizzle((int)(w >> 32), PAT);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Gram of one chunk straight into the slabs, on the 4x4x4 shape (fp64, K = 64): per group of 4 ratings
+// (k = lane >> 4 picks the rating) the B operand of slab column q is the gathered register itself --
+// lane (k, c) holds u_k[16 q + c] -- and the A operand of row block I is quad I & 3 of register I >> 2
+// splatted over the four quads (u_k[4 I + i] for every b).  40 instructions of ~18 cycles per 4 ratings
+// instead of 10 of ~105-130 (v_mfma_f64_16x16x4_f64 at two waves per SIMD).
+template <int K>
+__device__ __forceinline__ void gram_slab(const int32_t *__restrict__ rowidx, const double *__restrict__ vals, int len,
+                                          const double *__restrict__ other, const double *__restrict__ zero_row, double mean, double alpha,
+                                          double (&A)[GeoS<K>::NREG], double (&r)[K / 16], int lane)
+{
+    using G = GeoS<K>;
+    constexpr int NT = K / 16, NG = G::NG;
+    const int kq = lane >> 4, li = lane & 15;
+    if (len <= 0) return;
+    // index blocks of 64 ratings (lane l holds rating b0 + l): the current one and the next one
+    int ri = (lane < len) ? rowidx[lane] : -1;
+    double wv = (lane < len) ? (vals[lane] - mean) * alpha : 0.0;                // c++/sample.cpp:256
+    int ri_n = (64 + lane < len) ? rowidx[64 + lane] : -1;
+    double wv_n = (64 + lane < len) ? (vals[64 + lane] - mean) * alpha : 0.0;
+    // Group st of the block (4 ratings, k = lane >> 4 picks one); st = 16..18 are the first groups of the NEXT
+    // block: the gathers run THREE groups ahead of the MFMAs, across block boundaries too (one group of
+    // 40 MFMAs is ~700 cycles, an L2 hit under load about as much: one group ahead left 57 % of the wave
+    // cycles waiting).  No control flow around the loads -- the compiler's s_waitcnt counts stay exact --
+    // and slots beyond the end of the chunk gather a row of zeros.
+    auto gather = [&](int st, double (&yy)[NT], double &ww) {
+        const bool nx = st >= 16;
+        const int src = ((st & 15) * 4 + kq);
+        const int row = __shfl(nx ? ri_n : ri, src);
+        ww = __shfl(nx ? wv_n : wv, src);
+        const double *u = ((row >= 0) ? other + (size_t)row * K : zero_row) + li;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) yy[t] = u[16 * t];
+    };
+    auto contract = [&](const double (&yy)[NT], double ww) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) r[t] = fma(yy[t], ww, r[t]);
+#pragma unroll
+        for (int I = 0; I < NG; ++I) {
+            double aI;
+            switch (I & 3) {
+            case 0: aI = quad_splat<0>(yy[I >> 2]); break;
+            case 1: aI = quad_splat<1>(yy[I >> 2]); break;
+            case 2: aI = quad_splat<2>(yy[I >> 2]); break;
+            default: aI = quad_splat<3>(yy[I >> 2]); break;
+            }
+#pragma unroll
+            for (int q = I >> 2; q < NT; ++q) A[G::reg(I, q)] = mfma44(aI, yy[q], A[G::reg(I, q)]);
+        }
+    };
+    double y0[NT], y1[NT], y2[NT], y3[NT], w0, w1, w2, w3;
+    gather(0, y0, w0);
+    gather(1, y1, w1);
+    gather(2, y2, w2);
+    for (int b0 = 0; b0 < len; b0 += 64) {
+        const int nsteps = (len - b0 >= 64) ? 16 : ((len - b0 + 15) >> 4) * 4;   // groups of this block, rounded up to 4
+        for (int st = 0; st < nsteps; st += 4) {
+            gather(st + 3, y3, w3);
+            contract(y0, w0);
+            gather(st + 4, y0, w0);
+            contract(y1, w1);
+            gather(st + 5, y1, w1);
+            contract(y2, w2);
+            gather(st + 6, y2, w2);
+            contract(y3, w3);
+        }
+        // next block: its first three groups are in flight already
+        ri = ri_n; wv = wv_n;
+        const int q = b0 + 128 + lane;
+        ri_n = (q < len) ? rowidx[q] : -1;
+        wv_n = (q < len) ? (vals[q] - mean) * alpha : 0.0;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        r[t] += __shfl_xor(r[t], 16);
+        r[t] += __shfl_xor(r[t], 32);
+    }
+}
+
+// Lambda* (slabs A) and the rhs in, the sample out.  The rhs is PACKED like a slab column: bv[Q], lane
+// (i, b, j = 0) holds element 16 Q + 4 b + i (four row blocks per register, zero in the columns j > 0).
+// sz: the K normals; srow: 4 x LDR doubles of LDS (published block row); sw: NG x 16 doubles of LDS
+// (the inverted diagonal blocks, for the backward solve).  Single wave.
+template <int K>
+__device__ __forceinline__ void slab_cholesky_solve(double (&A)[GeoS<K>::NREG], double (&bv)[K / 16], const double *sz, double *srow, double *sw,
+                                                    int lane)
+{
+    using G = GeoS<K>;
+    constexpr int NG = G::NG, NQ = G::NQ, LDR = G::LDR;
+    const int kq = lane >> 4, b = (lane >> 2) & 3, x = lane & 3, c16 = lane & 15;
+#pragma unroll
+    for (int s = 0; s < NG; ++s) {
+        const int q0 = s >> 2, b0 = s & 3;
+        // the 10 upper entries of the diagonal block: entry (p, q) sits in lane 16 p + 4 b0 + q of slab (s, q0)
+        const double dblk = A[G::reg(s, q0)];
+        const double d00 = bcast(dblk, 4 * b0 + 0), d01 = bcast(dblk, 4 * b0 + 1), d02 = bcast(dblk, 4 * b0 + 2), d03 = bcast(dblk, 4 * b0 + 3),
+                     d11 = bcast(dblk, 16 + 4 * b0 + 1), d12 = bcast(dblk, 16 + 4 * b0 + 2), d13 = bcast(dblk, 16 + 4 * b0 + 3),
+                     d22 = bcast(dblk, 32 + 4 * b0 + 2), d23 = bcast(dblk, 32 + 4 * b0 + 3), d33 = bcast(dblk, 48 + 4 * b0 + 3);
+        double WA, WB;
+        factor_block44(d00, d01, d02, d03, d11, d12, d13, d22, d23, d33, kq, x, WA, WB);
+        if (b == 0) sw[16 * s + 4 * kq + x] = WB;                     // W_s as the A operand of the backward solve
+        // forward solve of this block row: y_s = W^T b_s (block b0 of bv[q0]); y_s in every b as a B operand
+        const double ys_all = mfma44(WA, bv[q0], 0.0);
+        bv[q0] = (b == b0) ? ys_all : bv[q0];
+        double ys = (b == b0) ? ys_all : 0.0;
+        ys = row_ror_add<0x124>(ys);
+        ys = row_ror_add<0x128>(ys);
+        // panel: R_sJ = W^T A_sJ (the block J = s becomes R_ss, blocks J < s of the first slab are never read again)
+#pragma unroll
+        for (int q = q0; q < NQ; ++q) A[G::reg(s, q)] = mfma44(WA, A[G::reg(s, q)], 0.0);
+        if (s + 1 < NG) {
+            // rhs: b_J -= R_sJ^T y_s for J > s -- the slab of block row s IS the A operand (four J per instruction)
+#pragma unroll
+            for (int q = q0; q < NQ; ++q) {
+                if (q == q0 && b0 == 3) continue;
+                const double nR = (q == q0 && b <= b0) ? 0.0 : -A[G::reg(s, q)];
+                bv[q] = mfma44(nR, ys, bv[q]);
+            }
+            // publish block row s; the A operand of row block I: lane (k, b, i) <- R[4 s + k][4 I + i]
+#pragma unroll
+            for (int q = q0; q < NQ; ++q) srow[kq * LDR + 16 * q + c16] = A[G::reg(s, q)];
+            __syncthreads();
+#pragma unroll
+            for (int I = s + 1; I < NG; ++I) {
+                const double nI = -srow[kq * LDR + 4 * I + x];
+#pragma unroll
+                for (int q = I >> 2; q < NQ; ++q) A[G::reg(I, q)] = mfma44(nI, A[G::reg(s, q)], A[G::reg(I, q)]);   // A_IJ -= R_sI^T R_sJ
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- y += z (:322); backward solve R x = y (:323).  bv[q] doubles as the B operand "x": lane (k, b, 0) = x[16 q + 4 b + k]
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) bv[q] += (x == 0) ? sz[16 * q + 4 * b + kq] : 0.0;
+    const int tsrc = 16 * x + 4 * b + kq;                             // lane holding the transposed entry of a block
+#pragma unroll
+    for (int s = NG - 1; s >= 0; --s) {
+        const int q0 = s >> 2, b0 = s & 3;
+        // sum_{J > s} R_sJ x_J: block b of slab q is J = 4 q + b
+        double part = 0.0;
+#pragma unroll
+        for (int q = q0; q < NQ; ++q) {
+            if (q == q0 && b0 == 3) continue;                         // (nothing solved in this slab yet)
+            const double RT = __shfl(A[G::reg(s, q)], tsrc);          // R_s,4q+b untransposed as the A operand
+            const double xq = (q == q0 && b <= b0) ? 0.0 : bv[q];     // the solved part of x
+            part = mfma44(RT, xq, part);
+        }
+        double tot = row_ror_add<0x124>(part);                        // + b rotated by 1
+        tot = row_ror_add<0x128>(tot);                                // + rotated by 2: all four b, in every b
+        const double t = bv[q0] - tot;                                // (block b0 is the one that counts)
+        const double WB = sw[16 * s + 4 * kq + x];
+        const double xs = mfma44(WB, t, 0.0);                         // x_s = W_s t
+        bv[q0] = (b == b0) ? xs : bv[q0];
+    }
+}
+
+template <int K, typename T>
+__global__ __launch_bounds__(64, GeoS<K>::WPS) void k_sample_slab(SampleArgs a)
+{
+    using G = GeoS<K>;
+    constexpr int NG = G::NG, NQ = G::NQ, NT = G::NT, NTRI = G::NTRI, NREG = G::NREG;
+    constexpr bool F32 = sizeof(T) == 4;
+    __shared__ __attribute__((aligned(16))) double lds[G::LDS_WORDS];
+    double *sz = lds, *sb = lds + K, *srow = lds + 2 * K, *sw = srow + 4 * G::LDR;
+    const int lane = threadIdx.x;
+    const int kq = lane >> 4, li = lane & 15, x = lane & 3;
+    const int w = blockIdx.x;
+    const int col = a.wi_col[w];
+    const int64_t p0 = a.wi_p0[w];
+    const int len = (a.ablate & 2u) ? 0 : a.wi_len[w];             // (profiling switch: no Gram)
+    const int mc = a.wi_mc[w];
+    const int64_t idx = a.col_from + col;
+    const T *other = reinterpret_cast<const T *>(a.other_items);
+
+    // whole column in one item: its normals do not depend on the Gram -- drawn first, in the shadow of the first loads
+    if (mc < 0) draw_normals_deferred<K>(sample_counter<K>(idx, a.iter_plus_1), K, sz, srow, lane);
+
+    double A[NREG];
+    double rsum[NT];                                                  // rr[16 t + li] (all kq)
+    if constexpr (!F32) {
+#pragma unroll
+        for (int t = 0; t < NREG; ++t) A[t] = 0.0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) rsum[t] = 0.0;
+        gram_slab<K>(a.rowidx + p0, a.vals + p0, len, a.other_items, a.zero_row, a.mean_rating, a.alpha, A, rsum, lane);
+        if (mc >= 0) {
+            // chunk of a heavy column: park the slabs; whichever chunk arrives last adds them up (chunk order)
+            constexpr int PART = G::PART;
+            const int nch = a.mc_nchunks[mc];
+            double *pbase = a.partials + (size_t)a.mc_slot0[mc] * PART;
+            double *p = pbase + (size_t)a.wi_chunk[w] * PART;
+#pragma unroll
+            for (int t = 0; t < NREG; ++t) __hip_atomic_store(&p[t * 64 + lane], A[t], BPMF_RLX_AGENT);
+            if (lane < 16) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) __hip_atomic_store(&p[NREG * 64 + t * 16 + lane], rsum[t], BPMF_RLX_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned tk = 0;
+            if (lane == 0) tk = __hip_atomic_fetch_add(&a.mc_count[mc], 1u, BPMF_RLX_AGENT);
+            tk = __builtin_amdgcn_readfirstlane(tk);
+            if ((int)tk != nch - 1) return;
+            if (lane == 0) __hip_atomic_store(&a.mc_count[mc], 0u, BPMF_RLX_AGENT);
+#pragma unroll
+            for (int t = 0; t < NREG; ++t) A[t] = 0.0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) rsum[t] = 0.0;
+            for (int ch = 0; ch < nch; ++ch) {                        // fixed chunk order: deterministic
+                const double *pc = pbase + (size_t)ch * PART;
+                double tmp[NREG];
+#pragma unroll
+                for (int t = 0; t < NREG; ++t) tmp[t] = __hip_atomic_load(&pc[t * 64 + lane], BPMF_RLX_AGENT);
+#pragma unroll
+                for (int t = 0; t < NREG; ++t) A[t] += tmp[t];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) rsum[t] += __hip_atomic_load(&pc[NREG * 64 + t * 16 + li], BPMF_RLX_AGENT);
+            }
+            draw_normals_deferred<K>(sample_counter<K>(idx, a.iter_plus_1), K, sz, srow, lane);
+        }
+    } else {
+        // fp32 Gram on v_mfma_f32_16x16x4_f32: D[i = 4 (lane / 16) + reg][j = lane % 16]
+        f4 acc[NTRI];
+        float r[NT];
+#pragma unroll
+        for (int t = 0; t < NTRI; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) r[t] = 0.f;
+        {
+            const int32_t *rowidx = a.rowidx + p0;
+            const double *vals = a.vals + p0;
+            int ri_n = (lane < len) ? rowidx[lane] : -1;
+            float wv_n = (lane < len) ? (float)((vals[lane] - a.mean_rating) * a.alpha) : 0.f;      // c++/sample.cpp:256
+            for (int b0 = 0; b0 < len; b0 += 64) {
+                const int ri = ri_n;
+                const float wv = wv_n;
+                if (b0 + 64 < len) {                                  // wave-uniform
+                    const int q = b0 + 64 + lane;
+                    ri_n = (q < len) ? rowidx[q] : -1;
+                    wv_n = (q < len) ? (float)((vals[q] - a.mean_rating) * a.alpha) : 0.f;
+                }
+                const int ngroups = (len - b0 >= 64) ? 4 : (len - b0 + 15) >> 4;
+                float y[4][NT], yn[4][NT], ww[4], wn[4];
+                auto gather = [&](int gg, float (&yy)[4][NT], float (&w1)[4]) {
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+                        const int src = (gg * 4 + st) * 4 + kq;
+                        const int row = __shfl(ri, src);
+                        w1[st] = __shfl(wv, src);
+                        const float *u = other + (size_t)(row >= 0 ? row : 0) * K + li;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) yy[st][t] = (row >= 0) ? u[16 * t] : 0.f;
+                    }
+                };
+                gather(0, y, ww);
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    if (gg >= ngroups) break;                         // wave-uniform
+                    const bool more = gg + 1 < ngroups;
+                    if (gg < 3 && more) gather(gg + 1, yn, wn);
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) r[t] = fmaf(y[st][t], ww[st], r[t]);
+                        int tri = 0;
+#pragma unroll
+                        for (int I = 0; I < NT; ++I)
+#pragma unroll
+                            for (int J = I; J < NT; ++J, ++tri)
+                                acc[tri] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[st][I], y[st][J], acc[tri], 0, 0, 0);
+                    }
+                    if (gg < 3 && more) {
+#pragma unroll
+                        for (int st = 0; st < 4; ++st) {
+                            ww[st] = wn[st];
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) y[st][t] = yn[st][t];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                r[t] += __shfl_xor(r[t], 16);
+                r[t] += __shfl_xor(r[t], 32);
+            }
+        }
+        if (mc >= 0) {
+            constexpr int PART = G::PART;                             // in doubles; the partial itself is floats
+            const int nch = a.mc_nchunks[mc];
+            float *pbase = reinterpret_cast<float *>(a.partials + (size_t)a.mc_slot0[mc] * PART);
+            float *p = pbase + (size_t)a.wi_chunk[w] * (2 * PART);
+#pragma unroll
+            for (int t = 0; t < NTRI; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) __hip_atomic_store(&p[(t * 4 + reg) * 64 + lane], acc[t][reg], BPMF_RLX_AGENT);
+            if (lane < 16) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) __hip_atomic_store(&p[NTRI * 256 + t * 16 + lane], r[t], BPMF_RLX_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned tk = 0;
+            if (lane == 0) tk = __hip_atomic_fetch_add(&a.mc_count[mc], 1u, BPMF_RLX_AGENT);
+            tk = __builtin_amdgcn_readfirstlane(tk);
+            if ((int)tk != nch - 1) return;
+            if (lane == 0) __hip_atomic_store(&a.mc_count[mc], 0u, BPMF_RLX_AGENT);
+#pragma unroll
+            for (int t = 0; t < NTRI; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) r[t] = 0.f;
+            for (int ch = 0; ch < nch; ++ch) {
+                const float *pc = pbase + (size_t)ch * (2 * PART);
+#pragma unroll
+                for (int t = 0; t < NTRI; ++t)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) acc[t][reg] += __hip_atomic_load(&pc[(t * 4 + reg) * 64 + lane], BPMF_RLX_AGENT);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) r[t] += __hip_atomic_load(&pc[NTRI * 256 + t * 16 + li], BPMF_RLX_AGENT);
+            }
+            draw_normals_deferred<K>(sample_counter<K>(idx, a.iter_plus_1), K, sz, srow, lane);
+        }
+        // widen: tile element (4 kq + reg, li) -> slab m lane (kq', li) = tile element (4 m + kq', li), through a 16 x 17 LDS tile
+        float *stile = reinterpret_cast<float *>(sw + 16 * NG);
+        int tri = 0;
+#pragma unroll
+        for (int TI = 0; TI < NT; ++TI)
+#pragma unroll
+            for (int TJ = TI; TJ < NT; ++TJ, ++tri) {
+                __syncthreads();
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) stile[(4 * kq + reg) * 17 + li] = acc[tri][reg];
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < 4; ++m) A[G::reg(4 * TI + m, TJ)] = (double)stile[(4 * m + kq) * 17 + li];
+            }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) rsum[t] = (double)r[t];
+    }
+
+    if (a.ablate & 1u) {                                              // (profiling switch: Gram only -- keep it live)
+        double v = rsum[0];
+#pragma unroll
+        for (int t = 0; t < NREG; ++t) v += A[t];
+        if (lane < K) reinterpret_cast<T *>(a.items)[(size_t)idx * K + lane] = (T)v;
+        return;
+    }
+    wait_params(a);
+    // ---- Lambda* = LambdaF + alpha G (:297-298); b = LambdaF mu + rr (:285,:256)
+    const double *LF = a.prop_lambda ? a.prop_lambda + (size_t)col * K * K : a.LambdaF;
+#pragma unroll
+    for (int I = 0; I < NG; ++I)
+#pragma unroll
+        for (int q = I >> 2; q < NQ; ++q) {
+            const int r_ = 4 * I + kq, c_ = 16 * q + li;
+            double v = fma(a.alpha, A[G::reg(I, q)], LF[r_ + (size_t)c_ * K]);
+            if (a.diag_only && r_ != c_) v = 0.0;                    // BPMF_NO_COVARIANCE (:300-304)
+            A[G::reg(I, q)] = v;
+        }
+    if (kq == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            double lm = a.Lmu[16 * t + li];
+            if (a.prop_lambda) {                                      // rr = Lambda_i * hp.mu (:285)
+                lm = 0.0;
+                for (int j = 0; j < K; ++j) lm = fma(LF[16 * t + li + (size_t)j * K], a.mu[j], lm);
+            }
+            sb[16 * t + li] = lm + rsum[t];
+        }
+    }
+    __syncthreads();                                                  // rhs and normals are in LDS
+    const int b = (lane >> 2) & 3;
+    double bv[NQ];                                                    // packed rhs: lane (i, b, 0) holds element 16 q + 4 b + i
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) bv[q] = (x == 0) ? sb[16 * q + 4 * b + kq] : 0.0;
+
+    slab_cholesky_solve<K>(A, bv, sz, srow, sw, lane);
+
+    // ---- items().col(idx) = rr (:324): through LDS for one coalesced store; a failed factorisation (:308) shows as a non-finite sample
+    bool bad = false;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        bad |= !(fabs(bv[q]) <= 1.79769313486231570815e+308);
+        if (x == 0) sb[16 * q + 4 * b + kq] = bv[q];
+    }
+    __syncthreads();
+    T *dst = reinterpret_cast<T *>(a.items) + (size_t)idx * K;
+    for (int i = lane; i < K; i += 64) dst[i] = (T)sb[i];
+    bad = bad && x == 0;
+    if (__any(bad) && lane == 0) atomicMin(a.fail, (unsigned long long)idx);
+}
+
+}  // namespace bpmf

@@ -26,6 +26,10 @@ void k64_wg(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::
 void k64_lr(int width, int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::LrArgs &a);     // sweep width 1..4
 void k64_pf(int cls, int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::LrArgs &a);       // class 0..2: <= 2 | 6 | 12 ratings
 
+// slab form (kernels_slab.h): K = 64 fp64 and K = 128 fp32 factors, one wave per work item
+void k64_slab(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a);
+void k128_slab(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a);
+
 // kernels that do not depend on K (kcommon.hip)
 void stage(const double *src_host_dev, double *dst, int n, hipStream_t st);
 void gate_stage(int nblocks, const unsigned *gate_host_dev, unsigned want, const double *src_host_dev, double *dst, int n,

@@ -52,9 +52,8 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
         }
     };
     if constexpr (K == 128) {
-        launch_wg(0.0f);
-        return 0;
-    } else {
+        if (self->mode == 2) { launch_wg(0.0f); return 0; }
+    }
     if constexpr (K == 64) {
         if (self->mode == 2) { launch_wg(0.0); return 0; }
     }
@@ -72,6 +71,10 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
     a.gate_flag = self->cur_gate_flag; a.gate_want = self->cur_gate_want;
     a.tmo = self->cur_gate_flag ? tmo_word(self->a_h_out_dev, K) : nullptr; a.wait_ticks = wait_ticks();
     a.zero_row = c->d_zero;
+    if constexpr (K == 128) {                                        // slab form, fp32 factors (items / other_items are float arrays)
+        if (self->nwork > 0) k128_slab(self->nwork, st, ev_start, ev_stop, a);
+        return 0;
+    } else {
     if constexpr (K <= 32) {
         if (self->nwork > 0 && self->mode == 3) {                    // four columns per wave (k_sample4)
             launch(k_sample4<K>, dim3((self->nwork + 3) / 4), dim3(64), a);
@@ -79,12 +82,14 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
         }
     }
     if constexpr (K == 64) {
-        if (self->lr_n > 0 && !self->d_prop && !c->diag_only && !c->ablate) {
+        if (self->lr_n > 0 && !self->d_prop && !c->diag_only && !(c->ablate & 3u)) {
             // light columns: rank-n update of the shared factor of LambdaF (k_sample_lr); the others as usual
             if (self->hv_nwork > 0) {
                 a.wi_col = self->d_hv_col; a.wi_p0 = self->d_hv_p0; a.wi_len = self->d_hv_len; a.wi_mc = self->d_hv_mc;
                 a.wi_chunk = self->d_hv_chunk; a.nwork = self->hv_nwork;
-                if (self->mode == 1) {
+                if (self->mode == 4) {
+                    k64_slab(self->hv_nwork, st, ev_start, nullptr, a);
+                } else if (self->mode == 1) {
                     const FusedArgs f0{};
                     if (ev_start) hipExtLaunchKernelGGL(k_sample1<K>, dim3(self->hv_nwork), dim3(64), 0, st, ev_start, nullptr, 0, a, f0);
                     else hipLaunchKernelGGL(k_sample1<K>, dim3(self->hv_nwork), dim3(64), 0, st, a, f0);
@@ -128,6 +133,9 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
             }
             return 0;
         }
+    }
+    if constexpr (K == 64) {
+        if (self->nwork > 0 && self->mode == 4) { k64_slab(self->nwork, st, ev_start, ev_stop, a); return 0; }
     }
     if (self->nwork > 0 && self->mode == 1) {
         const FusedArgs &f = self->cur_fused;                        // (all zero outside the fused stateful path)

@@ -272,6 +272,7 @@ inline size_t part_words_rt(int K)
     case 16: return part_words<16>();
     case 32: return part_words<32>();
     case 64: return part_words<64>();
+    case 128: return (size_t)(36 * 256 + 8 * 16) / 2;       // fp32 tiles + rhs of the slab form (GeoS<128>::PART)
     }
     return 0;
 }
