@@ -27,7 +27,7 @@ Rccl *rccl()
 #define BPMF_SYM(f) r.f = reinterpret_cast<decltype(r.f)>(dlsym(r.handle, "nccl" #f))
             BPMF_SYM(GetUniqueId); BPMF_SYM(CommInitRank); BPMF_SYM(CommDestroy); BPMF_SYM(AllReduce);
             BPMF_SYM(Broadcast); BPMF_SYM(GroupStart); BPMF_SYM(GroupEnd); BPMF_SYM(GetErrorString); BPMF_SYM(CommSplit);
-            BPMF_SYM(Send); BPMF_SYM(Recv);
+            BPMF_SYM(Send); BPMF_SYM(Recv); BPMF_SYM(AllGather);
 #undef BPMF_SYM
             if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.Broadcast || !r.GroupStart || !r.GroupEnd)
                 r.handle = nullptr;
@@ -173,6 +173,24 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
         std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.cost > b.cost; });
     }
 
+    // parts (bpmf_hip_side_set_overlap): the items of part c of this rank's columns form a contiguous window of the
+    // list (each window keeps the order chosen above), so that part c can be sampled -- and then exchanged -- on its own
+    s->sub_item_off.assign(1, 0);
+    if (s->nsub > 1 && !s->sub_bounds.empty()) {
+        const int64_t *sb = &s->sub_bounds[(size_t)s->ctx->rank * (s->nsub + 1)];
+        auto part_of = [&](const Item &it) {
+            const int64_t g = s->from + it.col;
+            int c = 0;
+            while (c + 1 < s->nsub && g >= sb[c + 1]) ++c;
+            return c;
+        };
+        std::stable_sort(items.begin(), items.end(), [&](const Item &a, const Item &b) { return part_of(a) < part_of(b); });
+        size_t i = 0;
+        for (int c = 0; c < s->nsub; ++c) {
+            while (i < items.size() && part_of(items[i]) == c) ++i;
+            s->sub_item_off.push_back((int)i);
+        }
+    }
     const size_t nw = items.size();
     std::vector<int32_t> wcol(nw), wlen(nw), wmc(nw), wchunk(nw);
     std::vector<int64_t> wp0(nw);
@@ -180,7 +198,7 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
 
     s->nwork = (int)nw; s->nmulti = (int)mc_slot0.size(); s->nslots = slots;
     int rc;
-    if (K == 64 && !f32 && (s->mode == 0 || s->mode == 1 || s->mode == 4)) {
+    if (K == 64 && !f32 && (s->mode == 0 || s->mode == 1 || s->mode == 4) && s->nsub <= 1) {
         // Low-rank form for the columns with at most BPMF_HIP_LOWRANK_MAX ratings (default 6; 0: off):
         // worth a second launch when they are at least half of the side (ChEMBL-shaped compounds)
         const int nlr = std::min(env_int("BPMF_HIP_LOWRANK_MAX", 12), 32);
@@ -239,6 +257,17 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     s->nstat_waves = (int)std::max<int64_t>(1, std::min<int64_t>((nloc + 31) / 32, (int64_t)s->ctx->num_cu * 2));
     if ((rc = dev_upload<double>(&s->d_stat_partials, nullptr, (size_t)s->nstat_waves * pw))) return rc;
     return 0;
+}
+
+// the device arrays build_schedule made (the schedule is rebuilt when the parts of the side change)
+void free_schedule(bpmf_hip_side *s)
+{
+    void **ptrs[] = {(void **)&s->d_wi_col, (void **)&s->d_wi_len, (void **)&s->d_wi_mc, (void **)&s->d_wi_chunk, (void **)&s->d_wi_p0,
+                     (void **)&s->d_mc_slot0, (void **)&s->d_mc_nch, (void **)&s->d_mc_count, (void **)&s->d_partials, (void **)&s->d_stat_partials,
+                     (void **)&s->d_lr_col, (void **)&s->d_lr_len, (void **)&s->d_lr_p0, (void **)&s->d_hv_col, (void **)&s->d_hv_len,
+                     (void **)&s->d_hv_mc, (void **)&s->d_hv_chunk, (void **)&s->d_hv_p0};
+    for (void **p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
+    s->lr_n = s->hv_nwork = 0;
 }
 
 }  // namespace
@@ -390,6 +419,7 @@ static int side_create_common(bpmf_hip_ctx *ctx, int64_t ncols, int64_t nrows, i
         (void)hipGetLastError();                                    // no second copy: samplers write in place
         s->d_items_alt = nullptr;
     }
+    s->h_colptr.assign(colptr, colptr + nloc + 1);
     if ((rc = build_schedule(s, colptr))) { bpmf_hip_side_destroy(s); return rc; }
     *out = s;
     return BPMF_HIP_OK;
@@ -435,6 +465,9 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
         auto &v = s->ctx->sides;
         v.erase(std::remove(v.begin(), v.end(), s), v.end());
     }
+    if (s->sx) { (void)hipStreamSynchronize(s->sx); (void)hipStreamDestroy(s->sx); }
+    for (hipEvent_t e : s->sub_ev) if (e) (void)hipEventDestroy(e);
+    if (s->sx_done) (void)hipEventDestroy(s->sx_done);
     if (s->own_csc) { if (s->d_rowidx) (void)hipFree(s->d_rowidx); if (s->d_vals) (void)hipFree(s->d_vals); }
     if (s->own_items && s->d_items) (void)hipFree(s->d_items);
     if (s->d_items_alt) (void)hipFree(s->d_items_alt);
@@ -579,6 +612,42 @@ int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, do
     return 0;
 }
 
+// Sampler + exchange of one half-iteration on stream `st`.  Sharded side with parts (bpmf_hip_side_set_overlap):
+// part c is sampled on `st`, then exchanged on the side's exchange stream `sx` while part c + 1 is being
+// sampled -- what the reference's MPI_ISEND back-end does with its chunks of 100 items sent during compute
+// (c++/mpi_isendirecv.h:222-260); `st` continues behind the last exchange.
+template <int K>
+int sample_and_exchange(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double alpha, double *d_in, hipStream_t st,
+                        hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    bpmf_hip_ctx *c = self->ctx;
+    const bool dist = c->comm != nullptr && !self->bounds.empty();
+    const bool parts = dist && self->nsub > 1 && self->sx && self->conn_send_ptr.empty() && (int)self->sub_item_off.size() == self->nsub + 1;
+    if (!parts) {
+        int rc = launch_sampler<K>(self, other, iter, alpha, d_in, st, ev_start, ev_stop);
+        if (!rc) rc = bpmf_launch::exchange<K>(self, st, -1);
+        return rc;
+    }
+    int rc = 0;
+    if (ev_start) HIP_TRY(hipEventRecord(ev_start, st));            // (markers instead of events on the dispatch packets: a part may be empty)
+    for (int p = 0; p < self->nsub && !rc; ++p) {
+        self->item_off = self->sub_item_off[(size_t)p];
+        self->item_n = self->sub_item_off[(size_t)p + 1] - self->item_off;
+        if (p == 0) rc = launch_sampler<K>(self, other, iter, alpha, d_in, st, nullptr, nullptr);       // (chooses / swaps the factor copy)
+        else rc = sampler_into<K>(self, self->d_items, other, iter, alpha, d_in, st, nullptr, nullptr);
+        if (rc) break;
+        if (p == self->nsub - 1 && ev_stop) HIP_TRY(hipEventRecord(ev_stop, st));
+        HIP_TRY(hipEventRecord(self->sub_ev[p], st));
+        HIP_TRY(hipStreamWaitEvent(self->sx, self->sub_ev[p], 0));
+        rc = bpmf_launch::exchange<K>(self, self->sx, p);
+    }
+    self->item_off = 0; self->item_n = -1;
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(self->sx_done, self->sx));
+    HIP_TRY(hipStreamWaitEvent(st, self->sx_done, 0));
+    return 0;
+}
+
 #define BPMF_DISPATCH_K(K_, CALL)                                                    \
     [&]() -> int {                                                                   \
         switch (K_) {                                                                \
@@ -667,9 +736,7 @@ extern "C" int bpmf_hip_sample_side_launch(bpmf_hip_side *self, const bpmf_hip_s
     bpmf_launch::stage(c->h_in_dev, c->d_in, (int)c->in_words, c->stream);
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     c->last_sampler_done = nullptr;
-    int rc = BPMF_DISPATCH_K(K, launch_sampler<KK>(self, other, iter, alpha, c->d_in, c->stream));
-    if (rc) return rc;
-    rc = BPMF_DISPATCH_K(K, bpmf_launch::exchange<KK>(self, c->stream));
+    int rc = BPMF_DISPATCH_K(K, sample_and_exchange<KK>(self, other, iter, alpha, c->d_in, c->stream, nullptr, nullptr));
     if (rc) return rc;
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     unsigned *flag = reinterpret_cast<unsigned *>(c->h_out_dev + c->out_words - 1);
@@ -1058,11 +1125,10 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     if (timed && !ride) HIP_TRY(hipEventRecord(ev[0], s0));
     self->cur_fused = fz;
     self->cur_gate_flag = fused ? self->a_dflag : nullptr; self->cur_gate_want = seq;
-    rc = BPMF_DISPATCH_K(K, launch_sampler<KK>(self, other, iter, alpha, self->a_d_in, s0, (ride && timed) ? ev[0] : nullptr,
-                                               ride ? ev[1] : nullptr));
+    rc = BPMF_DISPATCH_K(K, sample_and_exchange<KK>(self, other, iter, alpha, self->a_d_in, s0, (ride && timed) ? ev[0] : nullptr,
+                                                    ride ? ev[1] : nullptr));
     self->cur_gate_flag = nullptr;
     self->cur_fused = bpmf::FusedArgs{};
-    if (!rc) rc = BPMF_DISPATCH_K(K, bpmf_launch::exchange<KK>(self, s0));
     if (rc) return rc;
     if (!ride) HIP_TRY(hipEventRecord(ev[1], s0));
     c->last_sampler_done = (env_int("BPMF_HIP_EVAL_MARKER", 0) == 0) ? ev[1] : nullptr;   // an evaluation requested next waits for this: no marker of its own on S0
@@ -1161,7 +1227,67 @@ extern "C" int bpmf_hip_side_set_ranges(bpmf_hip_side *s, const int64_t *bounds)
     for (int r = 0; r < c->nranks; ++r)
         if (bounds[r + 1] < bounds[r]) return fail(BPMF_HIP_EINVAL, "side_set_ranges: ranges are not monotone");
     s->bounds.assign(bounds, bounds + c->nranks + 1);
+    // parts by default when the exchange is worth hiding: BPMF_HIP_OVERLAP = number of parts (0 / 1: off; unset: 4 parts
+    // once a half-iteration moves >= 64 MB of fresh columns into this rank)
+    const int want = env_int("BPMF_HIP_OVERLAP", -1);
+    const size_t esz = c->dtype == BPMF_HIP_F32 ? 4 : 8;
+    const size_t incoming = (size_t)(s->ncols - (s->to - s->from)) * (size_t)c->K * esz;
+    const int nsub = want >= 0 ? want : (c->nranks > 1 && incoming >= ((size_t)64 << 20) ? 4 : 1);
+    if (nsub > 1) return bpmf_hip_side_set_overlap(s, nsub);
     return BPMF_HIP_OK;
+}
+
+extern "C" int bpmf_hip_side_set_overlap(bpmf_hip_side *s, int nparts)
+{
+    if (!s || nparts < 1 || nparts > 8) return fail(BPMF_HIP_EINVAL, "side_set_overlap: 1..8 parts");
+    bpmf_hip_ctx *c = s->ctx;
+    if (!c->comm || s->bounds.empty()) return fail(BPMF_HIP_EINVAL, "side_set_overlap: set the communicator and the ranges first");
+    int rc;
+    if ((rc = settle_async(s))) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (s->saux) HIP_TRY(hipStreamSynchronize(s->saux));
+    Rccl *R = rccl();
+    if (nparts > 1 && (!R->AllGather || !R->Send || !R->Recv)) nparts = 1;          // (old RCCL: no parts)
+    const int64_t nloc = s->to - s->from;
+    // this rank's parts: equal work, a column counted as (K^2 / 4 + 64) ratings like in the schedule's cost model
+    std::vector<int64_t> mine((size_t)nparts + 1, s->from);
+    {
+        const double c0 = (double)c->K * c->K / 4.0 + 64.0;
+        const double total = (double)s->h_colptr[(size_t)nloc] + c0 * (double)nloc;
+        int64_t col = 0;
+        for (int p = 1; p < nparts; ++p) {
+            const double goal = total * p / nparts;
+            while (col < nloc && (double)s->h_colptr[(size_t)col + 1] + c0 * (double)(col + 1) <= goal) ++col;
+            mine[(size_t)p] = s->from + col;
+        }
+        mine[(size_t)nparts] = s->to;
+    }
+    // ... of every rank: one small all-gather (device buffers; once per side)
+    std::vector<int64_t> all((size_t)c->nranks * (nparts + 1));
+    if (nparts > 1) {
+        int64_t *d = nullptr;
+        HIP_TRY(hipMalloc((void **)&d, all.size() * sizeof(int64_t)));
+        HIP_TRY(hipMemcpy(d + (size_t)c->rank * (nparts + 1), mine.data(), mine.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        ncclResult_t nr = R->AllGather(d + (size_t)c->rank * (nparts + 1), d, (size_t)nparts + 1, ncclInt64, c->comm, c->stream);
+        hipError_t he = hipStreamSynchronize(c->stream);
+        if (nr == ncclSuccess && he == hipSuccess) he = hipMemcpy(all.data(), d, all.size() * sizeof(int64_t), hipMemcpyDeviceToHost);
+        (void)hipFree(d);
+        if (nr != ncclSuccess) return fail(BPMF_HIP_ENODEV, "side_set_overlap: ncclAllGather failed");
+        if (he != hipSuccess) return fail(BPMF_HIP_ENODEV, "side_set_overlap: HIP error");
+        for (int r = 0; r < c->nranks; ++r)
+            if (all[(size_t)r * (nparts + 1)] != s->bounds[(size_t)r] || all[(size_t)r * (nparts + 1) + nparts] != s->bounds[(size_t)r + 1])
+                return fail(BPMF_HIP_EINVAL, "side_set_overlap: the ranks disagree about the ranges or the number of parts");
+    }
+    if (nparts > 1 && !s->sx) {
+        HIP_TRY(hipStreamCreateWithFlags(&s->sx, hipStreamNonBlocking));
+        for (hipEvent_t &e : s->sub_ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s->sx_done, hipEventDisableTiming));
+    }
+    s->nsub = nparts;
+    s->sub_bounds = nparts > 1 ? all : std::vector<int64_t>();
+    free_schedule(s);
+    return build_schedule(s, s->h_colptr.data());
 }
 
 extern "C" int bpmf_hip_side_set_conn(bpmf_hip_side *s, const int64_t *send_ptr, const int32_t *send_cols,
@@ -1170,7 +1296,7 @@ extern "C" int bpmf_hip_side_set_conn(bpmf_hip_side *s, const int64_t *send_ptr,
     if (!s) return fail(BPMF_HIP_EINVAL, "side_set_conn: NULL");
     bpmf_hip_ctx *c = s->ctx;
     if (!c->comm || s->bounds.empty()) return fail(BPMF_HIP_EINVAL, "side_set_conn: set the communicator and the ranges first");
-    if (c->dtype != BPMF_HIP_F64) return fail(BPMF_HIP_EINVAL, "side_set_conn: the fp32 path is single-GPU for now");
+    if (c->dtype != BPMF_HIP_F64) return fail(BPMF_HIP_EINVAL, "side_set_conn: the packed exchange is fp64 only (the fp32 context uses the all-gather form)");
     int rc;
     if ((rc = settle_async(s))) return rc;
     HIP_TRY(hipSetDevice(c->device));
@@ -1215,7 +1341,7 @@ extern "C" int bpmf_hip_side_exchange(bpmf_hip_side *s)
     HIP_TRY(hipSetDevice(c->device));
     c->last_sampler_done = nullptr;
     switch (c->K) {
-#define BPMF_CASE(KK) case KK: rc = bpmf_launch::exchange<KK>(s, c->stream); break;
+#define BPMF_CASE(KK) case KK: rc = bpmf_launch::exchange<KK>(s, c->stream, -1); break;
         BPMF_CASE(8) BPMF_CASE(16) BPMF_CASE(32) BPMF_CASE(64) BPMF_CASE(128)
 #undef BPMF_CASE
         default: return fail(BPMF_HIP_EINVAL, "unsupported K");

@@ -49,7 +49,7 @@ struct GeoS {
     static constexpr int LDS_WORDS = 2 * K + 4 * LDR + 16 * NG + (K == 128 ? 16 * 17 / 2 + 8 : 0);
     // doubles in the partial of one chunk of a heavy column (tile layout)
     static constexpr int PART = K == 128 ? (NTRI * 256 + NT * 16) / 2 : NREG * 64 + NT * 16;
-    static constexpr int WPS = K == 64 ? 2 : 1;
+    static constexpr int WPS = K == 128 ? 1 : (K == 64 ? 2 : 4);    // waves per SIMD the kernels are compiled for
 };
 
 // W = R_ss^-1 of a 4x4 SPD block given by its 10 upper entries (wave-uniform values): returns the
@@ -249,17 +249,15 @@ __device__ __forceinline__ void slab_cholesky_solve(double (&A)[GeoS<K>::NREG], 
     }
 }
 
+// one work item (column or chunk of a heavy column) by one wave; lds: GeoS<K>::LDS_WORDS doubles
 template <int K, typename T>
-__global__ __launch_bounds__(64, GeoS<K>::WPS) void k_sample_slab(SampleArgs a)
+__device__ __forceinline__ void slab_item(const SampleArgs &a, int w, double *lds, int lane)
 {
     using G = GeoS<K>;
     constexpr int NG = G::NG, NQ = G::NQ, NT = G::NT, NTRI = G::NTRI, NREG = G::NREG;
     constexpr bool F32 = sizeof(T) == 4;
-    __shared__ __attribute__((aligned(16))) double lds[G::LDS_WORDS];
     double *sz = lds, *sb = lds + K, *srow = lds + 2 * K, *sw = srow + 4 * G::LDR;
-    const int lane = threadIdx.x;
     const int kq = lane >> 4, li = lane & 15, x = lane & 3;
-    const int w = blockIdx.x;
     const int col = a.wi_col[w];
     const int64_t p0 = a.wi_p0[w];
     const int len = (a.ablate & 2u) ? 0 : a.wi_len[w];             // (profiling switch: no Gram)
@@ -482,6 +480,32 @@ __global__ __launch_bounds__(64, GeoS<K>::WPS) void k_sample_slab(SampleArgs a)
     for (int i = lane; i < K; i += 64) dst[i] = (T)sb[i];
     bad = bad && x == 0;
     if (__any(bad) && lane == 0) atomicMin(a.fail, (unsigned long long)idx);
+}
+
+template <int K, typename T>
+__global__ __launch_bounds__(64, GeoS<K>::WPS) void k_sample_slab(SampleArgs a)
+{
+    __shared__ __attribute__((aligned(16))) double lds[GeoS<K>::LDS_WORDS];
+    slab_item<K, T>(a, (int)blockIdx.x, lds, (int)threadIdx.x);
+}
+
+// The same item body behind k_sample1's launch format (K <= 32, the fused stateful path: workgroup 0 = gate +
+// staging of this launch's parameters, the next f.nstat workgroups = column statistics of the previous side).
+template <int K>
+__global__ __launch_bounds__(64, GeoS<K>::WPS) void k_sample1s(SampleArgs a, FusedArgs f)
+{
+    __shared__ __attribute__((aligned(16))) double lds[GeoS<K>::LDS_WORDS];
+    int bid = blockIdx.x;
+    if (f.gate_host) {
+        if (bid == 0) { gate_stage_body(0, 1, f.gate_host, f.gate_want, f.src_host, f.dst, f.n, f.dflag, f.dval, a.tmo, a.wait_ticks); return; }
+        --bid;
+    }
+    if (bid < f.nstat) {
+        colstats_body<K>(bid, f.st_items, f.st_c0, f.st_c1, f.nstat, f.st_partials, f.st_fail, f.st_out, f.st_ticket, f.st_flag, f.st_seq,
+                         f.st_tmo, a.wait_ticks);
+        return;
+    }
+    slab_item<K, double>(a, bid - f.nstat, lds, (int)threadIdx.x);
 }
 
 }  // namespace bpmf

@@ -10,9 +10,11 @@ namespace bpmf_launch {
 template <int K>
 int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *other, int iter, double alpha, double *d_in, hipStream_t st,
                  hipEvent_t ev_start, hipEvent_t ev_stop);
-// multi-GPU: in-place broadcast / packed send-receive of every rank's fresh column range
+// multi-GPU: every rank's fresh columns travel to the others, in place in the replicated factor matrix.
+// sub < 0: the whole range of every rank; sub >= 0: sub-range `sub` of every rank (bpmf_hip_side_set_overlap:
+// the exchange of one part of a side's columns runs on a stream of its own beside the sampling of the next part)
 template <int K>
-int exchange(bpmf_hip_side *self, hipStream_t st);
+int exchange(bpmf_hip_side *self, hipStream_t st, int sub);
 // sum x / sum x x^T of this rank's columns (+ all-reduce), published to `out_host_dev`
 template <int K>
 int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_host_dev, unsigned *flag, unsigned seq, unsigned *ticket);

@@ -5,6 +5,7 @@
 #include "kernels.h"
 #include "kernels_f32.h"
 #include "kernels_q4.h"
+#include "kernels_slab.h"
 
 namespace bpmf_launch {
 
@@ -32,7 +33,8 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
         typedef decltype(zero) T;
         SampleArgsW<T> f;
         f.rowidx = self->d_rowidx; f.vals = self->d_vals;
-        f.wi_col = self->d_wi_col; f.wi_p0 = self->d_wi_p0; f.wi_len = self->d_wi_len;
+        const int fw0 = self->item_n >= 0 ? self->item_off : 0;
+        f.wi_col = self->d_wi_col + fw0; f.wi_p0 = self->d_wi_p0 + fw0; f.wi_len = self->d_wi_len + fw0;
         f.other_items = reinterpret_cast<const T *>(other->d_items); f.items = reinterpret_cast<T *>(out_items);
         f.col_from = self->from;
         f.LambdaF = d_in; f.Lmu = d_in + (size_t)K * K;
@@ -41,14 +43,15 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
         f.mean_rating = self->mean_rating; f.alpha = alpha; f.iter_plus_1 = (uint32_t)(iter + 1);
         // four waves per column at K = 128; one wave owning all tiles at K = 64 (no idle waves in the
         // serial phases of the factorisation: the column-dominated shapes are what K = 64 is run on)
-        if (self->nwork > 0) {
+        const int fnw = self->item_n >= 0 ? self->item_n : self->nwork;
+        if (fnw > 0) {
             if constexpr (K == 128) {
                 // two waves per column (18 tiles each) by default: three columns in flight per CU instead of two,
                 // and one idle wave instead of three through the serial phases (0.66 -> 0.58 ms per launch)
-                if (env_int("BPMF_HIP_WG_WAVES", 2) == 4) launch(k_sample_wg<K, T, 4>, dim3(self->nwork), dim3(256), f);
-                else launch(k_sample_wg<K, T, 2>, dim3(self->nwork), dim3(128), f);
+                if (env_int("BPMF_HIP_WG_WAVES", 2) == 4) launch(k_sample_wg<K, T, 4>, dim3(fnw), dim3(256), f);
+                else launch(k_sample_wg<K, T, 2>, dim3(fnw), dim3(128), f);
             }
-            else if constexpr (K == 64) k64_wg(self->nwork, st, ev_start, ev_stop, f);
+            else if constexpr (K == 64) k64_wg(fnw, st, ev_start, ev_stop, f);
         }
     };
     if constexpr (K == 128) {
@@ -59,9 +62,11 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
     }
     SampleArgs a;
     a.rowidx = self->d_rowidx; a.vals = self->d_vals;
-    a.wi_col = self->d_wi_col; a.wi_p0 = self->d_wi_p0; a.wi_len = self->d_wi_len; a.wi_mc = self->d_wi_mc; a.wi_chunk = self->d_wi_chunk;
+    // (item window: the whole list, or the items of one part of the columns -- bpmf_hip_side_set_overlap)
+    const int w0 = self->item_n >= 0 ? self->item_off : 0, nwork = self->item_n >= 0 ? self->item_n : self->nwork;
+    a.wi_col = self->d_wi_col + w0; a.wi_p0 = self->d_wi_p0 + w0; a.wi_len = self->d_wi_len + w0; a.wi_mc = self->d_wi_mc + w0; a.wi_chunk = self->d_wi_chunk + w0;
     a.mc_slot0 = self->d_mc_slot0; a.mc_nchunks = self->d_mc_nch; a.mc_count = self->d_mc_count;
-    a.partials = self->d_partials; a.nwork = self->nwork;
+    a.partials = self->d_partials; a.nwork = nwork;
     a.other_items = other->d_items; a.items = out_items; a.col_from = self->from;
     a.LambdaF = d_in; a.Lmu = d_in + (size_t)K * K;
     a.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
@@ -72,12 +77,12 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
     a.tmo = self->cur_gate_flag ? tmo_word(self->a_h_out_dev, K) : nullptr; a.wait_ticks = wait_ticks();
     a.zero_row = c->d_zero;
     if constexpr (K == 128) {                                        // slab form, fp32 factors (items / other_items are float arrays)
-        if (self->nwork > 0) k128_slab(self->nwork, st, ev_start, ev_stop, a);
+        if (nwork > 0) k128_slab(nwork, st, ev_start, ev_stop, a);
         return 0;
     } else {
     if constexpr (K <= 32) {
-        if (self->nwork > 0 && self->mode == 3) {                    // four columns per wave (k_sample4)
-            launch(k_sample4<K>, dim3((self->nwork + 3) / 4), dim3(64), a);
+        if (nwork > 0 && self->mode == 3) {                          // four columns per wave (k_sample4)
+            launch(k_sample4<K>, dim3((nwork + 3) / 4), dim3(64), a);
             return 0;
         }
     }
@@ -135,17 +140,26 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
         }
     }
     if constexpr (K == 64) {
-        if (self->nwork > 0 && self->mode == 4) { k64_slab(self->nwork, st, ev_start, ev_stop, a); return 0; }
+        if (nwork > 0 && self->mode == 4) { k64_slab(nwork, st, ev_start, ev_stop, a); return 0; }
     }
-    if (self->nwork > 0 && self->mode == 1) {
+    if (nwork > 0 && self->mode == 1) {
         const FusedArgs &f = self->cur_fused;                        // (all zero outside the fused stateful path)
-        const dim3 grid((unsigned)(self->nwork + (f.gate_host ? 1 : 0) + f.nstat));
+        const dim3 grid((unsigned)(nwork + (f.gate_host ? 1 : 0) + f.nstat));
+        if constexpr (K == 32 || K == 16) {
+            // the slab form of the item body (kernels_slab.h) behind the same launch format: BPMF_HIP_SLAB32
+            static const int slab = env_int("BPMF_HIP_SLAB32", 0);
+            if (slab) {
+                if (ev_start || ev_stop) hipExtLaunchKernelGGL(k_sample1s<K>, grid, dim3(64), 0, st, ev_start, ev_stop, 0, a, f);
+                else hipLaunchKernelGGL(k_sample1s<K>, grid, dim3(64), 0, st, a, f);
+                return 0;
+            }
+        }
         if (ev_start || ev_stop) hipExtLaunchKernelGGL(k_sample1<K>, grid, dim3(64), 0, st, ev_start, ev_stop, 0, a, f);
         else hipLaunchKernelGGL(k_sample1<K>, grid, dim3(64), 0, st, a, f);
-    } else if (self->nwork > 0) {
+    } else if (nwork > 0) {
         // persistent waves: as many single-wave workgroups as the chip holds at this kernel's occupancy
         const int resident = c->num_cu * 4 * Geo<K>::WPS;
-        const int grid = std::min(self->nwork, env_int("BPMF_HIP_GRID", resident));
+        const int grid = std::min(nwork, env_int("BPMF_HIP_GRID", resident));
         if constexpr (K == 64) k64_persistent(grid, st, ev_start, ev_stop, a);
         else launch(k_sample<K>, dim3(grid), dim3(64), a);
     }
@@ -154,19 +168,23 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
 }
 
 template <int K>
-int exchange(bpmf_hip_side *self, hipStream_t st)
+int exchange(bpmf_hip_side *self, hipStream_t st, int sub)
 {
     bpmf_hip_ctx *c = self->ctx;
     if (!(c->comm != nullptr && !self->bounds.empty())) return 0;
-    if constexpr (K == 128) return fail(BPMF_HIP_EINVAL, "the fp32 path is single-GPU for now");
-    else {
-    // every rank broadcasts the range it just sampled (= all-gather-v of disjoint, uneven
-    // ranges), in place in the replicated factor matrix, on the sampler's stream
+    // factors are fp64 (8 K bytes per column) or, in the fp32 context, fp32
+    const bool f32 = c->dtype == BPMF_HIP_F32;
+    const ncclDataType_t ty = f32 ? ncclFloat : ncclDouble;
+    const size_t esz = f32 ? sizeof(float) : sizeof(double);
+    char *items = reinterpret_cast<char *>(self->d_items);
     Rccl *R = rccl();
     if (!self->conn_send_ptr.empty()) {
+        if constexpr (K == 128) return fail(BPMF_HIP_EINVAL, "the connectivity-aware exchange is fp64 only");
+        else {
         // connectivity-aware form (c++/assign.cpp:204-241 conn_map + send_item, c++/sample.cpp:370): a column
         // only travels to the ranks whose ratings / test entries reference it.  Pack the columns of
         // every peer's list into one buffer, one grouped send / receive per peer, scatter what arrived.
+        if (sub > 0) return 0;                                      // (not cut into parts: everything goes with part 0)
         const int64_t ns = self->conn_send_ptr.back(), nr = self->conn_recv_ptr.back();
         constexpr int P = K / 2;                                   // 16-byte pieces per column
         if (ns > 0)
@@ -185,18 +203,41 @@ int exchange(bpmf_hip_side *self, hipStream_t st)
                                (const double *)self->d_conn_rbuf, (const int32_t *)self->d_conn_recv, nr, self->d_items);
         HIP_TRY(hipGetLastError());
         return 0;
+        }
     }
+    // columns [lo, hi) rank r contributes to this call
+    auto range = [&](int r, int64_t &lo, int64_t &hi) {
+        if (sub < 0 || self->nsub <= 1) { lo = self->bounds[(size_t)r]; hi = self->bounds[(size_t)r + 1]; }
+        else { lo = self->sub_bounds[(size_t)r * (self->nsub + 1) + sub]; hi = self->sub_bounds[(size_t)r * (self->nsub + 1) + sub + 1]; }
+    };
+    // All-gather-v of disjoint, uneven ranges.  Default: a MESH of point-to-point transfers -- one grouped
+    // ncclSend / ncclRecv pair per peer, every pair on its own xGMI link (the links are point-to-point:
+    // seven per GPU) -- instead of nranks broadcasts, each of which is a ring / tree collective over all ranks.
+    // BPMF_HIP_EXCHANGE=bcast keeps the broadcasts (and is what an RCCL without ncclSend / ncclRecv gets).
+    static const bool want_mesh = [] { const char *e = getenv("BPMF_HIP_EXCHANGE"); return !(e && std::string(e) == "bcast"); }();
+    int64_t mlo, mhi;
+    range(c->rank, mlo, mhi);
     NCCL_TRY(R->GroupStart());
-    for (int r = 0; r < c->nranks; ++r) {
-        const int64_t lo = self->bounds[(size_t)r], hi = self->bounds[(size_t)r + 1];
-        if (hi > lo) {
-            double *p = self->d_items + (size_t)lo * K;
-            NCCL_TRY(R->Broadcast(p, p, (size_t)(hi - lo) * K, ncclDouble, r, c->comm, st));
+    if (want_mesh && R->Send && R->Recv) {
+        for (int r = 0; r < c->nranks; ++r) {
+            if (r == c->rank) continue;
+            int64_t lo, hi;
+            range(r, lo, hi);
+            if (mhi > mlo) NCCL_TRY(R->Send(items + (size_t)mlo * K * esz, (size_t)(mhi - mlo) * K, ty, r, c->comm, st));
+            if (hi > lo) NCCL_TRY(R->Recv(items + (size_t)lo * K * esz, (size_t)(hi - lo) * K, ty, r, c->comm, st));
+        }
+    } else {
+        for (int r = 0; r < c->nranks; ++r) {
+            int64_t lo, hi;
+            range(r, lo, hi);
+            if (hi > lo) {
+                char *p = items + (size_t)lo * K * esz;
+                NCCL_TRY(R->Broadcast(p, p, (size_t)(hi - lo) * K, ty, r, c->comm, st));
+            }
         }
     }
     NCCL_TRY(R->GroupEnd());
     return 0;
-    }
 }
 
 template <int K>
@@ -205,12 +246,20 @@ int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_h
     using namespace bpmf;
     bpmf_hip_ctx *c = self->ctx;
     const unsigned long long *failp = (const unsigned long long *)(d_in + (size_t)K * K + K);
-    if constexpr (K == 128) {                           // fp32 factors, fp64 sums (single GPU)
-        if (c->comm != nullptr && !self->bounds.empty()) return fail(BPMF_HIP_EINVAL, "the fp32 path is single-GPU for now");
+    if constexpr (K == 128) {                           // fp32 factors, fp64 sums
+        const bool dist = c->comm != nullptr && !self->bounds.empty();
+        const bool own = st != c->stream && c->comm2 && self->a_d_red;
+        double *red = own ? self->a_d_red : c->d_red;
         hipLaunchKernelGGL(k_colstats_f32<K>, dim3(self->nstat_waves), dim3(256), 0, st, reinterpret_cast<const float *>(self->d_items),
                            self->from, self->to, self->nstat_waves, self->d_stat_partials);
+        // single GPU: the sums go straight to the pinned blob; sharded: into a device blob, all-reduced, then published
         hipLaunchKernelGGL(k_colstats_f32_final<K>, dim3((K * K + K + 255) / 256), dim3(256), 0, st,
-                           (const double *)self->d_stat_partials, self->nstat_waves, failp, out_host_dev, ticket, flag, seq);
+                           (const double *)self->d_stat_partials, self->nstat_waves, failp, dist ? red : out_host_dev, ticket,
+                           dist ? ticket + 8 : flag, dist ? 0u : seq);
+        if (dist) {
+            NCCL_TRY(rccl()->AllReduce(red, red, (size_t)K * K + K + 1, ncclDouble, ncclSum, own ? c->comm2 : c->comm, st));
+            publish(red, out_host_dev, K * K + K + 1, flag, seq, K * K + K, st);
+        }
         return 0;
     } else {
     if (!(c->comm != nullptr && !self->bounds.empty())) {
@@ -252,8 +301,12 @@ void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items
         hipLaunchKernelGGL(bpmf::k_predict_f32<K>, dim3((unsigned)t->nblocks), dim3(256), 0, ps,
                            (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz,
                            reinterpret_cast<const float *>(self_items), reinterpret_cast<const float *>(other_items), self->from,
-                           self->mean_rating, n, t->d_pavg, t->d_pm2, t->d_partial, t->h_res_dev, t->d_ticket, flag, ++t->seq);
-        (void)red; (void)dist;
+                           self->mean_rating, n, t->d_pavg, t->d_pm2, t->d_partial, dist ? red : t->h_res_dev, t->d_ticket,
+                           dist ? t->d_ticket + 8 : flag, dist ? 0u : ++t->seq);
+        if (dist) {
+            if (rccl()->AllReduce(red, red, 2, ncclDouble, ncclSum, c->comm, c->stream) != ncclSuccess) return;
+            publish(red, t->h_res_dev, 2, flag, ++t->seq, -1, c->stream);
+        }
     } else {
     hipLaunchKernelGGL(bpmf::k_predict<K>, dim3((unsigned)t->nblocks), dim3(256), 0, ps,
                        (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz,
@@ -273,6 +326,6 @@ void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items
 #define BPMF_INSTANTIATE_K(KK)                                                                                                   \
     template int bpmf_launch::sampler_into<KK>(bpmf_hip_side *, double *, const bpmf_hip_side *, int, double, double *, hipStream_t, \
                                                hipEvent_t, hipEvent_t);                                                          \
-    template int bpmf_launch::exchange<KK>(bpmf_hip_side *, hipStream_t);                                                        \
+    template int bpmf_launch::exchange<KK>(bpmf_hip_side *, hipStream_t, int);                                                        \
     template int bpmf_launch::stats<KK>(bpmf_hip_side *, hipStream_t, const double *, double *, unsigned *, unsigned, unsigned *); \
     template void bpmf_launch::predict<KK>(bpmf_hip_test *, const bpmf_hip_side *, const void *, const void *, int, hipStream_t, bool);

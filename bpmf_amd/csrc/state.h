@@ -88,6 +88,7 @@ struct Rccl {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;     // optional (bpmf_hip_side_set_overlap: the parts of every rank)
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -175,6 +176,15 @@ struct bpmf_hip_side {
     int nstat_waves = 0;
     double *d_stat_partials = nullptr;
     std::vector<int64_t> bounds;         // multi-GPU: column range of every rank (nranks + 1 entries)
+    // overlap of exchange and sampling (bpmf_hip_side_set_overlap): every rank's range is cut into nsub parts of
+    // equal work; part c of every rank is exchanged on the stream `sx` while part c + 1 is being sampled
+    int nsub = 1;
+    std::vector<int64_t> sub_bounds;     // nranks x (nsub + 1): global column bounds of the parts of every rank
+    std::vector<int> sub_item_off;       // nsub + 1: the work items of part c are [off[c], off[c+1]) of the item arrays
+    int item_off = 0, item_n = -1;       // item window of the launch being enqueued (-1: the whole list)
+    hipStream_t sx = nullptr;            // exchange stream
+    hipEvent_t sub_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, sx_done = nullptr;
+    std::vector<int64_t> h_colptr;       // host copy of the local column pointers (schedules are rebuilt when the parts change)
     // connectivity-aware exchange (bpmf_hip_side_set_conn): per peer, the columns of this rank's range the
     // peer reads (send) and the columns of the peer's range this rank reads (recv), as global column ids
     std::vector<int64_t> conn_send_ptr, conn_recv_ptr;

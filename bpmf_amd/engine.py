@@ -75,6 +75,10 @@ class HipEngine:
         b = np.ascontiguousarray(bounds, np.int64)
         _lib.check(self.lib.bpmf_hip_side_set_ranges(side.handle, _ptr(b)))
 
+    def side_set_overlap(self, side, nparts):
+        """Cut every rank's range into `nparts` parts: part c is exchanged while part c + 1 is sampled (collective)."""
+        _lib.check(self.lib.bpmf_hip_side_set_overlap(side.handle, int(nparts)))
+
     def side_set_conn(self, side, send_ptr=None, send_cols=None, recv_ptr=None, recv_cols=None):
         """Connectivity-aware exchange lists (include/bpmf_hip.h); all None: back to the all-gather form."""
         if send_ptr is None:

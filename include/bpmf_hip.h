@@ -90,11 +90,19 @@ BPMF_API void *bpmf_hip_ctx_stream(bpmf_hip_ctx *ctx);
  * from then on bpmf_hip_sample_side / bpmf_hip_sys_sample additionally broadcast each rank's fresh
  * range in place (all-gather-v over xGMI) and all-reduce sum | prod | norm on the device, so that
  * the values returned (and the cov formed from them) are the GLOBAL ones on every rank, and
- * bpmf_hip_predict returns the all-reduced se / se_avg / count.  RCCL is loaded on first use
+ * bpmf_hip_predict returns the all-reduced se / se_avg / count.  The all-gather-v is a mesh of grouped ncclSend /
+ * ncclRecv pairs, one pair per peer and xGMI link (BPMF_HIP_EXCHANGE=bcast: one ncclBroadcast per owner instead).  RCCL is loaded on first use
  * (dlopen of librccl.so.1), single-GPU use never touches it. */
 BPMF_API int bpmf_hip_comm_unique_id(void *id128);
 BPMF_API int bpmf_hip_ctx_comm_init(bpmf_hip_ctx *ctx, int nranks, int rank, const void *id128);
 BPMF_API int bpmf_hip_side_set_ranges(bpmf_hip_side *side, const int64_t *bounds);
+/* Overlap of exchange and sampling, the job of the reference's MPI_ISEND back-end (chunks of 100 fresh items are sent
+ * while the next ones are sampled, c++/mpi_isendirecv.h:13-14,222-260): every rank's column range is cut into `nparts`
+ * (1..8) parts of equal work; part c of all ranks is exchanged on a stream of its own while part c + 1 is being sampled.
+ * Collective: every rank calls it with the same nparts after _side_set_ranges (which already picks 4 parts when a
+ * half-iteration brings >= 64 MB of fresh columns to this rank; BPMF_HIP_OVERLAP=n overrides, 1 = off).  Same
+ * samples as without parts. */
+BPMF_API int bpmf_hip_side_set_overlap(bpmf_hip_side *side, int nparts);
 
 /* Connectivity-aware exchange.  Replaces Sys::update_conn's conn_map and the
  * per-item sends it steers (c++/assign.cpp:204-241; send_item at c++/sample.cpp:370,

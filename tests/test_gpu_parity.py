@@ -475,6 +475,19 @@ def test_connectivity_exchange_loopback(K):
     assert r.returncode == 0 and "CONN-OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
 
 
+@pytest.mark.parametrize("K", [32, 64, 128])
+def test_sharded_parts_single_rank(K):
+    """Sharded == plain, and bpmf_hip_side_set_overlap (exchange of part c beside the sampling of part c + 1) ==
+    uncut, over a one-rank RCCL communicator: tests/_parts_worker.py; K = 128: the fp32 context, sharded."""
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_parts_worker.py"), str(K)], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0 and "PARTS-OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
 @pytest.mark.parametrize("K", [16, 32, 64])
 def test_propagated_posterior_priors(oracle, hip_engine_factory, K, sampler_mode):
     """-m / -l of the reference (c++/sample.cpp:157-174,272-277): every column has its own prior
