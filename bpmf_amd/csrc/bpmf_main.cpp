@@ -3,7 +3,10 @@
 //
 // Host C++ only: it reads the matrices (io.cpp), mirrors them to the device through the C ABI of
 // include/bpmf_hip.h and runs main()'s Gibbs loop; every column update happens in the HIP kernels.
-// Flags: -n TRAIN -p TEST [-o DIR] [-i N] [-b N] [-a F] [-d K] [-t N] [-f N] [-k] [-r] [-v]
+// Flags: -n TRAIN -p TEST [-o DIR] [-i N] [-b N] [-a F] [-d K] [-t N] [-f N] [-k] [-r] [-v] [-g N]
+// -g N (or BPMF_NGPU=N): N GPUs of this node, the job of `mpirun -np N bpmf` (c++/bpmf.cpp:111-117, c++/mpi_common.h:14-50):
+// one host thread + one context per GPU in this process, RCCL id shared in memory, columns of both sides sharded,
+// `nprocs: N`, every rank writes bpmf_<rank>.out like the reference's ranks do.
 // -m / -l "MU_FILE,LAMBDA_FILE": propagated posteriors of a previous run (c++/bpmf.cpp:134-135).
 // K (the reference's compile-time BPMF_NUMLATENT) is chosen at run time: -d K, else the
 // environment variable BPMF_NUMLATENT, else 32.
@@ -17,8 +20,11 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <algorithm>
+#include <memory>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bpmf_hip.h"
@@ -48,8 +54,9 @@ void usage()
               << "  [-a F]: noise precision alpha (2.0)\n"
               << "  [-d K]: number of latent dimensions: 8, 16, 32 or 64 (32, or $BPMF_NUMLATENT)\n"
               << "\n"
-              << "  [-k]: do not optimise the item-to-node assignment (single process: no effect)\n"
-              << "  [-r]: redirect stdout to bpmf_0.out\n"
+              << "  [-g N]: shard users and items over N GPUs of this node (RCCL over xGMI; default $BPMF_NGPU or 1)\n"
+              << "  [-k]: do not balance the item-to-GPU assignment on work (equal column counts per GPU instead)\n"
+              << "  [-r]: redirect stdout to bpmf_<rank>.out (always with more than one GPU)\n"
               << "  [-v]: write every sample (U-<i>.ddm, V-<i>.ddm)\n"
               << "  [-t N]: host threads (accepted; the column loop runs on the GPU)\n"
               << "\n"
@@ -147,87 +154,100 @@ struct Aggregate {
     }
 };
 
-}  // namespace
-
-int main(int argc, char *argv[])
+// Contiguous column ranges of equal work, work = c0 + nnz per column -- the reference's assign() balances the same
+// quantity with c0 = 10 (c++/assign.cpp:109-120) and then permutes the columns; contiguous cuts of the original
+// order keep the column ids, hence the per-column RNG streams and the samples, independent of the GPU count.
+// c0: a column costs about as much as 64 ratings here (10M x 1M shard, K = 32: 463 555 columns cost 1.14 ms more
+// than 190 with the same 250 M ratings, a rating 0.038 ns: profiles/r01_shard_10Mx1M.txt); BPMF_ASSIGN_COST overrides.
+// balance = false (-k): equal column counts, the reference's `!permute` branch (c++/assign.cpp:60-65).
+std::vector<int64_t> column_ranges(const Csc &M, int nparts, bool balance)
 {
-    std::string fname, probename, mname, lname, odirname;
-    int nsims = 20, burnin = 5, update_freq = 1, nthrds = -1, K = 32;
-    double alpha = 2.0;
-    bool redirect = false, verbose = false, k_given = false;
-    if (const char *e = getenv("BPMF_NUMLATENT")) K = atoi(e);
-
-    int ch;
-    while ((ch = getopt(argc, argv, "krvn:t:p:i:b:f:o:m:l:a:d:h")) != -1) {
-        switch (ch) {
-        case 'i': nsims = atoi(optarg); break;
-        case 'b': burnin = atoi(optarg); break;
-        case 'f': update_freq = atoi(optarg); break;
-        case 't': nthrds = atoi(optarg); break;
-        case 'a': alpha = atof(optarg); break;
-        case 'd': K = atoi(optarg); break;
-        case 'n': fname = optarg; break;
-        case 'p': probename = optarg; break;
-        case 'o': odirname = optarg; break;
-        case 'm': mname = optarg; break;
-        case 'l': lname = optarg; break;
-        case 'r': redirect = true; break;
-        case 'k': k_given = true; break;
-        case 'v': verbose = true; break;
-        default: usage(); return 1;
-        }
+    std::vector<int64_t> b((size_t)nparts + 1, 0);
+    const int64_t n = M.ncols;
+    if (!balance) {
+        const int64_t per = n / nparts;
+        for (int p = 0; p < nparts; ++p) b[(size_t)p] = (int64_t)p * per;
+        b[(size_t)nparts] = n;
+        return b;
     }
-    (void)k_given;
-    if (fname.empty() || probename.empty()) { usage(); return 1; }
-    // fp64 like the reference for 8..64 latent dimensions; 128 selects the fp32 large-K path of the library
-    const int dtype = (K == 128) ? BPMF_HIP_F32 : BPMF_HIP_F64;
-    if (!bpmf_hip_supports(K, dtype)) die("unsupported number of latent dimensions " + std::to_string(K) + " (8, 16, 32, 64; 128 in fp32)");
+    const double c0 = getenv("BPMF_ASSIGN_COST") ? atof(getenv("BPMF_ASSIGN_COST")) : 64.0;
+    const double total = (double)M.nnz() + c0 * (double)n;
+    int64_t col = 0;
+    for (int p = 1; p < nparts; ++p) {
+        const double goal = total * p / nparts;
+        while (col < n && (double)M.colptr[(size_t)col + 1] + c0 * (double)(col + 1) <= goal) ++col;
+        b[(size_t)p] = col;
+    }
+    b[(size_t)nparts] = n;
+    return b;
+}
 
-    std::ofstream redirected;
-    if (redirect) redirected.open("bpmf_0.out");
-    std::ostream &os = redirect ? static_cast<std::ostream &>(redirected) : std::cout;
+struct Job {
+    // inputs (read-only for the ranks)
+    Csc M, Mt, T;
+    int K = 32, dtype = BPMF_HIP_F64, nsims = 20, burnin = 5, update_freq = 1, nthrds = -1, nranks = 1;
+    double alpha = 2.0, mean_m = 0.0, mean_u = 0.0;
+    bool verbose = false, redirect = false, sharded = false;
+    std::string odirname;
+    Dense prop_m_mu, prop_m_lambda, prop_u_mu, prop_u_lambda;       // -m / -l (empty: none)
+    std::vector<int64_t> bm, bu;                                     // column ranges of the ranks
+    char rccl_id[128];
+    // results
+    std::vector<double> pavg, pm2;                                   // test-set order of T; every rank fills its slice
+    Aggregate agg_u, agg_m;                                          // rank 0
+    double elapsed = 0.0, rmse_avg = NAN;
+    int64_t num_predict = 0;
+    long double average_items_sec = 0, average_ratings_sec = 0;
+    std::vector<std::string> errors;                                 // per rank
+};
 
-    // Sys::Sys (c++/sample.cpp:112-137): read, grow both to the common shape, transpose for the users
-    Csc M, T;
-    try {
-        M = bpmf::io::read_sparse(fname);
-        T = bpmf::io::read_sparse(probename);
-    } catch (const std::exception &e) { die(e.what()); }
-    const int64_t rows = std::max(M.nrows, T.nrows), cols = std::max(M.ncols, T.ncols);
-    bpmf::io::resize(M, rows, cols);
-    bpmf::io::resize(T, rows, cols);
-    if (M.nnz() == 0) die("the training matrix is empty");
-    const Csc Mt = bpmf::io::transpose(M);
-    const int64_t nmovies = cols, nusers = rows;
-
-    double msum = 0.0, usum = 0.0;                              // mean_rating = M.sum()/M.nonZeros() per Sys (:183)
-    for (double v : M.vals) msum += v;
-    for (double v : Mt.vals) usum += v;
-    const double mean_m = msum / (double)M.nnz(), mean_u = usum / (double)Mt.nnz();
-
+// one rank = one GPU: Sys::Sys + init (its shard), the Gibbs loop of c++/bpmf.cpp:180-253
+void rank_main(Job &J, int rank, std::ostream &os)
+{
+    const int K = J.K;
+    const int64_t nmovies = J.M.ncols, nusers = J.M.nrows;
+    const bool aggregate = !J.odirname.empty() && rank == 0;
     bpmf_hip_ctx *ctx = nullptr;
-    check(bpmf_hip_ctx_create_ex(0, K, dtype, nullptr, &ctx));
+    check(bpmf_hip_ctx_create_ex(rank, K, J.dtype, nullptr, &ctx));
+    if (J.sharded) check(bpmf_hip_ctx_comm_init(ctx, J.nranks, rank, J.rccl_id));
+    const int64_t m0 = J.bm[(size_t)rank], m1 = J.bm[(size_t)rank + 1], u0 = J.bu[(size_t)rank], u1 = J.bu[(size_t)rank + 1];
+    auto slice_ptr = [](const Csc &A, int64_t c0, int64_t c1) {       // colptr of the columns [c0, c1), rebased to 0
+        std::vector<int64_t> cp((size_t)(c1 - c0) + 1);
+        for (int64_t c = c0; c <= c1; ++c) cp[(size_t)(c - c0)] = A.colptr[(size_t)c] - A.colptr[(size_t)c0];
+        return cp;
+    };
     bpmf_hip_side *movies = nullptr, *users = nullptr;
     bpmf_hip_test *test = nullptr;
-    check(bpmf_hip_side_create(ctx, nmovies, nusers, 0, nmovies, M.colptr.data(), M.rowidx.data(), M.vals.data(), mean_m, &movies));
-    print_init(os, "movs", M, T.nnz(), mean_m);
-    check(bpmf_hip_side_create(ctx, nusers, nmovies, 0, nusers, Mt.colptr.data(), Mt.rowidx.data(), Mt.vals.data(), mean_u, &users));
-    // Sys::add_prop_posterior (c++/sample.cpp:157-174): "mu_file,lambda_file"; K x N and K*K x N dense matrices
-    auto add_prop_posterior = [&](bpmf_hip_side *side, const std::string &fnames, int64_t n, const char *what) {
-        if (fnames.empty()) return;
-        const size_t pos = fnames.find_first_of(",");
-        if (pos == std::string::npos) die(std::string("-") + what + " expects MU_FILE,LAMBDA_FILE");
-        const Dense mu = bpmf::io::read_dense(fnames.substr(0, pos));
-        const Dense lambda = bpmf::io::read_dense(fnames.substr(pos + 1));
-        if (mu.ncols != n || lambda.ncols != n || mu.nrows != K || lambda.nrows != (int64_t)K * K)
-            die(std::string("propagated posterior (-") + what + "): expected " + std::to_string(K) + " x " + std::to_string(n) + " and " +
-                std::to_string(K * K) + " x " + std::to_string(n) + " matrices");
-        check(bpmf_hip_side_set_prop_posterior(side, mu.data.data(), lambda.data.data()));
-    };
-    add_prop_posterior(movies, mname, nmovies, "m");
-    add_prop_posterior(users, lname, nusers, "l");
-    print_init(os, "users", Mt, T.nnz(), mean_u);
-    check(bpmf_hip_test_create(movies, T.colptr.data(), T.rowidx.data(), T.vals.data(), &test));
+    {
+        const std::vector<int64_t> cp = slice_ptr(J.M, m0, m1);
+        const size_t off = (size_t)J.M.colptr[(size_t)m0];
+        check(bpmf_hip_side_create(ctx, nmovies, nusers, m0, m1, cp.data(), J.M.rowidx.data() + off, J.M.vals.data() + off, J.mean_m, &movies));
+    }
+    print_init(os, "movs", J.M, J.T.nnz(), J.mean_m);
+    {
+        const std::vector<int64_t> cp = slice_ptr(J.Mt, u0, u1);
+        const size_t off = (size_t)J.Mt.colptr[(size_t)u0];
+        check(bpmf_hip_side_create(ctx, nusers, nmovies, u0, u1, cp.data(), J.Mt.rowidx.data() + off, J.Mt.vals.data() + off, J.mean_u, &users));
+    }
+    if (J.sharded) {
+        check(bpmf_hip_side_set_ranges(movies, J.bm.data()));
+        check(bpmf_hip_side_set_ranges(users, J.bu.data()));
+    }
+    // Sys::add_prop_posterior (c++/sample.cpp:157-174): the K*K x N precisions of this rank's columns
+    if (!J.prop_m_lambda.data.empty()) {
+        check(bpmf_hip_side_set_prop_posterior(movies, J.prop_m_mu.data.data() + (size_t)K * m0, J.prop_m_lambda.data.data() + (size_t)K * K * m0));
+        os << "with propagated posterior" << std::endl;               // c++/sample.cpp:221-222
+    }
+    print_init(os, "users", J.Mt, J.T.nnz(), J.mean_u);
+    if (!J.prop_u_lambda.data.empty()) {
+        check(bpmf_hip_side_set_prop_posterior(users, J.prop_u_mu.data.data() + (size_t)K * u0, J.prop_u_lambda.data.data() + (size_t)K * K * u0));
+        os << "with propagated posterior" << std::endl;
+    }
+    const size_t toff = (size_t)J.T.colptr[(size_t)m0];
+    {
+        const std::vector<int64_t> cp = slice_ptr(J.T, m0, m1);
+        check(bpmf_hip_test_create(movies, cp.data(), J.T.rowidx.data() + toff, J.T.vals.data() + toff, &test));
+    }
 
     char host[1024];
     gethostname(host, sizeof host);
@@ -235,17 +255,17 @@ int main(int argc, char *argv[])
     os << "pid: " << getpid() << std::endl;
     if (getenv("PBS_JOBID")) os << "jobid: " << getenv("PBS_JOBID") << std::endl;
     os << "num_latent: " << K << std::endl;
-    os << "nprocs: " << 1 << std::endl;
-    os << "nthrds: " << (nthrds > 0 ? nthrds : 1) << std::endl;
-    os << "nsims: " << nsims << std::endl;
-    os << "burnin: " << burnin << std::endl;
-    os << "alpha: " << alpha << std::endl;
-    os << "update_freq: " << update_freq << std::endl;
+    os << "nprocs: " << J.nranks << std::endl;
+    os << "nthrds: " << (J.nthrds > 0 ? J.nthrds : 1) << std::endl;
+    os << "nsims: " << J.nsims << std::endl;
+    os << "burnin: " << J.burnin << std::endl;
+    os << "alpha: " << J.alpha << std::endl;
+    os << "update_freq: " << J.update_freq << std::endl;
+    if (J.sharded) os << "movs domain: [" << m0 << ", " << m1 << ")  users domain: [" << u0 << ", " << u1 << ")" << std::endl;
 
-    Aggregate agg_u, agg_m;
-    const bool aggregate = !odirname.empty();
-    if (aggregate) { agg_u.init(K, nusers); agg_m.init(K, nmovies); }
-
+    if (aggregate) { J.agg_u.init(K, nusers); J.agg_m.init(K, nmovies); }
+    const int nsims = J.nsims, burnin = J.burnin;
+    const double alpha = J.alpha;
     long double average_items_sec = 0, average_ratings_sec = 0;
     double rmse = NAN, rmse_avg = NAN, se, se_avg;
     int64_t num_predict = 0;
@@ -254,15 +274,15 @@ int main(int argc, char *argv[])
     // Sys::print, c++/sample.cpp:101-107
     auto print_line = [&](int it, double rm, double rma, double nu, double nm, double secs) {
         const double items_per_sec = (double)(nusers + nmovies) / secs;
-        const double ratings_per_sec = (double)M.nnz() / secs;
+        const double ratings_per_sec = (double)J.M.nnz() / secs;
         char buf[1024];
         snprintf(buf, sizeof buf, "%d: %s iteration %d:\t RMSE: %3.4f\tavg RMSE: %3.4f\tFU(%6.2f)\tFM(%6.2f)\titems/sec: %6.2f\tratings/sec: %6.2fM\n",
-                 0, (it < burnin) ? "Burnin" : "Sampling", it, rm, rma, std::sqrt(nu), std::sqrt(nm), items_per_sec, ratings_per_sec / 1e6);
+                 rank, (it < burnin) ? "Burnin" : "Sampling", it, rm, rma, std::sqrt(nu), std::sqrt(nm), items_per_sec, ratings_per_sec / 1e6);
         os << buf << std::flush;
         average_items_sec += items_per_sec;
         average_ratings_sec += ratings_per_sec;
     };
-    if (!aggregate && !verbose) {
+    if (J.odirname.empty() && !J.verbose) {
         // Plain sampling run: the loop of c++/bpmf.cpp:180-198 software-pipelined by one half-iteration.
         // The library only enqueues in bpmf_hip_sys_sample; the line of iteration i-1 (its RMSE sums
         // and norms) is collected after iteration i has been queued, so the device
@@ -309,17 +329,18 @@ int main(int argc, char *argv[])
         check(bpmf_hip_sys_state(movies, nullptr, &norm_m, nullptr, nullptr, nullptr, nullptr));
         print_line(iter, rmse, rmse_avg, norm_u, norm_m, stop - start);
 
-        if (aggregate && iter >= burnin) { agg_u.add(users); agg_m.add(movies); }
-        if (verbose) {
-            if (odirname.empty()) die("-v needs -o DIR");       // the reference would write to "/U-0.ddm" 
+        // (the replicas of both factor matrices are complete on every rank: the all-gather form of the exchange --
+        // users.bcast() / movies.bcast() of c++/bpmf.cpp:202-203 have nothing left to do)
+        if (aggregate && iter >= burnin) { J.agg_u.add(users); J.agg_m.add(movies); }
+        if (J.verbose && rank == 0) {
             Dense d;
             d.nrows = K;
             d.ncols = nusers; d.data.resize((size_t)K * nusers);
             check(bpmf_hip_side_get_items(users, d.data.data()));
-            bpmf::io::write_dense(odirname + "/U-" + std::to_string(i) + ".ddm", d);
+            bpmf::io::write_dense(J.odirname + "/U-" + std::to_string(i) + ".ddm", d);
             d.ncols = nmovies; d.data.resize((size_t)K * nmovies);
             check(bpmf_hip_side_get_items(movies, d.data.data()));
-            bpmf::io::write_dense(odirname + "/V-" + std::to_string(i) + ".ddm", d);
+            bpmf::io::write_dense(J.odirname + "/V-" + std::to_string(i) + ".ddm", d);
         }
     }
     const double elapsed = tick() - begin;
@@ -330,40 +351,144 @@ int main(int argc, char *argv[])
         check(bpmf_hip_predict(test, movies, users, n, &se, &se_avg, &num_predict));
         rmse_avg = std::sqrt(se_avg / (double)num_predict);
     }
-    if (aggregate) {
-        try {
-            Csc P = T;
-            std::vector<double> pm2(T.vals.size());
-            check(bpmf_hip_test_get(test, P.vals.data(), pm2.data()));
-            bpmf::io::write_sparse(odirname + "/Pavg.sdm", P);
-            P.vals = pm2;
-            bpmf::io::write_sparse(odirname + "/Pm2.sdm", P);
-            const int nsamples = nsims - burnin;
-            Dense d;
-            agg_u.finalize(nsamples);
-            d.nrows = K; d.ncols = nusers; d.data = agg_u.mu;
-            bpmf::io::write_dense(odirname + "/U-mu.ddm", d);
-            d.nrows = (int64_t)K * K; d.data = agg_u.lambda;
-            bpmf::io::write_dense(odirname + "/U-Lambda.ddm", d);
-            agg_m.finalize(nsamples);
-            d.nrows = K; d.ncols = nmovies; d.data = agg_m.mu;
-            bpmf::io::write_dense(odirname + "/V-mu.ddm", d);
-            d.nrows = (int64_t)K * K; d.data = agg_m.lambda;
-            bpmf::io::write_dense(odirname + "/V-Lambda.ddm", d);
-        } catch (const std::exception &e) { die(e.what()); }
+    if (!J.odirname.empty()) {                                        // this rank's slice of Pavg / Pm2
+        const size_t tn = (size_t)(J.T.colptr[(size_t)m1] - J.T.colptr[(size_t)m0]);
+        if (tn) check(bpmf_hip_test_get(test, J.pavg.data() + toff, J.pm2.data() + toff));
     }
-
-    os << "Total time: " << elapsed << std::endl;
-    os << "Final Avg RMSE: " << rmse_avg << std::endl;
-    os << "  computed on " << num_predict << " items (" << (T.nnz() ? int(100. * (double)num_predict / (double)T.nnz()) : 0)
-       << "% of total items in test set)" << std::endl;
-    // the reference divides by movies.iter = nsims-1 (SURVEY Q7); this build reports the true mean
-    os << "Average items/sec: " << (double)(average_items_sec / std::max(nsims, 1)) << std::endl;
-    os << "Average ratings/sec: " << (double)(average_ratings_sec / std::max(nsims, 1)) << std::endl;
-
+    if (rank == 0) {
+        J.elapsed = elapsed; J.rmse_avg = rmse_avg; J.num_predict = num_predict;
+        J.average_items_sec = average_items_sec; J.average_ratings_sec = average_ratings_sec;
+    }
     bpmf_hip_test_destroy(test);
     bpmf_hip_side_destroy(movies);
     bpmf_hip_side_destroy(users);
     bpmf_hip_ctx_destroy(ctx);
+}
+
+}  // namespace
+
+int main(int argc, char *argv[])
+{
+    Job J;
+    std::string fname, probename, mname, lname;
+    bool balance = true;
+    int K = 32, ngpu = getenv("BPMF_NGPU") ? atoi(getenv("BPMF_NGPU")) : 0;
+    if (const char *e = getenv("BPMF_NUMLATENT")) K = atoi(e);
+
+    int ch;
+    while ((ch = getopt(argc, argv, "krvn:t:p:i:b:f:o:m:l:a:d:g:h")) != -1) {
+        switch (ch) {
+        case 'i': J.nsims = atoi(optarg); break;
+        case 'b': J.burnin = atoi(optarg); break;
+        case 'f': J.update_freq = atoi(optarg); break;
+        case 't': J.nthrds = atoi(optarg); break;
+        case 'a': J.alpha = atof(optarg); break;
+        case 'd': K = atoi(optarg); break;
+        case 'g': ngpu = atoi(optarg); break;
+        case 'n': fname = optarg; break;
+        case 'p': probename = optarg; break;
+        case 'o': J.odirname = optarg; break;
+        case 'm': mname = optarg; break;
+        case 'l': lname = optarg; break;
+        case 'r': J.redirect = true; break;
+        case 'k': balance = false; break;
+        case 'v': J.verbose = true; break;
+        default: usage(); return 1;
+        }
+    }
+    if (fname.empty() || probename.empty()) { usage(); return 1; }
+    // fp64 like the reference for 8..64 latent dimensions; 128 selects the fp32 large-K path of the library
+    J.K = K;
+    J.dtype = (K == 128) ? BPMF_HIP_F32 : BPMF_HIP_F64;
+    if (!bpmf_hip_supports(K, J.dtype)) die("unsupported number of latent dimensions " + std::to_string(K) + " (8, 16, 32, 64; 128 in fp32)");
+    if (J.verbose && J.odirname.empty()) die("-v needs -o DIR");   // the reference would write to "/U-0.ddm" 
+    // -g N: the sharded path (N = 1 too: one rank with a communicator -- what the tests can run on one GPU); no -g: NO_COMM
+    J.sharded = ngpu >= 1;
+    J.nranks = std::max(ngpu, 1);
+
+    // Sys::Sys (c++/sample.cpp:112-137): read, grow both to the common shape, transpose for the users
+    try {
+        J.M = bpmf::io::read_sparse(fname);
+        J.T = bpmf::io::read_sparse(probename);
+    } catch (const std::exception &e) { die(e.what()); }
+    const int64_t rows = std::max(J.M.nrows, J.T.nrows), cols = std::max(J.M.ncols, J.T.ncols);
+    bpmf::io::resize(J.M, rows, cols);
+    bpmf::io::resize(J.T, rows, cols);
+    if (J.M.nnz() == 0) die("the training matrix is empty");
+    J.Mt = bpmf::io::transpose(J.M);
+    const int64_t nmovies = cols, nusers = rows;
+    double msum = 0.0, usum = 0.0;                              // mean_rating = M.sum()/M.nonZeros() per Sys (:183)
+    for (double v : J.M.vals) msum += v;
+    for (double v : J.Mt.vals) usum += v;
+    J.mean_m = msum / (double)J.M.nnz(); J.mean_u = usum / (double)J.Mt.nnz();
+
+    // Sys::add_prop_posterior (c++/sample.cpp:157-174): "mu_file,lambda_file"; K x N and K*K x N dense matrices
+    auto read_prop = [&](const std::string &fnames, int64_t n, const char *what, Dense &mu, Dense &lambda) {
+        if (fnames.empty()) return;
+        const size_t pos = fnames.find_first_of(",");
+        if (pos == std::string::npos) die(std::string("-") + what + " expects MU_FILE,LAMBDA_FILE");
+        try {
+            mu = bpmf::io::read_dense(fnames.substr(0, pos));
+            lambda = bpmf::io::read_dense(fnames.substr(pos + 1));
+        } catch (const std::exception &e) { die(e.what()); }
+        if (mu.ncols != n || lambda.ncols != n || mu.nrows != K || lambda.nrows != (int64_t)K * K)
+            die(std::string("propagated posterior (-") + what + "): expected " + std::to_string(K) + " x " + std::to_string(n) + " and " +
+                std::to_string(K * K) + " x " + std::to_string(n) + " matrices");
+    };
+    read_prop(mname, nmovies, "m", J.prop_m_mu, J.prop_m_lambda);
+    read_prop(lname, nusers, "l", J.prop_u_mu, J.prop_u_lambda);
+
+    J.bm = column_ranges(J.M, J.nranks, balance);
+    J.bu = column_ranges(J.Mt, J.nranks, balance);
+    if (J.sharded) check(bpmf_hip_comm_unique_id(J.rccl_id));      // (also loads RCCL before the rank threads start)
+    if (!J.odirname.empty()) { J.pavg.assign(J.T.vals.size(), 0.0); J.pm2.assign(J.T.vals.size(), 0.0); }
+
+    // stdout of the ranks: bpmf_<rank>.out when there are several or with -r (c++/bpmf.cpp:111-117)
+    const bool to_files = J.nranks > 1 || J.redirect;
+    std::vector<std::unique_ptr<std::ofstream>> files;
+    auto rank_os = [&](int r) -> std::ostream & {
+        if (!to_files) return std::cout;
+        return *files[(size_t)r];
+    };
+    if (to_files) for (int r = 0; r < J.nranks; ++r) files.emplace_back(new std::ofstream("bpmf_" + std::to_string(r) + ".out"));
+
+    if (J.nranks == 1) {
+        rank_main(J, 0, rank_os(0));
+    } else {
+        std::vector<std::thread> th;
+        for (int r = 0; r < J.nranks; ++r) th.emplace_back([&J, r, &rank_os] { rank_main(J, r, rank_os(r)); });
+        for (auto &t : th) t.join();
+    }
+    std::ostream &os = rank_os(0);
+
+    if (!J.odirname.empty()) {
+        try {
+            Csc P = J.T;
+            P.vals = J.pavg;
+            bpmf::io::write_sparse(J.odirname + "/Pavg.sdm", P);
+            P.vals = J.pm2;
+            bpmf::io::write_sparse(J.odirname + "/Pm2.sdm", P);
+            const int nsamples = J.nsims - J.burnin;
+            Dense d;
+            J.agg_u.finalize(nsamples);
+            d.nrows = K; d.ncols = nusers; d.data = J.agg_u.mu;
+            bpmf::io::write_dense(J.odirname + "/U-mu.ddm", d);
+            d.nrows = (int64_t)K * K; d.data = J.agg_u.lambda;
+            bpmf::io::write_dense(J.odirname + "/U-Lambda.ddm", d);
+            J.agg_m.finalize(nsamples);
+            d.nrows = K; d.ncols = nmovies; d.data = J.agg_m.mu;
+            bpmf::io::write_dense(J.odirname + "/V-mu.ddm", d);
+            d.nrows = (int64_t)K * K; d.data = J.agg_m.lambda;
+            bpmf::io::write_dense(J.odirname + "/V-Lambda.ddm", d);
+        } catch (const std::exception &e) { die(e.what()); }
+    }
+
+    os << "Total time: " << J.elapsed << std::endl;
+    os << "Final Avg RMSE: " << J.rmse_avg << std::endl;
+    os << "  computed on " << J.num_predict << " items (" << (J.T.nnz() ? int(100. * (double)J.num_predict / (double)J.T.nnz()) : 0)
+       << "% of total items in test set)" << std::endl;
+    // the reference divides by movies.iter = nsims-1 (SURVEY Q7); this build reports the true mean
+    os << "Average items/sec: " << (double)(J.average_items_sec / std::max(J.nsims, 1)) << std::endl;
+    os << "Average ratings/sec: " << (double)(J.average_ratings_sec / std::max(J.nsims, 1)) << std::endl;
     return 0;
 }

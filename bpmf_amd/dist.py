@@ -84,6 +84,13 @@ class NativeComm:
         if conn is not None:
             self.engine.side_set_conn(sys.side, *conn)
 
+    def full_gather(self, sys):
+        """users.bcast() / movies.bcast() of the reference (c++/bpmf.cpp:217-218, 268-273): after a run with the
+        connectivity-aware exchange a replica only holds the columns its rank reads; before the factors are handed
+        out (outputs, -v dumps) every rank's range travels to everyone once, in the all-gather form."""
+        self.engine.side_set_conn(sys.side)
+        self.engine.side_exchange(sys.side)
+
 
 class TorchComm:
     def __init__(self, device):
@@ -129,6 +136,11 @@ class TorchComm:
             w.wait()
         if self.device.type == "cuda":
             torch.cuda.current_stream(self.device).synchronize()
+
+    def full_gather(self, sys):
+        t, bounds, conn = self._items[id(sys)]
+        self._items[id(sys)] = (t, bounds, None)
+        self.exchange_items(sys)
 
     def allreduce(self, arr):
         t = torch.as_tensor(np.ascontiguousarray(arr, np.float64)).to(self.device)
@@ -177,6 +189,12 @@ def gibbs_sharded(engine, comm, M, Mt, T, nusers, nmovies, nsims=20, burnin=5, a
         res["norm_u"].append(float(np.sqrt(users.norm))); res["norm_m"].append(float(np.sqrt(movies.norm)))
     movies.predict(users, True)
     res["final_rmse_avg"] = movies.rmse_avg
+    # replicas as the loop leaves them (with the connectivity-aware exchange: only the columns this rank reads are current)
+    res["U_replica"] = users.items(); res["V_replica"] = movies.items()
+    if movies.conn_used:
+        comm.full_gather(movies)
+    if users.conn_used:
+        comm.full_gather(users)
     res["U"] = users.items(); res["V"] = movies.items()
     res["conn_used"] = (movies.conn_used, users.conn_used)
     res["dom_m"], res["dom_u"] = movies.dom, users.dom

@@ -20,7 +20,7 @@ def main():
     M, Mt, T, Tt, nu, nm = {"tiny": util.tiny, "ml100k": util.ml100k, "blocks": util.blocks}[dataset]()
     comm = TorchComm("cpu")
     res = gibbs_sharded(OracleEngine(K), comm, M, Mt, T, nu, nm, nsims=nsims, burnin=burnin)
-    np.savez(out + ".rank%d.npz" % comm.rank, U=res["U"], V=res["V"], rmse=res["rmse"], rmse_avg=res["rmse_avg"],
+    np.savez(out + ".rank%d.npz" % comm.rank, U=res["U"], V=res["V"], U_replica=res["U_replica"], V_replica=res["V_replica"], rmse=res["rmse"], rmse_avg=res["rmse_avg"],
              norm_u=res["norm_u"], norm_m=res["norm_m"], final=res["final_rmse_avg"], conn_used=np.asarray(res["conn_used"]),
              dom_m=np.asarray(res["dom_m"]), dom_u=np.asarray(res["dom_u"]))
     dist.barrier()

@@ -132,3 +132,37 @@ def test_k128_selects_the_fp32_path(tmp_path):
     assert "num_latent: 128" in r.stdout
     final = float(re.search(r"Final Avg RMSE: (\S+)", r.stdout).group(1))
     assert 0.9 < final < 1.3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [32, 128])
+def test_g1_runs_the_sharded_path_and_equals_the_plain_run(tmp_path, K):
+    """bpmf -g N: the reference's `mpirun -np N bpmf` (c++/bpmf.cpp:111-117) as N rank threads in one process, RCCL id
+    shared in memory.  -g 1 drives everything but a second GPU -- communicator, ranges, the sharded sys_sample /
+    predict with their all-reduces, per-rank bpmf_<rank>.out -- and must print the chain of the plain run.
+    The ADVICE finding of round 1: nprocs was hard-wired to 1 and the sharded path unreachable from the CLI."""
+    args = ["-i", "6", "-b", "2", "-d", str(K), "-n", os.path.join(G, "ml100k-train.mtx.gz"), "-p", os.path.join(G, "ml100k-test.mtx.gz")]
+    plain = run(args, tmp_path)
+    assert plain.returncode == 0, plain.stderr
+    (tmp_path / "g").mkdir()
+    sharded = run(args + ["-g", "1", "-r"], tmp_path / "g")
+    assert sharded.returncode == 0, sharded.stderr
+    out = (tmp_path / "g" / "bpmf_0.out").read_text()
+    assert "nprocs: 1" in out and "movs domain: [0, 1682)" in out
+    pick = lambda text: [(m.group(1), m.group(2)) for m in re.finditer(r"\t RMSE: (\S+)\tavg RMSE: (\S+)", text)]
+    assert len(pick(out)) == 6 and pick(out) == pick(plain.stdout)
+    assert re.search(r"Final Avg RMSE: (\S+)", out).group(1) == re.search(r"Final Avg RMSE: (\S+)", plain.stdout).group(1)
+    # with outputs: Pavg / U-mu of the sharded run equal the plain run's
+    for d, extra in (("o_plain", []), ("o_g1", ["-g", "1"])):
+        (tmp_path / d).mkdir()
+        r = run(args + ["-o", d + "/"] + extra, tmp_path)
+        assert r.returncode == 0, r.stderr
+    a = bio.read_sparse(tmp_path / "o_plain" / "Pavg.sdm"); b = bio.read_sparse(tmp_path / "o_g1" / "Pavg.sdm")
+    assert np.array_equal(a[2][2], b[2][2])
+    assert np.array_equal(bio.read_dense(tmp_path / "o_plain" / "U-mu.ddm"), bio.read_dense(tmp_path / "o_g1" / "U-mu.ddm"))
+
+
+def test_more_gpus_than_devices_fails_cleanly(tmp_path):
+    """-g 2 on a box without two GPUs (here: none): an error message, not a hang or a crash."""
+    r = run(["-i", "1", "-g", "2", "-n", os.path.join(G, "tiny-train.mtx"), "-p", os.path.join(G, "tiny-test.mtx")], tmp_path)
+    assert r.returncode != 0 and "bpmf:" in r.stderr

@@ -63,10 +63,13 @@ def test_connectivity_aware_exchange(oracle, tmp_path):
         assert list(r["dom_m"]) == [bm[rank], bm[rank + 1]] and list(r["dom_u"]) == [bu[rank], bu[rank + 1]]
         assert np.allclose(r["rmse"], ref["rmse"], atol=1e-9) and np.allclose(r["rmse_avg"], ref["rmse_avg"], atol=1e-9)
         assert np.allclose(r["norm_u"], ref["norm_u"], rtol=1e-10) and np.allclose(r["norm_m"], ref["norm_m"], rtol=1e-10)
-        for X, Xref, dom, need in ((r["U"], ref["U"], r["dom_u"], need_u[rank]), (r["V"], ref["V"], r["dom_m"], need_m[rank])):
+        for X, Xref, dom, need in ((r["U_replica"], ref["U"], r["dom_u"], need_u[rank]), (r["V_replica"], ref["V"], r["dom_m"], need_m[rank])):
             held = np.zeros(len(X), bool); held[dom[0]:dom[1]] = True; held[need] = True
             assert np.allclose(X[held], Xref[held], rtol=1e-9, atol=1e-11)          # owned or read here: current
-            assert (~held).sum() > len(X) // 4 and np.all(X[~held] == 0.0)          # never shipped
+            assert (~held).sum() > len(X) // 4 and np.all(X[~held] == 0.0)          # never shipped during the loop
+        # what is handed out is the FULL factor on every rank (users.bcast() / movies.bcast(), c++/bpmf.cpp:217-218)
+        assert np.allclose(r["U"], ref["U"], rtol=1e-9, atol=1e-11) and np.allclose(r["V"], ref["V"], rtol=1e-9, atol=1e-11)
+        assert np.array_equal(r["U"], res[0]["U"]) and np.array_equal(r["V"], res[0]["V"])
     # the lists mirror each other: what q sends to r is what r expects from q, in the same order
     for need, bounds in ((need_u, bu), (need_m, bm)):
         L = [conn_lists(need, bounds, r) for r in range(world)]
