@@ -107,8 +107,12 @@ def cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies, budget_s=12.0):
         env = dict(os.environ)
         env.update({"OMP_PLACES": "cores", "OMP_PROC_BIND": "spread", "OMP_WAIT_POLICY": "active"})
         env.pop("OMP_NUM_THREADS", None)
+        try:
+            usable = len(os.sched_getaffinity(0))
+        except AttributeError:
+            usable = os.cpu_count() or 1
         r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--matrix", path, "--K", str(K),
-                            "--budget", str(budget_s)], env=env, capture_output=True, text=True, timeout=600)
+                            "--budget", str(budget_s), "--usable", str(usable)], env=env, capture_output=True, text=True, timeout=600)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not line:
             raise RuntimeError("cpu_baseline.py rc=%d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:]))

@@ -49,6 +49,7 @@ def cpu_info():
     except AttributeError:
         usable = os.cpu_count() or 1
     physical = min(len(pairs), usable) if pairs else usable
+    cpu_info.pairs_total = len(pairs) if pairs else usable
     return model, max(1, physical), usable
 
 
@@ -57,6 +58,8 @@ def main():
     ap.add_argument("--matrix", required=True)
     ap.add_argument("--K", type=int, default=32)
     ap.add_argument("--budget", type=float, default=12.0, help="seconds of CPU work for the final measurement")
+    ap.add_argument("--usable", type=int, default=0, help="hardware threads the launching process may use (with OMP_PROC_BIND "
+                    "the OpenMP runtime pins THIS process's initial thread to one core as soon as it loads, so sched_getaffinity here says 2)")
     args = ap.parse_args()
 
     from oracle import oracle as orc
@@ -71,6 +74,8 @@ def main():
     nusers, nmovies = int(z["shape"][0]), int(z["shape"][1])
     K = args.K
     model, physical, usable = cpu_info()
+    if args.usable > 0:
+        physical = max(physical, min(cpu_info.pairs_total, args.usable)); usable = args.usable
 
     def per_iter(nt, n):
         o.gibbs(K, M, Mt, T, Tt, nsims=1, burnin=0, nthreads=nt)               # first touch + warm-up
