@@ -81,6 +81,7 @@ struct SampleArgs {
     // host turns that into BPMF_HIP_ENODEV "device wait timed out" and ends the chain
     unsigned long long *tmo;
     unsigned long long wait_ticks;
+    unsigned long long *stamps; // profiling only (BPMF_HIP_STAMPS=1): s_memtime at phase boundaries of two probe items, or NULL
     uint32_t ablate;            // profiling only (BPMF_HIP_ABLATE): 1 = skip the factorisation, 2 = skip the Gram, 4 = gather from 64 hot rows only
 };
 

@@ -39,6 +39,7 @@ Rccl *rccl()
 
 static int settle_async(struct bpmf_hip_side *s);      // waits until the worker is done with `s`; returns its deferred error
 static void flush_deferred(struct bpmf_hip_test *t);   // enqueues an evaluation whose launch was put off
+namespace { void predraw_stop(struct bpmf_hip_side *s); }   // joins the side's pre-draw helper threads
 
 struct bpmf_hip_side;
 // host-side timeline for BPMF_HIP_TRACE=1: (time, tag, side) records, printed when the context dies
@@ -114,7 +115,8 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     s->mode = mode_env >= 0 ? mode_env : (K <= 32 ? (nloc >= 20000 ? 3 : 1) : 4);
     // K = 128: the slab form measured slower than the workgroup form (one wave per SIMD cannot hide the gather
     // latency of a 36-tile Gram, and its 120 KB of straight-line code thrash the instruction cache): opt-in
-    if (f32) s->mode = (mode_env == 4) ? 4 : 2;
+    // the default: workgroup per item, second form (kernels_wg2.h, mode 5); 2 = the first workgroup form (no chunking)
+    if (f32) s->mode = (mode_env == 4) ? 4 : (mode_env == 2 ? 2 : 5);
     else if (K == 64) { if (s->mode == 3) s->mode = 4; }
     else {
         if (s->mode == 2 || s->mode == 4) s->mode = 1;                             // (BPMF_HIP_MODE=2 / 4 exist for K >= 64 only)
@@ -132,7 +134,7 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
         // slab form: ONE wave walks an item, and a rating costs 36 (K = 128) / 10 (K = 64) tile MFMAs per 4
         // ratings: a launch lasts (average load of a wave slot) + (longest item), so items must stay short (ML-1M shape,
         // K = 64: 512-rating chunks 0.208 ms per launch, 256: 0.179)
-        const int64_t lo = s->mode == 4 ? 256 : 16 * K;
+        const int64_t lo = s->mode == 4 ? 256 : (s->mode == 5 ? 512 : 16 * K);
         chunk = (int)std::min<int64_t>(std::max<int64_t>(c, lo), 65536);   // (upper limit: 10M x 1M shards measured best with 64 K-rating chunks)
         // four columns per wave: a wave holds four items (and a chunk's partial is a quarter of the
         // size), so the same work per wave means chunks of a quarter of the length
@@ -331,6 +333,7 @@ static int ctx_create_impl(int device, int K, int dtype, void *stream, bpmf_hip_
     HIP_TRY(hipMemset(c->d_ticket, 0, 64));
     HIP_TRY(hipMalloc((void **)&c->d_zero, 1024));
     HIP_TRY(hipMemset(c->d_zero, 0, 1024));
+    if (env_int("BPMF_HIP_STAMPS", 0)) { HIP_TRY(hipMalloc((void **)&c->d_stamps, 4096)); HIP_TRY(hipMemset(c->d_stamps, 0, 4096)); }
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     *out = c;
     return BPMF_HIP_OK;
@@ -350,6 +353,16 @@ extern "C" int bpmf_hip_ctx_destroy(bpmf_hip_ctx *c)
     if (g_trace_on) trace_dump();
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->d_stamps) {                                              // the last launch's stamps of the two probe items
+        unsigned long long h[512];
+        if (hipMemcpy(h, c->d_stamps, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+            for (int probe = 0; probe < 2; ++probe) {
+                fprintf(stderr, "[bpmf_hip] stamps of probe item %d (100 MHz ticks since its start):", probe);
+                for (int i = 1; i < 64 && h[probe * 64 + i]; ++i) fprintf(stderr, " %d:%lld", i, (long long)(h[probe * 64 + i] - h[probe * 64]));
+                fprintf(stderr, "\n");
+            }
+        (void)hipFree(c->d_stamps);
+    }
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_out) (void)hipHostFree(c->h_out);
@@ -448,6 +461,7 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
         s->wcv.notify_all();
         s->worker.join();
     }
+    predraw_stop(s);
     (void)hipSetDevice(s->ctx->device);
     if (g_trace_on && s->n_gap > 0)
         fprintf(stderr, "[bpmf_hip] side %04x: previous sampler's end -> this sampler's start: %.2f us (mean of %lld timed launches)\n",
@@ -859,6 +873,68 @@ int ensure_state(bpmf_hip_side *s)
     return 0;
 }
 
+void predraw_main(bpmf_hip_side *s)
+{
+    auto &P = s->predraw;
+    const int K = s->ctx->K;
+    std::unique_lock<std::mutex> lk(P.m);
+    for (;;) {
+        P.cv.wait(lk, [&] { return P.stop || P.next <= P.consumed + bpmf_hip_side::Predraw::DEPTH; });
+        if (P.stop) return;
+        const int it = P.next++;
+        auto &sl = P.slot[it % bpmf_hip_side::Predraw::DEPTH];
+        lk.unlock();
+        sl.au.resize((size_t)K * K); sl.z.resize(K);
+        const int rc = bpmf_hyper_draws(K, s->ncols, (uint32_t)it, sl.au.data(), sl.z.data());
+        lk.lock();
+        sl.iter = rc ? -3 - it : it;                                  // (a failed draw is recomputed inline by the consumer)
+        P.cv.notify_all();
+    }
+}
+
+// the random part of iteration `iter` into rd_au / rd_z (from the ring; iterations are asked for in order)
+int predraw_get(bpmf_hip_side *s, int iter)
+{
+    auto &P = s->predraw;
+    const int K = s->ctx->K;
+    if (P.threads.empty()) {
+        const int n = std::max(1, env_int("BPMF_HIP_PREDRAW_THREADS", K >= 128 ? 3 : 1));
+        { std::lock_guard<std::mutex> lk(P.m); P.next = iter; P.consumed = iter - 1; }
+        for (int i = 0; i < n; ++i) P.threads.emplace_back(predraw_main, s);
+    }
+    std::unique_lock<std::mutex> lk(P.m);
+    auto &sl = P.slot[((iter % bpmf_hip_side::Predraw::DEPTH) + bpmf_hip_side::Predraw::DEPTH) % bpmf_hip_side::Predraw::DEPTH];
+    if (iter < P.consumed + 1 || iter >= P.next + bpmf_hip_side::Predraw::DEPTH) {      // out of order (never in a chain): inline
+        lk.unlock();
+        s->rd_au.resize((size_t)K * K); s->rd_z.resize(K);
+        const int rc = bpmf_hyper_draws(K, s->ncols, (uint32_t)iter, s->rd_au.data(), s->rd_z.data());
+        if (!rc) s->rd_iter = iter;
+        return rc;
+    }
+    P.cv.wait(lk, [&] { return sl.iter == iter || sl.iter == -3 - iter; });
+    const bool ok = sl.iter == iter;
+    if (ok) { s->rd_au.swap(sl.au); s->rd_z.swap(sl.z); }
+    P.consumed = iter;
+    P.cv.notify_all();
+    lk.unlock();
+    if (!ok) {
+        s->rd_au.resize((size_t)K * K); s->rd_z.resize(K);
+        const int rc = bpmf_hyper_draws(K, s->ncols, (uint32_t)iter, s->rd_au.data(), s->rd_z.data());
+        if (rc) return rc;
+    }
+    s->rd_iter = iter;
+    return 0;
+}
+
+void predraw_stop(bpmf_hip_side *s)
+{
+    auto &P = s->predraw;
+    { std::lock_guard<std::mutex> lk(P.m); P.stop = true; }
+    P.cv.notify_all();
+    for (auto &t : P.threads) if (t.joinable()) t.join();
+    P.threads.clear();
+}
+
 // hyper-parameters of iteration `iter` from the side's current cov, into (mu, LU, LF); the matching
 // parameter blob goes into the side's pinned memory and the gate of that iteration is opened
 int draw_and_release(bpmf_hip_side *s, int iter, double *mu, double *LU, double *LF)
@@ -868,11 +944,7 @@ int draw_and_release(bpmf_hip_side *s, int iter, double *mu, double *LU, double 
     // rng_set_pos(iter); hp.sample(num(), sum = 0, cov)  (c++/sample.cpp:349-350); the random part
     // may have been drawn ahead of time (it does not depend on cov)
     int rc = 0;
-    if (s->rd_iter != iter) {
-        s->rd_au.resize((size_t)K * K); s->rd_z.resize(K);
-        rc = bpmf_hyper_draws(K, s->ncols, (uint32_t)iter, s->rd_au.data(), s->rd_z.data());
-        if (!rc) s->rd_iter = iter;
-    }
+    if (s->rd_iter != iter) rc = predraw_get(s, iter);
     if (!rc) rc = bpmf_hyper_finish(K, s->ncols, s->cov.data(), nullptr, s->rd_au.data(), s->rd_z.data(), mu, LU, LF);
     if (!rc) fill_blob(K, mu, LF, s->a_h_in, K == 64 && s->ctx->dtype == BPMF_HIP_F64 && s->lr_n > 0);   // (R0, R0^-1: only the low-rank forms read them)
     // the gate is opened even after an error: a sampler may already be queued behind it and must
@@ -895,10 +967,6 @@ void collect(bpmf_hip_side *s, const bpmf_hip_side::Job &job)
     unsigned *flag = reinterpret_cast<unsigned *>(s->a_h_out + c->out_words - 1);
     // while the device is still sampling: the random part of the next draw (gamma / normal stream
     // of WishartUnitChol and MvNormalChol_prec), which needs no result of this half-iteration
-    if (s->rd_iter != job.iter + 1) {
-        s->rd_au.resize((size_t)K * K); s->rd_z.resize(K);
-        if (bpmf_hyper_draws(K, s->ncols, (uint32_t)(job.iter + 1), s->rd_au.data(), s->rd_z.data()) == 0) s->rd_iter = job.iter + 1;
-    }
     if (s->nx_iter == job.iter) {                                     // the parameters this half-iteration ran with
         s->hp_mu.swap(s->nx_mu); s->hp_LambdaU.swap(s->nx_LambdaU); s->hp_LambdaF.swap(s->nx_LambdaF);
         s->nx_iter = -2;
@@ -951,10 +1019,6 @@ void collect(bpmf_hip_side *s, const bpmf_hip_side::Job &job)
     trace("collect: gate of the next half-iteration opened", s, job.iter);
     if (!rc && rd) { rc = rd; msg = g_err; }
     if (!rc) s->nx_iter = job.iter + 1;
-    // the gate is open: NOW, while the device samples the other side and then this one, draw the random part
-    // of the draw after next (it depends on nothing but the counter).  At the head of collect() it sat between
-    // "sampler enqueued" and "sums landed": at K = 64 it takes longer than the sampler itself
-    if (!rc && bpmf_hyper_draws(K, s->ncols, (uint32_t)(job.iter + 2), s->rd_au.data(), s->rd_z.data()) == 0) s->rd_iter = job.iter + 2;
     {   // kernel times of this launch (its events are complete: the flag is published behind them)
         float a = 0.f, b = 0.f;
         const bool own_stats = s->stats_ev[job.evset].load(std::memory_order_acquire) == ev[2];   // else: inside another launch

@@ -1,0 +1,19 @@
+// k128_wg2.hip -- K = 128 fp32 factors: workgroup per item, diagonal blocks factored + inverted on the 4x4x4 f64 MFMA,
+// panel / solves as products with the inverted blocks, heavy columns chunked (the default form; see launch.h)
+#include "launch.h"
+#include "kernels_wg2.h"
+
+namespace bpmf_launch {
+
+void k128_wg2(int grid, int nwaves, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a)
+{
+    if (nwaves == 4) {
+        if (e0 || e1) hipExtLaunchKernelGGL((bpmf::k_sample_wg2<128, 4>), dim3(grid), dim3(256), 0, st, e0, e1, 0, a);
+        else hipLaunchKernelGGL((bpmf::k_sample_wg2<128, 4>), dim3(grid), dim3(256), 0, st, a);
+    } else {
+        if (e0 || e1) hipExtLaunchKernelGGL((bpmf::k_sample_wg2<128, 2>), dim3(grid), dim3(128), 0, st, e0, e1, 0, a);
+        else hipLaunchKernelGGL((bpmf::k_sample_wg2<128, 2>), dim3(grid), dim3(128), 0, st, a);
+    }
+}
+
+}  // namespace bpmf_launch

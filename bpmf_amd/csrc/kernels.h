@@ -138,6 +138,14 @@ __device__ __forceinline__ void wait_params(const SampleArgs &a)
     asm volatile("" ::: "memory");
 }
 
+// profiling (BPMF_HIP_STAMPS=1): work items 0 and nwork / 2 of a launch record the wall clock at phase boundaries
+__device__ __forceinline__ void stamp(const SampleArgs &a, int w, int slot)
+{
+    if (a.stamps == nullptr || threadIdx.x != 0) return;
+    const int probe = (w == 0) ? 0 : ((w == a.nwork / 2) ? 1 : -1);
+    if (probe >= 0 && slot < 64) a.stamps[probe * 64 + slot] = wall_clock64();
+}
+
 template <int NMAX>
 __device__ __forceinline__ void draw_normals(uint32_t counter, int n, double *out_lds, int lane)
 {

@@ -31,6 +31,8 @@ void k64_pf(int cls, int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, con
 // slab form (kernels_slab.h): K = 64 fp64 and K = 128 fp32 factors, one wave per work item
 void k64_slab(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a);
 void k128_slab(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a);
+// K = 128 fp32: workgroup of 2 / 4 waves per item, second form (kernels_wg2.h)
+void k128_wg2(int grid, int nwaves, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a);
 
 // kernels that do not depend on K (kcommon.hip)
 void stage(const double *src_host_dev, double *dst, int n, hipStream_t st);

@@ -72,12 +72,15 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
     a.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
     a.mu = d_in + (size_t)K * K + K + 2; a.prop_lambda = self->d_prop; a.diag_only = c->diag_only;
     a.mean_rating = self->mean_rating; a.alpha = alpha; a.iter_plus_1 = (uint32_t)(iter + 1);
-    a.ablate = c->ablate;
+    a.ablate = c->ablate; a.stamps = c->d_stamps;
     a.gate_flag = self->cur_gate_flag; a.gate_want = self->cur_gate_want;
     a.tmo = self->cur_gate_flag ? tmo_word(self->a_h_out_dev, K) : nullptr; a.wait_ticks = wait_ticks();
     a.zero_row = c->d_zero;
-    if constexpr (K == 128) {                                        // slab form, fp32 factors (items / other_items are float arrays)
-        if (nwork > 0) k128_slab(nwork, st, ev_start, ev_stop, a);
+    if constexpr (K == 128) {                                        // fp32 factors (items / other_items are float arrays)
+        if (nwork > 0) {
+            if (self->mode == 4) k128_slab(nwork, st, ev_start, ev_stop, a);
+            else k128_wg2(nwork, env_int("BPMF_HIP_WG_WAVES", 2) == 4 ? 4 : 2, st, ev_start, ev_stop, a);
+        }
         return 0;
     } else {
     if constexpr (K <= 32) {

@@ -141,6 +141,7 @@ struct bpmf_hip_ctx {
     double *d_red = nullptr;
     unsigned seq = 0;                    // value the next publishing kernel writes behind its results
     unsigned *d_ticket = nullptr;        // arrival counters of k_colstats' waves (stateless path)
+    unsigned long long *d_stamps = nullptr;   // BPMF_HIP_STAMPS=1: phase time stamps of two probe work items (printed when the context dies)
     double *d_zero = nullptr;            // K zeros: the row padding slots of a ragged rating group gather from
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 };
@@ -233,6 +234,21 @@ struct bpmf_hip_side {
     int nx_iter = -2;
     std::vector<double> rd_au, rd_z;                             // cov-independent random part, drawn for iteration rd_iter
     int rd_iter = -2;
+    // The random part of a hyper-parameter draw (Wishart gammas / normals, K (K - 1) + 2 K numbers from the Philox
+    // stream `iter`) depends on nothing but the iteration number and costs more than a whole sampler launch at
+    // K >= 64 (K = 128: ~1 ms on the host): helper threads draw a few iterations AHEAD into a ring, the collector
+    // thread only picks the finished draw up.
+    struct Predraw {
+        static constexpr int DEPTH = 8;
+        struct Slot { std::vector<double> au, z; int iter = -1; };
+        Slot slot[DEPTH];
+        std::vector<std::thread> threads;
+        std::mutex m;
+        std::condition_variable cv;
+        int next = 0;                    // first iteration no helper has claimed
+        int consumed = -1;               // last iteration handed out
+        bool stop = false;
+    } predraw;
 };
 
 struct bpmf_hip_test {

@@ -512,6 +512,31 @@ ORACLE_API int64_t bpmf_oracle_sample_side(int K, int64_t from, int64_t to, cons
 #undef DISPATCH
 }
 
+/*
+ * One column, given by its own ratings: Sys::sample(long idx, Sys&) for global column id `idx` whose `n` ratings sit
+ * in (rowidx, vals) with row ids into `other_items` -- for spot checks of matrices too big to hand over whole
+ * (BASELINE configs[3]: 10M x 1M; the rows a column reads are gathered into a small `other_items` and renumbered).
+ * out[K] receives the sample; returns 0 or 1 (Cholesky failed).
+ */
+ORACLE_API int bpmf_oracle_sample_column(int K, int64_t idx, int64_t n, const int32_t *rowidx, const double *vals,
+                                         double mean_rating, double alpha, const double *other_items, int iter,
+                                         const double *mu, const double *LambdaF, double *out)
+{
+    double *Lmu = (double *)malloc(sizeof(double) * K);
+    double *MM = (double *)malloc(sizeof(double) * K * K), *L = (double *)malloc(sizeof(double) * K * K);
+    int64_t *cp = (int64_t *)malloc(sizeof(int64_t) * 2);
+    for (int i = 0; i < K; ++i) {                      /* rr = hp_LambdaF * hp.mu, :285 */
+        double s = 0.0;
+        for (int j = 0; j < K; ++j) s += AT(LambdaF, i, j) * mu[j];
+        Lmu[i] = s;
+    }
+    cp[0] = 0; cp[1] = n;
+    /* sample_col reads colptr[idx], colptr[idx + 1]: hand it a view whose element `idx` is cp[0] */
+    const int rc = sample_col(K, idx, cp - idx, rowidx, vals, mean_rating, alpha, other_items, iter, Lmu, LambdaF, MM, L, out, 0);
+    free(Lmu); free(MM); free(L); free(cp);
+    return rc;
+}
+
 /* the same with propagated-posterior priors (-m / -l, c++/sample.cpp:152-174,272-277):
  * propLambda holds one column-major K x K matrix per column of this side (global column index) */
 ORACLE_API int64_t bpmf_oracle_sample_side_prop(int K, int64_t from, int64_t to, const int64_t *colptr,

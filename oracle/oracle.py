@@ -50,6 +50,9 @@ class Oracle:
             C.c_int, C.c_int64, C.c_int64, _i64p, _i32p, _f64p, C.c_double, C.c_double, _f64p, _f64p,
             C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_int]
         lib.bpmf_oracle_sample_side.restype = C.c_int64
+        lib.bpmf_oracle_sample_column.argtypes = [C.c_int, C.c_int64, C.c_int64, _i32p, _f64p, C.c_double, C.c_double, _f64p, C.c_int,
+                                                  _f64p, _f64p, _f64p]
+        lib.bpmf_oracle_sample_column.restype = C.c_int
         lib.bpmf_oracle_sample_side_prop.argtypes = [
             C.c_int, C.c_int64, C.c_int64, _i64p, _i32p, _f64p, C.c_double, C.c_double, _f64p, _f64p,
             C.c_int, _f64p, _f64p, _f64p, _f64p, _f64p, _f64p, C.c_int]
@@ -128,6 +131,18 @@ class Oracle:
         if rc:
             raise RuntimeError("Cholesky failed in column %d" % (-rc - 1))
         return s, prod, float(nrm[0])
+
+    def sample_column(self, K, idx, rowidx, vals, mean_rating, alpha, other_items, it, mu, LambdaF):
+        """One column (global id `idx`) from its own ratings; rowidx index the rows of `other_items` ([n_rows, K])."""
+        out = np.zeros(K)
+        LF = np.asfortranarray(LambdaF, np.float64)
+        rc = self.lib.bpmf_oracle_sample_column(K, int(idx), len(rowidx), np.ascontiguousarray(rowidx, np.int32),
+                                                np.ascontiguousarray(vals, np.float64), float(mean_rating), float(alpha),
+                                                np.ascontiguousarray(other_items, np.float64), int(it),
+                                                np.ascontiguousarray(mu, np.float64), LF.T, out)
+        if rc:
+            raise RuntimeError("Cholesky failed in column %d" % idx)
+        return out
 
     def cov(self, K, N, s, prod):
         c = np.zeros((K, K), order="F")
