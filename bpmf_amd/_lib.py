@@ -46,6 +46,8 @@ _SIGNATURES = {
     "bpmf_hip_sys_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
     "bpmf_hip_failed_column": (C.c_int64, [C.c_void_p]),
+    "bpmf_hip_side_aggr_add": (C.c_int, [C.c_void_p]),
+    "bpmf_hip_side_aggr_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "bpmf_hip_test_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "bpmf_hip_test_destroy": (C.c_int, [C.c_void_p]),
     "bpmf_hip_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

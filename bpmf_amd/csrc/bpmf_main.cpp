@@ -97,63 +97,6 @@ void print_init(std::ostream &os, const char *name, const Csc &M, int64_t test_n
     os << "num " << name << ": " << M.ncols << std::endl;
 }
 
-// K x K inverse by Gauss-Jordan with partial pivoting (finalize_mu_lambda's cov.inverse(), c++/bpmf.cpp:291)
-bool invert_inplace(int K, std::vector<double> &a)
-{
-    std::vector<double> inv((size_t)K * K, 0.0);
-    for (int i = 0; i < K; ++i) inv[(size_t)i * K + i] = 1.0;
-    auto A = [&](int r, int c) -> double & { return a[(size_t)c * K + r]; };
-    auto B = [&](int r, int c) -> double & { return inv[(size_t)c * K + r]; };
-    for (int c = 0; c < K; ++c) {
-        int p = c;
-        for (int r = c + 1; r < K; ++r) if (std::fabs(A(r, c)) > std::fabs(A(p, c))) p = r;
-        if (A(p, c) == 0.0) return false;
-        if (p != c) for (int j = 0; j < K; ++j) { std::swap(A(c, j), A(p, j)); std::swap(B(c, j), B(p, j)); }
-        const double d = A(c, c);
-        for (int j = 0; j < K; ++j) { A(c, j) /= d; B(c, j) /= d; }
-        for (int r = 0; r < K; ++r) {
-            if (r == c) continue;
-            const double f = A(r, c);
-            if (f == 0.0) continue;
-            for (int j = 0; j < K; ++j) { A(r, j) -= f * A(c, j); B(r, j) -= f * B(c, j); }
-        }
-    }
-    a.swap(inv);
-    return true;
-}
-
-// posterior aggregation of one side (aggrMu / aggrLambda, c++/sample.cpp:364-368; c++/bpmf.cpp:281-295)
-struct Aggregate {
-    int K = 0; int64_t N = 0;
-    std::vector<double> mu, lambda, items;
-    void init(int K_, int64_t N_) { K = K_; N = N_; mu.assign((size_t)K * N, 0.0); lambda.assign((size_t)K * K * N, 0.0); items.resize((size_t)K * N); }
-    void add(bpmf_hip_side *side)
-    {
-        check(bpmf_hip_side_get_items(side, items.data()));
-        for (int64_t c = 0; c < N; ++c) {
-            const double *r = &items[(size_t)c * K];
-            double *m = &mu[(size_t)c * K], *l = &lambda[(size_t)c * K * K];
-            for (int j = 0; j < K; ++j) {
-                m[j] += r[j];
-                for (int i = 0; i < K; ++i) l[(size_t)j * K + i] += r[i] * r[j];
-            }
-        }
-    }
-    void finalize(int nsamples)
-    {
-        std::vector<double> cov((size_t)K * K);
-        const double nan = std::nan("");
-        for (int64_t c = 0; c < N; ++c) {
-            double *m = &mu[(size_t)c * K], *l = &lambda[(size_t)c * K * K];
-            for (int j = 0; j < K; ++j)
-                for (int i = 0; i < K; ++i) cov[(size_t)j * K + i] = (l[(size_t)j * K + i] - (m[i] * m[j] / nsamples)) / (nsamples - 1);
-            if (!invert_inplace(K, cov)) std::fill(cov.begin(), cov.end(), nan);     // singular when nsamples <= K
-            memcpy(l, cov.data(), sizeof(double) * K * K);
-            for (int j = 0; j < K; ++j) m[j] /= nsamples;
-        }
-    }
-};
-
 // Contiguous column ranges of equal work, work = c0 + nnz per column -- the reference's assign() balances the same
 // quantity with c0 = 10 (c++/assign.cpp:109-120) and then permutes the columns; contiguous cuts of the original
 // order keep the column ids, hence the per-column RNG streams and the samples, independent of the GPU count.
@@ -194,7 +137,7 @@ struct Job {
     char rccl_id[128];
     // results
     std::vector<double> pavg, pm2;                                   // test-set order of T; every rank fills its slice
-    Aggregate agg_u, agg_m;                                          // rank 0
+    std::vector<double> u_mu, u_lambda, m_mu, m_lambda;              // -o: K x N means, K*K x N precisions; every rank fills its columns
     double elapsed = 0.0, rmse_avg = NAN;
     int64_t num_predict = 0;
     long double average_items_sec = 0, average_ratings_sec = 0;
@@ -206,7 +149,7 @@ void rank_main(Job &J, int rank, std::ostream &os)
 {
     const int K = J.K;
     const int64_t nmovies = J.M.ncols, nusers = J.M.nrows;
-    const bool aggregate = !J.odirname.empty() && rank == 0;
+    const bool aggregate = !J.odirname.empty();
     bpmf_hip_ctx *ctx = nullptr;
     check(bpmf_hip_ctx_create_ex(rank, K, J.dtype, nullptr, &ctx));
     if (J.sharded) check(bpmf_hip_ctx_comm_init(ctx, J.nranks, rank, J.rccl_id));
@@ -263,7 +206,6 @@ void rank_main(Job &J, int rank, std::ostream &os)
     os << "update_freq: " << J.update_freq << std::endl;
     if (J.sharded) os << "movs domain: [" << m0 << ", " << m1 << ")  users domain: [" << u0 << ", " << u1 << ")" << std::endl;
 
-    if (aggregate) { J.agg_u.init(K, nusers); J.agg_m.init(K, nmovies); }
     const int nsims = J.nsims, burnin = J.burnin;
     const double alpha = J.alpha;
     long double average_items_sec = 0, average_ratings_sec = 0;
@@ -329,9 +271,10 @@ void rank_main(Job &J, int rank, std::ostream &os)
         check(bpmf_hip_sys_state(movies, nullptr, &norm_m, nullptr, nullptr, nullptr, nullptr));
         print_line(iter, rmse, rmse_avg, norm_u, norm_m, stop - start);
 
-        // (the replicas of both factor matrices are complete on every rank: the all-gather form of the exchange --
+        // aggrMu / aggrLambda of this rank's columns, on the device (c++/sample.cpp:364-368)
+        if (aggregate && iter >= burnin) { check(bpmf_hip_side_aggr_add(users)); check(bpmf_hip_side_aggr_add(movies)); }
+        // (-v: the replicas of both factor matrices are complete on every rank -- the all-gather form of the exchange;
         // users.bcast() / movies.bcast() of c++/bpmf.cpp:202-203 have nothing left to do)
-        if (aggregate && iter >= burnin) { J.agg_u.add(users); J.agg_m.add(movies); }
         if (J.verbose && rank == 0) {
             Dense d;
             d.nrows = K;
@@ -351,9 +294,14 @@ void rank_main(Job &J, int rank, std::ostream &os)
         check(bpmf_hip_predict(test, movies, users, n, &se, &se_avg, &num_predict));
         rmse_avg = std::sqrt(se_avg / (double)num_predict);
     }
-    if (!J.odirname.empty()) {                                        // this rank's slice of Pavg / Pm2
+    if (!J.odirname.empty()) {                                        // this rank's slice of Pavg / Pm2 and of the posterior
         const size_t tn = (size_t)(J.T.colptr[(size_t)m1] - J.T.colptr[(size_t)m0]);
         if (tn) check(bpmf_hip_test_get(test, J.pavg.data() + toff, J.pm2.data() + toff));
+        const int nsamples = nsims - burnin;
+        if (nsamples > 0) {                                           // Sys::finalize_mu_lambda (c++/bpmf.cpp:281-295), batched on the device
+            check(bpmf_hip_side_aggr_finalize(users, nsamples, J.u_mu.data() + (size_t)K * u0, J.u_lambda.data() + (size_t)K * K * u0));
+            check(bpmf_hip_side_aggr_finalize(movies, nsamples, J.m_mu.data() + (size_t)K * m0, J.m_lambda.data() + (size_t)K * K * m0));
+        }
     }
     if (rank == 0) {
         J.elapsed = elapsed; J.rmse_avg = rmse_avg; J.num_predict = num_predict;
@@ -441,7 +389,12 @@ int main(int argc, char *argv[])
     J.bm = column_ranges(J.M, J.nranks, balance);
     J.bu = column_ranges(J.Mt, J.nranks, balance);
     if (J.sharded) check(bpmf_hip_comm_unique_id(J.rccl_id));      // (also loads RCCL before the rank threads start)
-    if (!J.odirname.empty()) { J.pavg.assign(J.T.vals.size(), 0.0); J.pm2.assign(J.T.vals.size(), 0.0); }
+    if (!J.odirname.empty()) {
+        J.pavg.assign(J.T.vals.size(), 0.0); J.pm2.assign(J.T.vals.size(), 0.0);
+        const double nan = std::nan("");                              // (no post-burn-in sample: the reference divides 0 by 0)
+        J.u_mu.assign((size_t)K * nusers, nan); J.u_lambda.assign((size_t)K * K * nusers, nan);
+        J.m_mu.assign((size_t)K * nmovies, nan); J.m_lambda.assign((size_t)K * K * nmovies, nan);
+    }
 
     // stdout of the ranks: bpmf_<rank>.out when there are several or with -r (c++/bpmf.cpp:111-117)
     const bool to_files = J.nranks > 1 || J.redirect;
@@ -468,17 +421,14 @@ int main(int argc, char *argv[])
             bpmf::io::write_sparse(J.odirname + "/Pavg.sdm", P);
             P.vals = J.pm2;
             bpmf::io::write_sparse(J.odirname + "/Pm2.sdm", P);
-            const int nsamples = J.nsims - J.burnin;
             Dense d;
-            J.agg_u.finalize(nsamples);
-            d.nrows = K; d.ncols = nusers; d.data = J.agg_u.mu;
+            d.nrows = K; d.ncols = nusers; d.data.swap(J.u_mu);
             bpmf::io::write_dense(J.odirname + "/U-mu.ddm", d);
-            d.nrows = (int64_t)K * K; d.data = J.agg_u.lambda;
+            d.nrows = (int64_t)K * K; d.data.swap(J.u_lambda);
             bpmf::io::write_dense(J.odirname + "/U-Lambda.ddm", d);
-            J.agg_m.finalize(nsamples);
-            d.nrows = K; d.ncols = nmovies; d.data = J.agg_m.mu;
+            d.nrows = K; d.ncols = nmovies; d.data.swap(J.m_mu);
             bpmf::io::write_dense(J.odirname + "/V-mu.ddm", d);
-            d.nrows = (int64_t)K * K; d.data = J.agg_m.lambda;
+            d.nrows = (int64_t)K * K; d.data.swap(J.m_lambda);
             bpmf::io::write_dense(J.odirname + "/V-Lambda.ddm", d);
         } catch (const std::exception &e) { die(e.what()); }
     }

@@ -486,6 +486,8 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
     if (s->own_items && s->d_items) (void)hipFree(s->d_items);
     if (s->d_items_alt) (void)hipFree(s->d_items_alt);
     if (s->d_prop) (void)hipFree(s->d_prop);
+    if (s->d_aggr_mu) (void)hipFree(s->d_aggr_mu);
+    if (s->d_aggr_lambda) (void)hipFree(s->d_aggr_lambda);
     void *ptrs[] = {s->d_wi_col, s->d_wi_len, s->d_wi_mc, s->d_wi_chunk, s->d_wi_p0, s->d_mc_slot0, s->d_mc_nch, s->d_mc_count, s->d_partials, s->d_stat_partials, s->a_d_in,
                     s->d_lr_col, s->d_lr_len, s->d_lr_p0, s->d_hv_col, s->d_hv_len, s->d_hv_mc, s->d_hv_chunk, s->d_hv_p0,
                     s->d_conn_send, s->d_conn_recv, s->d_conn_sbuf, s->d_conn_rbuf};
@@ -802,6 +804,44 @@ extern "C" int bpmf_hip_sample_side(bpmf_hip_side *self, const bpmf_hip_side *ot
 }
 
 extern "C" int64_t bpmf_hip_failed_column(const bpmf_hip_side *s) { return s ? s->failed_column : -1; }
+
+// aggrMu.col(i) += r; aggrLambda.col(i) += r r^T for this rank's columns (c++/sample.cpp:364-368), on the device
+extern "C" int bpmf_hip_side_aggr_add(bpmf_hip_side *s)
+{
+    if (!s) return fail(BPMF_HIP_EINVAL, "aggr_add: NULL");
+    bpmf_hip_ctx *c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    { const int rc = settle_async(s); if (rc) return rc; }
+    const size_t K = (size_t)c->K, nloc = (size_t)(s->to - s->from);
+    if (!s->d_aggr_mu) {
+        if (hipMalloc((void **)&s->d_aggr_mu, std::max<size_t>(K * nloc, 1) * sizeof(double)) != hipSuccess ||
+            hipMalloc((void **)&s->d_aggr_lambda, std::max<size_t>(K * K * nloc, 1) * sizeof(double)) != hipSuccess)
+            return fail(BPMF_HIP_ENOMEM, "aggr_add: K*K doubles per column do not fit in device memory");
+        HIP_TRY(hipMemsetAsync(s->d_aggr_mu, 0, K * nloc * sizeof(double), c->stream));
+        HIP_TRY(hipMemsetAsync(s->d_aggr_lambda, 0, K * K * nloc * sizeof(double), c->stream));
+    }
+    bpmf_launch::aggr_add(s->d_items, c->dtype == BPMF_HIP_F32, c->K, s->from, (int64_t)nloc, s->d_aggr_mu, s->d_aggr_lambda, c->stream);
+    HIP_TRY(hipGetLastError());
+    c->last_sampler_done = nullptr;
+    return BPMF_HIP_OK;
+}
+
+// Sys::finalize_mu_lambda (c++/bpmf.cpp:281-295): one K x K inverse per column, batched on the device
+extern "C" int bpmf_hip_side_aggr_finalize(bpmf_hip_side *s, int nsamples, double *mu_host, double *lambda_host)
+{
+    if (!s || !mu_host || !lambda_host) return fail(BPMF_HIP_EINVAL, "aggr_finalize: NULL");
+    if (!s->d_aggr_mu) return fail(BPMF_HIP_EINVAL, "aggr_finalize: nothing was aggregated");
+    bpmf_hip_ctx *c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t K = (size_t)c->K, nloc = (size_t)(s->to - s->from);
+    bpmf_launch::aggr_finalize(c->K, nsamples, (int64_t)nloc, s->d_aggr_mu, s->d_aggr_lambda, c->stream);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(mu_host, s->d_aggr_mu, K * nloc * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(lambda_host, s->d_aggr_lambda, K * K * nloc * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(s->d_aggr_mu); (void)hipFree(s->d_aggr_lambda);
+    s->d_aggr_mu = s->d_aggr_lambda = nullptr;
+    return BPMF_HIP_OK;
+}
 
 extern "C" int bpmf_hip_side_last_kernel_ms(bpmf_hip_side *s, float *sample_ms, float *reduce_ms)
 {

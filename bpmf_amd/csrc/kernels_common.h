@@ -46,4 +46,84 @@ __global__ __launch_bounds__(64) void k_randn_probe(uint32_t counter, int n, dou
     for (int i = threadIdx.x; i < n; i += 64) out[i] = z[i];
 }
 
+// ---------------------------------------------------------------------------
+// Posterior aggregation for the -o outputs (c++/sample.cpp:364-368, c++/bpmf.cpp:281-295), on the device: the
+// reference adds r and r r^T of every post-burn-in sample into aggrMu (K x N) / aggrLambda (K*K x N) and inverts one
+// K x K covariance per column at the end.  One workgroup per column; K is a run-time argument.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_aggr_add(const T *__restrict__ items, int K, int64_t c0, double *__restrict__ mu, double *__restrict__ lambda)
+{
+    const int64_t c = blockIdx.x;                                   // local column
+    const T *x = items + (size_t)(c0 + c) * K;
+    double *l = lambda + (size_t)c * K * K;
+    for (int e = threadIdx.x; e < K * K; e += 256) l[e] += (double)x[e % K] * (double)x[e / K];     // column-major K x K: (i, j) at i + j K
+    if ((int)threadIdx.x < K) mu[(size_t)c * K + threadIdx.x] += (double)x[threadIdx.x];
+    for (int e = 256 + (int)threadIdx.x; e < K; e += 256) mu[(size_t)c * K + e] += (double)x[e];
+}
+
+// cov = (prod - sum sum^T / n) / (n - 1); Lambda = cov^-1 (in-place Gauss-Jordan with partial pivoting, the matrix
+// stays in global memory -- a column's K x K block is L2-resident while its workgroup works on it); mu = sum / n.
+// A singular covariance (n <= K samples) gives NaN like the reference's inverse of a singular matrix gives inf / NaN.
+__global__ __launch_bounds__(256) void k_aggr_finalize(int K, int nsamples, double *__restrict__ mu, double *__restrict__ lambda)
+{
+    __shared__ int piv[256];
+    __shared__ double red_v[256];
+    __shared__ int red_i[256];
+    __shared__ int singular;
+    const int64_t c = blockIdx.x;
+    const int tid = threadIdx.x;
+    double *a = lambda + (size_t)c * K * K;
+    double *m = mu + (size_t)c * K;
+    auto A = [&](int r, int cc) -> double & { return a[(size_t)cc * K + r]; };
+    for (int e = tid; e < K * K; e += 256) {
+        const int i = e % K, j = e / K;
+        a[e] = (a[e] - (m[i] * m[j] / nsamples)) / (nsamples - 1);
+    }
+    if (tid == 0) singular = 0;
+    __syncthreads();
+    for (int k = 0; k < K; ++k) {
+        // pivot: largest |A(r, k)|, r >= k
+        double best = -1.0; int bi = k;
+        for (int r = k + tid; r < K; r += 256) { const double v = fabs(A(r, k)); if (v > best) { best = v; bi = r; } }
+        red_v[tid] = best; red_i[tid] = bi;
+        __syncthreads();
+        for (int st = 128; st >= 1; st >>= 1) {
+            if (tid < st && (red_v[tid + st] > red_v[tid] || (red_v[tid + st] == red_v[tid] && red_i[tid + st] < red_i[tid]))) { red_v[tid] = red_v[tid + st]; red_i[tid] = red_i[tid + st]; }
+            __syncthreads();
+        }
+        const int p = red_i[0];
+        if (tid == 0) { piv[k] = p; if (!(red_v[0] > 0.0)) singular = 1; }
+        if (p != k) for (int j = tid; j < K; j += 256) { const double t = A(k, j); A(k, j) = A(p, j); A(p, j) = t; }
+        __syncthreads();
+        if (singular) break;
+        const double d = A(k, k);
+        __syncthreads();
+        for (int j = tid; j < K; j += 256) A(k, j) = (j == k) ? 1.0 / d : A(k, j) / d;
+        __syncthreads();
+        // eliminate column k from the other rows: thread (r, j) tiles over the matrix; f = A(r, k) is read before it is overwritten
+        for (int r0 = 0; r0 < K; r0 += 256 / 32) {                   // 8 rows at a time, 32 column lanes
+            const int r = r0 + (tid >> 5);
+            double f = 0.0;
+            if (r < K && r != k) f = A(r, k);
+            __syncthreads();
+            if (r < K && r != k) {
+                for (int j = (tid & 31); j < K; j += 32) A(r, j) = (j == k) ? -f * A(k, k) : A(r, j) - f * A(k, j);
+            }
+            __syncthreads();
+        }
+    }
+    if (singular) {
+        for (int e = tid; e < K * K; e += 256) a[e] = __builtin_nan("");
+    } else {
+        // undo the row interchanges as column interchanges, in reverse order
+        for (int k = K - 1; k >= 0; --k) {
+            const int p = piv[k];
+            if (p != k) for (int r = tid; r < K; r += 256) { const double t = A(r, k); A(r, k) = A(r, p); A(r, p) = t; }
+            __syncthreads();
+        }
+    }
+    for (int e = tid; e < K; e += 256) m[e] /= nsamples;
+}
+
 }  // namespace bpmf

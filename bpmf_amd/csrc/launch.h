@@ -40,5 +40,7 @@ void gate_stage(int nblocks, const unsigned *gate_host_dev, unsigned want, const
                 unsigned long long *tmo, unsigned long long ticks, hipStream_t st);
 void publish(const double *src, double *dst_host_dev, int n, unsigned *flag_host_dev, unsigned seq, int fail_at, hipStream_t st);
 void randn_probe(uint32_t counter, int n, double *out_dev, hipStream_t st);
+void aggr_add(const void *items, bool f32, int K, int64_t c0, int64_t ncols, double *mu, double *lambda, hipStream_t st);
+void aggr_finalize(int K, int nsamples, int64_t ncols, double *mu, double *lambda, hipStream_t st);
 
 }  // namespace bpmf_launch

@@ -159,6 +159,7 @@ struct bpmf_hip_side {
     double *d_items_alt = nullptr; bool items_exposed = false; int cur_buf = 0;
     struct Reader { struct bpmf_hip_test *t = nullptr; unsigned seq = 0; } readers[2];   // last evaluation that read buffer 0 / 1
     struct bpmf_hip_test *deferred_eval = nullptr;      // evaluation waiting for this side's next gate kernel (flush_deferred)
+    double *d_aggr_mu = nullptr, *d_aggr_lambda = nullptr;   // -o: aggrMu (K x nloc) / aggrLambda (K*K x nloc) of the local columns
     double *d_prop = nullptr;            // propagated posterior (-m / -l): K x K prior precision per local column, or NULL
     // schedule
     int nwork = 0, nmulti = 0, nslots = 0, mode = 0;

@@ -190,6 +190,17 @@ class HipEngine:
         _lib.check(self.lib.bpmf_hip_sys_state(side.handle, C.byref(it), C.byref(nrm), _ptr(cov), _ptr(mu), _ptr(LF), _ptr(LU)))
         return it.value, nrm.value, cov, mu, LF, LU
 
+    def aggr_add(self, side):
+        """aggrMu / aggrLambda += r, r r^T of the side's local columns (device)."""
+        _lib.check(self.lib.bpmf_hip_side_aggr_add(side.handle))
+
+    def aggr_finalize(self, side, nsamples):
+        """Sys::finalize_mu_lambda: (mu [nloc, K], Lambda [nloc, K*K]) of the local columns."""
+        nloc = side.col_to - side.col_from
+        mu = np.empty((nloc, self.K)); lam = np.empty((nloc, self.K * self.K))
+        _lib.check(self.lib.bpmf_hip_side_aggr_finalize(side.handle, int(nsamples), _ptr(mu), _ptr(lam)))
+        return mu, lam
+
     def kernel_ms_sum(self, side):
         """(sampler ms, statistics ms, launches) summed over the half-iterations run through sys_sample."""
         a = C.c_double(); b = C.c_double(); n = C.c_int64()

@@ -197,6 +197,14 @@ BPMF_API int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, doub
  * any output pointer may be NULL */
 BPMF_API int bpmf_hip_sys_state(const bpmf_hip_side *side, int *iter, double *norm, double *cov, double *mu,
                                 double *LambdaF, double *LambdaU);
+/* Posterior aggregation for the -o outputs.  _aggr_add replaces `aggrMu.col(i) += r; aggrLambda.col(i) += r r^T` of
+ * Sys::sample(Sys&) (c++/sample.cpp:364-368): call it after a post-burn-in bpmf_hip_sys_sample; the K + K*K doubles
+ * per LOCAL column live on the device.  _aggr_finalize replaces Sys::finalize_mu_lambda (c++/bpmf.cpp:281-295):
+ * cov = (prod - sum sum^T / n) / (n - 1), Lambda = cov^-1 (batched, one workgroup per column), mu = sum / n; it
+ * copies this rank's K x nloc means and K*K x nloc precisions (column-major per column, the layout of U-mu.ddm /
+ * U-Lambda.ddm) to the host and frees the device buffers.  A singular covariance (n <= K) gives NaN. */
+BPMF_API int bpmf_hip_side_aggr_add(bpmf_hip_side *side);
+BPMF_API int bpmf_hip_side_aggr_finalize(bpmf_hip_side *side, int nsamples, double *mu_host, double *lambda_host);
 /* global id of the first column whose factorisation failed, or -1 */
 BPMF_API int64_t bpmf_hip_failed_column(const bpmf_hip_side *side);
 
