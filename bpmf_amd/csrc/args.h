@@ -125,6 +125,7 @@ struct LrArgs {
     const double *R0;          // K x K, row-major upper factor of LambdaF (zeros below the diagonal)
     const double *S0t;         // K x K: S0t[j * K + i] = (R0^-1)[i][j] -- columns without ratings: x = R0^-1 (y0 + z)
     const double *y0;          // K: R0^-T (LambdaF mu), the forward solve every such column would repeat
+    const double *Q;           // nrows x K: R0^-T u_row for every row of the other side (k_pf_prepare), product form only
     const double *Lmu;         // LambdaF * mu
     unsigned long long *fail;
     double mean_rating, alpha, sqrt_alpha;

@@ -129,7 +129,7 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
         // mode 0: >= 8 work items per SIMD so the tail of the launch stays short.  Lower bound
         // 16 K: a chunk's partial tiles are ~1.3 K^2 doubles written and read back, against 8 K
         // bytes gathered per rating, so shorter chunks make the partials a first-order traffic term.
-        int64_t c = (s->mode == 0) ? s->nnz / (simds * 8) : (s->nnz * 2) / (simds * 3);
+        int64_t c = (s->mode == 0) ? s->nnz / (simds * 8) : (s->mode == 4 ? s->nnz / (simds * 3) : (s->nnz * 2) / (simds * 3));
         c = (c + 63) / 64 * 64;
         // slab form: ONE wave walks an item, and a rating costs 36 (K = 128) / 10 (K = 64) tile MFMAs per 4
         // ratings: a launch lasts (average load of a wave slot) + (longest item), so items must stay short (ML-1M shape,
@@ -228,6 +228,7 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
             if (!(it.mc < 0 && it.len <= nlr)) { hc.push_back(it.col); hl.push_back(it.len); hm.push_back(it.mc); hk.push_back(it.chunk); hp.push_back(it.p0); }
         if (nlr > 0 && (int64_t)lc.size() * 2 >= nloc && !lc.empty()) {
             s->lr_n = (int)lc.size(); s->hv_nwork = (int)hc.size();
+            if (s->pf_class[3] > 0 && (rc = dev_upload<double>(&s->d_pf_q, nullptr, (size_t)s->nrows * K))) return rc;
             if ((rc = dev_upload(&s->d_lr_col, lc.data(), lc.size())) || (rc = dev_upload(&s->d_lr_len, ll.data(), ll.size())) ||
                 (rc = dev_upload(&s->d_lr_p0, lp.data(), lp.size())) || (rc = dev_upload(&s->d_hv_col, hc.data(), hc.size())) ||
                 (rc = dev_upload(&s->d_hv_len, hl.data(), hl.size())) || (rc = dev_upload(&s->d_hv_mc, hm.data(), hm.size())) ||
@@ -267,7 +268,7 @@ void free_schedule(bpmf_hip_side *s)
     void **ptrs[] = {(void **)&s->d_wi_col, (void **)&s->d_wi_len, (void **)&s->d_wi_mc, (void **)&s->d_wi_chunk, (void **)&s->d_wi_p0,
                      (void **)&s->d_mc_slot0, (void **)&s->d_mc_nch, (void **)&s->d_mc_count, (void **)&s->d_partials, (void **)&s->d_stat_partials,
                      (void **)&s->d_lr_col, (void **)&s->d_lr_len, (void **)&s->d_lr_p0, (void **)&s->d_hv_col, (void **)&s->d_hv_len,
-                     (void **)&s->d_hv_mc, (void **)&s->d_hv_chunk, (void **)&s->d_hv_p0};
+                     (void **)&s->d_hv_mc, (void **)&s->d_hv_chunk, (void **)&s->d_hv_p0, (void **)&s->d_pf_q};
     for (void **p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
     s->lr_n = s->hv_nwork = 0;
 }
@@ -490,7 +491,7 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
     if (s->d_aggr_lambda) (void)hipFree(s->d_aggr_lambda);
     void *ptrs[] = {s->d_wi_col, s->d_wi_len, s->d_wi_mc, s->d_wi_chunk, s->d_wi_p0, s->d_mc_slot0, s->d_mc_nch, s->d_mc_count, s->d_partials, s->d_stat_partials, s->a_d_in,
                     s->d_lr_col, s->d_lr_len, s->d_lr_p0, s->d_hv_col, s->d_hv_len, s->d_hv_mc, s->d_hv_chunk, s->d_hv_p0,
-                    s->d_conn_send, s->d_conn_recv, s->d_conn_sbuf, s->d_conn_rbuf};
+                    s->d_conn_send, s->d_conn_recv, s->d_conn_sbuf, s->d_conn_rbuf, s->d_pf_q};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (s->a_h_in) (void)hipHostFree(s->a_h_in);
     if (s->a_h_out) (void)hipHostFree(s->a_h_out);

@@ -20,4 +20,10 @@ void k64_pf(int cls, int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, con
     }
 }
 
+void k64_pf_prepare(int grid, hipStream_t st, hipEvent_t e0, const double *S0t, const double *other_items, int64_t nrows, double *Q)
+{
+    if (e0) hipExtLaunchKernelGGL(bpmf::k_pf_prepare<64>, dim3(grid), dim3(512), 0, st, e0, nullptr, 0, S0t, other_items, nrows, Q);
+    else hipLaunchKernelGGL(bpmf::k_pf_prepare<64>, dim3(grid), dim3(512), 0, st, S0t, other_items, nrows, Q);
+}
+
 }  // namespace bpmf_launch

@@ -239,6 +239,34 @@ __device__ __forceinline__ double pf_solve(const PfFactor &f, double w, int lane
     return (w - (f.p * f.irs) * F) * f.rs;
 }
 
+// q_row = R0^-T u_row depends on the ROW (a column of the other side), not on the column that reads it: it is
+// computed ONCE per half-iteration for every row (Q = U_other R0^-1, nrows x K) instead of once per rating --
+// on the ChEMBL-shaped compounds side that turns n + 1 = 2.7 matrix-vector products per column into one (plus n
+// gathers of 512 bytes).  Same instruction sequence per entry as the in-line product had: bit-identical q.
+template <int K>
+__global__ __launch_bounds__(512, 4) void k_pf_prepare(const double *__restrict__ S0t, const double *__restrict__ other_items, int64_t nrows,
+                                                       double *__restrict__ Q)
+{
+    static_assert(K == 64, "one lane per latent index");
+    constexpr int LD = K + 1, NW = 8;
+    __shared__ double S0[K * LD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int q = tid; q < K * K; q += 64 * NW) {                       // S0t[j * K + i] = (R0^-1)[i][j]
+        const int j = q / K, i = q % K;
+        S0[i * LD + j] = S0t[q];
+    }
+    __syncthreads();
+    for (int64_t row = (int64_t)blockIdx.x * NW + wave; row < nrows; row += (int64_t)gridDim.x * NW) {
+        const double u = other_items[(size_t)row * K + lane];
+        int ln = lane;                                                // (opaque per row: column `lane` of S0 is not to be hoisted into 128 registers)
+        asm volatile("" : "+v"(ln));
+        double q = 0.0;                                               // q_j = sum_i S0[i][j] u_i
+#pragma unroll
+        for (int i = 0; i < K; ++i) q = fma(S0[i * LD + ln], readlane_d(u, i), q);
+        Q[(size_t)row * K + lane] = q;
+    }
+}
+
 template <int K, int NCAP>
 __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
 {
@@ -267,11 +295,8 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
         for (int m = 0; m < NCAP; ++m) {
             if (m < len) {                                            // wave-uniform
                 const int row = a.rowidx[p0 + m];
-                const double u = a.other_items[(size_t)row * K + lane];
                 const double wv = (a.vals[p0 + m] - a.mean_rating) * a.alpha;                       // c++/sample.cpp:256
-                double q = 0.0;                                       // q = R0^-T u: q_j = sum_i S0[i][j] u_i
-#pragma unroll
-                for (int i = 0; i < K; ++i) q = fma(S0[i * LD + lane], readlane_d(u, i), q);
+                double q = a.Q[(size_t)row * K + lane];               // q = R0^-T u_row (k_pf_prepare)
                 c = fma(wv, q, c);                                    // R0^-T b = y0 + sum_m wv_m R0^-T u_m
                 q *= a.sqrt_alpha;                                    // R0^-T x_m, x_m = sqrt(alpha) u_m
 #pragma unroll
@@ -288,10 +313,14 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
         for (int m = NCAP - 1; m >= 0; --m)
             if (m < len) v = pf_solve(f[m], v, lane);
         double x0 = 0.0, x1 = 0.0;                                    // x = R0^-1 v: x_i = sum_j S0[i][j] v_j
+        // (a fresh, opaque copy of the lane id per column: row `lane` of S0 is loop-invariant, and hoisted out of the
+        // column loop it is 128 registers in a kernel compiled for 64 -- the spills cost more than the LDS reads)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
 #pragma unroll
         for (int j = 0; j < K; j += 2) {
-            x0 = fma(S0[lane * LD + j], readlane_d(v, j), x0);
-            x1 = fma(S0[lane * LD + j + 1], readlane_d(v, j + 1), x1);
+            x0 = fma(S0[ln * LD + j], readlane_d(v, j), x0);
+            x1 = fma(S0[ln * LD + j + 1], readlane_d(v, j + 1), x1);
         }
         const double xs = x0 + x1;
         a.items[(size_t)(a.col_from + col) * K + lane] = xs;

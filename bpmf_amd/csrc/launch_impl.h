@@ -115,9 +115,16 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
             // product form for the columns with <= 6 ratings: two instantiations (<= 2, <= 6), persistent workgroups
             // of eight waves with R0^-1 in LDS; then one launch per sweep width for the rest (the events ride on
             // the first / last launch of the side)
+            l.Q = self->d_pf_q;
             int first = 0, last = 0;
             for (int cls = 1; cls <= 4; ++cls) if (self->lr_class[cls] > self->lr_class[cls - 1]) { if (!first) first = cls; last = cls; }
             bool started = self->hv_nwork > 0;
+            if (self->pf_class[3] > self->pf_class[0] && self->d_pf_q) {
+                // Q = U_other R0^-1 once per half-iteration (k_pf_prepare), ahead of the product-form launches
+                const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((self->nrows + 7) / 8, (int64_t)c->num_cu * 4));
+                k64_pf_prepare(grid, st, started ? nullptr : ev_start, l.S0t, other->d_items, self->nrows, self->d_pf_q);
+                started = true;
+            }
             int last_pf = -1;
             for (int pc = 0; pc < 3; ++pc) if (self->pf_class[pc + 1] > self->pf_class[pc]) last_pf = pc;
             for (int pc = 0; pc < 3; ++pc) {

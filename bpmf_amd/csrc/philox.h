@@ -39,8 +39,11 @@ BPMF_HD Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 #pragma unroll
 #endif
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = mulhi32(M0, c0), lo0 = M0 * c0;
-        const uint32_t hi1 = mulhi32(M1, c2), lo1 = M1 * c2;
+        // one 32 x 32 -> 64 product per multiplier (v_mad_u64_u32 on the device: both halves from ONE quarter-rate
+        // instruction instead of v_mul_hi_u32 + v_mul_lo_u32)
+        const uint64_t p0 = (uint64_t)M0 * (uint64_t)c0, p1 = (uint64_t)M1 * (uint64_t)c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += W0; k1 += W1;

@@ -168,6 +168,7 @@ struct bpmf_hip_side {
     int lr_n = 0, hv_nwork = 0;
     int lr_class[5] = {0, 0, 0, 0, 0};     // light items sorted by sweep width: class c (1..4 ratings per sweep) is [lr_class[c-1], lr_class[c])
     int pf_class[4] = {0, 0, 0, 0};        // ahead of them: product-form items (k_sample_pf): <= 2 ratings, 3..6, 7..12 -- class c is [pf_class[c], pf_class[c+1])
+    double *d_pf_q = nullptr;              // product form: R0^-T u_row for every row of the other side (nrows x K), per half-iteration
     int32_t *d_lr_col = nullptr, *d_lr_len = nullptr; int64_t *d_lr_p0 = nullptr;
     int32_t *d_hv_col = nullptr, *d_hv_len = nullptr, *d_hv_mc = nullptr, *d_hv_chunk = nullptr; int64_t *d_hv_p0 = nullptr;
     int32_t *d_wi_col = nullptr, *d_wi_len = nullptr, *d_wi_mc = nullptr, *d_wi_chunk = nullptr;
