@@ -70,6 +70,8 @@ _SIGNATURES = {
     "bpmf_io_read_dense": (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(c_f64p)]),
     "bpmf_io_write_dense": (C.c_int, [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p]),
     "bpmf_io_free": (None, [C.c_void_p]),
+    "bpmf_assign_greedy": (C.c_int, [C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "bpmf_assign_contiguous": (C.c_int, [C.c_int64, C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
 }
 
 

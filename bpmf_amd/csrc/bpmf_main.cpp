@@ -29,6 +29,7 @@
 
 #include "../../include/bpmf_hip.h"
 #include "io.h"
+#include "../../include/bpmf_io.h"
 
 namespace {
 
@@ -125,6 +126,44 @@ std::vector<int64_t> column_ranges(const Csc &M, int nparts, bool balance)
     return b;
 }
 
+// B = A with its columns renumbered (column j of B = column col_new2old[j] of A) and its row ids mapped through
+// row_old2new, rows ascending inside every column again: Sys::permuteCols (c++/assign.cpp:17-36) for both sides at once
+Csc permute(const Csc &A, const std::vector<int64_t> &col_new2old, const std::vector<int64_t> &row_old2new)
+{
+    Csc B;
+    B.nrows = A.nrows; B.ncols = A.ncols;
+    B.colptr.assign((size_t)A.ncols + 1, 0);
+    B.rowidx.resize(A.rowidx.size()); B.vals.resize(A.vals.size());
+    std::vector<std::pair<int32_t, double>> tmp;
+    int64_t q = 0;
+    for (int64_t j = 0; j < A.ncols; ++j) {
+        const int64_t o = col_new2old[(size_t)j];
+        tmp.clear();
+        for (int64_t p = A.colptr[(size_t)o]; p < A.colptr[(size_t)o + 1]; ++p)
+            tmp.emplace_back((int32_t)row_old2new[(size_t)A.rowidx[(size_t)p]], A.vals[(size_t)p]);
+        std::sort(tmp.begin(), tmp.end(), [](const std::pair<int32_t, double> &a, const std::pair<int32_t, double> &b) { return a.first < b.first; });
+        for (auto &e : tmp) { B.rowidx[(size_t)q] = e.first; B.vals[(size_t)q] = e.second; ++q; }
+        B.colptr[(size_t)j + 1] = q;
+    }
+    return B;
+}
+
+std::vector<int64_t> inverse(const std::vector<int64_t> &p)
+{
+    std::vector<int64_t> r(p.size());
+    for (size_t i = 0; i < p.size(); ++i) r[(size_t)p[i]] = (int64_t)i;
+    return r;
+}
+
+// dense K' x N matrix (column-major, one block of `rows` doubles per column): out column j = in column map[j]
+void permute_columns(std::vector<double> &d, int64_t rows, const std::vector<int64_t> &map)
+{
+    if (d.empty()) return;
+    std::vector<double> o(d.size());
+    for (size_t j = 0; j < map.size(); ++j) memcpy(&o[j * (size_t)rows], &d[(size_t)map[j] * (size_t)rows], sizeof(double) * (size_t)rows);
+    d.swap(o);
+}
+
 struct Job {
     // inputs (read-only for the ranks)
     Csc M, Mt, T;
@@ -134,6 +173,7 @@ struct Job {
     std::string odirname;
     Dense prop_m_mu, prop_m_lambda, prop_u_mu, prop_u_lambda;       // -m / -l (empty: none)
     std::vector<int64_t> bm, bu;                                     // column ranges of the ranks
+    std::vector<int64_t> perm_m, perm_u;                             // greedy assignment: new column id -> original (empty: none)
     char rccl_id[128];
     // results
     std::vector<double> pavg, pm2;                                   // test-set order of T; every rank fills its slice
@@ -204,6 +244,7 @@ void rank_main(Job &J, int rank, std::ostream &os)
     os << "burnin: " << J.burnin << std::endl;
     os << "alpha: " << J.alpha << std::endl;
     os << "update_freq: " << J.update_freq << std::endl;
+    if (!J.perm_m.empty()) os << "assignment: greedy (c++/assign.cpp), columns renumbered" << std::endl;
     if (J.sharded) os << "movs domain: [" << m0 << ", " << m1 << ")  users domain: [" << u0 << ", " << u1 << ")" << std::endl;
 
     const int nsims = J.nsims, burnin = J.burnin;
@@ -280,9 +321,11 @@ void rank_main(Job &J, int rank, std::ostream &os)
             d.nrows = K;
             d.ncols = nusers; d.data.resize((size_t)K * nusers);
             check(bpmf_hip_side_get_items(users, d.data.data()));
+            if (!J.perm_u.empty()) permute_columns(d.data, K, inverse(J.perm_u));
             bpmf::io::write_dense(J.odirname + "/U-" + std::to_string(i) + ".ddm", d);
             d.ncols = nmovies; d.data.resize((size_t)K * nmovies);
             check(bpmf_hip_side_get_items(movies, d.data.data()));
+            if (!J.perm_m.empty()) permute_columns(d.data, K, inverse(J.perm_m));
             bpmf::io::write_dense(J.odirname + "/V-" + std::to_string(i) + ".ddm", d);
         }
     }
@@ -386,8 +429,45 @@ int main(int argc, char *argv[])
     read_prop(mname, nmovies, "m", J.prop_m_mu, J.prop_m_lambda);
     read_prop(lname, nusers, "l", J.prop_u_mu, J.prop_u_lambda);
 
-    J.bm = column_ranges(J.M, J.nranks, balance);
-    J.bu = column_ranges(J.Mt, J.nranks, balance);
+    // Assignment of the columns to the GPUs.  -k: equal column counts (c++/assign.cpp:60-65).  Otherwise the reference's
+    // greedy, permuting assign() (BPMF_ASSIGN=greedy, the default with more than one GPU: `bpmf -g N` then behaves like
+    // `mpirun -np N bpmf`, including column ids -- and RNG streams -- that depend on N), or BPMF_ASSIGN=contiguous:
+    // cuts of the original order at equal work, which keep the samples independent of N.
+    const char *assign_env = getenv("BPMF_ASSIGN");
+    // (test hook: BPMF_TEST_ASSIGN_PARTS=P renumbers as for P ranks while running on the ranks there are -- what one
+    // GPU can check of the permute / unpermute plumbing)
+    const int assign_parts = getenv("BPMF_TEST_ASSIGN_PARTS") ? atoi(getenv("BPMF_TEST_ASSIGN_PARTS")) : J.nranks;
+    const bool greedy = balance && assign_parts > 1 && !(assign_env && std::string(assign_env) == "contiguous");
+    if (greedy) {
+        J.perm_m.resize((size_t)nmovies); J.perm_u.resize((size_t)nusers);
+        for (int64_t i = 0; i < nmovies; ++i) J.perm_m[(size_t)i] = i;
+        for (int64_t i = 0; i < nusers; ++i) J.perm_u[(size_t)i] = i;
+        std::vector<int64_t> dm((size_t)assign_parts + 1, 0), du((size_t)assign_parts + 1, 0);
+        for (int pass = 0; pass < 2; ++pass) {                       // movies.assign(users); users.assign(movies); twice (c++/bpmf.cpp:140-143)
+            for (int side = 0; side < 2; ++side) {
+                std::vector<int64_t> &perm = side == 0 ? J.perm_m : J.perm_u;
+                const Csc &A = side == 0 ? J.M : J.Mt;
+                std::vector<int64_t> cp(perm.size() + 1, 0), order(perm.size());
+                for (size_t j = 0; j < perm.size(); ++j) cp[j + 1] = cp[j] + (A.colptr[(size_t)perm[j] + 1] - A.colptr[(size_t)perm[j]]);
+                if (bpmf_assign_greedy((int64_t)perm.size(), cp.data(), assign_parts, order.data(), side == 0 ? dm.data() : du.data()))
+                    die("assignment failed");
+                std::vector<int64_t> np(perm.size());
+                for (size_t j = 0; j < perm.size(); ++j) np[j] = perm[(size_t)order[j]];
+                perm.swap(np);
+            }
+        }
+        if (assign_parts == J.nranks) { J.bm = dm; J.bu = du; }
+        else { J.bm = {0, nmovies}; J.bu = {0, nusers}; if (J.nranks != 1) die("BPMF_TEST_ASSIGN_PARTS needs one rank"); }
+        const std::vector<int64_t> inv_u = inverse(J.perm_u);
+        J.M = permute(J.M, J.perm_m, inv_u);
+        J.T = permute(J.T, J.perm_m, inv_u);
+        J.Mt = bpmf::io::transpose(J.M);
+        permute_columns(J.prop_m_mu.data, K, J.perm_m); permute_columns(J.prop_m_lambda.data, (int64_t)K * K, J.perm_m);
+        permute_columns(J.prop_u_mu.data, K, J.perm_u); permute_columns(J.prop_u_lambda.data, (int64_t)K * K, J.perm_u);
+    } else {
+        J.bm = column_ranges(J.M, J.nranks, balance);
+        J.bu = column_ranges(J.Mt, J.nranks, balance);
+    }
     if (J.sharded) check(bpmf_hip_comm_unique_id(J.rccl_id));      // (also loads RCCL before the rank threads start)
     if (!J.odirname.empty()) {
         J.pavg.assign(J.T.vals.size(), 0.0); J.pm2.assign(J.T.vals.size(), 0.0);
@@ -416,11 +496,20 @@ int main(int argc, char *argv[])
 
     if (!J.odirname.empty()) {
         try {
+            // everything that is written is in the ORIGINAL numbering (users.unpermuteCols / movies.unpermuteCols,
+            // c++/bpmf.cpp:223-224; the reference leaves items() / aggrMu in the permuted order: not reproduced)
             Csc P = J.T;
             P.vals = J.pavg;
+            if (!J.perm_m.empty()) P = permute(P, inverse(J.perm_m), J.perm_u);
             bpmf::io::write_sparse(J.odirname + "/Pavg.sdm", P);
-            P.vals = J.pm2;
+            P = J.T; P.vals = J.pm2;
+            if (!J.perm_m.empty()) P = permute(P, inverse(J.perm_m), J.perm_u);
             bpmf::io::write_sparse(J.odirname + "/Pm2.sdm", P);
+            if (!J.perm_m.empty()) {
+                const std::vector<int64_t> im = inverse(J.perm_m), iu = inverse(J.perm_u);
+                permute_columns(J.u_mu, K, iu); permute_columns(J.u_lambda, (int64_t)K * K, iu);
+                permute_columns(J.m_mu, K, im); permute_columns(J.m_lambda, (int64_t)K * K, im);
+            }
             Dense d;
             d.nrows = K; d.ncols = nusers; d.data.swap(J.u_mu);
             bpmf::io::write_dense(J.odirname + "/U-mu.ddm", d);

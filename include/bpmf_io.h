@@ -37,6 +37,14 @@ BPMF_IO_API int bpmf_io_read_dense(const char *path, int64_t *nrows, int64_t *nc
 BPMF_IO_API int bpmf_io_write_dense(const char *path, int64_t nrows, int64_t ncols, const double *data);
 BPMF_IO_API void bpmf_io_free(void *p);
 
+/* Assignment of the columns of a side to `nparts` ranks (host; bpmf_amd/csrc/assign.cpp).
+ * _greedy: Sys::assign of the reference (c++/assign.cpp:52-201, default weights): least-loaded rank on work = 10 + nnz,
+ *   three sweeps, then a renumbering that makes every rank's columns contiguous -- order[new] = old column, dom[p] .. dom[p+1]
+ *   = the new range of rank p.
+ * _contiguous: cuts of the ORIGINAL order at equal c0 + nnz (no permutation: samples independent of the rank count). */
+BPMF_IO_API int bpmf_assign_greedy(int64_t n, const int64_t *colptr, int nparts, int64_t *order, int64_t *dom);
+BPMF_IO_API int bpmf_assign_contiguous(int64_t n, const int64_t *colptr, int nparts, double c0, int64_t *dom);
+
 #ifdef __cplusplus
 }
 #endif
