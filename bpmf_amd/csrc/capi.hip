@@ -257,7 +257,8 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     const size_t pw = part_words_rt(K);
     if ((rc = dev_upload<double>(&s->d_partials, nullptr, (size_t)slots * pw))) return rc;
     // column statistics: one wave per 64+ columns, at most 2 waves per CU
-    s->nstat_waves = (int)std::max<int64_t>(1, std::min<int64_t>((nloc + 31) / 32, (int64_t)s->ctx->num_cu * 2));
+    // (sides with hundreds of thousands of columns: the pass is a 8 K-byte-per-column stream, four times the waves)
+    s->nstat_waves = (int)std::max<int64_t>(1, std::min<int64_t>((nloc + 31) / 32, (int64_t)s->ctx->num_cu * (nloc > 100000 ? 8 : 2)));
     if ((rc = dev_upload<double>(&s->d_stat_partials, nullptr, (size_t)s->nstat_waves * pw))) return rc;
     return 0;
 }

@@ -192,23 +192,34 @@ __global__ __launch_bounds__(64, 3) void k_sample_lr(LrArgs a)
 // n + 1 matrix-vector products with R0^-1 (256 instructions each) and n (n - 1) / 2 + 3 n scans
 // (~35 each) instead of ~25-43 instructions x 64 steps per sweep plus two triangular solves.
 // ---------------------------------------------------------------------------
+// Wave-wide inclusive prefix sum on the DPP network (no LDS crossbar round trips): four shifts inside the rows of 16
+// lanes (zeros shifted in), then lane 15 of row 0 / 2 into rows 1 / 3 (row_bcast:15) and lane 31 into rows 2, 3
+// (row_bcast:31).  A 64-lane __shfl_up ladder is six dependent ds_bpermute pairs (~100+ cycles each): these scans are
+// the critical chain of a product-form column (n (n - 1) / 2 + 3 n of them).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    const long long w = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)w, CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(w >> 32), CTRL, ROW_MASK, 0xF, true);
+    return v + __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ double wave_incl_prefix(double v, int lane)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double o = __shfl_up(v, d);
-        v += (lane >= d) ? o : 0.0;
-    }
+    (void)lane;
+    v = dpp_add<0x111, 0xF>(v);                                       // row_shr:1
+    v = dpp_add<0x112, 0xF>(v);                                       // row_shr:2
+    v = dpp_add<0x114, 0xF>(v);                                       // row_shr:4
+    v = dpp_add<0x118, 0xF>(v);                                       // row_shr:8
+    v = dpp_add<0x142, 0xA>(v);                                       // row_bcast:15 -> rows 1, 3
+    v = dpp_add<0x143, 0xC>(v);                                       // row_bcast:31 -> rows 2, 3
     return v;
 }
 __device__ __forceinline__ double wave_incl_suffix(double v, int lane)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double o = __shfl_down(v, d);
-        v += (lane + d < 64) ? o : 0.0;
-    }
-    return v;
+    const double p = wave_incl_prefix(v, lane);                       // sum_{k <= lane}
+    const double total = readlane_d(p, 63);
+    return total - p + v;                                             // sum_{k >= lane}
 }
 
 struct PfFactor { double p, is, rs, irs; };                        // p_j, 1 / s_j, sqrt(s_j / s_{j+1}), sqrt(s_{j+1} / s_j)
@@ -271,10 +282,11 @@ template <int K, int NCAP>
 __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
 {
     static_assert(K == 64, "one lane per latent index");
-    constexpr int LD = K + 1, NW = 8;
+    constexpr int LD = K + 1, NW = 8, NB = 4;                         // NB columns per wave and pass: their final products x = R0^-1 v run as ONE MFMA GEMM
     __shared__ double S0[K * LD];                                     // S0[i * LD + j] = (R0^-1)[i][j]
     __shared__ double sz[NW][K];
     __shared__ double sr[NW][K];                                      // r2 of the accepted polar attempts (draw_normals_deferred)
+    __shared__ double sv[NW][NB][K];                                  // v of the NB columns of a pass (then their x)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int q = tid; q < K * K; q += 64 * NW) {                       // a.S0t[j * K + i] = (R0^-1)[i][j]
         const int j = q / K, i = q % K;
@@ -282,50 +294,74 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
     }
     const double y0 = a.y0[lane];
     __syncthreads();
+    const int kq = lane >> 4, bq = (lane >> 2) & 3, xq = lane & 3;      // operand view of v_mfma_f64_4x4x4_4b_f64: lane (k, b, x)
 
-    for (int w = (int)blockIdx.x * NW + wave; w < a.nitems; w += (int)gridDim.x * NW) {
-        const int col = a.col[w];
-        const int64_t p0 = a.p0[w];
-        const int len = a.len[w];
-        draw_normals_deferred<K>(sample_counter<K>(a.col_from + col, a.iter_plus_1), K, sz[wave], sr[wave], lane);
+    for (int w0 = ((int)blockIdx.x * NW + wave) * NB; w0 < a.nitems; w0 += (int)gridDim.x * NW * NB) {
+#pragma unroll 1
+        for (int cb = 0; cb < NB; ++cb) {
+            const int w = w0 + cb;
+            if (w >= a.nitems) { sv[wave][cb][lane] = 0.0; continue; }    // wave-uniform
+            const int col = a.col[w];
+            const int64_t p0 = a.p0[w];
+            const int len = a.len[w];
+            draw_normals_deferred<K>(sample_counter<K>(a.col_from + col, a.iter_plus_1), K, sz[wave], sr[wave], lane);
 
-        PfFactor f[NCAP];
-        double c = y0;                                                // R0^-T b = y0 + sum_m kappa_m R0^-T x_m
+            PfFactor f[NCAP];
+            double c = y0;                                            // R0^-T b = y0 + sum_m kappa_m R0^-T x_m
 #pragma unroll
-        for (int m = 0; m < NCAP; ++m) {
-            if (m < len) {                                            // wave-uniform
-                const int row = a.rowidx[p0 + m];
-                const double wv = (a.vals[p0 + m] - a.mean_rating) * a.alpha;                       // c++/sample.cpp:256
-                double q = a.Q[(size_t)row * K + lane];               // q = R0^-T u_row (k_pf_prepare)
-                c = fma(wv, q, c);                                    // R0^-T b = y0 + sum_m wv_m R0^-T u_m
-                q *= a.sqrt_alpha;                                    // R0^-T x_m, x_m = sqrt(alpha) u_m
+            for (int m = 0; m < NCAP; ++m) {
+                if (m < len) {                                        // wave-uniform
+                    const int row = a.rowidx[p0 + m];
+                    const double wv = (a.vals[p0 + m] - a.mean_rating) * a.alpha;                   // c++/sample.cpp:256
+                    double q = a.Q[(size_t)row * K + lane];           // q = R0^-T u_row (k_pf_prepare)
+                    c = fma(wv, q, c);                                // R0^-T b = y0 + sum_m wv_m R0^-T u_m
+                    q *= a.sqrt_alpha;                                // R0^-T x_m, x_m = sqrt(alpha) u_m
 #pragma unroll
-                for (int k = 0; k < m; ++k) q = pf_solve_t(f[k], q, lane);      // p_m = C_{m-1}^-T ... C_1^-T q
-                f[m] = pf_make(q, lane);
+                    for (int k = 0; k < m; ++k) q = pf_solve_t(f[k], q, lane);  // p_m = C_{m-1}^-T ... C_1^-T q
+                    f[m] = pf_make(q, lane);
+                }
+            }
+            double t = c;
+#pragma unroll
+            for (int m = 0; m < NCAP; ++m)
+                if (m < len) t = pf_solve_t(f[m], t, lane);
+            double v = t + sz[wave][lane];                            // :322 (same wave wrote the normals)
+#pragma unroll
+            for (int m = NCAP - 1; m >= 0; --m)
+                if (m < len) v = pf_solve(f[m], v, lane);
+            sv[wave][cb][lane] = v;
+        }
+        // x = R0^-1 v for the NB columns at once: X (K x NB) = S0 (K x K) V (K x NB) on the 4x4x4 shape -- block b of an
+        // instruction is row block 4 It + b of S0, the B operand (the four v's, k = lane / 16 picks the latent index
+        // 4 kk + k, x = lane % 4 the column) is the same for every b: 64 MFMAs of 16 cycles for four columns against
+        // 4 x 64 x (LDS read + two v_readlane + FMA) on the VALU.  D[b][i][j]: lane (i, b, j), register It = x[16 It + 4 b + i] of column j.
+        double X[4] = {0.0, 0.0, 0.0, 0.0};
+        int ln = lane;                                                // (opaque: the operand addresses are not to be hoisted out of the column loop)
+        asm volatile("" : "+v"(ln));
+        const int kq2 = ln >> 4, bq2 = (ln >> 2) & 3, xq2 = ln & 3;
+#pragma unroll
+        for (int kk = 0; kk < K / 4; ++kk) {
+            const double vb = sv[wave][xq2][4 * kk + kq2];           // B[k][j] = v_j[4 kk + k]
+#pragma unroll
+            for (int It = 0; It < 4; ++It) {
+                const double sa = S0[(16 * It + 4 * bq2 + xq2) * LD + 4 * kk + kq2];   // A[b][i][k] = S0[16 It + 4 b + i][4 kk + k]
+                X[It] = mfma44(sa, vb, X[It]);
             }
         }
-        double t = c;
+        (void)kq; (void)bq; (void)xq;
+        // back to one lane per latent index (through the same LDS tile), coalesced stores
 #pragma unroll
-        for (int m = 0; m < NCAP; ++m)
-            if (m < len) t = pf_solve_t(f[m], t, lane);
-        double v = t + sz[wave][lane];                                // :322 (same wave wrote the normals)
-#pragma unroll
-        for (int m = NCAP - 1; m >= 0; --m)
-            if (m < len) v = pf_solve(f[m], v, lane);
-        double x0 = 0.0, x1 = 0.0;                                    // x = R0^-1 v: x_i = sum_j S0[i][j] v_j
-        // (a fresh, opaque copy of the lane id per column: row `lane` of S0 is loop-invariant, and hoisted out of the
-        // column loop it is 128 registers in a kernel compiled for 64 -- the spills cost more than the LDS reads)
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-#pragma unroll
-        for (int j = 0; j < K; j += 2) {
-            x0 = fma(S0[ln * LD + j], readlane_d(v, j), x0);
-            x1 = fma(S0[ln * LD + j + 1], readlane_d(v, j + 1), x1);
+        for (int It = 0; It < 4; ++It) sv[wave][xq2][16 * It + 4 * bq2 + kq2] = X[It];
+#pragma unroll 1
+        for (int cb = 0; cb < NB; ++cb) {
+            const int w = w0 + cb;
+            if (w >= a.nitems) break;                                 // wave-uniform
+            const int col = a.col[w];
+            const double xs = sv[wave][cb][lane];
+            a.items[(size_t)(a.col_from + col) * K + lane] = xs;
+            const bool bad = !(fabs(xs) <= 1.79769313486231570815e+308);
+            if (__any(bad)) { if (lane == 0) atomicMin(a.fail, (unsigned long long)(a.col_from + col)); }
         }
-        const double xs = x0 + x1;
-        a.items[(size_t)(a.col_from + col) * K + lane] = xs;
-        const bool bad = !(fabs(xs) <= 1.79769313486231570815e+308);
-        if (__any(bad)) { if (lane == 0) atomicMin(a.fail, (unsigned long long)(a.col_from + col)); }
     }
 }
 

@@ -135,7 +135,7 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
                 const bool is_last = last == 0 && pc == last_pf;
                 hipEvent_t e0 = started ? nullptr : ev_start, e1 = is_last ? ev_stop : nullptr;
                 started = true;
-                const int grid = std::max(1, std::min((n1 - n0 + 7) / 8, c->num_cu * 4));
+                const int grid = std::max(1, std::min((n1 - n0 + 31) / 32, c->num_cu * 4));     // eight waves x four columns per pass
                 k64_pf(pc, grid, st, e0, e1, lc);
             }
             for (int cls = 1; cls <= 4; ++cls) {
