@@ -1191,7 +1191,11 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     // has finished reading the columns the sampler overwrites: the gate only opens after its sums
     // were seen.)
     const bool dist = c->comm != nullptr && !self->bounds.empty();
-    const bool fused = s1 != s0 && !dist && c->in_words <= 8192 && K <= 32 && self->mode == 1 && self->nwork > 0 &&
+    // (K = 64, slab form without low-rank columns: the same launch format, k_sample1s<64>; only the words the slab
+    // form reads are staged -- the R0 / R0^-1 tail of the K = 64 blob belongs to the low-rank forms)
+    const size_t stage_words = (K == 64 && self->lr_n == 0) ? (size_t)K * K + K + 2 + K : c->in_words;
+    const bool fusable_form = (K <= 32 && self->mode == 1) || (K == 64 && self->mode == 4 && self->lr_n == 0 && self->nsub <= 1);
+    const bool fused = s1 != s0 && !dist && stage_words <= 8192 && fusable_form && self->nwork > 0 &&
                        c->dtype == BPMF_HIP_F64 && env_int("BPMF_HIP_FUSED", 1) != 0;
     bpmf::FusedArgs fz{};
     bpmf_hip_side *P = c->pending_stats;
@@ -1202,7 +1206,7 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     if (P && !carry) { if ((rc = flush_pending_stats(c))) return rc; }
     if (fused) {
         fz.gate_host = self->a_gate_dev; fz.gate_want = (unsigned)(iter + 1); fz.src_host = self->a_h_in_dev;
-        fz.dst = self->a_d_in; fz.n = (int)c->in_words; fz.dflag = self->a_dflag; fz.dval = seq;
+        fz.dst = self->a_d_in; fz.n = (int)stage_words; fz.dflag = self->a_dflag; fz.dval = seq;
         if (carry) {
             fz.nstat = P->nstat_waves; fz.st_items = P->d_items; fz.st_c0 = P->from; fz.st_c1 = P->to;
             fz.st_partials = P->d_stat_partials;

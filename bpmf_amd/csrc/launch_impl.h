@@ -150,7 +150,17 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
         }
     }
     if constexpr (K == 64) {
-        if (nwork > 0 && self->mode == 4) { k64_slab(nwork, st, ev_start, ev_stop, a); return 0; }
+        if (nwork > 0 && self->mode == 4) {
+            const FusedArgs &f = self->cur_fused;                    // (all zero outside the fused stateful path)
+            if (f.gate_host || f.nstat) {                            // gate workgroup + statistics riders + items in one launch
+                const dim3 grid((unsigned)(nwork + (f.gate_host ? 1 : 0) + f.nstat));
+                if (ev_start || ev_stop) hipExtLaunchKernelGGL(k_sample1s<K>, grid, dim3(64), 0, st, ev_start, ev_stop, 0, a, f);
+                else hipLaunchKernelGGL(k_sample1s<K>, grid, dim3(64), 0, st, a, f);
+            } else {
+                k64_slab(nwork, st, ev_start, ev_stop, a);
+            }
+            return 0;
+        }
     }
     if (nwork > 0 && self->mode == 1) {
         const FusedArgs &f = self->cur_fused;                        // (all zero outside the fused stateful path)
