@@ -265,9 +265,11 @@ __device__ __forceinline__ void slab_item(const SampleArgs &a, int w, double *ld
     const int64_t idx = a.col_from + col;
     const T *other = reinterpret_cast<const T *>(a.other_items);
 
+    stamp(a, w, 0);
     // whole column in one item: its normals do not depend on the Gram -- drawn first, in the shadow of the first loads
     if (mc < 0) draw_normals_deferred<K>(sample_counter<K>(idx, a.iter_plus_1), K, sz, srow, lane);
 
+    stamp(a, w, 1);
     double A[NREG];
     double rsum[NT];                                                  // rr[16 t + li] (all kq)
     if constexpr (!F32) {
@@ -429,6 +431,7 @@ __device__ __forceinline__ void slab_item(const SampleArgs &a, int w, double *ld
         for (int t = 0; t < NT; ++t) rsum[t] = (double)r[t];
     }
 
+    stamp(a, w, 2);
     if (a.ablate & 1u) {                                              // (profiling switch: Gram only -- keep it live)
         double v = rsum[0];
 #pragma unroll
@@ -465,7 +468,9 @@ __device__ __forceinline__ void slab_item(const SampleArgs &a, int w, double *ld
 #pragma unroll
     for (int q = 0; q < NQ; ++q) bv[q] = (x == 0) ? sb[16 * q + 4 * b + kq] : 0.0;
 
+    stamp(a, w, 3);
     slab_cholesky_solve<K>(A, bv, sz, srow, sw, lane);
+    stamp(a, w, 4);
 
     // ---- items().col(idx) = rr (:324): through LDS for one coalesced store; a failed factorisation (:308) shows as a non-finite sample
     bool bad = false;
@@ -480,6 +485,7 @@ __device__ __forceinline__ void slab_item(const SampleArgs &a, int w, double *ld
     for (int i = lane; i < K; i += 64) dst[i] = (T)sb[i];
     bad = bad && x == 0;
     if (__any(bad) && lane == 0) atomicMin(a.fail, (unsigned long long)idx);
+    stamp(a, w, 5);
 }
 
 template <int K, typename T>
