@@ -26,6 +26,7 @@ _SIGNATURES = {
     "bpmf_hip_ctx_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "bpmf_hip_side_set_ranges": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bpmf_hip_side_set_overlap": (C.c_int, [C.c_void_p, C.c_int]),
+    "bpmf_hip_sys_set_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "bpmf_hip_side_set_conn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bpmf_hip_side_exchange": (C.c_int, [C.c_void_p]),
     "bpmf_hip_side_create": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,

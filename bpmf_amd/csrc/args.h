@@ -132,4 +132,17 @@ struct LrArgs {
     uint32_t iter_plus_1;
 };
 
+// BPMF_REDUCE formulation (kernels_reduce.h): the pass that computes the other side's precomputed Gram parts
+struct PrecArgs {
+    const int64_t *t_colptr;    // ncols_O + 1: ratings of O's column j that sit in this rank's columns of S
+    const int32_t *t_rowidx;    // GLOBAL column ids of S (rows of O's matrix), ascending inside a column
+    const double *t_vals;
+    const int32_t *order;       // O's columns, longest first
+    int64_t ncols;              // of O
+    const double *s_items;      // S's factors (only this rank's columns are read)
+    double *prec;               // O's prec: ncols x PART
+    double mean_rating;         // of O (computeMuLambda is O's member: c++/sample.cpp:256)
+    double alpha;
+};
+
 }  // namespace bpmf

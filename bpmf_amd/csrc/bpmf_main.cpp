@@ -226,6 +226,10 @@ void rank_main(Job &J, int rank, std::ostream &os)
         check(bpmf_hip_side_set_prop_posterior(users, J.prop_u_mu.data.data() + (size_t)K * u0, J.prop_u_lambda.data.data() + (size_t)K * K * u0));
         os << "with propagated posterior" << std::endl;
     }
+    // the reference's BPMF_REDUCE build (a compile-time variant there, c++/bpmf.h:30-42; a run-time switch here)
+    if (const char *e = getenv("BPMF_REDUCE")) {
+        if (atoi(e) != 0) check(bpmf_hip_sys_set_reduce(movies, users, 1));
+    }
     const size_t toff = (size_t)J.T.colptr[(size_t)m0];
     {
         const std::vector<int64_t> cp = slice_ptr(J.T, m0, m1);

@@ -27,7 +27,7 @@ Rccl *rccl()
 #define BPMF_SYM(f) r.f = reinterpret_cast<decltype(r.f)>(dlsym(r.handle, "nccl" #f))
             BPMF_SYM(GetUniqueId); BPMF_SYM(CommInitRank); BPMF_SYM(CommDestroy); BPMF_SYM(AllReduce);
             BPMF_SYM(Broadcast); BPMF_SYM(GroupStart); BPMF_SYM(GroupEnd); BPMF_SYM(GetErrorString); BPMF_SYM(CommSplit);
-            BPMF_SYM(Send); BPMF_SYM(Recv); BPMF_SYM(AllGather);
+            BPMF_SYM(Send); BPMF_SYM(Recv); BPMF_SYM(AllGather); BPMF_SYM(Reduce);
 #undef BPMF_SYM
             if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.Broadcast || !r.GroupStart || !r.GroupEnd)
                 r.handle = nullptr;
@@ -492,7 +492,8 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
     if (s->d_aggr_lambda) (void)hipFree(s->d_aggr_lambda);
     void *ptrs[] = {s->d_wi_col, s->d_wi_len, s->d_wi_mc, s->d_wi_chunk, s->d_wi_p0, s->d_mc_slot0, s->d_mc_nch, s->d_mc_count, s->d_partials, s->d_stat_partials, s->a_d_in,
                     s->d_lr_col, s->d_lr_len, s->d_lr_p0, s->d_hv_col, s->d_hv_len, s->d_hv_mc, s->d_hv_chunk, s->d_hv_p0,
-                    s->d_conn_send, s->d_conn_recv, s->d_conn_sbuf, s->d_conn_rbuf, s->d_pf_q};
+                    s->d_conn_send, s->d_conn_recv, s->d_conn_sbuf, s->d_conn_rbuf, s->d_pf_q,
+                    s->d_prec, s->d_t_colptr, s->d_t_rowidx, s->d_t_vals, s->d_t_order};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (s->a_h_in) (void)hipHostFree(s->a_h_in);
     if (s->a_h_out) (void)hipHostFree(s->a_h_out);
@@ -630,6 +631,73 @@ int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, do
     return 0;
 }
 
+// One half-iteration in the BPMF_REDUCE formulation (c++/sample.cpp:289-291,375-377; c++/mpi_reduce.h:24-47):
+//   1. multi-GPU: the Gram parts every rank precomputed for this side's columns are summed onto the owner of each
+//      range (one ncclReduce per owner, grouped -- MPI_Reduce per owner in the reference)
+//   2. the local columns are sampled from prior + precomputed sums (k_sample_prec)
+//   3. other.preComputeMuLambda(self): the parts of EVERY column of the other side that come from this rank's
+//      fresh columns (k_precompute over the transposed local block)
+// The factors themselves are still exchanged afterwards: the sampler no longer needs them, but the evaluation over
+// the whole test set and the outputs do (the reference's predict is restricted to local rows in this mode, with a
+// warning: c++/sample.cpp:59-61,71-74).
+template <int K>
+int reduce_half_iteration(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double alpha, double *d_in, hipStream_t st,
+                          hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    bpmf_hip_ctx *c = self->ctx;
+    if (!other->reduce_on || !self->d_prec || !other->d_prec || !self->d_t_colptr)
+        return fail(BPMF_HIP_EINVAL, "BPMF_REDUCE formulation: enable it for both sides (bpmf_hip_sys_set_reduce)");
+    const size_t part = (size_t)bpmf_launch::reduce_part_words(K);
+    const bool dist = c->comm != nullptr && !self->bounds.empty();
+    if (dist) {                                                     // (one rank: the reduce is the identity, the path is the same)
+        Rccl *R = rccl();
+        if (!R->Reduce) return fail(BPMF_HIP_ENODEV, "BPMF_REDUCE formulation: this RCCL has no ncclReduce");
+        NCCL_TRY(R->GroupStart());
+        for (int r = 0; r < c->nranks; ++r) {
+            const int64_t lo = self->bounds[(size_t)r], hi = self->bounds[(size_t)r + 1];
+            if (hi > lo) {
+                double *p = self->d_prec + (size_t)lo * part;
+                NCCL_TRY(R->Reduce(p, p, (size_t)(hi - lo) * part, ncclDouble, ncclSum, r, c->comm, st));
+            }
+        }
+        NCCL_TRY(R->GroupEnd());
+    }
+    // the factor copy this half-iteration writes (second copy: see launch_sampler)
+    double *out_items = self->d_items;
+    const bool swap = second_copy_usable(self);
+    if (swap) {
+        const int tgt = self->cur_buf ^ 1;
+        bpmf_hip_side::Reader &rd = self->readers[tgt];
+        if (rd.t) {
+            if (rd.t->deferred && rd.seq == rd.t->seq + 1) flush_deferred(rd.t);
+            if (rd.t->done_seq < rd.seq) HIP_TRY(hipStreamWaitEvent(st, rd.t->ev_done[rd.seq & 1u], 0));
+        }
+        rd.t = nullptr;
+        out_items = self->d_items_alt;                              // (complete after this launch + the exchange: second_copy_usable)
+    }
+    bpmf::SampleArgs a{};
+    a.nwork = (int)(self->to - self->from);
+    a.items = out_items; a.col_from = self->from;
+    a.LambdaF = d_in; a.Lmu = d_in + (size_t)K * K;
+    a.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
+    a.mu = d_in + (size_t)K * K + K + 2; a.prop_lambda = self->d_prop; a.diag_only = c->diag_only;
+    a.mean_rating = self->mean_rating; a.alpha = alpha; a.iter_plus_1 = (uint32_t)(iter + 1);
+    const int resident = c->num_cu * 4 * bpmf_launch::reduce_waves_per_simd(K);
+    const int C = 64 / K;
+    const int grid = std::max(1, std::min((a.nwork + C - 1) / C, resident));
+    bpmf_launch::reduce_sample(K, grid, st, ev_start, nullptr, a, self->d_prec);
+    if (a.nwork <= 0 && ev_start) HIP_TRY(hipEventRecord(ev_start, st));
+    if (swap) { std::swap(self->d_items, self->d_items_alt); self->cur_buf ^= 1; }
+
+    bpmf::PrecArgs p{};
+    p.t_colptr = self->d_t_colptr; p.t_rowidx = self->d_t_rowidx; p.t_vals = self->d_t_vals; p.order = self->d_t_order;
+    p.ncols = other->ncols; p.s_items = self->d_items; p.prec = other->d_prec;
+    p.mean_rating = other->mean_rating; p.alpha = alpha;
+    bpmf_launch::reduce_precompute(K, st, nullptr, ev_stop, p);
+    HIP_TRY(hipGetLastError());
+    return bpmf_launch::exchange<K>(self, st, -1);
+}
+
 // Sampler + exchange of one half-iteration on stream `st`.  Sharded side with parts (bpmf_hip_side_set_overlap):
 // part c is sampled on `st`, then exchanged on the side's exchange stream `sx` while part c + 1 is being
 // sampled -- what the reference's MPI_ISEND back-end does with its chunks of 100 items sent during compute
@@ -641,6 +709,10 @@ int sample_and_exchange(bpmf_hip_side *self, const bpmf_hip_side *other, int ite
     bpmf_hip_ctx *c = self->ctx;
     const bool dist = c->comm != nullptr && !self->bounds.empty();
     const bool parts = dist && self->nsub > 1 && self->sx && self->conn_send_ptr.empty() && (int)self->sub_item_off.size() == self->nsub + 1;
+    if (self->reduce_on) {
+        if constexpr (K == 128) return fail(BPMF_HIP_EINVAL, "the BPMF_REDUCE formulation is fp64 only");
+        else return reduce_half_iteration<K>(self, other, iter, alpha, d_in, st, ev_start, ev_stop);
+    }
     if (!parts) {
         int rc = launch_sampler<K>(self, other, iter, alpha, d_in, st, ev_start, ev_stop);
         if (!rc) rc = bpmf_launch::exchange<K>(self, st, -1);
@@ -1195,7 +1267,7 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     // form reads are staged -- the R0 / R0^-1 tail of the K = 64 blob belongs to the low-rank forms)
     const size_t stage_words = (K == 64 && self->lr_n == 0) ? (size_t)K * K + K + 2 + K : c->in_words;
     const bool fusable_form = (K <= 32 && self->mode == 1) || (K == 64 && self->mode == 4 && self->lr_n == 0 && self->nsub <= 1);
-    const bool fused = s1 != s0 && !dist && stage_words <= 8192 && fusable_form && self->nwork > 0 &&
+    const bool fused = s1 != s0 && !dist && stage_words <= 8192 && fusable_form && self->nwork > 0 && !self->reduce_on &&
                        c->dtype == BPMF_HIP_F64 && env_int("BPMF_HIP_FUSED", 1) != 0;
     bpmf::FusedArgs fz{};
     bpmf_hip_side *P = c->pending_stats;
@@ -1344,6 +1416,66 @@ extern "C" int bpmf_hip_side_set_ranges(bpmf_hip_side *s, const int64_t *bounds)
     const size_t incoming = (size_t)(s->ncols - (s->to - s->from)) * (size_t)c->K * esz;
     const int nsub = want >= 0 ? want : (c->nranks > 1 && incoming >= ((size_t)64 << 20) ? 4 : 1);
     if (nsub > 1) return bpmf_hip_side_set_overlap(s, nsub);
+    return BPMF_HIP_OK;
+}
+
+// The BPMF_REDUCE formulation of the reference for a pair of sides (see reduce_half_iteration): storage for the
+// precomputed parts (zero, like Sys::init: c++/sample.cpp:192-195) and, per side, the transpose of this rank's block
+// of ratings.  on = 0 returns to the gather formulation (the storage is kept).
+static int reduce_prepare(bpmf_hip_side *s, const bpmf_hip_side *o)
+{
+    bpmf_hip_ctx *c = s->ctx;
+    const size_t part = (size_t)bpmf_launch::reduce_part_words(c->K);
+    if (!s->d_prec) {
+        HIP_TRY(hipMalloc((void **)&s->d_prec, std::max<size_t>(1, (size_t)s->ncols * part) * sizeof(double)));
+    }
+    HIP_TRY(hipMemset(s->d_prec, 0, std::max<size_t>(1, (size_t)s->ncols * part) * sizeof(double)));
+    if (s->d_t_colptr) return 0;
+    // transpose of the local block: for every column j of the other side, the local columns of this side (global
+    // ids, ascending) with a rating in row j
+    const int64_t nloc = s->to - s->from, nnz = s->nnz, nr = s->nrows;
+    if ((int64_t)s->h_colptr.size() != nloc + 1) return fail(BPMF_HIP_EINVAL, "set_reduce: the side has no host column pointers");
+    std::vector<int32_t> ri((size_t)std::max<int64_t>(nnz, 1)); std::vector<double> rv((size_t)std::max<int64_t>(nnz, 1));
+    if (nnz > 0) {
+        HIP_TRY(hipMemcpy(ri.data(), s->d_rowidx, (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(rv.data(), s->d_vals, (size_t)nnz * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    std::vector<int64_t> tp((size_t)nr + 1, 0);
+    for (int64_t q = 0; q < nnz; ++q) tp[(size_t)ri[(size_t)q] + 1]++;
+    for (int64_t j = 0; j < nr; ++j) tp[(size_t)j + 1] += tp[(size_t)j];
+    std::vector<int64_t> fill(tp.begin(), tp.end() - 1);
+    std::vector<int32_t> tr((size_t)std::max<int64_t>(nnz, 1)); std::vector<double> tv((size_t)std::max<int64_t>(nnz, 1));
+    for (int64_t cl = 0; cl < nloc; ++cl)
+        for (int64_t q = s->h_colptr[(size_t)cl]; q < s->h_colptr[(size_t)cl + 1]; ++q) {
+            const int64_t d = fill[(size_t)ri[(size_t)q]]++;
+            tr[(size_t)d] = (int32_t)(s->from + cl); tv[(size_t)d] = rv[(size_t)q];
+        }
+    std::vector<int32_t> order((size_t)nr);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return tp[(size_t)x + 1] - tp[(size_t)x] > tp[(size_t)y + 1] - tp[(size_t)y]; });
+    int rc;
+    if ((rc = dev_upload(&s->d_t_colptr, tp.data(), tp.size())) || (rc = dev_upload(&s->d_t_rowidx, tr.data(), (size_t)nnz)) ||
+        (rc = dev_upload(&s->d_t_vals, tv.data(), (size_t)nnz)) || (rc = dev_upload(&s->d_t_order, order.data(), order.size()))) return rc;
+    (void)o;
+    return 0;
+}
+
+extern "C" int bpmf_hip_sys_set_reduce(bpmf_hip_side *a, bpmf_hip_side *b, int on)
+{
+    if (!a || !b) return fail(BPMF_HIP_EINVAL, "sys_set_reduce: NULL");
+    bpmf_hip_ctx *c = a->ctx;
+    if (b->ctx != c || a->ncols != b->nrows || b->ncols != a->nrows) return fail(BPMF_HIP_EINVAL, "sys_set_reduce: the two sides do not belong together");
+    if (c->dtype != BPMF_HIP_F64 || bpmf_launch::reduce_part_words(c->K) == 0)
+        return fail(BPMF_HIP_EINVAL, "sys_set_reduce: the BPMF_REDUCE formulation exists for fp64, K = 8 .. 64");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = settle_async(a)) || (rc = settle_async(b))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!on) { a->reduce_on = b->reduce_on = false; return BPMF_HIP_OK; }
+    if (!a->conn_send_ptr.empty() || !b->conn_send_ptr.empty())
+        return fail(BPMF_HIP_EINVAL, "sys_set_reduce: not together with the connectivity-aware exchange");
+    if ((rc = reduce_prepare(a, b)) || (rc = reduce_prepare(b, a))) return rc;
+    a->reduce_on = b->reduce_on = true;
     return BPMF_HIP_OK;
 }
 

@@ -35,6 +35,12 @@ void k128_slab(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpm
 // K = 128 fp32: workgroup of 2 / 4 waves per item, second form (kernels_wg2.h)
 void k128_wg2(int grid, int nwaves, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a);
 
+// BPMF_REDUCE formulation (kernels_reduce.h, kreduce.hip): fp64, K = 8 .. 64
+int reduce_part_words(int K);                  // doubles per column of a side's `prec` array (0: K not supported)
+int reduce_waves_per_simd(int K);
+void reduce_precompute(int K, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::PrecArgs &p);
+void reduce_sample(int K, int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a, const double *prec);
+
 // kernels that do not depend on K (kcommon.hip)
 void stage(const double *src_host_dev, double *dst, int n, hipStream_t st);
 void gate_stage(int nblocks, const unsigned *gate_host_dev, unsigned want, const double *src_host_dev, double *dst, int n,

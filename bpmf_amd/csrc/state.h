@@ -96,6 +96,7 @@ struct Rccl {
     decltype(&ncclCommSplit) CommSplit = nullptr;       // optional (second communicator for the statistics streams)
     decltype(&ncclSend) Send = nullptr;                 // optional (connectivity-aware exchange)
     decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclReduce) Reduce = nullptr;             // optional (BPMF_REDUCE formulation: the parts of a side's Gram onto the owners)
 };
 
 Rccl *rccl();      // capi.hip
@@ -187,6 +188,12 @@ struct bpmf_hip_side {
     int item_off = 0, item_n = -1;       // item window of the launch being enqueued (-1: the whole list)
     hipStream_t sx = nullptr;            // exchange stream
     hipEvent_t sub_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, sx_done = nullptr;
+    // BPMF_REDUCE formulation (bpmf_hip_sys_set_reduce, kernels_reduce.h): this side's precomputed Gram parts
+    // (ncols x part words, every column -- not only the local ones) and the transpose of this rank's block of
+    // ratings (for every column of the OTHER side: the local columns of this side that rate it), longest first
+    bool reduce_on = false;
+    double *d_prec = nullptr;
+    int64_t *d_t_colptr = nullptr; int32_t *d_t_rowidx = nullptr; double *d_t_vals = nullptr; int32_t *d_t_order = nullptr;
     std::vector<int64_t> h_colptr;       // host copy of the local column pointers (schedules are rebuilt when the parts change)
     // connectivity-aware exchange (bpmf_hip_side_set_conn): per peer, the columns of this rank's range the
     // peer reads (send) and the columns of the peer's range this rank reads (recv), as global column ids

@@ -79,6 +79,10 @@ class HipEngine:
         """Cut every rank's range into `nparts` parts: part c is exchanged while part c + 1 is sampled (collective)."""
         _lib.check(self.lib.bpmf_hip_side_set_overlap(side.handle, int(nparts)))
 
+    def sys_set_reduce(self, a, b, on=True):
+        """BPMF_REDUCE formulation for the pair of sides (preComputeMuLambda + reduce onto the owners; include/bpmf_hip.h)."""
+        _lib.check(self.lib.bpmf_hip_sys_set_reduce(a.handle, b.handle, 1 if on else 0))
+
     def side_set_conn(self, side, send_ptr=None, send_cols=None, recv_ptr=None, recv_cols=None):
         """Connectivity-aware exchange lists (include/bpmf_hip.h); all None: back to the all-gather form."""
         if send_ptr is None:

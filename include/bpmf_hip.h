@@ -104,6 +104,20 @@ BPMF_API int bpmf_hip_side_set_ranges(bpmf_hip_side *side, const int64_t *bounds
  * samples as without parts. */
 BPMF_API int bpmf_hip_side_set_overlap(bpmf_hip_side *side, int nparts);
 
+/* The BPMF_REDUCE formulation of the reference (`Sys::preComputeMuLambda`, c++/sample.cpp:234-246; the
+ * sampler reading precMu / precLambda, :289-291; `other.preComputeMuLambda(*this)` after a side's columns, :375-377; the
+ * per-owner MPI_Reduce of c++/mpi_reduce.h:24-47).  For a pair of sides: after side S has been sampled, the Gram and rhs
+ * parts of EVERY column of the other side that come from this rank's columns of S are computed and kept
+ * (ncols x ~(K^2/2 + K) doubles per side and rank: the K^2 N memory the reference pays); before a side is sampled the
+ * parts of all ranks are summed onto the owners (ncclReduce per owner range) and the column update adds the prior to the
+ * sums instead of gathering the other side's factors.  Both sides start from zero parts, as Sys::init leaves them
+ * (c++/sample.cpp:192-195) -- the chain is the reference's BPMF_REDUCE chain, which differs from the default one only in
+ * the order of the floating-point sums.  fp64, K = 8 .. 64; not together with _side_set_conn.  The fresh columns are
+ * still exchanged afterwards for _predict over the whole test set and for the outputs (the reference's predict covers
+ * local rows only in this mode and says so: c++/sample.cpp:59-61).  on = 0: back to the gather formulation.
+ * `bpmf`: BPMF_REDUCE=1 in the environment. */
+BPMF_API int bpmf_hip_sys_set_reduce(bpmf_hip_side *a, bpmf_hip_side *b, int on);
+
 /* Connectivity-aware exchange.  Replaces Sys::update_conn's conn_map and the
  * per-item sends it steers (c++/assign.cpp:204-241; send_item at c++/sample.cpp:370,
  * c++/mpi_isendirecv.h:222-250, c++/bpmf_gaspi.h:140-172: `if (!conn(i, k)) continue`): a fresh column travels only to the ranks whose stored

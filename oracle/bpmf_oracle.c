@@ -359,7 +359,8 @@ static inline __attribute__((always_inline)) int
 sample_col(const int K, int64_t idx, const int64_t *colptr, const int32_t *rowidx, const double *vals,
            double mean_rating, double alpha, const double *other_items, int iter,
            const double *Lmu /* LambdaF*mu */, const double *LambdaF,
-           double *MM, double *L, double *rr /* out: the sample */, int no_covariance)
+           double *MM, double *L, double *rr /* out: the sample */, int no_covariance,
+           const double *precMu, const double *precLambda /* BPMF_REDUCE build (:289-291): K / K x K per column, or NULL */)
 {
     urng_t u;
     urng_reset(&u, (uint32_t)((idx + 1) * (int64_t)K * ((int64_t)iter + 1)));   /* :266, truncated to uint32 (Q3) */
@@ -367,6 +368,12 @@ sample_col(const int K, int64_t idx, const int64_t *colptr, const int32_t *rowid
     for (int i = 0; i < K; ++i) rr[i] = Lmu[i];                                   /* :285 */
     memset(MM, 0, sizeof(double) * K * K);                                        /* :286 */
 
+    if (precMu) {                                                                 /* #ifdef BPMF_REDUCE, :289-291 */
+        for (int i = 0; i < K; ++i) rr[i] += precMu[(size_t)idx * K + i];
+        const double *PL = precLambda + (size_t)idx * K * K;
+        for (int j = 0; j < K; ++j)
+            for (int i = 0; i < K; ++i) AT(MM, i, j) += AT(PL, i, j);
+    } else
     for (int64_t p = colptr[idx]; p < colptr[idx + 1]; ++p) {                     /* :251, ascending row */
         const double *col = other_items + (size_t)rowidx[p] * K;                  /* :254 */
         const double w = (vals[p] - mean_rating) * alpha;                         /* :256 */
@@ -419,7 +426,8 @@ static inline __attribute__((always_inline)) int64_t
 sample_side_K(const int K, int64_t from, int64_t to, const int64_t *colptr, const int32_t *rowidx,
               const double *vals, double mean_rating, double alpha, const double *other_items,
               double *items, int iter, const double *mu, const double *LambdaF,
-              double *sum_out, double *prod_out, double *norm_out, int nthreads, const double *propLambda, int no_covariance)
+              double *sum_out, double *prod_out, double *norm_out, int nthreads, const double *propLambda, int no_covariance,
+              const double *precMu, const double *precLambda)
 {
     int64_t failed = 0;
     double *Lmu = (double *)malloc(sizeof(double) * K);
@@ -466,7 +474,7 @@ sample_side_K(const int K, int64_t from, int64_t to, const int64_t *colptr, cons
                 }
                 Lm = Lmu_i;
             }
-            if (sample_col(K, i, colptr, rowidx, vals, mean_rating, alpha, other_items, iter, Lm, LF_i, MM, L, r, no_covariance)) {
+            if (sample_col(K, i, colptr, rowidx, vals, mean_rating, alpha, other_items, iter, Lm, LF_i, MM, L, r, no_covariance, precMu, precLambda)) {
 #pragma omp critical
                 if (!failed || -(i + 1) > failed) failed = -(i + 1);
                 continue;
@@ -503,11 +511,11 @@ ORACLE_API int64_t bpmf_oracle_sample_side(int K, int64_t from, int64_t to, cons
                                            const double *mu, const double *LambdaF, double *sum_out,
                                            double *prod_out, double *norm_out, int nthreads)
 {
-#define DISPATCH(KK) case KK: return sample_side_K(KK, from, to, colptr, rowidx, vals, mean_rating, alpha, other_items, items, iter, mu, LambdaF, sum_out, prod_out, norm_out, nthreads, NULL, 0)
+#define DISPATCH(KK) case KK: return sample_side_K(KK, from, to, colptr, rowidx, vals, mean_rating, alpha, other_items, items, iter, mu, LambdaF, sum_out, prod_out, norm_out, nthreads, NULL, 0, NULL, NULL)
     switch (K) {
         DISPATCH(8); DISPATCH(16); DISPATCH(32); DISPATCH(64); DISPATCH(128);
     default:
-        return sample_side_K(K, from, to, colptr, rowidx, vals, mean_rating, alpha, other_items, items, iter, mu, LambdaF, sum_out, prod_out, norm_out, nthreads, NULL, 0);
+        return sample_side_K(K, from, to, colptr, rowidx, vals, mean_rating, alpha, other_items, items, iter, mu, LambdaF, sum_out, prod_out, norm_out, nthreads, NULL, 0, NULL, NULL);
     }
 #undef DISPATCH
 }
@@ -532,7 +540,7 @@ ORACLE_API int bpmf_oracle_sample_column(int K, int64_t idx, int64_t n, const in
     }
     cp[0] = 0; cp[1] = n;
     /* sample_col reads colptr[idx], colptr[idx + 1]: hand it a view whose element `idx` is cp[0] */
-    const int rc = sample_col(K, idx, cp - idx, rowidx, vals, mean_rating, alpha, other_items, iter, Lmu, LambdaF, MM, L, out, 0);
+    const int rc = sample_col(K, idx, cp - idx, rowidx, vals, mean_rating, alpha, other_items, iter, Lmu, LambdaF, MM, L, out, 0, NULL, NULL);
     free(Lmu); free(MM); free(L); free(cp);
     return rc;
 }
@@ -546,7 +554,7 @@ ORACLE_API int64_t bpmf_oracle_sample_side_prop(int K, int64_t from, int64_t to,
                                                 double *sum_out, double *prod_out, double *norm_out, int nthreads)
 {
     return sample_side_K(K, from, to, colptr, rowidx, vals, mean_rating, alpha, other_items, items, iter, mu, LambdaF, sum_out,
-                         prod_out, norm_out, nthreads, propLambda, 0);
+                         prod_out, norm_out, nthreads, propLambda, 0, NULL, NULL);
 }
 
 /* the BPMF_NO_COVARIANCE build of the reference (c++/sample.cpp:300-304): only the diagonal of
@@ -558,9 +566,47 @@ ORACLE_API int64_t bpmf_oracle_sample_side_nocov(int K, int64_t from, int64_t to
                                                  double *sum_out, double *prod_out, double *norm_out, int nthreads)
 {
     return sample_side_K(K, from, to, colptr, rowidx, vals, mean_rating, alpha, other_items, items, iter, mu, LambdaF, sum_out,
-                         prod_out, norm_out, nthreads, NULL, 1);
+                         prod_out, norm_out, nthreads, NULL, 1, NULL, NULL);
 }
 
+
+/*
+ * BPMF_REDUCE build of the reference.  Sys::preComputeMuLambda (c++/sample.cpp:234-246) with computeMuLambda's
+ * local_only filter (:248-258): for EVERY column i of this Sys (colptr / rowidx / vals: its whole matrix), mu and the
+ * UPPER triangle of Lambda accumulated from zero over the ratings whose row lies in [other_from, other_to) -- the rows
+ * this rank owns of the other side.  precMu: K per column; precLambda: K x K column-major per column (lower part zero).
+ */
+ORACLE_API void bpmf_oracle_precompute(int K, int64_t n, const int64_t *colptr, const int32_t *rowidx, const double *vals,
+                                       double mean_rating, double alpha, const double *other_items,
+                                       int64_t other_from, int64_t other_to, double *precMu, double *precLambda)
+{
+    for (int64_t idx = 0; idx < n; ++idx) {
+        double *mu = precMu + (size_t)idx * K, *MM = precLambda + (size_t)idx * K * K;
+        memset(mu, 0, sizeof(double) * K);                                            /* :240-241 */
+        memset(MM, 0, sizeof(double) * K * K);
+        for (int64_t p = colptr[idx]; p < colptr[idx + 1]; ++p) {
+            if (rowidx[p] < other_from || rowidx[p] >= other_to) continue;            /* :253 */
+            const double *col = other_items + (size_t)rowidx[p] * K;
+            const double w = (vals[p] - mean_rating) * alpha;
+            for (int j = 0; j < K; ++j) {
+                const double cj = col[j];
+                for (int i = 0; i <= j; ++i) AT(MM, i, j) += col[i] * cj;             /* :255 upper */
+            }
+            for (int i = 0; i < K; ++i) mu[i] += col[i] * w;                          /* :256 */
+        }
+    }
+}
+
+/* Sys::sample(Sys&) of the BPMF_REDUCE build: columns [from, to) from rr = LambdaF mu + precMu.col(idx), MM = precLambda
+ * (c++/sample.cpp:285-291); the ratings are not read */
+ORACLE_API int64_t bpmf_oracle_sample_side_prec(int K, int64_t from, int64_t to, double alpha, const double *precMu,
+                                                const double *precLambda, double *items, int iter, const double *mu,
+                                                const double *LambdaF, double *sum_out, double *prod_out, double *norm_out,
+                                                int nthreads, int no_covariance)
+{
+    return sample_side_K(K, from, to, NULL, NULL, NULL, 0.0, alpha, NULL, items, iter, mu, LambdaF, sum_out, prod_out, norm_out,
+                         nthreads, NULL, no_covariance, precMu, precLambda);
+}
 
 /* cov = (prod - sum sum^T / N) / (N-1), c++/sample.cpp:383-384 */
 ORACLE_API void bpmf_oracle_cov(int K, int64_t N, const double *sum, const double *prod, double *cov)

@@ -144,6 +144,70 @@ class Oracle:
             raise RuntimeError("Cholesky failed in column %d" % idx)
         return out
 
+    # -- BPMF_REDUCE build (c++/sample.cpp:234-246, 289-291, 375-377; c++/mpi_reduce.h) -----------------
+    def precompute(self, K, csc, mean_rating, alpha, other_items, other_from=0, other_to=None):
+        """preComputeMuLambda of the Sys whose matrix is `csc`: (precMu [N, K], precLambda [N, K, K] -- each [i].T the
+        column-major matrix, upper triangle) from the rows [other_from, other_to) of `other_items`."""
+        colptr, rowidx, vals = csc
+        n = len(colptr) - 1
+        other_to = len(other_items) if other_to is None else other_to
+        pmu = np.zeros((n, K)); plam = np.zeros((n, K, K))
+        self.lib.bpmf_oracle_precompute.restype = None
+        self.lib.bpmf_oracle_precompute(K, C.c_int64(n), colptr.ctypes.data_as(C.c_void_p), rowidx.ctypes.data_as(C.c_void_p),
+                                        vals.ctypes.data_as(C.c_void_p), C.c_double(mean_rating), C.c_double(alpha),
+                                        other_items.ctypes.data_as(C.c_void_p), C.c_int64(other_from), C.c_int64(other_to),
+                                        pmu.ctypes.data_as(C.c_void_p), plam.ctypes.data_as(C.c_void_p))
+        return pmu, plam
+
+    def sample_side_prec(self, K, alpha, prec, items, it, mu, LambdaF, from_=0, to=None, nthreads=1, no_covariance=False):
+        """Sys::sample(Sys&) of the BPMF_REDUCE build over columns [from_, to): prec = (precMu, precLambda) already
+        summed over the ranks."""
+        pmu, plam = prec
+        to = len(items) if to is None else to
+        s = np.zeros(K); prod = np.zeros((K, K), order="F"); nrm = np.zeros(1)
+        LF = np.asfortranarray(LambdaF, np.float64)
+        f = self.lib.bpmf_oracle_sample_side_prec
+        f.restype = C.c_int64
+        rc = f(K, C.c_int64(from_), C.c_int64(to), C.c_double(alpha), pmu.ctypes.data_as(C.c_void_p), plam.ctypes.data_as(C.c_void_p),
+               items.ctypes.data_as(C.c_void_p), int(it), np.ascontiguousarray(mu, np.float64).ctypes.data_as(C.c_void_p),
+               LF.T.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p), prod.T.ctypes.data_as(C.c_void_p),
+               nrm.ctypes.data_as(C.c_void_p), int(nthreads), 1 if no_covariance else 0)
+        if rc:
+            raise RuntimeError("Cholesky failed in column %d" % (-rc - 1))
+        return s, prod, float(nrm[0])
+
+    def gibbs_reduce(self, K, M, Mt, T, alpha=2.0, nsims=4, burnin=0, bounds_m=None, bounds_u=None):
+        """The Gibbs loop of the BPMF_REDUCE build for `nranks` simulated ranks (bounds_*: column ranges per rank; None: one
+        rank): per half-iteration the parts of all ranks are summed in rank order (MPI_Reduce), the owners sample their
+        ranges, every rank precomputes the other side's parts from its own fresh columns.  Returns U, V, rmse per iteration."""
+        nmovies, nusers = len(M[0]) - 1, len(Mt[0]) - 1
+        bounds_m = [0, nmovies] if bounds_m is None else list(bounds_m)
+        bounds_u = [0, nusers] if bounds_u is None else list(bounds_u)
+        nr = len(bounds_m) - 1
+        mean_m = float(M[2].sum() / len(M[2])); mean_u = float(Mt[2].sum() / len(Mt[2]))
+        U = np.zeros((nusers, K)); V = np.zeros((nmovies, K))
+        cov_m = np.zeros((K, K)); cov_u = np.zeros((K, K))
+        zero = lambda n: [(np.zeros((n, K)), np.zeros((n, K, K))) for _ in range(nr)]      # Sys::init, :192-195
+        prec_m, prec_u = zero(nmovies), zero(nusers)
+        Pavg = T[2].copy(); Pm2 = T[2].copy()
+        rmse = []
+        for it in range(nsims):
+            for (n, csc_o, mean_o, X, cov, prec, prec_o, b, who) in (
+                    (nmovies, Mt, mean_u, V, cov_m, prec_m, prec_u, bounds_m, "m"), (nusers, M, mean_m, U, cov_u, prec_u, prec_m, bounds_u, "u")):
+                mu, LU, LF = self.hyper_sample(K, n, cov, it)
+                tot = (sum(p[0] for p in prec), sum(p[1] for p in prec))                   # the reduction onto the owners
+                s = np.zeros(K); prod = np.zeros((K, K))
+                for r in range(nr):
+                    sr, pr, _ = self.sample_side_prec(K, alpha, tot, X, it, mu, LF, b[r], b[r + 1])
+                    s += sr; prod += pr
+                for r in range(nr):                                                         # other.preComputeMuLambda(*this)
+                    prec_o[r] = self.precompute(K, csc_o, mean_o, alpha, X, b[r], b[r + 1])
+                cov[:] = self.cov(K, n, s, prod)
+            nn = 0 if it < burnin else it - burnin
+            se, _, nump = self.predict(K, T, V, U, mean_m, nn, Pavg, Pm2)
+            rmse.append(float(np.sqrt(se / max(nump, 1))))
+        return dict(U=U, V=V, rmse=np.array(rmse))
+
     def cov(self, K, N, s, prod):
         c = np.zeros((K, K), order="F")
         self.lib.bpmf_oracle_cov(K, N, np.ascontiguousarray(s), np.asfortranarray(prod).T, c.T)

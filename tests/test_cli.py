@@ -166,3 +166,20 @@ def test_more_gpus_than_devices_fails_cleanly(tmp_path):
     """-g 2 on a box without two GPUs (here: none): an error message, not a hang or a crash."""
     r = run(["-i", "1", "-g", "2", "-n", os.path.join(G, "tiny-train.mtx"), "-p", os.path.join(G, "tiny-test.mtx")], tmp_path)
     assert r.returncode != 0 and "bpmf:" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bpmf_reduce_env_runs_the_reduce_build(tmp_path):
+    """BPMF_REDUCE=1: the reference's BPMF_REDUCE build (c++/bpmf.h:30-42, sample.cpp:289-291) as a run-time switch of
+    `bpmf`; its chain equals the default one up to the order of the floating-point sums (RMSE printed with 5 digits),
+    also over the one-rank communicator of -g 1 (grouped ncclReduce onto the owner)."""
+    args = ["-i", "6", "-b", "2", "-n", os.path.join(G, "ml100k-train.mtx.gz"), "-p", os.path.join(G, "ml100k-test.mtx.gz")]
+    plain = run(args, tmp_path)
+    assert plain.returncode == 0, plain.stderr
+    pick = lambda text: [(float(m.group(1)), float(m.group(2))) for m in re.finditer(r"\t RMSE: (\S+)\tavg RMSE: (\S+)", text)]
+    env = dict(os.environ, BPMF_REDUCE="1")
+    for extra in ([], ["-g", "1"]):
+        r = subprocess.run([BPMF] + args + extra, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr
+        got, want = pick(r.stdout), pick(plain.stdout)
+        assert len(got) == 6 and np.allclose(got, want, atol=2e-4), (got, want)
