@@ -64,6 +64,7 @@ struct SampleArgs {
     const double *LambdaF;      // K x K col-major (device)
     const double *Lmu;          // LambdaF * mu (device)
     const double *mu;           // hp.mu (device)
+    const float *lf32;          // fp32 path: LambdaF as fp32 in tile layout (k_lf32_tiles), or NULL
     // propagated posterior (-m / -l, c++/sample.cpp:152-174,272-277): one K x K col-major prior
     // precision per LOCAL column replaces LambdaF; rr = Lambda_i * hp.mu keeps the global mu (Q2)
     const double *prop_lambda;

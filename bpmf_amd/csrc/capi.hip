@@ -329,7 +329,7 @@ static int ctx_create_impl(int device, int K, int dtype, void *stream, bpmf_hip_
     HIP_TRY(hipHostGetDevicePointer((void **)&c->h_in_dev, c->h_in, 0));
     HIP_TRY(hipHostGetDevicePointer((void **)&c->h_out_dev, c->h_out, 0));
     memset(c->h_out, 0, c->out_words * sizeof(double));
-    HIP_TRY(hipMalloc((void **)&c->d_in, c->in_words * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&c->d_in, (c->in_words + lf32_words(c)) * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&c->d_red, (c->out_words + 8) * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&c->d_ticket, 64));
     HIP_TRY(hipMemset(c->d_ticket, 0, 64));
@@ -360,9 +360,10 @@ extern "C" int bpmf_hip_ctx_destroy(bpmf_hip_ctx *c)
         if (hipMemcpy(h, c->d_stamps, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
             for (int probe = 0; probe < 2; ++probe) {
                 fprintf(stderr, "[bpmf_hip] stamps of probe item %d (100 MHz ticks since its start):", probe);
-                for (int i = 1; i < 64 && h[probe * 64 + i]; ++i) fprintf(stderr, " %d:%lld", i, (long long)(h[probe * 64 + i] - h[probe * 64]));
+                for (int i = 1; i < 64; ++i) if (h[probe * 64 + i]) fprintf(stderr, " %d:%lld", i, (long long)(h[probe * 64 + i] - h[probe * 64]));
                 fprintf(stderr, "\n");
             }
+            if (h[129]) fprintf(stderr, "[bpmf_hip] all launches: %llu items, mean life of wave 0 %.1f us\n", h[129], (double)h[128] / (double)h[129] / 100.0);
         (void)hipFree(c->d_stamps);
     }
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -824,6 +825,7 @@ extern "C" int bpmf_hip_sample_side_launch(bpmf_hip_side *self, const bpmf_hip_s
     if (self->saux) HIP_TRY(hipStreamSynchronize(self->saux));
     fill_blob(K, mu, LambdaF, c->h_in, K == 64 && c->dtype == BPMF_HIP_F64 && self->lr_n > 0);
     bpmf_launch::stage(c->h_in_dev, c->d_in, (int)c->in_words, c->stream);
+    if (lf32_words(c)) bpmf_launch::lf32_tiles(c->d_in, reinterpret_cast<float *>(c->d_in + c->in_words), K, c->stream);
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     c->last_sampler_done = nullptr;
     int rc = BPMF_DISPATCH_K(K, sample_and_exchange<KK>(self, other, iter, alpha, c->d_in, c->stream, nullptr, nullptr));
@@ -969,7 +971,7 @@ int ensure_state(bpmf_hip_side *s)
     HIP_TRY(hipHostGetDevicePointer((void **)&s->a_gate_dev, s->a_gate, 0));
     memset(s->a_h_out, 0, c->out_words * sizeof(double));
     memset(s->a_gate, 0, 64);
-    HIP_TRY(hipMalloc((void **)&s->a_d_in, c->in_words * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&s->a_d_in, (c->in_words + lf32_words(c)) * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&s->a_ticket, 64));
     HIP_TRY(hipMemset(s->a_ticket, 0, 64));
     HIP_TRY(hipMalloc((void **)&s->a_dflag, 64));
@@ -1290,6 +1292,7 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     } else {
         bpmf_launch::gate_stage(c->in_words > 8192 ? 16 : 1, self->a_gate_dev, (unsigned)(iter + 1), self->a_h_in_dev, self->a_d_in, (int)c->in_words,
                                 tmo_word(self->a_h_out_dev, K), wait_ticks(), s1);
+        if (lf32_words(c)) bpmf_launch::lf32_tiles(self->a_d_in, reinterpret_cast<float *>(self->a_d_in + c->in_words), K, s1);
         if (s1 != s0) {
             HIP_TRY(hipEventRecord(ev[3], s1));
             HIP_TRY(hipStreamWaitEvent(s0, ev[3], 0));

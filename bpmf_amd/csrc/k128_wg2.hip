@@ -7,6 +7,15 @@ namespace bpmf_launch {
 
 void k128_wg2(int grid, int nwaves, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a)
 {
+    if (a.stamps) {                                                 // profiling: what the runtime says about residency
+        static bool said = false;
+        if (!said) {
+            said = true;
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, bpmf::k_sample_wg2<128, 2>, 128, 0);
+            fprintf(stderr, "[bpmf_hip] k_sample_wg2<128,2>: %d workgroups per CU (runtime), grid %d\n", nb, grid);
+        }
+    }
     if (nwaves == 4) {
         if (e0 || e1) hipExtLaunchKernelGGL((bpmf::k_sample_wg2<128, 4>), dim3(grid), dim3(256), 0, st, e0, e1, 0, a);
         else hipLaunchKernelGGL((bpmf::k_sample_wg2<128, 4>), dim3(grid), dim3(256), 0, st, a);

@@ -15,6 +15,12 @@ void gate_stage(int nblocks, const unsigned *gate_host_dev, unsigned want, const
     hipLaunchKernelGGL(bpmf::k_gate_stage, dim3(nblocks), dim3(64), 0, st, gate_host_dev, want, src_host_dev, dst, n, tmo, ticks);
 }
 
+void lf32_tiles(const double *LambdaF_dev, float *out, int K, hipStream_t st)
+{
+    const int nt = K / 16;
+    hipLaunchKernelGGL(bpmf::k_lf32_tiles, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(64), 0, st, LambdaF_dev, out, K);
+}
+
 void publish(const double *src, double *dst_host_dev, int n, unsigned *flag_host_dev, unsigned seq, int fail_at, hipStream_t st)
 {
     hipLaunchKernelGGL(bpmf::k_publish, dim3(1), dim3(256), 0, st, src, dst_host_dev, n, flag_host_dev, seq, fail_at);

@@ -18,6 +18,23 @@ __global__ __launch_bounds__(64) void k_gate_stage(const unsigned *gate_host, un
     gate_stage_body((int)blockIdx.x, (int)gridDim.x, gate_host, want, src_host, dst, n, nullptr, 0u, tmo, wait_ticks);
 }
 
+// fp32 path (K = 128): LambdaF as fp32 in the accumulator layout of the sampler's 16 x 16 tiles -- tile (I <= J) of the
+// upper block triangle, lane (kq, li), register reg <-> LambdaF(16 J + li, 16 I + 4 kq + reg) (the lower-triangle entry:
+// what LLT reads, c++/sample.cpp:306) -- so that a column adds its prior with one 16-byte load per tile and lane
+// instead of four strided fp64 loads.  One single-wave workgroup per tile, once per half-iteration behind the staging.
+__global__ __launch_bounds__(64) void k_lf32_tiles(const double *__restrict__ LF, float *__restrict__ out, int K)
+{
+    const int NT = K / 16;
+    int t = blockIdx.x, I = 0;
+    while (t >= NT - I) { t -= NT - I; ++I; }
+    const int J = I + t, lane = threadIdx.x, kq = lane >> 4, li = lane & 15;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 v;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) v[reg] = (float)LF[(16 * J + li) + (size_t)(16 * I + 4 * kq + reg) * K];
+    reinterpret_cast<f4 *>(out)[(size_t)blockIdx.x * 64 + lane] = v;
+}
+
 // multi-GPU: the all-reduced sums sit in device memory; copy them to the pinned result blob and
 // publish the sequence number behind them.  fail_at >= 0: src[fail_at] is the summed "failed
 // column + 1" word of k_colstats (0 = no rank failed; with several failing ranks the id is only a

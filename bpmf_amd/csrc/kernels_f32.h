@@ -55,6 +55,9 @@ struct GeoF {
     template <typename T> static constexpr size_t lds_bytes() { return (size_t)K * 8 + (size_t)RWORDS * sizeof(T) + 2 * K * sizeof(T); }
     // row-major upper index of tile (I, J), I <= J; with NW waves its owner is wave tri % NW, slot tri / NW
     __host__ __device__ static constexpr int tri(int I, int J) { return I * NT - (I * (I - 1)) / 2 + (J - I); }
+    // ... and back: block row / column of tile `t`
+    __host__ __device__ static constexpr int tile_i(int t) { int I = 0; while (t >= NT - I) { t -= NT - I; ++I; } return I; }
+    __host__ __device__ static constexpr int tile_j(int t) { int I = 0; while (t >= NT - I) { t -= NT - I; ++I; } return I + t; }
 };
 
 // ---------------------------------------------------------------------------

@@ -27,8 +27,10 @@ template <int K>
 struct GeoW2 {
     using F = GeoF<K>;
     static constexpr int NT = F::NT;
-    // LDS (floats unless noted): zs [K doubles] | R by block rows | b / y [K] | x [K] | t [16] | W_s^T, s < NT [NT][256] | ticket
-    static constexpr size_t lds_bytes() { return (size_t)K * 8 + ((size_t)F::RWORDS + 2 * K + 16 + NT * 256 + 4) * 4; }
+    // LDS (floats unless noted): zs [K doubles] | R by block rows | b / y, later x [K] | t [16] | ticket.  W_s^T = R_ss^-T takes
+    // the place of the diagonal block R_ss in block row s (nothing reads R_ss once it is inverted), and x_s overwrites
+    // y_s in the backward solve: 40 528 B, FOUR workgroups per CU (with W^T and x on their own: 49 232 B, three)
+    static constexpr size_t lds_bytes() { return (size_t)K * 8 + ((size_t)F::RWORDS + K + 16 + 4) * 4; }
     static constexpr int PART_FLOATS = F::NTRI * 256 + NT * 16;   // partial of one chunk: all tiles + rhs
 };
 
@@ -71,8 +73,8 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
     constexpr int NT = G::NT, TPW = (G::NTRI + NW - 1) / NW;
     double *zs = reinterpret_cast<double *>(smem);
     T *R = reinterpret_cast<T *>(zs + K);
-    T *bv = R + G::RWORDS, *xs = bv + K, *ts = xs + K, *Wt = ts + 16;
-    unsigned *sticket = reinterpret_cast<unsigned *>(Wt + NT * 256);
+    T *bv = R + G::RWORDS, *xs = bv, *ts = bv + K;
+    unsigned *sticket = reinterpret_cast<unsigned *>(ts + 16);
     const int lane = tid & 63;
     const int kq = lane >> 4, li = lane & 15;
     const int col = a.wi_col[w];
@@ -82,10 +84,7 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
     const int64_t idx = a.col_from + col;
     const T *other = reinterpret_cast<const T *>(a.other_items);
 
-    // z ~ N(0, I): stream (idx+1)*K*(iter+1) mod 2^32 (c++/sample.cpp:266), by the last wave (fewest tiles);
-    // a chunked column draws when its last chunk has arrived
     stamp(a, w, 0);
-    if (mc < 0 && W == NW - 1) draw_normals<K>(sample_counter<K>(idx, a.iter_plus_1), K, zs, lane);
 
     f4 acc[TPW];
     T r[NT];
@@ -106,6 +105,8 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
         int ri_n = (64 + lane < len) ? rowidx[64 + lane] : -1;
         T wv_n = (64 + lane < len) ? (T)((vals[64 + lane] - a.mean_rating) * a.alpha) : (T)0;
         T yA[4][NT], yB[4][NT], wA[4], wB[4];
+        const int rowmask = (a.ablate & 4u) ? 63 : -1;                 // (profiling switch: gather from 64 hot rows only)
+        const bool no_mfma = (a.ablate & 8u) != 0;                     // (profiling switch: operands are loaded and summed, no MFMA)
         auto gather = [&](int gg, T (&yy)[4][NT], T (&w1)[4]) {
             const bool nx = gg >= 4;
 #pragma unroll
@@ -113,7 +114,7 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
                 const int src = ((gg & 3) * 4 + st) * 4 + kq;
                 const int row = __shfl(nx ? ri_n : ri, src);
                 w1[st] = __shfl(nx ? wv_n : wv, src);
-                const T *u = ((row >= 0) ? other + (size_t)row * K : reinterpret_cast<const T *>(a.zero_row)) + li;
+                const T *u = ((row >= 0) ? other + (size_t)(row & rowmask) * K : reinterpret_cast<const T *>(a.zero_row)) + li;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) yy[st][t] = u[16 * t];
             }
@@ -121,10 +122,11 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
         auto contract = [&](const T (&yy)[4][NT], const T (&w1)[4]) {
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
-                if (W == 0) {
+                if (W == 0 || no_mfma) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) r[t] = fmaf(yy[st][t], w1[st], r[t]);
                 }
+                if (no_mfma) continue;
 #pragma unroll
                 for (int I = 0; I < NT; ++I)
 #pragma unroll
@@ -156,7 +158,11 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
         }
     }
 
+    // the rest of the item is a latency-bound chain of short VALU / LDS / MFMA steps: let it win the SIMD's issue
+    // arbitration over the co-resident workgroups' Gram loops (throughput-bound, they only lose slots they can spare)
+    __builtin_amdgcn_s_setprio(3);
     stamp(a, w, 1);
+    if (W == 1 && a.stamps && lane == 0 && (w == 0 || w == a.nwork / 2)) a.stamps[(w == 0 ? 0 : 64) + 48] = wall_clock64();   // (wave 1's Gram ends)
     if (mc >= 0) {
         // chunk of a heavy column: every wave parks its tiles (tile `tri` at [tri * 256 + reg * 64 + lane]), wave 0 the rhs;
         // the workgroup that draws the last ticket adds the partials in chunk order
@@ -202,7 +208,6 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
                 for (int t = 0; t < NT; ++t) r[t] += __hip_atomic_load(&pc[G::NTRI * 256 + t * 16 + li], BPMF_RLX_AGENT);
             }
         }
-        if (W == NW - 1) draw_normals<K>(sample_counter<K>(idx, a.iter_plus_1), K, zs, lane);
     }
 
     if (a.ablate & 1u) {                                              // (profiling switch: Gram only -- keep it live)
@@ -214,17 +219,58 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
     }
     // Lambda* = LambdaF + alpha G in the register tiles (:297-298); b = LambdaF mu + rr (:285,:256)
     const double *LF = a.prop_lambda ? a.prop_lambda + (size_t)col * K * K : a.LambdaF;
+    if (a.lf32) {                                                     // (workgroup-uniform) the prior as fp32 tiles: one 16-byte load per tile
+        const f4 *lt = reinterpret_cast<const f4 *>(a.lf32);
+        const T alpha_f = (T)a.alpha;
+        f4 lf[TPW];
 #pragma unroll
-    for (int I = 0; I < NT; ++I)
+        for (int I = 0; I < NT; ++I)
 #pragma unroll
-        for (int J = I; J < NT; ++J)
-            if ((G::tri(I, J) % NW) == W) {
+            for (int J = I; J < NT; ++J)
+                if ((G::tri(I, J) % NW) == W) lf[G::tri(I, J) / NW] = lt[G::tri(I, J) * 64 + lane];
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int gi = 16 * I + 4 * kq + reg, gj = 16 * J + li;
-                    acc[G::tri(I, J) / NW][reg] = (a.diag_only && gi != gj) ? (T)0 : (T)fma(a.alpha, (double)acc[G::tri(I, J) / NW][reg], LF[gi + (size_t)gj * K]);
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int J = I; J < NT; ++J)
+                if ((G::tri(I, J) % NW) == W) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const T v = fmaf(alpha_f, acc[G::tri(I, J) / NW][reg], lf[G::tri(I, J) / NW][reg]);
+                        acc[G::tri(I, J) / NW][reg] = (a.diag_only && (16 * I + 4 * kq + reg) != (16 * J + li)) ? (T)0 : v;
+                    }
+                }
+    } else {
+        // LambdaF(gj, gi): the lower triangle, which is what LLT reads (:306); 16 lanes = one 128-byte line.  The loads of
+        // a batch of tiles are issued together and without control flow around them (with the diag_only select wrapped
+        // around each load they were 72 serialised L2 round trips: 14.6 of the ~50 us a mid-size column lived)
+        constexpr int BATCH = 6;
+#pragma unroll
+        for (int t0 = 0; t0 < TPW; t0 += BATCH) {
+            double lf[BATCH][4];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int tri = (t0 + u) * NW + W;
+                if (t0 + u < TPW && tri < G::NTRI) {
+                    const int I = G::tile_i(tri), J = G::tile_j(tri);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) lf[u][reg] = LF[(16 * J + li) + (size_t)(16 * I + 4 * kq + reg) * K];
                 }
             }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int tri = (t0 + u) * NW + W;
+                if (t0 + u < TPW && tri < G::NTRI) {
+                    const int I = G::tile_i(tri), J = G::tile_j(tri);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const T v = (T)fma(a.alpha, (double)acc[t0 + u][reg], lf[u][reg]);
+                        acc[t0 + u][reg] = (a.diag_only && (16 * I + 4 * kq + reg) != (16 * J + li)) ? (T)0 : v;
+                    }
+                }
+            }
+        }
+    }
+    stamp(a, w, 42);
     if (W == 0 && kq == 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -241,7 +287,6 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
     for (int s = 0; s < NT; ++s) {
         T *Rs = R + G::roff(s);
         const int LDs = G::ld(s), Ws = G::width(s);
-        T *Wts = Wt + 256 * s;
         // A: park the tiles of block row s
 #pragma unroll
         for (int J = s; J < NT; ++J)
@@ -251,6 +296,9 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
             }
         __syncthreads();
         stamp(a, w, 2 + 4 * s);
+        // z ~ N(0, I): stream (idx+1)*K*(iter+1) mod 2^32 (c++/sample.cpp:266) -- by the last wave while wave 0 factors the
+        // first diagonal block (it would idle at the next barrier otherwise; the backward solve is what reads z)
+        if (s == 0 && W == NW - 1) draw_normals<K>(sample_counter<K>(idx, a.iter_plus_1), K, zs, lane);
         // B: diagonal block in fp64 on the 4x4x4 shape: R_ss (upper) and W_s^T = R_ss^-T; then y_s = W_s^T b_s
         if (W == 0) {
             double A16[4], E[4];
@@ -260,18 +308,17 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
 #pragma unroll
             for (int I = 0; I < 4; ++I) {
                 const int row = 4 * I + kq;
-                Rs[row * LDs + li] = (li >= row) ? (T)A16[I] : (T)0;
-                Wts[row * 16 + li] = (T)E[I];                             // W_s^T [row][li] (lower triangular)
+                Rs[row * LDs + li] = (T)E[I];                             // W_s^T [row][li] (lower triangular) in the place of R_ss
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // forward solve of the block row (:321): y_s = W_s^T b_s, lanes 0..15 (the wave is in lockstep: no barrier)
-            double ysum = 0.0;
+            T ysum = 0;
             if (lane < 16) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) ysum = fma((double)Wts[lane * 16 + k], (double)bv[16 * s + k], ysum);
+                for (int k = 0; k < 16; ++k) ysum = fmaf(Rs[lane * LDs + k], bv[16 * s + k], ysum);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane < 16) bv[16 * s + lane] = (T)ysum;
+            if (lane < 16) bv[16 * s + lane] = ysum;
         }
         stamp(a, w, 3 + 4 * s);
         __syncthreads();
@@ -280,7 +327,7 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
             // C: panel  R_sJ = W_s^T A_sJ  by the owner of tile (s, J): operands from LDS, result back to LDS
             T opA[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) opA[q] = Wts[li * 16 + 4 * q + kq];           // A[i = li][k = 4 q + kq]
+            for (int q = 0; q < 4; ++q) opA[q] = Rs[li * LDs + 4 * q + kq];           // A[i = li][k = 4 q + kq] of W_s^T
 #pragma unroll
             for (int J = s + 1; J < NT; ++J)
                 if ((G::tri(s, J) % NW) == W) {
@@ -297,10 +344,10 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
             stamp(a, w, 5 + 4 * s);
             // rhs: b_j -= sum_k R_s[k][j] y_s[k] for the entries right of the block, one thread each
             for (int cc = tid; cc < Ws - 16; cc += 64 * NW) {
-                double sacc = 0.0;
+                T sacc = 0;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) sacc = fma((double)Rs[k * LDs + 16 + cc], (double)bv[16 * s + k], sacc);
-                bv[16 * (s + 1) + cc] -= (T)sacc;
+                for (int k = 0; k < 16; ++k) sacc = fmaf(Rs[k * LDs + 16 + cc], bv[16 * s + k], sacc);
+                bv[16 * (s + 1) + cc] -= sacc;
             }
             // D: trailing update of this wave's tiles  A_IJ -= R_sI^T R_sJ
 #pragma unroll
@@ -333,19 +380,18 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
         for (int s = NT - 1; s >= 0; --s) {
             const T *Rs = R + G::roff(s);
             const int LDs = G::ld(s), Ws = G::width(s);
-            double t = 0.0;
-            for (int j = 16 + kq; j < Ws; j += 4) t = fma((double)Rs[li * LDs + j], (double)xs[16 * s + j], t);
+            T t = 0;                                                  // (fp32 products and sums: half the issue slots of the widened form)
+            for (int j = 16 + kq; j < Ws; j += 4) t = fmaf(Rs[li * LDs + j], xs[16 * s + j], t);
             t += __shfl_xor(t, 16);
             t += __shfl_xor(t, 32);
-            const double tt = (double)bv[16 * s + li] + zs[16 * s + li] - t;
+            const double tt = (double)bv[16 * s + li] + zs[16 * s + li] - (double)t;
             if (kq == 0) ts[li] = (T)tt;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             // x_s = W_s t: x_i = sum_k W_s[i][k] t_k = sum_k Wt_s[k][i] t_k
-            double xsum = 0.0;
-            const T *Wts = Wt + 256 * s;
+            T xsum = 0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) xsum = fma((double)Wts[k * 16 + li], (double)ts[k], xsum);
-            if (kq == 0) xs[16 * s + li] = (T)xsum;
+            for (int k = 0; k < 16; ++k) xsum = fmaf(Rs[k * LDs + li], ts[k], xsum);
+            if (kq == 0) xs[16 * s + li] = xsum;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         T *dst = reinterpret_cast<T *>(a.items) + (size_t)idx * K;                 // items().col(idx) = rr (:324)
@@ -367,6 +413,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sample_wg2(SampleArgs a)
     __shared__ __attribute__((aligned(16))) unsigned char smem[GeoW2<K>::lds_bytes()];
     const int tid = threadIdx.x, wave = tid >> 6;
     const int w = blockIdx.x;
+    const unsigned long long t_begin = a.stamps ? wall_clock64() : 0ull;
     if constexpr (NW == 2) {
         if (wave == 0) wg2_column<K, 2, 0>(a, w, smem, tid);
         else wg2_column<K, 2, 1>(a, w, smem, tid);
@@ -377,6 +424,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sample_wg2(SampleArgs a)
         case 2: wg2_column<K, 4, 2>(a, w, smem, tid); break;
         default: wg2_column<K, 4, 3>(a, w, smem, tid); break;
         }
+    }
+    if (a.stamps && tid == 0) {                                        // profiling: sum of the items' lifetimes (wave 0), their number, first start / last end
+        atomicAdd(&a.stamps[128 + 0], wall_clock64() - t_begin);
+        atomicAdd(&a.stamps[128 + 1], 1ull);
+        atomicMin(&a.stamps[128 + 2], t_begin);
+        atomicMax(&a.stamps[128 + 3], wall_clock64());
     }
 }
 

@@ -45,6 +45,7 @@ void reduce_sample(int K, int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1
 void stage(const double *src_host_dev, double *dst, int n, hipStream_t st);
 void gate_stage(int nblocks, const unsigned *gate_host_dev, unsigned want, const double *src_host_dev, double *dst, int n,
                 unsigned long long *tmo, unsigned long long ticks, hipStream_t st);
+void lf32_tiles(const double *LambdaF_dev, float *out, int K, hipStream_t st);    // fp32 path: LambdaF in tile layout behind the blob
 void publish(const double *src, double *dst_host_dev, int n, unsigned *flag_host_dev, unsigned seq, int fail_at, hipStream_t st);
 void randn_probe(uint32_t counter, int n, double *out_dev, hipStream_t st);
 void aggr_add(const void *items, bool f32, int K, int64_t c0, int64_t ncols, double *mu, double *lambda, hipStream_t st);

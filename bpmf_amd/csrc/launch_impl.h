@@ -76,6 +76,7 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
     a.gate_flag = self->cur_gate_flag; a.gate_want = self->cur_gate_want;
     a.tmo = self->cur_gate_flag ? tmo_word(self->a_h_out_dev, K) : nullptr; a.wait_ticks = wait_ticks();
     a.zero_row = c->d_zero;
+    a.lf32 = (lf32_words(c) && !self->d_prop) ? reinterpret_cast<const float *>(d_in + c->in_words) : nullptr;
     if constexpr (K == 128) {                                        // fp32 factors (items / other_items are float arrays)
         if (nwork > 0) {
             if (self->mode == 4) k128_slab(nwork, st, ev_start, ev_stop, a);

@@ -313,6 +313,9 @@ inline size_t part_words_rt(int K)
 }
 
 
+// doubles behind the parameter blob of a half-iteration that hold LambdaF as fp32 tiles (fp32 path only)
+inline size_t lf32_words(const bpmf_hip_ctx *c) { return c->dtype == BPMF_HIP_F32 ? (size_t)(c->K / 16) * (c->K / 16 + 1) / 2 * 256 / 2 : 0; }
+
 // may this side's samplers write the second copy of the factors?  Every column of the new copy must
 // be produced by this launch or arrive through the exchange that follows it.
 inline bool second_copy_usable(const bpmf_hip_side *s)
