@@ -377,11 +377,18 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
 
     // ---- y += z (:322); backward solve R x = y (:323) block by block, wave 0: lane (kq, li) = row li, column group kq
     if (W == 0) {
+#pragma unroll
         for (int s = NT - 1; s >= 0; --s) {
             const T *Rs = R + G::roff(s);
             const int LDs = G::ld(s), Ws = G::width(s);
-            T t = 0;                                                  // (fp32 products and sums: half the issue slots of the widened form)
-            for (int j = 16 + kq; j < Ws; j += 4) t = fmaf(Rs[li * LDs + j], xs[16 * s + j], t);
+            // (unrolled with compile-time bounds: the LDS reads of a step are issued together; two partial sums halve the chain)
+            T t = 0, t2 = 0;                                          // (fp32 products and sums: half the issue slots of the widened form)
+#pragma unroll
+            for (int j = 16; j < Ws; j += 8) {
+                t = fmaf(Rs[li * LDs + j + kq], xs[16 * s + j + kq], t);
+                if (j + 4 < Ws) t2 = fmaf(Rs[li * LDs + j + 4 + kq], xs[16 * s + j + 4 + kq], t2);
+            }
+            t += t2;
             t += __shfl_xor(t, 16);
             t += __shfl_xor(t, 32);
             const double tt = (double)bv[16 * s + li] + zs[16 * s + li] - (double)t;
