@@ -129,12 +129,12 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
         // mode 0: >= 8 work items per SIMD so the tail of the launch stays short.  Lower bound
         // 16 K: a chunk's partial tiles are ~1.3 K^2 doubles written and read back, against 8 K
         // bytes gathered per rating, so shorter chunks make the partials a first-order traffic term.
-        int64_t c = (s->mode == 0) ? s->nnz / (simds * 8) : (s->mode == 4 ? s->nnz / (simds * 3) : (s->nnz * 2) / (simds * 3));
+        int64_t c = (s->mode == 0) ? s->nnz / (simds * 8) : (s->mode == 4 ? s->nnz / (simds * 3) : (s->mode == 5 ? (s->nnz * 3) / (simds * 7) : (s->nnz * 2) / (simds * 3)));
         c = (c + 63) / 64 * 64;
         // slab form: ONE wave walks an item, and a rating costs 36 (K = 128) / 10 (K = 64) tile MFMAs per 4
         // ratings: a launch lasts (average load of a wave slot) + (longest item), so items must stay short (ML-1M shape,
         // K = 64: 512-rating chunks 0.208 ms per launch, 256: 0.179)
-        const int64_t lo = s->mode == 4 ? 256 : (s->mode == 5 ? 512 : 16 * K);
+        const int64_t lo = s->mode == 4 ? 256 : (s->mode == 5 ? 256 : 16 * K);     // (mode 5, ML-1M shape: 384-rating chunks 0.875 ms per iteration, 640: 0.90)
         chunk = (int)std::min<int64_t>(std::max<int64_t>(c, lo), 65536);   // (upper limit: 10M x 1M shards measured best with 64 K-rating chunks)
         // four columns per wave: a wave holds four items (and a chunk's partial is a quarter of the
         // size), so the same work per wave means chunks of a quarter of the length
@@ -248,8 +248,9 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
         if ((rc = dev_upload(&s->d_mc_count, zeros.data(), std::max<size_t>(mc_slot0.size(), 1)))) return rc;
     }
     if (f32) {
-        // column statistics: <= 128 workgroups, each writing one partial of K*K + K doubles
-        s->nstat_waves = (int)std::max<int64_t>(1, std::min<int64_t>((nloc + 15) / 16, 128));
+        // column statistics: <= 32 slices of columns x 36 tiles (k_colstats_f32), one partial (tiles | sum) per slice
+        // (128 partials of 132 KB were 17 MB written and read back per half-iteration: the two kernels took 55 us alone)
+        s->nstat_waves = (int)std::max<int64_t>(1, std::min<int64_t>((nloc + 63) / 64, 32));
         if ((rc = dev_upload<double>(&s->d_stat_partials, nullptr, (size_t)s->nstat_waves * ((size_t)K * K + K)))) return rc;
         if ((rc = dev_upload<double>(&s->d_partials, nullptr, (size_t)slots * part_words_rt(K)))) return rc;     // chunks of heavy columns (slab form)
         return 0;
@@ -1325,11 +1326,18 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     if (fused) {
         c->pending_stats = self; c->pending_seq = seq; c->pending_evset = evset;     // ride in the next launch
     } else {
-        if (s1 != s0) HIP_TRY(hipStreamWaitEvent(s1, ev[1], 0));
+        // fp32 path: the statistics used to take 0.2 ms from the end of the sampler to the sums, on the critical path of
+        // the side's host chain: their 256-thread workgroups had to find room beside the NEXT side's sampler, whose
+        // 128-thread workgroups refill every slot that frees up.  Now single-wave workgroups without LDS (k_colstats_f32:
+        // they fit beside four sampler workgroups per CU at once).  BPMF_HIP_STATS_S0=1 puts them on S0 directly behind
+        // their sampler instead (measured even to slightly slower: ~50 us of device time per iteration).
+        static const int stats_s0 = env_int("BPMF_HIP_STATS_S0", 0);
+        hipStream_t sst = (c->dtype == BPMF_HIP_F32 && !dist && stats_s0) ? s0 : s1;
+        if (sst != s0) HIP_TRY(hipStreamWaitEvent(sst, ev[1], 0));
         unsigned *flag = reinterpret_cast<unsigned *>(self->a_h_out_dev + c->out_words - 1);
-        rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK>(self, s1, self->a_d_in, self->a_h_out_dev, flag, seq, self->a_ticket));
+        rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK>(self, sst, self->a_d_in, self->a_h_out_dev, flag, seq, self->a_ticket));
         if (rc) return rc;
-        HIP_TRY(hipEventRecord(ev[2], s1));
+        HIP_TRY(hipEventRecord(ev[2], sst));
         self->stats_ev[evset].store(ev[2], std::memory_order_release);
     }
     HIP_TRY(hipGetLastError());

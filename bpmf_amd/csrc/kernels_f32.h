@@ -357,47 +357,87 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sample_wg(SampleArgsW<T> a)
 // of columns, thread t owns the outputs e = t, t + 256, ... of  prod[K*K] | sum[K]; the partials
 // are added in workgroup order by k_colstats_f32_final, whose last block publishes the blob.
 // ---------------------------------------------------------------------------
+// sum x x^T = X X^T on the 16x16x4 f64 MFMA (the fp32 entries widened: products exact, sums fp64).  One single-wave
+// workgroup per (slice of columns, upper 16 x 16 tile): nsl x 36 waves spread over the chip, each loading only the two
+// row blocks of its tile, four k-steps (16 columns) of loads in flight.  The diagonal tiles also sum x.  Partial of a
+// slice: the tiles in accumulator layout | sum[K]; k_colstats_f32_final adds the slices in order and un-tiles.
+// (First form: one output per thread and column on the VALU, 128 partials of 132 KB: 55 us alone, 0.2 ms beside the
+// next sampler.  With the select wrapped around each load the loads of a k-step were serialised: see kernels_wg2.h.)
 template <int K>
-__global__ __launch_bounds__(256) void k_colstats_f32(const float *__restrict__ items, int64_t c0, int64_t c1, int nwg,
-                                                      double *__restrict__ partials)
+__global__ __launch_bounds__(64) void k_colstats_f32(const float *__restrict__ items, int64_t c0, int64_t c1, int nsl,
+                                                     double *__restrict__ partials)
 {
-    constexpr int NOUT = K * K + K, PER = (NOUT + 255) / 256;
-    __shared__ float x[K];
+    constexpr int NT = K / 16, NTRI = NT * (NT + 1) / 2, PARTW = NTRI * 256 + K;
+    const int tri = blockIdx.x % NTRI, sl = blockIdx.x / NTRI;
+    int I = 0, t = tri;
+    while (t >= NT - I) { t -= NT - I; ++I; }
+    const int J = I + t;
+    const int lane = threadIdx.x, kq = lane >> 4, li = lane & 15;
     const int64_t n = c1 - c0;
-    const int64_t per = (n + nwg - 1) / nwg;
-    const int64_t b = c0 + blockIdx.x * per, e = (b + per < c1) ? b + per : c1;
-    double acc[PER];
+    const int64_t per = ((n + nsl - 1) / nsl + 3) / 4 * 4;
+    const int64_t b = c0 + sl * per, e = (b + per < c1) ? b + per : c1;
+    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+    double r = 0.0;
+    const float *xi = items + 16 * I + li, *xj = items + 16 * J + li;
+    // 16 columns per trip; the loads of the next trip are issued before the MFMAs of the current one
+    float fa[4], fb[4], na[4], nb[4];
+    auto fetch = [&](int64_t c, float (&a4)[4], float (&b4)[4]) {
 #pragma unroll
-    for (int u = 0; u < PER; ++u) acc[u] = 0.0;
-    for (int64_t c = b; c < e; ++c) {
-        __syncthreads();
-        if (threadIdx.x < K) x[threadIdx.x] = items[(size_t)c * K + threadIdx.x];
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int o = threadIdx.x + 256 * u;
-            if (o < K * K) acc[u] = fma((double)x[o % K], (double)x[o / K], acc[u]);
-            else if (o < NOUT) acc[u] += (double)x[o - K * K];
+        for (int u = 0; u < 4; ++u) {
+            const int64_t cc = c + 4 * u + kq;
+            const size_t at = (size_t)((cc < e) ? cc : b) * K;       // (beyond the slice: any valid column, masked below)
+            a4[u] = xi[at];
+            b4[u] = xj[at];
         }
-    }
-    double *p = partials + (size_t)blockIdx.x * NOUT;
+    };
+    if (b < e) fetch(b, fa, fb);
+    for (int64_t c = b; c < e; c += 16) {
+        fetch(c + 16 < e ? c + 16 : b, na, nb);
 #pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        const int o = threadIdx.x + 256 * u;
-        if (o < NOUT) p[o] = acc[u];
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = c + 4 * u + kq < e;
+            const double ya = ok ? (double)fa[u] : 0.0, yb = ok ? (double)fb[u] : 0.0;
+            acc = mfma16(ya, yb, acc);
+            r += ya;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { fa[u] = na[u]; fb[u] = nb[u]; }
+    }
+    double *p = partials + (size_t)sl * PARTW;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) p[tri * 256 + reg * 64 + lane] = acc[reg];
+    if (I == J) {                                                     // (workgroup-uniform)
+        r += __shfl_xor(r, 16);
+        r += __shfl_xor(r, 32);
+        if (kq == 0) p[NTRI * 256 + 16 * I + li] = r;
     }
 }
 
 template <int K>
-__global__ __launch_bounds__(256) void k_colstats_f32_final(const double *__restrict__ partials, int nwg,
+__global__ __launch_bounds__(256) void k_colstats_f32_final(const double *__restrict__ partials, int nsl,
                                                             const unsigned long long *__restrict__ fail_in,
                                                             double *__restrict__ out, unsigned *ticket, unsigned *flag, unsigned seq)
 {
-    constexpr int NOUT = K * K + K;
+    constexpr int NT = K / 16, NTRI = NT * (NT + 1) / 2, PARTW = NTRI * 256 + K, NOUT = K * K + K;
     const int o = blockIdx.x * 256 + threadIdx.x;
     if (o < NOUT) {
+        int at;
+        if (o < K * K) {                                              // prod(gi, gj) at gi + gj K: from tile (min, max) of the block pair
+            int gi = o % K, gj = o / K;
+            if (gi / 16 > gj / 16) { const int x = gi; gi = gj; gj = x; }
+            const int I = gi / 16, J = gj / 16, ii = gi % 16;
+            at = (I * NT - (I * (I - 1)) / 2 + (J - I)) * 256 + (ii >> 2) * 64 + (ii & 3) * 16 + (gj % 16);   // D[kq + 4 reg][li] of the f64 16x16x4 shape
+        } else {
+            at = NTRI * 256 + (o - K * K);
+        }
         double s = 0.0;
-        for (int wgi = 0; wgi < nwg; ++wgi) s += partials[(size_t)wgi * NOUT + o];
+        for (int q0 = 0; q0 < nsl; q0 += 8) {                         // eight loads in flight, added in slice order
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)((q0 + u < nsl) ? q0 + u : q0) * PARTW + at];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (q0 + u < nsl) ? v[u] : 0.0;
+        }
         __hip_atomic_store(&out[o], s, BPMF_RLX_SYSTEM);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {

@@ -271,7 +271,7 @@ int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_h
         const bool dist = c->comm != nullptr && !self->bounds.empty();
         const bool own = st != c->stream && c->comm2 && self->a_d_red;
         double *red = own ? self->a_d_red : c->d_red;
-        hipLaunchKernelGGL(k_colstats_f32<K>, dim3(self->nstat_waves), dim3(256), 0, st, reinterpret_cast<const float *>(self->d_items),
+        hipLaunchKernelGGL(k_colstats_f32<K>, dim3(self->nstat_waves * (K / 16) * (K / 16 + 1) / 2), dim3(64), 0, st, reinterpret_cast<const float *>(self->d_items),
                            self->from, self->to, self->nstat_waves, self->d_stat_partials);
         // single GPU: the sums go straight to the pinned blob; sharded: into a device blob, all-reduced, then published
         hipLaunchKernelGGL(k_colstats_f32_final<K>, dim3((K * K + K + 255) / 256), dim3(256), 0, st,
