@@ -282,13 +282,21 @@ __device__ __forceinline__ double row_ror_add(double x)
 
 // first two 64-rating index blocks of a chunk: issued by the caller ahead of the normal draw, whose
 // Philox / log / sqrt arithmetic then runs in the shadow of these loads
-struct IdxBlock { int ri; double wv; };
-__device__ __forceinline__ IdxBlock load_idx_block(const int32_t *__restrict__ rowidx, const double *__restrict__ vals, int q, int len,
-                                                   double mean, double alpha)
+// The block keeps what was LOADED (row id and rating of slot base + lane; slots beyond the chunk read `safe`, K zeros):
+// nothing is computed from the loads here, so the wave does not wait for them before their first use in gather().
+// (With `(q < len) ? (vals[q] - mean) * alpha : 0` the compiler put each load in a branch of its own and waited for it
+// on the spot: the normal draw that was meant to run in the shadow of these loads started after them.)
+struct IdxBlock { int ri; double v; int base; };
+__device__ __forceinline__ IdxBlock load_idx_block(const int32_t *__restrict__ rowidx, const double *__restrict__ vals, int base, int lane, int len,
+                                                   const double *__restrict__ safe)
 {
     IdxBlock r;
-    r.ri = (q < len) ? rowidx[q] : -1;
-    r.wv = (q < len) ? (vals[q] - mean) * alpha : 0.0;                          // c++/sample.cpp:256
+    const int q = base + lane;
+    const int32_t *pr = (q < len) ? rowidx + q : reinterpret_cast<const int32_t *>(safe);
+    const double *pv = (q < len) ? vals + q : safe;
+    r.ri = *pr;
+    r.v = *pv;
+    r.base = base;
     return r;
 }
 
@@ -309,8 +317,8 @@ __device__ __forceinline__ void gram_chunk44(const int32_t *__restrict__ rowidx,
     auto gather = [&](const IdxBlock &ib, int gg, dd2 (&yy)[NL], double &ww) {
         const int src = gg * 16 + slot;
         const int row = __shfl(ib.ri, src);
-        ww = __shfl(ib.wv, src);
-        const double *base = (row >= 0) ? other + (size_t)(row & rowmask) * K : zero_row;
+        ww = (__shfl(ib.v, src) - mean) * alpha;                                  // c++/sample.cpp:256 (padding slots: times a row of zeros)
+        const double *base = (ib.base + src < len) ? other + (size_t)(row & rowmask) * K : zero_row;
         const dd2 *p = reinterpret_cast<const dd2 *>(base + 2 * x);
 #pragma unroll
         for (int h = 0; h < NL; ++h) yy[h] = p[4 * h];
@@ -334,9 +342,7 @@ __device__ __forceinline__ void gram_chunk44(const int32_t *__restrict__ rowidx,
     int b0 = 0;
     // full blocks that have a successor: straight-line code, the operand sets simply alternate
     for (; b0 + 64 < len; b0 += 64) {
-        IdxBlock nn;                                                             // index block after the next one
-        nn.ri = -1; nn.wv = 0.0;
-        if (b0 + 128 < len) nn = load_idx_block(rowidx, vals, b0 + 128 + lane, len, mean, alpha);   // wave-uniform
+        const IdxBlock nn = load_idx_block(rowidx, vals, b0 + 128, lane, len, zero_row);   // index block after the next one
         gather(cur, 1, yB, wB);
         contract(yA, wA);
         gather(cur, 2, yA, wA);
@@ -957,8 +963,8 @@ __global__ __launch_bounds__(64, Geo1<K>::WPS) void k_sample1(SampleArgs a, Fuse
 
     // the first index blocks of the chunk are requested before anything else
     const int glen = (a.ablate & 2u) ? 0 : len;
-    const IdxBlock ib0 = load_idx_block(a.rowidx + p0, a.vals + p0, lane, glen, a.mean_rating, a.alpha);
-    const IdxBlock ib1 = load_idx_block(a.rowidx + p0, a.vals + p0, 64 + lane, glen, a.mean_rating, a.alpha);
+    const IdxBlock ib0 = load_idx_block(a.rowidx + p0, a.vals + p0, 0, lane, glen, a.zero_row);
+    const IdxBlock ib1 = load_idx_block(a.rowidx + p0, a.vals + p0, 64, lane, glen, a.zero_row);
 
     // whole column in one item: its normals do not depend on the Gram -- draw them first so that
     // the Philox / log / sqrt chain is off the critical path between the last MFMA and the factorisation
