@@ -141,6 +141,7 @@ struct PrecArgs {
     const int32_t *order;       // O's columns, longest first
     int64_t ncols;              // of O
     const double *s_items;      // S's factors (only this rank's columns are read)
+    const double *zero_row;     // K zeros (gather target of padding slots)
     double *prec;               // O's prec: ncols x PART
     double mean_rating;         // of O (computeMuLambda is O's member: c++/sample.cpp:256)
     double alpha;

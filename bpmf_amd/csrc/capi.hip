@@ -693,7 +693,7 @@ int reduce_half_iteration(bpmf_hip_side *self, const bpmf_hip_side *other, int i
 
     bpmf::PrecArgs p{};
     p.t_colptr = self->d_t_colptr; p.t_rowidx = self->d_t_rowidx; p.t_vals = self->d_t_vals; p.order = self->d_t_order;
-    p.ncols = other->ncols; p.s_items = self->d_items; p.prec = other->d_prec;
+    p.ncols = other->ncols; p.s_items = self->d_items; p.zero_row = c->d_zero; p.prec = other->d_prec;
     p.mean_rating = other->mean_rating; p.alpha = alpha;
     bpmf_launch::reduce_precompute(K, st, nullptr, ev_stop, p);
     HIP_TRY(hipGetLastError());
@@ -1323,16 +1323,21 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
         c->pending_stats = nullptr;
     }
     self->stats_ev[evset].store(nullptr, std::memory_order_release);
-    if (fused) {
+    // An unfused side whose partner launches in the fused format (ChEMBL shape: the compounds side runs the low-rank
+    // forms, the targets side k_sample1s<64>) hands its statistics to the partner's launch as well: as a kernel of their
+    // own on S1 their 2 048 waves only got wave slots as the partner's sampler -- which fills the chip -- drained, i.e.
+    // the sums of the 483 k compounds arrived when the targets' sampler ended (0.34 ms after their own sampler), and the
+    // compounds' host chain (cov, Normal-Wishart draw, factor of LambdaF: 0.12 ms) started only then.
+    const bool partner_fusable = (K <= 32 && other->mode == 1) || (K == 64 && other->mode == 4 && other->lr_n == 0 && other->nsub <= 1);
+    const bool defer = !fused && !dist && s1 != s0 && c->dtype == BPMF_HIP_F64 && partner_fusable && other->nwork > 0 && other->a_d_in &&
+                       self->nwork > 0 && env_int("BPMF_HIP_FUSED", 1) != 0 && env_int("BPMF_HIP_DEFER_STATS", 0) != 0;   // (measured slower: 1.72 against 1.26 ms -- the 2 048 rider waves stream 247 MB at the head of the partner's launch; kept as a switch)
+    if (fused || defer) {
         c->pending_stats = self; c->pending_seq = seq; c->pending_evset = evset;     // ride in the next launch
     } else {
-        // fp32 path: the statistics used to take 0.2 ms from the end of the sampler to the sums, on the critical path of
+        // (fp32 path: the statistics used to take 0.2 ms from the end of the sampler to the sums, on the critical path of
         // the side's host chain: their 256-thread workgroups had to find room beside the NEXT side's sampler, whose
-        // 128-thread workgroups refill every slot that frees up.  Now single-wave workgroups without LDS (k_colstats_f32:
-        // they fit beside four sampler workgroups per CU at once).  BPMF_HIP_STATS_S0=1 puts them on S0 directly behind
-        // their sampler instead (measured even to slightly slower: ~50 us of device time per iteration).
-        static const int stats_s0 = env_int("BPMF_HIP_STATS_S0", 0);
-        hipStream_t sst = (c->dtype == BPMF_HIP_F32 && !dist && stats_s0) ? s0 : s1;
+        // 128-thread workgroups refill every slot that frees up.  Now single-wave workgroups without LDS: k_colstats_f32.)
+        hipStream_t sst = s1;
         if (sst != s0) HIP_TRY(hipStreamWaitEvent(sst, ev[1], 0));
         unsigned *flag = reinterpret_cast<unsigned *>(self->a_h_out_dev + c->out_words - 1);
         rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK>(self, sst, self->a_d_in, self->a_h_out_dev, flag, seq, self->a_ticket));

@@ -200,7 +200,7 @@ __device__ __forceinline__ void draw_normals_deferred(uint32_t counter, int n, d
 // ---------------------------------------------------------------------------
 template <int K>
 __device__ __forceinline__ void gram_chunk(const int32_t *__restrict__ rowidx, const double *__restrict__ vals, int len,
-                                           const double *__restrict__ other, double mean, double alpha,
+                                           const double *__restrict__ other, const double *__restrict__ zero_row, double mean, double alpha,
                                            d4 (&acc)[Geo<K>::NTRI], double (&r)[Geo<K>::NT], int lane, int rowmask = -1)
 {
     constexpr int NT = Geo<K>::NT;
@@ -227,10 +227,12 @@ __device__ __forceinline__ void gram_chunk(const int32_t *__restrict__ rowidx, c
                 const int src = (g * 4 + s) * 4 + kq;
                 const int row = __shfl(ri, src);
                 ww[s] = __shfl(wv, src);
-                const bool ok = row >= 0;
-                const double *col = other + (size_t)(ok ? (row & rowmask) : 0) * K + li;   // rowmask: profiling only (ablate 4)
+                // No select around the loads (the compiler would branch around each one and wait for it on the spot):
+                // padding slots gather a row of zeros; K = 8: the lanes li >= 8 read entry 0 and feed only the rows /
+                // columns >= 8 of the padded 16 x 16 tile, which nobody reads.
+                const double *col = (row >= 0) ? other + (size_t)(row & rowmask) * K : zero_row;   // rowmask: profiling only (ablate 4)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) yy[s][t] = (ok && (t * 16 + li < K)) ? col[t * 16] : 0.0;
+                for (int t = 0; t < NT; ++t) yy[s][t] = col[(t * 16 + li < K) ? t * 16 + li : 0];
             }
         };
         gather(0, y, w);
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(64, Geo<K>::WPS) void k_sample(SampleArgs a)
 #pragma unroll
         for (int t = 0; t < NT; ++t) r[t] = 0.0;
 
-        gram_chunk<K>(a.rowidx + p0, a.vals + p0, (a.ablate & 2u) ? 0 : len, a.other_items, a.mean_rating, a.alpha, acc, r, lane, (a.ablate & 4u) ? 63 : -1);
+        gram_chunk<K>(a.rowidx + p0, a.vals + p0, (a.ablate & 2u) ? 0 : len, a.other_items, a.zero_row, a.mean_rating, a.alpha, acc, r, lane, (a.ablate & 4u) ? 63 : -1);
 
         if (a.ablate & 1u) {                                       // timing ablation: keep the Gram live, skip the rest
             double v = r[0];
@@ -1030,7 +1032,7 @@ __global__ __launch_bounds__(64, Geo1<K>::WPS) void k_sample1(SampleArgs a, Fuse
         for (int t = 0; t < NTRI; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int t = 0; t < NT; ++t) r[t] = 0.0;
-        gram_chunk<K>(a.rowidx + p0, a.vals + p0, (a.ablate & 2u) ? 0 : len, a.other_items, a.mean_rating, a.alpha, acc, r, lane, (a.ablate & 4u) ? 63 : -1);
+        gram_chunk<K>(a.rowidx + p0, a.vals + p0, (a.ablate & 2u) ? 0 : len, a.other_items, a.zero_row, a.mean_rating, a.alpha, acc, r, lane, (a.ablate & 4u) ? 63 : -1);
 
         if (a.ablate & 1u) {
             double v = r[0];
@@ -1134,16 +1136,30 @@ __device__ __forceinline__ void colstats_body(int w, const double *__restrict__ 
 #pragma unroll
         for (int t = 0; t < NT; ++t) r[t] = 0.0;
 
+        // Eight columns per trip; the loads of the NEXT trip are issued before the MFMAs of the current one, and no load
+        // sits inside a select (slots beyond the slice read a valid column and are zeroed afterwards): with
+        // `ok ? items[..] : 0.0` every load got a branch and a wait of its own, and the pass over the 483 k columns of
+        // the ChEMBL-shaped compounds side took 0.32-0.38 ms instead of the ~60 us its 247 MB need.
+        double yn[2][NT];
+        auto fetch = [&](int64_t c, double (&yy)[2][NT]) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int64_t col = c + s * 4 + kq;
+                const double *x = items + (size_t)((col < e) ? col : b) * K;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) yy[s][t] = x[(t * 16 + li < K) ? t * 16 + li : 0];
+            }
+        };
+        if (b < e) fetch(b, yn);
         for (int64_t c = b; c < e; c += 8) {
             double y[2][NT];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const int64_t col = c + s * 4 + kq;
-                const bool ok = col < e;
+                const bool ok = c + s * 4 + kq < e;
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    y[s][t] = (ok && (t * 16 + li < K)) ? items[(size_t)col * K + t * 16 + li] : 0.0;
+                for (int t = 0; t < NT; ++t) y[s][t] = (ok && (t * 16 + li < K)) ? yn[s][t] : 0.0;
             }
+            fetch((c + 8 < e) ? c + 8 : b, yn);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
 #pragma unroll

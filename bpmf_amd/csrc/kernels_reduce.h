@@ -32,7 +32,7 @@ __global__ __launch_bounds__(64, Geo<K>::WPS) void k_precompute(PrecArgs p)
     for (int t = 0; t < NTRI; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int t = 0; t < NT; ++t) r[t] = 0.0;
-    gram_chunk<K>(p.t_rowidx + p0, p.t_vals + p0, len, p.s_items, p.mean_rating, p.alpha, acc, r, lane);
+    gram_chunk<K>(p.t_rowidx + p0, p.t_vals + p0, len, p.s_items, p.zero_row, p.mean_rating, p.alpha, acc, r, lane);
     double *out = p.prec + (size_t)j * PART;
 #pragma unroll
     for (int t = 0; t < NTRI; ++t)
