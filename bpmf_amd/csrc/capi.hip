@@ -228,6 +228,19 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
             if (!(it.mc < 0 && it.len <= nlr)) { hc.push_back(it.col); hl.push_back(it.len); hm.push_back(it.mc); hk.push_back(it.chunk); hp.push_back(it.p0); }
         if (nlr > 0 && (int64_t)lc.size() * 2 >= nloc && !lc.empty()) {
             s->lr_n = (int)lc.size(); s->hv_nwork = (int)hc.size();
+            if (nloc > 100000 && env_int("BPMF_HIP_STATS_SPLIT", 0) != 0 && s->pf_class[1] > 0 && s->pf_class[1] < (int)lc.size()) {
+                // statistics in two groups (bpmf_hip_side::d_stat_list): A = heavy columns + product-form class 0.
+                // Measured SLOWER on the ChEMBL shape (1.25 against 1.18 ms): group A's pass beside k_sample_pf<64,6> costs that
+                // launch 0.11 ms, and group B's 256-thread workgroups still only get in as the partner's sampler drains.  Off.
+                std::vector<int32_t> list; list.reserve((size_t)nloc);
+                std::vector<char> seen((size_t)nloc, 0);
+                for (int32_t col : hc) if (!seen[(size_t)col]) { seen[(size_t)col] = 1; list.push_back(col); }
+                for (int q = 0; q < s->pf_class[1]; ++q) list.push_back(lc[(size_t)q]);
+                s->stat_nA = (int64_t)list.size();
+                for (size_t q = (size_t)s->pf_class[1]; q < lc.size(); ++q) list.push_back(lc[q]);
+                s->stat_n = (int64_t)list.size();
+                if (s->stat_n == nloc && (rc = dev_upload(&s->d_stat_list, list.data(), list.size()))) return rc;
+            }
             if (s->pf_class[3] > 0 && (rc = dev_upload<double>(&s->d_pf_q, nullptr, (size_t)s->nrows * K))) return rc;
             if ((rc = dev_upload(&s->d_lr_col, lc.data(), lc.size())) || (rc = dev_upload(&s->d_lr_len, ll.data(), ll.size())) ||
                 (rc = dev_upload(&s->d_lr_p0, lp.data(), lp.size())) || (rc = dev_upload(&s->d_hv_col, hc.data(), hc.size())) ||
@@ -260,7 +273,15 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     // column statistics: one wave per 64+ columns, at most 2 waves per CU
     // (sides with hundreds of thousands of columns: the pass is a 8 K-byte-per-column stream, four times the waves)
     s->nstat_waves = (int)std::max<int64_t>(1, std::min<int64_t>((nloc + 31) / 32, (int64_t)s->ctx->num_cu * (nloc > 100000 ? 8 : 2)));
-    if ((rc = dev_upload<double>(&s->d_stat_partials, nullptr, (size_t)s->nstat_waves * pw))) return rc;
+    if (env_int("BPMF_HIP_NSTAT", 0) > 0) s->nstat_waves = (int)std::min<int64_t>(env_int("BPMF_HIP_NSTAT", 0), std::max<int64_t>(1, (nloc + 31) / 32));   // (experiments)
+    // big sides: four-wave workgroups with a finisher that reads the partials contiguously (k_colstats_wg)
+    s->nstat_wg = (nloc > 100000 && env_int("BPMF_HIP_STATS_WG", 1) != 0) ? (int)std::min<int64_t>((nloc + 127) / 128, (int64_t)s->ctx->num_cu * 2) : 0;
+    if (s->d_stat_list && s->nstat_wg > 0) {
+        s->stat_wgA = (int)std::max<int64_t>(1, std::min<int64_t>((s->stat_nA + 127) / 128, s->nstat_wg));
+        s->stat_wgB = (int)std::max<int64_t>(1, std::min<int64_t>((s->stat_n - s->stat_nA + 127) / 128, s->nstat_wg));
+        if (!s->ev_stat_a) HIP_TRY(hipEventCreate(&s->ev_stat_a));
+    }
+    if ((rc = dev_upload<double>(&s->d_stat_partials, nullptr, (size_t)std::max(s->nstat_waves, 2 * s->nstat_wg) * pw))) return rc;
     return 0;
 }
 
@@ -270,9 +291,10 @@ void free_schedule(bpmf_hip_side *s)
     void **ptrs[] = {(void **)&s->d_wi_col, (void **)&s->d_wi_len, (void **)&s->d_wi_mc, (void **)&s->d_wi_chunk, (void **)&s->d_wi_p0,
                      (void **)&s->d_mc_slot0, (void **)&s->d_mc_nch, (void **)&s->d_mc_count, (void **)&s->d_partials, (void **)&s->d_stat_partials,
                      (void **)&s->d_lr_col, (void **)&s->d_lr_len, (void **)&s->d_lr_p0, (void **)&s->d_hv_col, (void **)&s->d_hv_len,
-                     (void **)&s->d_hv_mc, (void **)&s->d_hv_chunk, (void **)&s->d_hv_p0, (void **)&s->d_pf_q};
+                     (void **)&s->d_hv_mc, (void **)&s->d_hv_chunk, (void **)&s->d_hv_p0, (void **)&s->d_pf_q, (void **)&s->d_stat_list};
     for (void **p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
     s->lr_n = s->hv_nwork = 0;
+    s->stat_nA = s->stat_n = 0; s->stat_wgA = s->stat_wgB = 0; s->stat_a_ready = s->stat_a_done = false;
 }
 
 }  // namespace
@@ -364,7 +386,7 @@ extern "C" int bpmf_hip_ctx_destroy(bpmf_hip_ctx *c)
                 for (int i = 1; i < 64; ++i) if (h[probe * 64 + i]) fprintf(stderr, " %d:%lld", i, (long long)(h[probe * 64 + i] - h[probe * 64]));
                 fprintf(stderr, "\n");
             }
-            if (h[129]) fprintf(stderr, "[bpmf_hip] all launches: %llu items, mean life of wave 0 %.1f us\n", h[129], (double)h[128] / (double)h[129] / 100.0);
+        if (h[129]) fprintf(stderr, "[bpmf_hip] all launches: %llu items, mean life of wave 0 %.1f us\n", h[129], (double)h[128] / (double)h[129] / 100.0);
         (void)hipFree(c->d_stamps);
     }
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -486,6 +508,7 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
     if (s->sx) { (void)hipStreamSynchronize(s->sx); (void)hipStreamDestroy(s->sx); }
     for (hipEvent_t e : s->sub_ev) if (e) (void)hipEventDestroy(e);
     if (s->sx_done) (void)hipEventDestroy(s->sx_done);
+    if (s->ev_stat_a) (void)hipEventDestroy(s->ev_stat_a);
     if (s->own_csc) { if (s->d_rowidx) (void)hipFree(s->d_rowidx); if (s->d_vals) (void)hipFree(s->d_vals); }
     if (s->own_items && s->d_items) (void)hipFree(s->d_items);
     if (s->d_items_alt) (void)hipFree(s->d_items_alt);
@@ -831,6 +854,7 @@ extern "C" int bpmf_hip_sample_side_launch(bpmf_hip_side *self, const bpmf_hip_s
     c->last_sampler_done = nullptr;
     int rc = BPMF_DISPATCH_K(K, sample_and_exchange<KK>(self, other, iter, alpha, c->d_in, c->stream, nullptr, nullptr));
     if (rc) return rc;
+    self->stat_a_ready = false;                                     // (the split statistics pass belongs to the asynchronous path)
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     unsigned *flag = reinterpret_cast<unsigned *>(c->h_out_dev + c->out_words - 1);
     rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK>(self, c->stream, c->d_in, c->h_out_dev, flag, ++c->seq, c->d_ticket));
@@ -1189,6 +1213,7 @@ int flush_pending_stats(bpmf_hip_ctx *c)
     hipEvent_t *ev = P->evs[c->pending_evset];
     HIP_TRY(hipStreamWaitEvent(P->saux, ev[1], 0));                  // (ev[1]: recorded with / behind P's sampler)
     unsigned *flag = reinterpret_cast<unsigned *>(P->a_h_out_dev + c->out_words - 1);
+    P->stat_a_ready = false;
     const int rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK>(P, P->saux, P->a_d_in, P->a_h_out_dev, flag, c->pending_seq, P->a_ticket));
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ev[2], P->saux));
@@ -1337,7 +1362,14 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
         // (fp32 path: the statistics used to take 0.2 ms from the end of the sampler to the sums, on the critical path of
         // the side's host chain: their 256-thread workgroups had to find room beside the NEXT side's sampler, whose
         // 128-thread workgroups refill every slot that frees up.  Now single-wave workgroups without LDS: k_colstats_f32.)
-        hipStream_t sst = s1;
+        static const int stats_s0 = env_int("BPMF_HIP_STATS_S0", 0);   // experiment: big sides' statistics on S0 directly behind their sampler
+        hipStream_t sst = (stats_s0 && !dist && s1 != s0 && self->nstat_waves >= 1024) ? s0 : s1;
+        if (self->stat_a_ready && sst != s0) {                        // group A of a split pass: behind the launch of its columns
+            HIP_TRY(hipStreamWaitEvent(sst, self->ev_stat_a, 0));
+            rc = BPMF_DISPATCH_K(K, bpmf_launch::stats_a<KK>(self, sst, self->a_d_in, self->a_h_out_dev, self->a_ticket));
+            if (rc) return rc;
+        }
+        self->stat_a_ready = false;
         if (sst != s0) HIP_TRY(hipStreamWaitEvent(sst, ev[1], 0));
         unsigned *flag = reinterpret_cast<unsigned *>(self->a_h_out_dev + c->out_words - 1);
         rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK>(self, sst, self->a_d_in, self->a_h_out_dev, flag, seq, self->a_ticket));

@@ -1114,6 +1114,75 @@ __device__ __forceinline__ void publish_when_last(unsigned *ticket, unsigned nbl
     }
 }
 
+// sum x x^T (upper 16 x 16 tiles, accumulator layout of the f64 16x16x4 MFMA) and sum x of the columns [b, e): one wave
+// (list != NULL: positions [b, e) of a list of LOCAL column ids, column = c0 + list[position]; the ids of a trip are
+//  requested two trips ahead, its columns one trip ahead)
+template <int K>
+__device__ __forceinline__ void colstats_accumulate(const double *__restrict__ items, int64_t b, int64_t e,
+                                                    d4 (&acc)[Geo<K>::NTRI], double (&r)[Geo<K>::NT], int lane,
+                                                    const int32_t *__restrict__ list = nullptr, int64_t c0 = 0)
+{
+    constexpr int NT = Geo<K>::NT;
+    const int kq = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int t = 0; t < Geo<K>::NTRI; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) r[t] = 0.0;
+    // Eight columns per trip; the loads of the NEXT trip are issued before the MFMAs of the current one, and no load
+    // sits inside a select (slots beyond the slice read a valid column and are zeroed afterwards): with
+    // `ok ? items[..] : 0.0` every load got a branch and a wait of its own, and the pass over the 483 k columns of
+    // the ChEMBL-shaped compounds side took 0.32-0.38 ms instead of the ~60 us its 247 MB need.
+    double yn[2][NT];
+    int64_t idn[2];                                                   // columns of the trip after the next one
+    auto ids = [&](int64_t c, int64_t (&id)[2]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int64_t pos = (c + s * 4 + kq < e) ? c + s * 4 + kq : b;
+            id[s] = list ? c0 + (int64_t)list[pos] : pos;
+        }
+    };
+    auto fetch = [&](const int64_t (&id)[2], double (&yy)[2][NT]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const double *x = items + (size_t)id[s] * K;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) yy[s][t] = x[(t * 16 + li < K) ? t * 16 + li : 0];
+        }
+    };
+    if (b < e) {
+        int64_t id0[2];
+        ids(b, id0);
+        fetch(id0, yn);
+        ids((b + 8 < e) ? b + 8 : b, idn);
+    }
+    for (int64_t c = b; c < e; c += 8) {
+        double y[2][NT];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bool ok = c + s * 4 + kq < e;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) y[s][t] = (ok && (t * 16 + li < K)) ? yn[s][t] : 0.0;
+        }
+        fetch(idn, yn);                                               // (beyond the end: position b again, dropped by `ok`)
+        ids((c + 16 < e) ? c + 16 : b, idn);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) r[t] += y[s][t];
+            int tri = 0;
+#pragma unroll
+            for (int I = 0; I < NT; ++I)
+#pragma unroll
+                for (int J = I; J < NT; ++J, ++tri) acc[tri] = mfma16(y[s][I], y[s][J], acc[tri]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        r[t] += __shfl_xor(r[t], 16);
+        r[t] += __shfl_xor(r[t], 32);
+    }
+}
+
 template <int K>
 __device__ __forceinline__ void colstats_body(int w, const double *__restrict__ items, int64_t c0, int64_t c1, int nwaves,
                                               double *partials, const unsigned long long *__restrict__ fail_in,
@@ -1122,7 +1191,7 @@ __device__ __forceinline__ void colstats_body(int w, const double *__restrict__ 
 {
     constexpr int NT = Geo<K>::NT, NTRI = Geo<K>::NTRI, PART = Geo<K>::PART;
     constexpr int NSLICE = (K * K + K + 15) / 16;
-    const int lane = threadIdx.x, kq = lane >> 4, li = lane & 15;
+    const int lane = threadIdx.x;
     const int64_t n = c1 - c0;
     const int64_t per = (((n + nwaves - 1) / nwaves) + 3) & ~(int64_t)3;
     const int64_t b = c0 + w * per;
@@ -1131,51 +1200,7 @@ __device__ __forceinline__ void colstats_body(int w, const double *__restrict__ 
     {
         d4 acc[NTRI];
         double r[NT];
-#pragma unroll
-        for (int t = 0; t < NTRI; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int t = 0; t < NT; ++t) r[t] = 0.0;
-
-        // Eight columns per trip; the loads of the NEXT trip are issued before the MFMAs of the current one, and no load
-        // sits inside a select (slots beyond the slice read a valid column and are zeroed afterwards): with
-        // `ok ? items[..] : 0.0` every load got a branch and a wait of its own, and the pass over the 483 k columns of
-        // the ChEMBL-shaped compounds side took 0.32-0.38 ms instead of the ~60 us its 247 MB need.
-        double yn[2][NT];
-        auto fetch = [&](int64_t c, double (&yy)[2][NT]) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int64_t col = c + s * 4 + kq;
-                const double *x = items + (size_t)((col < e) ? col : b) * K;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) yy[s][t] = x[(t * 16 + li < K) ? t * 16 + li : 0];
-            }
-        };
-        if (b < e) fetch(b, yn);
-        for (int64_t c = b; c < e; c += 8) {
-            double y[2][NT];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bool ok = c + s * 4 + kq < e;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) y[s][t] = (ok && (t * 16 + li < K)) ? yn[s][t] : 0.0;
-            }
-            fetch((c + 8 < e) ? c + 8 : b, yn);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) r[t] += y[s][t];
-                int tri = 0;
-#pragma unroll
-                for (int I = 0; I < NT; ++I)
-#pragma unroll
-                    for (int J = I; J < NT; ++J, ++tri) acc[tri] = mfma16(y[s][I], y[s][J], acc[tri]);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            r[t] += __shfl_xor(r[t], 16);
-            r[t] += __shfl_xor(r[t], 32);
-        }
+        colstats_accumulate<K>(items, b, e, acc, r, lane);
         double *p = partials + (size_t)w * PART;
 #pragma unroll
         for (int t = 0; t < NTRI; ++t)
@@ -1231,12 +1256,15 @@ __device__ __forceinline__ void colstats_body(int w, const double *__restrict__ 
 #pragma unroll
             for (int u = 0; u < 16; ++u) acc[u] = 0.0;
             for (int ww = w0; ww < w1; ww += 16) {
+                // (sixteen loads in flight: none of them inside a select -- beyond the end they re-read partial w0 and are
+                //  dropped afterwards; with `(ww + u < w1) ? load : 0` every load got a branch and a wait of its own and the
+                //  finishers of a 2 048-wave pass took 0.6 ms)
                 double v[16];
 #pragma unroll
                 for (int u = 0; u < 16; ++u)
-                    v[u] = (ww + u < w1) ? __hip_atomic_load(&partials[(size_t)(ww + u) * PART + off], BPMF_RLX_AGENT) : 0.0;
+                    v[u] = __hip_atomic_load(&partials[(size_t)((ww + u < w1) ? ww + u : w0) * PART + off], BPMF_RLX_AGENT);
 #pragma unroll
-                for (int u = 0; u < 16; ++u) acc[u] += v[u];
+                for (int u = 0; u < 16; ++u) acc[u] += (ww + u < w1) ? v[u] : 0.0;
             }
 #pragma unroll
             for (int h = 8; h >= 1; h >>= 1)
@@ -1271,6 +1299,140 @@ __global__ __launch_bounds__(64) void k_colstats(const double *__restrict__ item
 // Sys::predict (c++/sample.cpp:48-96): one lane per test rating; each lane walks its two
 // K-vectors with 16-byte loads (a 128-B line is consumed by one lane in 8 consecutive loads).
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// Column statistics of a BIG side (hundreds of thousands of columns; stand-alone launches only).  k_colstats' 2 048
+// single-wave workgroups each leave a partial of PART doubles and 260 finisher waves then read those partials in
+// 128-byte pieces 21 KB apart: 68 MB of page-missing reads -- 0.65 ms for the 483 k compounds of the ChEMBL shape,
+// whatever ran beside it.  Here: workgroups of four waves that add their accumulators through LDS (a quarter of the
+// partials), and finishers that walk the partials in THEIR order -- 512 contiguous bytes per partial and wave, sixteen
+// loads in flight, four waves splitting the partials -- and scatter the few sums into the result.
+// Order of every sum fixed: waves 0..3 of a workgroup, then the workgroups in quarters, ascending.
+// ---------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void k_colstats_wg(const double *__restrict__ items, int64_t c0, int64_t c1, int nwg,
+                                                    double *partials, const unsigned long long *__restrict__ fail_in,
+                                                    double *__restrict__ out, unsigned *ticket, unsigned *flag, unsigned seq,
+                                                    unsigned long long *tmo, unsigned long long wait_ticks,
+                                                    const int32_t *__restrict__ list, int part0, int ntot, int finish)
+{
+    // list == NULL: the columns [c0, c1).  Else: positions [c0 .. c1) of `list` (local column ids; the side's first column is
+    // items' column `from` = part of the pointer: `items` already points at local column 0).  This launch's workgroups write
+    // the partials part0 .. part0 + nwg - 1; with `finish` its last arrivals add all `ntot` partials (those of earlier
+    // launches on the same stream included) and publish, without it the launch only leaves its partials.
+    constexpr int NT = Geo<K>::NT, NTRI = Geo<K>::NTRI, PART = Geo<K>::PART, NBLK = (PART + 63) / 64;
+    __shared__ double red[PART];
+    __shared__ double fin[4][64];
+    __shared__ unsigned stk;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t n = c1 - c0;
+    const int nvw = nwg * 4, vw = (int)blockIdx.x * 4 + wave;
+    const int64_t per = (((n + nvw - 1) / nvw) + 3) & ~(int64_t)3;
+    const int64_t b = c0 + vw * per;
+    const int64_t e = (b + per < c1) ? b + per : c1;
+    {
+        d4 acc[NTRI];
+        double r[NT];
+        colstats_accumulate<K>(items, b, e, acc, r, lane, list, 0);   // (list mode: `items` points at local column 0)
+        // waves 1, 2, 3 hand their sums to wave 0 through LDS, one after the other
+        for (int src = 1; src < 4; ++src) {
+            if (wave == src) {
+#pragma unroll
+                for (int t = 0; t < NTRI; ++t)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) red[(t * 4 + reg) * 64 + lane] = acc[t][reg];
+                if (lane < 16) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) red[NTRI * 256 + t * 16 + lane] = r[t];
+                }
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int t = 0; t < NTRI; ++t)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) acc[t][reg] += red[(t * 4 + reg) * 64 + lane];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) r[t] += red[NTRI * 256 + t * 16 + (lane & 15)];
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+            double *p = partials + (size_t)(part0 + (int)blockIdx.x) * PART;
+#pragma unroll
+            for (int t = 0; t < NTRI; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) __hip_atomic_store(&p[(t * 4 + reg) * 64 + lane], acc[t][reg], BPMF_RLX_AGENT);
+            if (lane < 16) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) __hip_atomic_store(&p[NTRI * 256 + t * 16 + lane], r[t], BPMF_RLX_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the partial has landed before the ticket is taken
+        }
+    }
+    if (!finish) return;
+    const int nfin = nwg < NBLK ? nwg : NBLK;
+    if (tid == 0) stk = __hip_atomic_fetch_add(ticket, 1u, BPMF_RLX_AGENT);
+    __syncthreads();
+    const unsigned tk = stk;
+    if ((int)tk < nwg - nfin) return;                                 // (the whole workgroup)
+    const int f = (int)tk - (nwg - nfin);                             // finisher 0 .. nfin-1
+    if (tid == 0) {                                                   // bounded like every in-kernel wait (see colstats_body)
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(ticket, BPMF_RLX_AGENT) < (unsigned)nwg) {
+            __builtin_amdgcn_s_sleep(1);
+            if (wait_ticks && wall_clock64() - t0 > wait_ticks) { flag_timeout(tmo, BPMF_TMO_STATS); break; }
+        }
+    }
+    __syncthreads();
+    const int pw = (ntot + 3) >> 2;
+    const int w0 = wave * pw, w1 = (w0 + pw < ntot) ? w0 + pw : ntot;
+    for (int blk = f; blk < NBLK; blk += nfin) {
+        const int po = blk * 64 + lane;                               // position in the partial
+        const int pc = po < PART ? po : 0;
+        double acc[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+        for (int ww = w0; ww < w1; ww += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                v[u] = __hip_atomic_load(&partials[(size_t)((ww + u < w1) ? ww + u : w0) * PART + pc], BPMF_RLX_AGENT);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc[u] += (ww + u < w1) ? v[u] : 0.0;
+        }
+#pragma unroll
+        for (int h = 8; h >= 1; h >>= 1)
+#pragma unroll
+            for (int u = 0; u < h; ++u) acc[u] += acc[u + h];
+        fin[wave][lane] = acc[0];
+        __syncthreads();
+        if (wave == 0 && po < PART) {
+            const double sum = ((fin[0][lane] + fin[1][lane]) + fin[2][lane]) + fin[3][lane];
+            if (po < NTRI * 256) {                                    // tile `tri`, register reg, lane ln of the accumulator layout
+                const int tri = po >> 8, reg = (po >> 6) & 3, ln = po & 63;
+                int I = 0, t = tri;
+                while (t >= NT - I) { t -= NT - I; ++I; }
+                const int J = I + t;
+                const int gi = 16 * I + (ln >> 4) + 4 * reg, gj = 16 * J + (ln & 15);
+                if (gi < K && gj < K) {
+                    __hip_atomic_store(&out[gi + (size_t)gj * K], sum, BPMF_RLX_SYSTEM);
+                    if (I != J) __hip_atomic_store(&out[gj + (size_t)gi * K], sum, BPMF_RLX_SYSTEM);
+                }
+            } else {
+                const int el = po - NTRI * 256;
+                if (el < K) __hip_atomic_store(&out[K * K + el], sum, BPMF_RLX_SYSTEM);
+            }
+        }
+        __syncthreads();
+    }
+    if (f == 0 && tid == 0) {
+        const unsigned long long fw = *fail_in;
+        __hip_atomic_store(&out[K * K + K], (fw == ~0ull) ? 0.0 : (double)(fw + 1ull), BPMF_RLX_SYSTEM);
+        __hip_atomic_store(&reinterpret_cast<unsigned long long *>(out)[K * K + K + 1], fw, BPMF_RLX_SYSTEM);
+    }
+    publish_when_last(ticket + 1, (unsigned)nfin, flag, seq, ticket);
+}
+
 template <int K>
 __global__ __launch_bounds__(256) void k_predict(const int32_t *__restrict__ tcol, const int32_t *__restrict__ trow,
                                                  const double *__restrict__ tval, int64_t nnz,

@@ -18,6 +18,9 @@ int exchange(bpmf_hip_side *self, hipStream_t st, int sub);
 // sum x / sum x x^T of this rank's columns (+ all-reduce), published to `out_host_dev`
 template <int K>
 int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_host_dev, unsigned *flag, unsigned seq, unsigned *ticket);
+// group A of a split statistics pass (see bpmf_hip_side::d_stat_list): partials only, behind the side's ev_stat_a
+template <int K>
+int stats_a(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_host_dev, unsigned *ticket);
 template <int K>
 void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items, const void *other_items, int n, hipStream_t ps, bool beside);
 

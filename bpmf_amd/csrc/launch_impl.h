@@ -135,6 +135,10 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
                 lc.col = l.col + n0; lc.p0 = l.p0 + n0; lc.len = l.len + n0; lc.nitems = n1 - n0;
                 const bool is_last = last == 0 && pc == last_pf;
                 hipEvent_t e0 = started ? nullptr : ev_start, e1 = is_last ? ev_stop : nullptr;
+                if (pc == 0 && !is_last && self->d_stat_list && self->ev_stat_a && self->stat_nA > 0 && self->item_n < 0 && !(c->comm != nullptr && !self->bounds.empty())) {
+                    e1 = self->ev_stat_a;                                 // group A of the statistics may start behind this launch
+                    self->stat_a_ready = true;
+                }
                 started = true;
                 const int grid = std::max(1, std::min((n1 - n0 + 31) / 32, c->num_cu * 4));     // eight waves x four columns per pass
                 k64_pf(pc, grid, st, e0, e1, lc);
@@ -284,6 +288,18 @@ int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_h
         return 0;
     } else {
     if (!(c->comm != nullptr && !self->bounds.empty())) {
+        if (self->nstat_wg > 0 && self->stat_a_done) {                // group B + the sum over both groups' partials
+            self->stat_a_done = false;
+            hipLaunchKernelGGL(k_colstats_wg<K>, dim3(self->stat_wgB), dim3(256), 0, st,
+                               (const double *)self->d_items + (size_t)self->from * K, self->stat_nA, self->stat_n, self->stat_wgB, self->d_stat_partials,
+                               failp, out_host_dev, ticket, flag, seq, tmo_word(out_host_dev, K), wait_ticks(),
+                               (const int32_t *)self->d_stat_list, self->stat_wgA, self->stat_wgA + self->stat_wgB, 1);
+        } else if (self->nstat_wg > 0)
+            hipLaunchKernelGGL(k_colstats_wg<K>, dim3(self->nstat_wg), dim3(256), 0, st,
+                               (const double *)self->d_items, self->from, self->to, self->nstat_wg, self->d_stat_partials,
+                               failp, out_host_dev, ticket, flag, seq, tmo_word(out_host_dev, K), wait_ticks(),
+                               (const int32_t *)nullptr, 0, self->nstat_wg, 1);
+        else
         hipLaunchKernelGGL(k_colstats<K>, dim3(self->nstat_waves), dim3(64), 0, st,
                            (const double *)self->d_items, self->from, self->to, self->nstat_waves, self->d_stat_partials,
                            failp, out_host_dev, ticket, flag, seq, tmo_word(out_host_dev, K), wait_ticks());
@@ -294,12 +310,36 @@ int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_h
         // on the side's own stream: its own reduction blob and the second communicator
         const bool own = st != c->stream && c->comm2 && self->a_d_red;
         double *red = own ? self->a_d_red : c->d_red;
+        if (self->nstat_wg > 0)
+            hipLaunchKernelGGL(k_colstats_wg<K>, dim3(self->nstat_wg), dim3(256), 0, st,
+                               (const double *)self->d_items, self->from, self->to, self->nstat_wg, self->d_stat_partials,
+                               failp, red, ticket, ticket + 8, 0u, tmo_word(out_host_dev, K), wait_ticks(),
+                               (const int32_t *)nullptr, 0, self->nstat_wg, 1);
+        else
         hipLaunchKernelGGL(k_colstats<K>, dim3(self->nstat_waves), dim3(64), 0, st,
                            (const double *)self->d_items, self->from, self->to, self->nstat_waves, self->d_stat_partials,
                            failp, red, ticket, ticket + 8, 0u, tmo_word(out_host_dev, K), wait_ticks());
         NCCL_TRY(R->AllReduce(red, red, (size_t)K * K + K + 1, ncclDouble, ncclSum, own ? c->comm2 : c->comm, st));   // prod | sum | failed-column word
         publish(red, out_host_dev, K * K + K + 1, flag, seq, K * K + K, st);
     }
+    return 0;
+    }
+}
+
+template <int K>
+int stats_a(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_host_dev, unsigned *ticket)
+{
+    using namespace bpmf;
+    if constexpr (K == 128) return 0;
+    else {
+    if (!(self->nstat_wg > 0 && self->d_stat_list && self->stat_a_ready)) return 0;
+    self->stat_a_ready = false;
+    const unsigned long long *failp = (const unsigned long long *)(d_in + (size_t)K * K + K);
+    hipLaunchKernelGGL(k_colstats_wg<K>, dim3(self->stat_wgA), dim3(256), 0, st,
+                       (const double *)self->d_items + (size_t)self->from * K, (int64_t)0, self->stat_nA, self->stat_wgA, self->d_stat_partials,
+                       failp, out_host_dev, ticket, (unsigned *)nullptr, 0u, tmo_word(out_host_dev, K), wait_ticks(),
+                       (const int32_t *)self->d_stat_list, 0, self->stat_wgA + self->stat_wgB, 0);
+    self->stat_a_done = true;
     return 0;
     }
 }
@@ -349,4 +389,5 @@ void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items
                                                hipEvent_t, hipEvent_t);                                                          \
     template int bpmf_launch::exchange<KK>(bpmf_hip_side *, hipStream_t, int);                                                        \
     template int bpmf_launch::stats<KK>(bpmf_hip_side *, hipStream_t, const double *, double *, unsigned *, unsigned, unsigned *); \
+    template int bpmf_launch::stats_a<KK>(bpmf_hip_side *, hipStream_t, const double *, double *, unsigned *);                       \
     template void bpmf_launch::predict<KK>(bpmf_hip_test *, const bpmf_hip_side *, const void *, const void *, int, hipStream_t, bool);

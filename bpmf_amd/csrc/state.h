@@ -178,6 +178,12 @@ struct bpmf_hip_side {
     unsigned *d_mc_count = nullptr;
     double *d_partials = nullptr;
     int nstat_waves = 0;
+    int nstat_wg = 0;                    // > 0: the side's stand-alone statistics pass runs as this many four-wave workgroups (k_colstats_wg: big sides)
+    // big side with several sampler launches per half-iteration (K = 64 low-rank classes): the statistics of the columns
+    // of the FIRST launches (heavy + <= 2 ratings: group A, the first stat_nA entries of d_stat_list) run beside the later
+    // launches, only the rest waits for the end of the side's samplers
+    int32_t *d_stat_list = nullptr; int64_t stat_nA = 0, stat_n = 0; int stat_wgA = 0, stat_wgB = 0;
+    hipEvent_t ev_stat_a = nullptr; bool stat_a_ready = false, stat_a_done = false;
     double *d_stat_partials = nullptr;
     std::vector<int64_t> bounds;         // multi-GPU: column range of every rank (nranks + 1 entries)
     // overlap of exchange and sampling (bpmf_hip_side_set_overlap): every rank's range is cut into nsub parts of
