@@ -475,6 +475,19 @@ def test_connectivity_exchange_loopback(K):
     assert r.returncode == 0 and "CONN-OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
 
 
+@pytest.mark.parametrize("K", [16, 64])
+def test_sharded_big_side_single_rank(K):
+    """A side with > 100 000 columns (workgroup form of the statistics pass, k_colstats_wg): sharded over a one-rank
+    communicator == plain, and both against the oracle: tests/_bigside_worker.py."""
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_bigside_worker.py"), str(K)], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0 and "BIGSIDE-OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
 @pytest.mark.parametrize("K", [32, 64, 128])
 def test_sharded_parts_single_rank(K):
     """Sharded == plain, and bpmf_hip_side_set_overlap (exchange of part c beside the sampling of part c + 1) ==
