@@ -776,7 +776,9 @@ int sample_and_exchange(bpmf_hip_side *self, const bpmf_hip_side *other, int ite
     }()
 
 // parameter blob of one half-iteration: LambdaF | LambdaF*mu | "no column failed"
-void fill_blob(int K, const double *mu, const double *LambdaF, double *h_in, bool with_factor)
+// LambdaU (optional): the upper factor the hyper-parameter draw produced, LambdaF = LambdaU^T LambdaU (c++/bpmf.h:101) -- it IS
+// chol(LambdaF).matrixU() up to rounding (upper triangular, positive diagonal), so the factorisation below is skipped
+void fill_blob(int K, const double *mu, const double *LambdaF, double *h_in, bool with_factor, const double *LambdaU = nullptr)
 {
     // rr = hp_LambdaF * hp.mu is the same for every column (c++/sample.cpp:285)
     memcpy(h_in, LambdaF, sizeof(double) * K * K);
@@ -795,6 +797,11 @@ void fill_blob(int K, const double *mu, const double *LambdaF, double *h_in, boo
         // and is reported as "Cholesky failed" like the reference's own LLT (c++/sample.cpp:306-308).
         double *R = h_in + (size_t)K * K + K + 2 + K;
         bool ok = true;
+        if (LambdaU) {
+            for (int i = 0; i < K; ++i)
+                for (int j = 0; j < K; ++j) R[(size_t)i * K + j] = (j >= i) ? LambdaU[(size_t)j * K + i] : 0.0;     // column-major U(i, j) -> row-major
+            for (int i = 0; i < K; ++i) ok = ok && (R[(size_t)i * K + i] > 0.0);
+        } else
         for (int i = 0; i < K && ok; ++i) {
             for (int j = 0; j < K; ++j) R[(size_t)i * K + j] = 0.0;
             for (int j = i; j < K; ++j) {
@@ -1087,7 +1094,7 @@ int draw_and_release(bpmf_hip_side *s, int iter, double *mu, double *LU, double 
     int rc = 0;
     if (s->rd_iter != iter) rc = predraw_get(s, iter);
     if (!rc) rc = bpmf_hyper_finish(K, s->ncols, s->cov.data(), nullptr, s->rd_au.data(), s->rd_z.data(), mu, LU, LF);
-    if (!rc) fill_blob(K, mu, LF, s->a_h_in, K == 64 && s->ctx->dtype == BPMF_HIP_F64 && s->lr_n > 0);   // (R0, R0^-1: only the low-rank forms read them)
+    if (!rc) fill_blob(K, mu, LF, s->a_h_in, K == 64 && s->ctx->dtype == BPMF_HIP_F64 && s->lr_n > 0, LU);   // (R0, R0^-1: only the low-rank forms read them)
     // the gate is opened even after an error: a sampler may already be queued behind it and must
     // not be left spinning (its results are never looked at: the error is reported first)
     {   // test hook: a host worker that is descheduled for a while (SIGSTOP, debugger, oversubscription)
