@@ -509,6 +509,7 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
     for (hipEvent_t e : s->sub_ev) if (e) (void)hipEventDestroy(e);
     if (s->sx_done) (void)hipEventDestroy(s->sx_done);
     if (s->ev_stat_a) (void)hipEventDestroy(s->ev_stat_a);
+    if (s->ev_stat_go) (void)hipEventDestroy(s->ev_stat_go);
     if (s->own_csc) { if (s->d_rowidx) (void)hipFree(s->d_rowidx); if (s->d_vals) (void)hipFree(s->d_vals); }
     if (s->own_items && s->d_items) (void)hipFree(s->d_items);
     if (s->d_items_alt) (void)hipFree(s->d_items_alt);
@@ -1378,6 +1379,17 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
         }
         self->stat_a_ready = false;
         if (sst != s0) HIP_TRY(hipStreamWaitEvent(sst, ev[1], 0));
+        // Big side (k_colstats_wg): its 256-thread workgroups only find room beside the partner's sampler if they are
+        // dispatched first -- both kernels become ready when this side's sampler ends, and the partner's launch, sitting
+        // in the same queue as that sampler, wins by the ~6 us of the cross-queue hop.  S0 therefore waits for a marker
+        // S1 passes just ahead of the statistics kernel: the pass (0.1 ms alone) starts a hop ahead of the sampler, keeps
+        // its slots, and the side's host chain is done before the partner's sampler is.
+        static const int head_start = env_int("BPMF_HIP_STATS_HEADSTART", 1);
+        if (head_start && sst != s0 && !dist && (self->nstat_wg > 0 || c->dtype == BPMF_HIP_F32)) {   // (fp32 path: 1 152 single-wave tile workgroups, same reasoning: 0.84 -> 0.81 ms)
+            if (!self->ev_stat_go) HIP_TRY(hipEventCreateWithFlags(&self->ev_stat_go, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(self->ev_stat_go, sst));
+            HIP_TRY(hipStreamWaitEvent(s0, self->ev_stat_go, 0));
+        }
         unsigned *flag = reinterpret_cast<unsigned *>(self->a_h_out_dev + c->out_words - 1);
         rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK>(self, sst, self->a_d_in, self->a_h_out_dev, flag, seq, self->a_ticket));
         if (rc) return rc;

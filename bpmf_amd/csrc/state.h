@@ -184,6 +184,7 @@ struct bpmf_hip_side {
     // launches, only the rest waits for the end of the side's samplers
     int32_t *d_stat_list = nullptr; int64_t stat_nA = 0, stat_n = 0; int stat_wgA = 0, stat_wgB = 0;
     hipEvent_t ev_stat_a = nullptr; bool stat_a_ready = false, stat_a_done = false;
+    hipEvent_t ev_stat_go = nullptr;     // big side: S0 continues only once S1 has reached the statistics kernel (head start for its workgroups)
     double *d_stat_partials = nullptr;
     std::vector<int64_t> bounds;         // multi-GPU: column range of every rank (nranks + 1 entries)
     // overlap of exchange and sampling (bpmf_hip_side_set_overlap): every rank's range is cut into nsub parts of
