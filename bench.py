@@ -52,7 +52,7 @@ WORKLOADS = {
     #            K    dtype  dominant kernel            LDS bytes / workgroup, workgroups resident per CU (launch bounds, LDS)
     "ml1m":      (32, "f64", "k_sample1<32>",           (32 * 34 + 4 * 32 + 2) * 8, 12),
     "ml1m_k64":  (64, "f64", "k_sample1<64>",           None, None),
-    "chembl":    (64, "f64", "k_sample_pf<64,NB> + k_sample1<64>", None, None),
+    "chembl":    (64, "f64", "k_sample_pf<64,NB> + k_sample1s<64>", None, None),
     "ml1m_k128": (128, "f32", "k_sample_wg<128,float>", None, None),
 }
 
