@@ -14,7 +14,11 @@ Workloads (BASELINE.json configs; synthetic stand-ins, the reference ships only 
   ml1m_k64                the same matrix, K = 64 fp64
   chembl      configs[2]  483 500 x 5 775, 1 023 952 real-valued activities, K = 64 fp64
   ml1m_k128   configs[4]  the ML-1M shape, K = 128, fp32 factors (mixed-precision path)
-N > 1 (one rank per GPU, torch.distributed launcher, RCCL inside the library): weak scaling of the
+N > 1: one rank per GPU, RCCL inside the library.  Under a launcher (WORLD_SIZE / RANK / LOCAL_RANK set, e.g.
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) this process is one of the N ranks; without one,
+`bench.py --gpus N` starts the N ranks itself (the job of `mpirun -np N` for the reference, c++/mpi_common.h:11-50) and
+fails if fewer than N devices are visible -- it never reports a 1-rank run as N GPUs.  The line carries `rccl_nranks`,
+the rank count the communication library reports (ncclCommCount).  Weak scaling of the
 selected workload (N times the users and ratings) AND, next to it, the north star's strong-scaling
 experiment as the sub-record `strong_10Mx1M` (configs[3]: the SAME device-generated 10M x 1M x 200
 matrix at every N, N = 1 included; --no-strong skips it).
@@ -49,11 +53,12 @@ FP32_PEAK_TFLOPS = 157.3
 LDS_PER_CU = 160 * 1024
 
 WORKLOADS = {
-    #            K    dtype  dominant kernel            LDS bytes / workgroup, workgroups resident per CU (launch bounds, LDS)
-    "ml1m":      (32, "f64", "k_sample1<32>",           (32 * 34 + 4 * 32 + 2) * 8, 12),
-    "ml1m_k64":  (64, "f64", "k_sample1<64>",           None, None),
-    "chembl":    (64, "f64", "k_sample_pf<64,NB> + k_sample1s<64>", None, None),
-    "ml1m_k128": (128, "f32", "k_sample_wg<128,float>", None, None),
+    #            K    dtype  LDS bytes / workgroup, workgroups resident per CU (launch bounds, LDS) of the K = 32 sampler
+    # (the kernel names of the roofline object come from the library: bpmf_hip_side_kernel_name)
+    "ml1m":      (32, "f64", (32 * 34 + 4 * 32 + 2) * 8, 12),
+    "ml1m_k64":  (64, "f64", None, None),
+    "chembl":    (64, "f64", None, None),
+    "ml1m_k128": (128, "f32", None, None),
 }
 
 
@@ -67,6 +72,31 @@ def algorithmic_flops(nnz, ncols, K):
     return nnz * (K * (K + 1) + 2 * K) + ncols * (K ** 3 / 3.0 + 4 * K * K + 3 * K)
 
 
+def executed_flops(info, nnz, ncols, K):
+    """Flops one sampler launch of a side EXECUTES, given its schedule (bpmf_hip_side_schedule_info).  Columns in the
+    regular forms: the algorithmic count.  Columns in the product form (k_sample_pf, K = 64, <= 12 ratings) are never
+    factorised -- that is the point of the form -- so they are charged what the kernel does per column with n ratings:
+    one dense K x K matrix-vector product on the MFMA (2 K^2), n(n-1)/2 + 2n solves with a rank-one factor (~11 K flops
+    each: one product, a 6-step wave scan, the combine), n rank-one factors (~30 K: scan, two rsqrt + Newton, ratios),
+    3 K per rating for the right-hand side, ~30 K for the normal draw; plus k_pf_prepare: 2 K^2 per ROW of the side."""
+    npf = info["pf_le2"] + info["pf_3to6"] + info["pf_7to12"]
+    if npf == 0:
+        return algorithmic_flops(nnz, ncols, K)
+    n1, n2 = info["pf_ratings"], info["pf_ratings_sq"]
+    pf = npf * (2.0 * K * K + 30.0 * K) + K * (11.0 * ((n2 - n1) / 2.0 + 2.0 * n1) + 33.0 * n1)
+    return pf + algorithmic_flops(nnz - n1, ncols - npf, K)
+
+
+def kernel_source_sha():
+    """sha256 (16 hex digits) over the sources the device code is built from: a PMC profile names the sha it was taken
+    with, and figures of a profile of OTHER code are reported as stale, not as this run's."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "bpmf_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "bpmf_amd", "csrc", "*.hip"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def profiled(workload):
     """Per-launch PMC figures of the sampler from the committed rocprofv3 passes of this same command
     (profiles/r*_pmc_<workload>.txt, newest round; separate --pmc passes): HBM-side bytes and the LDS
@@ -78,9 +108,12 @@ def profiled(workload):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.txt" % workload)) +
                    glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.txt" % names.get(workload, "-"))))
     if not files:
-        return None, None, None
+        return None, None, None, None
     vals = {}
+    sha = None
     for line in open(files[-1]):
+        if line.startswith("# kernel-source-sha:"):
+            sha = line.split(":", 1)[1].strip()
         f = line.replace("avg=", "avg= ").split()
         if len(f) >= 4 and f[2] == "avg=":
             try:
@@ -91,7 +124,7 @@ def profiled(workload):
     conflict = None
     if vals.get("SQ_LDS_IDX_ACTIVE") or vals.get("SQ_ACTIVE_INST_LDS"):
         conflict = vals.get("SQ_LDS_BANK_CONFLICT", 0.0) / (vals.get("SQ_LDS_IDX_ACTIVE") or vals.get("SQ_ACTIVE_INST_LDS"))
-    return traffic, conflict, os.path.basename(files[-1])
+    return traffic, conflict, os.path.basename(files[-1]), sha
 
 
 def cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies, budget_s=12.0):
@@ -139,13 +172,110 @@ def timed_blocks(step_block, fence, steps, dist_max, min_blocks=5, max_blocks=25
             return times
 
 
-def strong_10Mx1M(world, rank, local_rank, steps, scale=1.0):
+class Ranks:
+    """The launcher side of a run: who am I, how do the ranks talk (torch.distributed is only the launcher and the
+    clock here: barriers, the max of the block times, gathering the per-rank records; the data path is RCCL inside the
+    library).  BPMF_BENCH_SHARED_GPU=1 (test set-up: every rank on device 0, the tests' RCCL double as
+    BPMF_HIP_RCCL_LIBRARY) uses gloo for that, since the real RCCL -- torch's included -- refuses two ranks per device."""
+
+    def __init__(self):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.shared_gpu = os.environ.get("BPMF_BENCH_SHARED_GPU") == "1"
+        self.local_rank = 0 if self.shared_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+        self.force_dist = os.environ.get("BPMF_BENCH_FORCE_DIST") == "1"        # test hook: the sharded path with 1 rank
+        self.dist = self.world > 1 or self.force_dist
+
+    def init(self):
+        import torch
+        torch.cuda.set_device(self.local_rank)
+        if self.dist:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+            if self.shared_gpu:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def max(self, x):
+        if self.world == 1:
+            return x
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if self.shared_gpu else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(self, obj):
+        """[obj of rank 0, obj of rank 1, ...] on every rank"""
+        if self.world == 1:
+            return [obj]
+        import torch.distributed as dist
+        out = [None] * self.world
+        dist.all_gather_object(out, obj)
+        return out
+
+    def finish(self):
+        if self.dist:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+
+
+def spot_check(sd, other, csc, cols, iter_, alpha):
+    """Recomputes columns `cols` (global ids) of side `sd` on the host from nothing but the library's host-side normal
+    stream (bpmf_randn_stream: rng_set_pos + randn of c++/mvnormal.cpp:34-43) and a dense solve -- Lambda* = LambdaF +
+    alpha sum u u^T, b = LambdaF mu + alpha sum (r - mean) u, x = L^-T (L^-1 b + z), c++/sample.cpp:285-323 -- from the
+    other side's CURRENT factors and the hyper-parameters the side was last sampled with, and returns
+    max |x_host - x_device| / max |x|.  Valid straight after sd.sample(other).  No oracle involved."""
+    import scipy.linalg
+    from bpmf_amd import engine as _engine
+    K = sd.K
+    colptr, rowidx, vals = csc
+    sd.refresh()
+    mu, LF = np.asarray(sd.hp.mu), np.asarray(sd.hp.LambdaF)
+    X = sd.engine.get_items(sd.side)
+    O = other.engine.get_items(other.side)
+    worst, scale = 0.0, 0.0
+    for c in cols:
+        l = c - sd.dom[0]
+        p0, p1 = int(colptr[l]), int(colptr[l + 1])
+        rows = rowidx[p0:p1]; v = vals[p0:p1]
+        if hasattr(rows, "cpu"):
+            rows = rows.cpu().numpy(); v = v.cpu().numpy()
+        Uo = O[np.asarray(rows, np.int64)]
+        Lam = LF + alpha * (Uo.T @ Uo)
+        b = LF @ mu + alpha * (Uo.T @ (np.asarray(v, np.float64) - sd.mean_rating))
+        L = np.linalg.cholesky(Lam)
+        y = scipy.linalg.solve_triangular(L, b, lower=True)
+        z = _engine.randn_host(((c + 1) * K * (iter_ + 1)) & 0xFFFFFFFF, K)
+        x = scipy.linalg.solve_triangular(L.T, y + z, lower=False)
+        worst = max(worst, float(np.abs(x - X[c]).max())); scale = max(scale, float(np.abs(x).max()))
+    return worst / max(scale, 1e-300)
+
+
+def pick_columns(colptr, c0, n=16, seed=1):
+    """heaviest, lightest and random local columns (global ids)"""
+    deg = np.diff(np.asarray(colptr))
+    order = np.argsort(deg, kind="stable")
+    rng = np.random.default_rng(seed)
+    pick = list(order[-4:]) + list(order[:4]) + list(rng.choice(len(deg), size=min(n - 8, len(deg)), replace=False))
+    return [int(c0 + c) for c in dict.fromkeys(pick)]
+
+
+def strong_10Mx1M(R, steps, scale=1.0, check=True):
     """The north star's strong-scaling experiment (configs[3]): 10M x 1M x 200 per user, K = 32, the same
     matrix whatever N; rank r of N holds user chunks / item ranges [8r/N, 8(r+1)/N)."""
     import torch
     import bpmf_amd
     from bpmf_amd.synth_dev import BigMatrix
     from bpmf_amd.sys import Sys
+    world, rank, local_rank = R.world, R.rank, R.local_rank
     K, G = 32, 8
     if G % world:
         return {"skipped": "needs a rank count that divides %d" % G}
@@ -174,17 +304,7 @@ def strong_10Mx1M(world, rank, local_rank, steps, scale=1.0):
 
     def fence():
         eng.sync(); torch.cuda.synchronize()
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier(); torch.cuda.synchronize()
-
-    def dist_max(x):
-        if world == 1:
-            return x
-        import torch.distributed as dist
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+        R.barrier(); torch.cuda.synchronize()
 
     def block(n):
         for i in range(n):
@@ -200,27 +320,81 @@ def strong_10Mx1M(world, rank, local_rank, steps, scale=1.0):
     t0 = time.perf_counter()
     block(steps)
     fence()
-    dt = dist_max(time.perf_counter() - t0)
+    dt = R.max(time.perf_counter() - t0)
     out = {"workload": "device-generated %d users x %d items, %d ratings per user, K=32 fp64 (BASELINE configs[3]); the same matrix at every N"
                        % (big.NU, big.NI, big.PER),
-           "n_gpus": world, "steps": steps, "ms_per_step": dt / steps * 1e3, "value": (big.NU + big.NI) * steps / dt, "unit": "samples/s",
-           "scaling": "strong", "rmse": movies.rmse, "generate_s": gen_s}
+           "n_gpus": world, "rccl_nranks": eng.comm_nranks(), "steps": steps, "ms_per_step": dt / steps * 1e3,
+           "value": (big.NU + big.NI) * steps / dt, "unit": "samples/s",
+           "scaling": "strong", "rmse": movies.rmse, "generate_s": gen_s,
+           "kernel": {"items_side": eng.kernel_name(movies.side), "users_side": eng.kernel_name(users.side)}}
     kern = {}
     for sd in (movies, users):
         a1 = eng.kernel_ms_sum(sd.side); a0 = base[sd.name]
         nl = a1[2] - a0[2]
         kern[sd.name] = (a1[0] - a0[0]) / nl if nl > 0 else None
+    mine = {"rank": rank, "items_side_columns": i1 - i0, "users_side_columns": u1 - u0}
     if kern["movs"] and kern["users"]:
         byt = algorithmic_bytes(movies.local_nnz, i1 - i0, K) + algorithmic_bytes(users.local_nnz, u1 - u0, K)
         ks = (kern["movs"] + kern["users"]) * 1e-3
-        out.update({"sampler_ms": {"items_side": kern["movs"], "users_side": kern["users"]},
-                    "hbm_achieved_gbs": byt / ks / 1e9, "hbm_frac": byt / ks / 1e9 / HBM_PEAK_GBS,
-                    "algorithmic_bytes_per_iteration_this_rank": byt,
-                    # what one Gibbs iteration spends outside this rank's two sampler launches: exchange
-                    # (all-gather of the fresh ranges + all-reduce of the sums), statistics, host draws
-                    "exchange_and_rest_ms": dt / steps * 1e3 - (kern["movs"] + kern["users"])})
+        mine.update({"sampler_ms": {"items_side": kern["movs"], "users_side": kern["users"]},
+                     "hbm_achieved_gbs": byt / ks / 1e9, "hbm_frac": byt / ks / 1e9 / HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_iteration_this_rank": byt,
+                     # what one Gibbs iteration spends outside this rank's two sampler launches: exchange
+                     # (all-gather of the fresh ranges + all-reduce of the sums), statistics, host draws
+                     "exchange_and_rest_ms": dt / steps * 1e3 - (kern["movs"] + kern["users"])})
+    if check:
+        # parity probe of the very chain that was timed: >= 16 columns per side of this rank against a host solve.
+        # users(i) were drawn from movies(i); one more movies.sample(users) gives movies(i+1) drawn from users(i).
+        t_chk = time.perf_counter()
+        errs, problems = {}, []
+        for name, sd, other, csc, c0 in (("users_side", users, movies, (ucp, uri, uva), u0), ("items_side", movies, users, (mcp, mri, mva), i0)):
+            if name == "items_side":
+                movies.sample(users)                                   # (collective: every rank, whatever its own check did)
+            try:
+                errs[name] = spot_check(sd, other, csc, pick_columns(csc[0], c0), sd.iter, Sys.alpha)
+            except Exception as e:
+                problems.append("%s: %r" % (name, e))
+        if problems:
+            mine["spot_check"] = {"error": "; ".join(problems)[:400]}
+        else:
+            worst = max(errs.values())
+            mine["spot_check"] = {"columns_per_side": 16, "max_err_users_side": errs["users_side"], "max_err_items_side": errs["items_side"],
+                                  "max_err": worst, "tolerance": 1e-9, "ok": bool(worst < 1e-9),
+                                  "against": "host solve + bpmf_randn_stream (no oracle)", "seconds": time.perf_counter() - t_chk}
+    ranks = R.gather(mine)
+    out.update({k: v for k, v in ranks[0].items() if k != "rank"})          # rank 0's figures at top level (as before)
+    if world > 1:
+        out["per_rank"] = ranks
+        errs = [r.get("spot_check", {}).get("max_err") for r in ranks]
+        if all(e is not None for e in errs):
+            out["spot_check"] = dict(ranks[0]["spot_check"], max_err=max(errs), ok=bool(max(errs) < 1e-9))
     eng.close()
     return out
+
+
+def self_launch(n):
+    """`bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) and relay their exit code."""
+    import socket
+    import torch
+    shared = os.environ.get("BPMF_BENCH_SHARED_GPU") == "1"
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and not shared:
+        raise SystemExit("bench.py: --gpus %d asked for, %d HIP device(s) visible: refusing to report fewer ranks as %d GPUs "
+                         "(one rank per GPU; a launcher may set WORLD_SIZE / RANK / LOCAL_RANK instead)" % (n, have, n))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), BPMF_BENCH_SELF_LAUNCHED="1")
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r))))
+    rc = 0
+    for pr in procs:
+        rc = pr.wait() or rc
+    if rc:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    raise SystemExit(rc)
 
 
 def main():
@@ -236,11 +410,27 @@ def main():
     ap.add_argument("--no-strong", action="store_true", help="skip the strong_10Mx1M sub-record")
     ap.add_argument("--strong-steps", type=int, default=8, help="timed steps of the strong_10Mx1M record (>= 8: the library times every 8th launch of a side)")
     ap.add_argument("--strong-scale", type=float, default=float(os.environ.get("BPMF_BENCH_STRONG_SCALE", "1.0")))
+    ap.add_argument("--ablate", type=int, default=None, help="profiling only: run with BPMF_HIP_ABLATE=<bits> (phases of the sampler skipped, samples WRONG); the line is marked invalid")
     args = ap.parse_args()
     wl = args.workload or {None: "ml1m", 32: "ml1m", 64: "ml1m_k64", 128: "ml1m_k128"}.get(args.K)
     if wl is None:
         raise SystemExit("bench.py: --K must be 32, 64 or 128 (or use --workload)")
-    K, dtype, kernel_name, lds_wg, wg_per_cu = WORKLOADS[wl]
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    # BPMF_HIP_ABLATE makes the sampler skip the Gram or the factorisation (tools/gpu_ablate.sh): a number measured
+    # that way is not a throughput.  Only behind --ablate, and then the line says so.
+    env_ablate = os.environ.get("BPMF_HIP_ABLATE", "0") or "0"
+    if args.ablate is not None:
+        os.environ["BPMF_HIP_ABLATE"] = str(args.ablate)
+    elif env_ablate not in ("0", ""):
+        raise SystemExit("bench.py: BPMF_HIP_ABLATE=%s is set (the sampler would skip work and return wrong samples); "
+                         "unset it, or ask for it with --ablate N" % env_ablate)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)                                         # (does not return)
+    R = Ranks()
+    if R.world != args.gpus and not R.force_dist:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): the two must agree" % (args.gpus, R.world))
+    K, dtype, lds_wg, wg_per_cu = WORKLOADS[wl]
     t_process = time.perf_counter()
 
     import torch
@@ -248,19 +438,14 @@ def main():
     from bpmf_amd import synth
     from bpmf_amd.sys import Sys
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world, rank, local_rank = R.world, R.rank, R.local_rank
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (bpmf_amd has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d wants device %d, %d visible" % (rank, local_rank, torch.cuda.device_count()))
+    R.init()
     comm = None
-    force_dist = os.environ.get("BPMF_BENCH_FORCE_DIST") == "1"        # test hook: run the sharded path with 1 rank
-    if world > 1 or force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
-        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    force_dist = R.force_dist
 
     mult = world if (world > 1 or force_dist) else 1
     if wl == "chembl":
@@ -291,23 +476,17 @@ def main():
         from bpmf_amd.dist import build_sharded
         movies, users = build_sharded(eng, comm, M, Mt, T, nusers, nmovies, mean_rating=mean)
         dom_m, dom_u = movies.dom, users.dom
+    rccl_nranks = eng.comm_nranks() if getattr(comm, "native", False) else (world if comm is not None else 1)
+    if world > 1 and getattr(comm, "native", False) and rccl_nranks != world:
+        raise SystemExit("bench.py: the communicator has %d rank(s), the launcher started %d" % (rccl_nranks, world))
 
     def fence():
         eng.sync()
         torch.cuda.synchronize()
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-            torch.cuda.synchronize()
+        R.barrier()
+        torch.cuda.synchronize()
 
-    def dist_max(x):
-        if world == 1:
-            return x
-        import torch.distributed as dist
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
+    dist_max = R.max
     pipelined = comm is None or getattr(comm, "native", False)
 
     def step_block(n):
@@ -347,8 +526,11 @@ def main():
 
     # roofline of the dominant kernel (the sampler), per launch, this rank's shard
     nnz_m = movies.local_nnz; nnz_u = users.local_nnz
+    info_m, info_u = eng.schedule_info(movies.side), eng.schedule_info(users.side)
     bytes_launch = 0.5 * (algorithmic_bytes(nnz_m, dom_m[1] - dom_m[0], K, esz) + algorithmic_bytes(nnz_u, dom_u[1] - dom_u[0], K, esz))
-    flops_launch = 0.5 * (algorithmic_flops(nnz_m, dom_m[1] - dom_m[0], K) + algorithmic_flops(nnz_u, dom_u[1] - dom_u[0], K))
+    flops_alg = 0.5 * (algorithmic_flops(nnz_m, dom_m[1] - dom_m[0], K) + algorithmic_flops(nnz_u, dom_u[1] - dom_u[0], K))
+    # what the launches execute: differs from the algorithmic count where columns take the product form (ChEMBL shape)
+    flops_launch = 0.5 * (executed_flops(info_m, nnz_m, dom_m[1] - dom_m[0], K) + executed_flops(info_u, nnz_u, dom_u[1] - dom_u[0], K))
     # HIP-event times of the sampler / statistics kernels on their streams, summed by the library
     # over the timed steps (events ride on every 8th launch of a side: BPMF_HIP_TIMING_EVERY)
     kern_ms, red_ms, nl, per_side = 0.0, 0.0, 0, {}
@@ -364,7 +546,14 @@ def main():
     hbm_gbs = bytes_launch / launch_s / 1e9 if launch_s > 0 else 0.0
     tflops = flops_launch / launch_s / 1e12 if launch_s > 0 else 0.0
     flop_peak = FP32_PEAK_TFLOPS if dtype == "f32" else FP64_PEAK_TFLOPS
-    traffic, conflict, pmc_file = profiled(wl) if world == 1 else (None, None, None)
+    # HBM-side bytes and LDS bank conflicts need rocprofv3 --pmc passes (not available inside a plain run): they come
+    # from the committed profile of this command IF that profile was taken with these very kernel sources
+    p_traffic, p_conflict, pmc_file, pmc_sha = profiled(wl) if world == 1 else (None, None, None, None)
+    src_sha = kernel_source_sha()
+    pmc_current = pmc_file is not None and pmc_sha == src_sha
+    traffic = p_traffic if pmc_current else None
+    kernel_names = {"movs": eng.kernel_name(movies.side), "users": eng.kernel_name(users.side)}
+    kernel_name = kernel_names["movs"] if kernel_names["movs"] == kernel_names["users"] else "%s | %s" % (kernel_names["movs"], kernel_names["users"])
 
     movies.predict(users, True)
     # Which resource binds?  K = 32 on this matrix: the factors (1.5 + 0.95 MB) live in L2 / MALL -- HBM-side
@@ -374,15 +563,28 @@ def main():
                                                   "the factor matrices sit in L2/MALL at this size, HBM is secondary")
                 if dtype == "f64" else "fp32 MFMA Gram + blocked factorisation",
                 "achieved": tflops, "peak": flop_peak, "unit": "TFLOP/s", "frac": tflops / flop_peak,
-                "traffic": traffic, "kernel": kernel_name, "launch_ms": launch_s * 1e3,
-                "launch_ms_per_side": per_side, "algorithmic_flops_per_launch": flops_launch,
-                "algorithmic_bytes_per_launch": bytes_launch,
+                "traffic": traffic, "kernel": kernel_name, "kernel_per_side": kernel_names, "launch_ms": launch_s * 1e3,
+                "launch_ms_per_side": per_side, "executed_flops_per_launch": flops_launch,
+                "algorithmic_flops_per_launch": flops_alg, "algorithmic_bytes_per_launch": bytes_launch,
                 "hbm_achieved_gbs": hbm_gbs, "hbm_frac": hbm_gbs / HBM_PEAK_GBS,
                 "hbm_traffic_over_algorithmic": (traffic / bytes_launch) if traffic else None,
-                "colstats_ms": red_ms / max(nl, 1), "pmc_source": pmc_file}
+                "colstats_ms": red_ms / max(nl, 1),
+                # the committed PMC passes these two figures come from, the kernel sources they were taken with, and
+                # whether those are the sources of this run (if not: `traffic` stays null, the figures are history)
+                "profiled": {"source": pmc_file, "kernel_source_sha": pmc_sha, "current": bool(pmc_current),
+                             "traffic": p_traffic, "bank_conflict_rate": p_conflict},
+                "kernel_source_sha": src_sha}
+    if abs(flops_launch - flops_alg) > 1e-6 * flops_alg:
+        # the product form never factorises its columns: K^3/3 per column is what the REFERENCE's algorithm would spend
+        eff = flops_alg / launch_s / 1e12 if launch_s > 0 else 0.0
+        roofline["effective_tflops"] = eff
+        roofline["effective_frac"] = eff / flop_peak
+        roofline["effective_note"] = ("algorithmic flops of the reference's per-column factorisation / launch time: an algorithmic "
+                                      "speed-up figure, not a fraction of the MFMA peak; `achieved` / `frac` count executed flops")
     if lds_wg:
         roofline["lds"] = {"bytes_per_workgroup": lds_wg, "workgroups_per_cu": wg_per_cu, "occupancy": lds_wg * wg_per_cu / LDS_PER_CU,
-                           "bank_conflict_rate": conflict}
+                           "bank_conflict_rate": p_conflict if pmc_current else None}
+    bpmf_env = {k: v for k, v in sorted(os.environ.items()) if k.startswith("BPMF_") and k != "BPMF_BENCH_SELF_LAUNCHED"}
     out = {
         "metric": "user+item column samples/sec per Gibbs iter; test RMSE vs reference",
         "value": (nusers + nmovies) * args.steps / dt,
@@ -394,10 +596,13 @@ def main():
         "vs_baseline": None,
         "dtype": dtype,
         "data": "synthetic",
-        "config": {"workload": (shape_note + ", K=%d, alpha=2, full Gibbs iteration incl. host Normal-Wishart draws and RMSE")
+        "config": {"workload": (shape_note + ", K=%d, alpha=2, full Gibbs iteration incl. host Normal-Wishart draws and RMSE "
+                                "(movies.predict(users); users.predict(movies) of c++/bpmf.cpp:190 -- same predictions into a second copy "
+                                "of Pavg that nothing reads -- is not run)")
                                % (nusers, nmovies, nnz + int(T[0][-1]), K),
                    "name": wl, "nnz_train": nnz, "nnz_test": int(T[0][-1]), "K": K,
                    "parallelism": "columns of U and V sharded over %d GPU(s)" % world},
+        "rccl_nranks": rccl_nranks, "launcher": "self" if os.environ.get("BPMF_BENCH_SELF_LAUNCHED") else ("external" if "WORLD_SIZE" in os.environ else "none"),
         "repeats": len(times), "prewarm_ms": prewarm_ms, "prewarm_extra_steps": extra,
         "ms_per_step_median": dt / args.steps * 1e3, "ms_per_step_min": min(times) / args.steps * 1e3,
         "ms_per_step_max": max(times) / args.steps * 1e3, "ms_per_step_first_block": times[0] / args.steps * 1e3,
@@ -407,7 +612,19 @@ def main():
         # the sampling-only rate (columns of both sides / the two sampler launches of one iteration)
         "ratings_per_s": nnz * args.steps / dt,
         "sampling_only_samples_per_s": (nusers + nmovies) / (2.0 * launch_s) if (launch_s > 0 and world == 1) else None,
+        # every BPMF_* variable of the environment this line was measured under (switches of the library included)
+        "env": bpmf_env,
+        # true iff the oracle has been diffed against dumps of the real reference build (oracle/build_ref.sh +
+        # tests/test_oracle_vs_ref.py, which leaves the marker); false: "parity unpinned" 
+        "oracle_pinned": os.path.exists(os.path.join(ROOT, "oracle", "_ref", "PINNED")),
     }
+    if args.ablate is not None:
+        out["ablate"] = args.ablate
+        out["invalid"] = "BPMF_HIP_ABLATE=%d: phases of the sampler were skipped, the samples are wrong; a profiling run, not a throughput" % args.ablate
+    if world > 1:
+        out["per_rank"] = R.gather({"rank": rank, "device": local_rank, "columns": {"movs": dom_m[1] - dom_m[0], "users": dom_u[1] - dom_u[0]},
+                                    "launch_ms_per_side": per_side, "hbm_frac": hbm_gbs / HBM_PEAK_GBS,
+                                    "exchange_and_rest_ms": dt / args.steps * 1e3 - sum(per_side.values())})
     try:
         eng.close()                      # sides, collector threads, streams, (RCCL communicator)
     except Exception:
@@ -416,7 +633,7 @@ def main():
 
     if not args.no_strong and wl == "ml1m":
         try:
-            out["strong_10Mx1M"] = strong_10Mx1M(world, rank, local_rank, args.strong_steps, args.strong_scale)
+            out["strong_10Mx1M"] = strong_10Mx1M(R, args.strong_steps, args.strong_scale)
         except Exception as e:               # the headline must still be reported
             out["strong_10Mx1M"] = {"error": repr(e)[:400]}
     if rank == 0:
@@ -428,9 +645,7 @@ def main():
                                        "sample": "failed: %r" % (e,)}
         out["wall_s"] = time.perf_counter() - t_process
         print(json.dumps(out), flush=True)
-    if world > 1 or force_dist:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    R.finish()
 
 
 if __name__ == "__main__":

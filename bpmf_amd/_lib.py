@@ -24,6 +24,7 @@ _SIGNATURES = {
     "bpmf_hip_ctx_stream": (C.c_void_p, [C.c_void_p]),
     "bpmf_hip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "bpmf_hip_ctx_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "bpmf_hip_ctx_comm_nranks": (C.c_int, [C.c_void_p]),
     "bpmf_hip_side_set_ranges": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bpmf_hip_side_set_overlap": (C.c_int, [C.c_void_p, C.c_int]),
     "bpmf_hip_sys_set_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
@@ -61,6 +62,8 @@ _SIGNATURES = {
     "bpmf_cov_from_sums": (None, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bpmf_randn_stream": (None, [C.c_uint32, C.c_int, C.c_void_p]),
     "bpmf_hip_randn_stream": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
+    "bpmf_hip_side_kernel_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "bpmf_hip_side_schedule_info": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "bpmf_hip_side_kernel_ms_sum": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "bpmf_hip_side_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     # include/bpmf_io.h

@@ -21,6 +21,8 @@
 #include <fstream>
 #include <iostream>
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <memory>
 #include <sstream>
 #include <string>
@@ -43,7 +45,7 @@ double tick()
 
 void usage()
 {
-    std::cout << "Usage: bpmf -n <MTX> -p <MTX> [-o DIR/] [-i N] [-b N] [-f N] [-a F] [-d K] [-krv] [-t N]\n"
+    std::cout << "Usage: bpmf -n <MTX> -p <MTX> [-o DIR/] [-i N] [-b N] [-f N] [-a F] [-d K] [-krv] [-t N] [-m MTX,MTX] [-l MTX,MTX] [-g N]\n"
               << "\n"
               << "Parameters:\n"
               << "  -n MTX: training matrix (rows = users, columns = items)\n"
@@ -53,7 +55,10 @@ void usage()
               << "  [-b N]: number of burn-in iterations (5)\n"
               << "  [-f N]: update frequency (accepted, unused)\n"
               << "  [-a F]: noise precision alpha (2.0)\n"
-              << "  [-d K]: number of latent dimensions: 8, 16, 32 or 64 (32, or $BPMF_NUMLATENT)\n"
+              << "  [-d K]: number of latent dimensions: 8, 16, 32, 64 in fp64, 128 in fp32 (32, or $BPMF_NUMLATENT)\n"
+              << "\n"
+              << "  [-l MTX,MTX]: propagated posterior mu and Lambda matrices for U\n"
+              << "  [-m MTX,MTX]: propagated posterior mu and Lambda matrices for V\n"
               << "\n"
               << "  [-g N]: shard users and items over N GPUs of this node (RCCL over xGMI; default $BPMF_NGPU or 1)\n"
               << "  [-k]: do not balance the item-to-GPU assignment on work (equal column counts per GPU instead)\n"
@@ -68,8 +73,19 @@ void usage()
               << std::endl;
 }
 
+// With -g N > 1 the ranks are threads of this process: a rank that fails (Cholesky failed, device wait timed out, a
+// collective that gave up) must not run static destructors and the HIP / RCCL teardown under the other ranks' live
+// threads -- they may be blocked inside a collective.  Sys::Abort of the reference's MPI back-ends is MPI_Abort
+// (c++/mpi_common.h:28-31): the message, then the process ends at once.
+std::atomic<bool> g_rank_threads{false};
+std::mutex g_die_mutex;
+
 [[noreturn]] void die(const std::string &msg)
 {
+    if (g_rank_threads.load()) {
+        { std::lock_guard<std::mutex> lk(g_die_mutex); std::cerr << "bpmf: " << msg << std::endl; fflush(nullptr); }
+        std::_Exit(1);
+    }
     std::cerr << "bpmf: " << msg << std::endl;
     exit(1);
 }
@@ -175,6 +191,7 @@ struct Job {
     std::vector<int64_t> bm, bu;                                     // column ranges of the ranks
     std::vector<int64_t> perm_m, perm_u;                             // greedy assignment: new column id -> original (empty: none)
     char rccl_id[128];
+    std::vector<int> devices;                                        // BPMF_HIP_DEVICES: device of rank r (default: device r)
     // results
     std::vector<double> pavg, pm2;                                   // test-set order of T; every rank fills its slice
     std::vector<double> u_mu, u_lambda, m_mu, m_lambda;              // -o: K x N means, K*K x N precisions; every rank fills its columns
@@ -191,7 +208,7 @@ void rank_main(Job &J, int rank, std::ostream &os)
     const int64_t nmovies = J.M.ncols, nusers = J.M.nrows;
     const bool aggregate = !J.odirname.empty();
     bpmf_hip_ctx *ctx = nullptr;
-    check(bpmf_hip_ctx_create_ex(rank, K, J.dtype, nullptr, &ctx));
+    check(bpmf_hip_ctx_create_ex(J.devices.empty() ? rank : J.devices[(size_t)rank % J.devices.size()], K, J.dtype, nullptr, &ctx));
     if (J.sharded) check(bpmf_hip_ctx_comm_init(ctx, J.nranks, rank, J.rccl_id));
     const int64_t m0 = J.bm[(size_t)rank], m1 = J.bm[(size_t)rank + 1], u0 = J.bu[(size_t)rank], u1 = J.bu[(size_t)rank + 1];
     auto slice_ptr = [](const Csc &A, int64_t c0, int64_t c1) {       // colptr of the columns [c0, c1), rebased to 0
@@ -472,6 +489,13 @@ int main(int argc, char *argv[])
         J.bm = column_ranges(J.M, J.nranks, balance);
         J.bu = column_ranges(J.Mt, J.nranks, balance);
     }
+    // BPMF_HIP_DEVICES=d0,d1,...: the HIP device of every rank (default: rank r on device r).  Two ranks on one device
+    // need a communication library that serves them (BPMF_HIP_RCCL_LIBRARY: RCCL itself refuses) -- the tests' set-up.
+    if (const char *e = getenv("BPMF_HIP_DEVICES")) {
+        std::stringstream ss(e);
+        std::string tok;
+        while (std::getline(ss, tok, ',')) if (!tok.empty()) J.devices.push_back(atoi(tok.c_str()));
+    }
     if (J.sharded) check(bpmf_hip_comm_unique_id(J.rccl_id));      // (also loads RCCL before the rank threads start)
     if (!J.odirname.empty()) {
         J.pavg.assign(J.T.vals.size(), 0.0); J.pm2.assign(J.T.vals.size(), 0.0);
@@ -493,8 +517,10 @@ int main(int argc, char *argv[])
         rank_main(J, 0, rank_os(0));
     } else {
         std::vector<std::thread> th;
+        g_rank_threads.store(true);
         for (int r = 0; r < J.nranks; ++r) th.emplace_back([&J, r, &rank_os] { rank_main(J, r, rank_os(r)); });
         for (auto &t : th) t.join();
+        g_rank_threads.store(false);
     }
     std::ostream &os = rank_os(0);
 

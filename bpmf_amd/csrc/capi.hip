@@ -19,6 +19,13 @@ Rccl *rccl()
     static bool tried = false;
     if (!tried) {
         tried = true;
+        // BPMF_HIP_RCCL_LIBRARY: another implementation of the nccl* entry points below -- the tests name their
+        // double for ranks that share one GPU (tests/rccl_double), which the real library refuses to serve
+        const char *over = getenv("BPMF_HIP_RCCL_LIBRARY");
+        if (over && *over) {
+            r.handle = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+            if (!r.handle) fprintf(stderr, "[bpmf_hip] BPMF_HIP_RCCL_LIBRARY=%s: %s\n", over, dlerror());
+        } else
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (r.handle) break;
@@ -27,7 +34,7 @@ Rccl *rccl()
 #define BPMF_SYM(f) r.f = reinterpret_cast<decltype(r.f)>(dlsym(r.handle, "nccl" #f))
             BPMF_SYM(GetUniqueId); BPMF_SYM(CommInitRank); BPMF_SYM(CommDestroy); BPMF_SYM(AllReduce);
             BPMF_SYM(Broadcast); BPMF_SYM(GroupStart); BPMF_SYM(GroupEnd); BPMF_SYM(GetErrorString); BPMF_SYM(CommSplit);
-            BPMF_SYM(Send); BPMF_SYM(Recv); BPMF_SYM(AllGather); BPMF_SYM(Reduce);
+            BPMF_SYM(Send); BPMF_SYM(Recv); BPMF_SYM(AllGather); BPMF_SYM(Reduce); BPMF_SYM(CommCount);
 #undef BPMF_SYM
             if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.Broadcast || !r.GroupStart || !r.GroupEnd)
                 r.handle = nullptr;
@@ -215,6 +222,8 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
             if (n == 2) s->pf_class[1] = (int)lc.size();
             if (n == 6) s->pf_class[2] = (int)lc.size();
         }
+        s->pf_ratings = s->pf_ratings2 = 0;
+        for (int32_t l : ll) { s->pf_ratings += l; s->pf_ratings2 += (int64_t)l * l; }
         if (pfmax < 2) s->pf_class[1] = (int)lc.size();
         if (pfmax < 6) s->pf_class[2] = (int)lc.size();
         s->pf_class[3] = (int)lc.size();
@@ -678,7 +687,8 @@ int reduce_half_iteration(bpmf_hip_side *self, const bpmf_hip_side *other, int i
     if (dist) {                                                     // (one rank: the reduce is the identity, the path is the same)
         Rccl *R = rccl();
         if (!R->Reduce) return fail(BPMF_HIP_ENODEV, "BPMF_REDUCE formulation: this RCCL has no ncclReduce");
-        NCCL_TRY(R->GroupStart());
+        NcclGroup group(R);
+        NCCL_TRY(group.start());
         for (int r = 0; r < c->nranks; ++r) {
             const int64_t lo = self->bounds[(size_t)r], hi = self->bounds[(size_t)r + 1];
             if (hi > lo) {
@@ -686,7 +696,7 @@ int reduce_half_iteration(bpmf_hip_side *self, const bpmf_hip_side *other, int i
                 NCCL_TRY(R->Reduce(p, p, (size_t)(hi - lo) * part, ncclDouble, ncclSum, r, c->comm, st));
             }
         }
-        NCCL_TRY(R->GroupEnd());
+        NCCL_TRY(group.end());
     }
     // the factor copy this half-iteration writes (second copy: see launch_sampler)
     double *out_items = self->d_items;
@@ -752,12 +762,14 @@ int sample_and_exchange(bpmf_hip_side *self, const bpmf_hip_side *other, int ite
         if (p == 0) rc = launch_sampler<K>(self, other, iter, alpha, d_in, st, nullptr, nullptr);       // (chooses / swaps the factor copy)
         else rc = sampler_into<K>(self, self->d_items, other, iter, alpha, d_in, st, nullptr, nullptr);
         if (rc) break;
-        if (p == self->nsub - 1 && ev_stop) HIP_TRY(hipEventRecord(ev_stop, st));
-        HIP_TRY(hipEventRecord(self->sub_ev[p], st));
-        HIP_TRY(hipStreamWaitEvent(self->sx, self->sub_ev[p], 0));
+        hipError_t he = hipSuccess;
+        if (p == self->nsub - 1 && ev_stop) he = hipEventRecord(ev_stop, st);
+        if (he == hipSuccess) he = hipEventRecord(self->sub_ev[p], st);
+        if (he == hipSuccess) he = hipStreamWaitEvent(self->sx, self->sub_ev[p], 0);
+        if (he != hipSuccess) { rc = fail(BPMF_HIP_ENODEV, std::string("sample_and_exchange: ") + hipGetErrorString(he)); break; }
         rc = bpmf_launch::exchange<K>(self, self->sx, p);
     }
-    self->item_off = 0; self->item_n = -1;
+    self->item_off = 0; self->item_n = -1;                           // (whatever happened: later launches see the whole item list again)
     if (rc) return rc;
     HIP_TRY(hipEventRecord(self->sx_done, self->sx));
     HIP_TRY(hipStreamWaitEvent(st, self->sx_done, 0));
@@ -922,10 +934,15 @@ extern "C" int bpmf_hip_side_aggr_add(bpmf_hip_side *s)
     HIP_TRY(hipSetDevice(c->device));
     { const int rc = settle_async(s); if (rc) return rc; }
     const size_t K = (size_t)c->K, nloc = (size_t)(s->to - s->from);
-    if (!s->d_aggr_mu) {
+    if (!s->d_aggr_mu || !s->d_aggr_lambda) {
+        if (s->d_aggr_mu) { (void)hipFree(s->d_aggr_mu); s->d_aggr_mu = nullptr; }
         if (hipMalloc((void **)&s->d_aggr_mu, std::max<size_t>(K * nloc, 1) * sizeof(double)) != hipSuccess ||
-            hipMalloc((void **)&s->d_aggr_lambda, std::max<size_t>(K * K * nloc, 1) * sizeof(double)) != hipSuccess)
+            hipMalloc((void **)&s->d_aggr_lambda, std::max<size_t>(K * K * nloc, 1) * sizeof(double)) != hipSuccess) {
+            (void)hipGetLastError();
+            if (s->d_aggr_mu) { (void)hipFree(s->d_aggr_mu); s->d_aggr_mu = nullptr; }
+            s->d_aggr_lambda = nullptr;
             return fail(BPMF_HIP_ENOMEM, "aggr_add: K*K doubles per column do not fit in device memory");
+        }
         HIP_TRY(hipMemsetAsync(s->d_aggr_mu, 0, K * nloc * sizeof(double), c->stream));
         HIP_TRY(hipMemsetAsync(s->d_aggr_lambda, 0, K * K * nloc * sizeof(double), c->stream));
     }
@@ -939,7 +956,7 @@ extern "C" int bpmf_hip_side_aggr_add(bpmf_hip_side *s)
 extern "C" int bpmf_hip_side_aggr_finalize(bpmf_hip_side *s, int nsamples, double *mu_host, double *lambda_host)
 {
     if (!s || !mu_host || !lambda_host) return fail(BPMF_HIP_EINVAL, "aggr_finalize: NULL");
-    if (!s->d_aggr_mu) return fail(BPMF_HIP_EINVAL, "aggr_finalize: nothing was aggregated");
+    if (!s->d_aggr_mu || !s->d_aggr_lambda) return fail(BPMF_HIP_EINVAL, "aggr_finalize: nothing was aggregated");
     bpmf_hip_ctx *c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
     const size_t K = (size_t)c->K, nloc = (size_t)(s->to - s->from);
@@ -1421,6 +1438,61 @@ extern "C" int bpmf_hip_sys_state(const bpmf_hip_side *cs, int *iter, double *no
     return BPMF_HIP_OK;
 }
 
+// Which kernel(s) the sampler launch of this side is, as the dispatch in launch_impl.h (sampler_into) decides it:
+// what a profile of the run shows, for the labels of bench.py's roofline object.
+extern "C" int bpmf_hip_side_kernel_name(const bpmf_hip_side *s, char *buf, int n)
+{
+    if (!s || !buf || n <= 0) return fail(BPMF_HIP_EINVAL, "side_kernel_name: bad argument");
+    const bpmf_hip_ctx *c = s->ctx;
+    const int K = c->K;
+    const std::string k = std::to_string(K);
+    const bool dist = c->comm != nullptr && !s->bounds.empty();
+    const bool fusable = !dist && !s->reduce_on && env_int("BPMF_HIP_FUSED", 1) != 0 && s->nwork > 0;
+    std::string name;
+    if (s->reduce_on) name = "k_sample_prec<" + k + "> + k_precompute<" + k + ">";
+    else if (c->dtype == BPMF_HIP_F32) {
+        const std::string w = env_int("BPMF_HIP_WG_WAVES", 2) == 4 ? "4" : "2";
+        name = s->mode == 4 ? "k_sample_slab<128>" : s->mode == 2 ? "k_sample_wg<128,float," + w + ">" : "k_sample_wg2<128," + w + ">";
+    } else if (K == 64) {
+        auto heavy = [&]() -> std::string {
+            if (s->mode == 2) return "k_sample_wg<64,double,1>";
+            if (s->mode == 4) return (fusable && s->lr_n == 0 && s->nsub <= 1) ? "k_sample1s<64>" : "k_sample_slab<64>";
+            return s->mode == 1 ? "k_sample1<64>" : "k_sample<64>";
+        };
+        if (s->lr_n > 0 && s->mode != 2 && !s->d_prop && !c->diag_only) {
+            static const char *nb[3] = {"2", "6", "12"};
+            for (int pc = 0; pc < 3; ++pc)
+                if (s->pf_class[pc + 1] > s->pf_class[pc]) name += std::string(name.empty() ? "" : " + ") + "k_sample_pf<64," + nb[pc] + ">";
+            for (int cls = 1; cls <= 4; ++cls)
+                if (s->lr_class[cls] > s->lr_class[cls - 1]) name += std::string(name.empty() ? "" : " + ") + "k_sample_lr<64," + std::to_string(cls) + ">";
+            if (s->hv_nwork > 0) name += " + " + (s->mode == 4 ? std::string("k_sample_slab<64>") : heavy());
+        } else name = heavy();
+    } else {
+        if (s->mode == 3) name = "k_sample4<" + k + ">";
+        else if (s->mode == 1) name = ((K == 32 || K == 16) && env_int("BPMF_HIP_SLAB32", 0) ? "k_sample1s<" : "k_sample1<") + k + ">";
+        else name = "k_sample<" + k + ">";
+    }
+    snprintf(buf, (size_t)n, "%s", name.c_str());
+    return BPMF_HIP_OK;
+}
+
+// The static schedule of a side in numbers (build_schedule), for reports: out[0..15] =
+//   0 sampler form (mode)   1 work items   2 chunks of heavy columns (partial slots)   3 heavy columns cut into chunks
+//   4 light columns in the low-rank / product forms   5 work items of the others   6..8 product-form columns with <= 2 | 3..6 | 7..12 ratings
+//   9 columns in k_sample_lr   10 parts (bpmf_hip_side_set_overlap)   11 local columns   12 local ratings
+//   13, 14 sum over the product-form columns of their number of ratings n, of n^2   15 reserved (0)
+extern "C" int bpmf_hip_side_schedule_info(const bpmf_hip_side *s, int64_t *out, int n)
+{
+    if (!s || !out || n < 16) return fail(BPMF_HIP_EINVAL, "side_schedule_info: bad argument (16 words)");
+    for (int i = 0; i < n; ++i) out[i] = 0;
+    out[0] = s->mode; out[1] = s->nwork; out[2] = s->nslots; out[3] = s->nmulti;
+    out[4] = s->lr_n; out[5] = s->lr_n > 0 ? s->hv_nwork : s->nwork;
+    for (int pc = 0; pc < 3; ++pc) out[6 + pc] = s->pf_class[pc + 1] - s->pf_class[pc];
+    out[9] = s->lr_n > 0 ? s->lr_class[4] - s->lr_class[0] : 0;
+    out[10] = s->nsub; out[11] = s->to - s->from; out[12] = s->nnz; out[13] = s->pf_ratings; out[14] = s->pf_ratings2;
+    return BPMF_HIP_OK;
+}
+
 // sum of the sampler / statistics kernel times over all collected launches of the stateful path
 extern "C" int bpmf_hip_side_kernel_ms_sum(bpmf_hip_side *s, double *sample_ms, double *reduce_ms, int64_t *launches)
 {
@@ -1466,6 +1538,18 @@ extern "C" int bpmf_hip_ctx_comm_init(bpmf_hip_ctx *c, int nranks, int rank, con
     return BPMF_HIP_OK;
 }
 
+// number of ranks of the context's communicator as the communication library itself counts them (ncclCommCount);
+// 1 without a communicator
+extern "C" int bpmf_hip_ctx_comm_nranks(const bpmf_hip_ctx *c)
+{
+    if (!c) return 0;
+    if (!c->comm) return 1;
+    Rccl *R = rccl();
+    int n = 0;
+    if (R && R->CommCount && R->CommCount(c->comm, &n) == ncclSuccess) return n;
+    return c->nranks;
+}
+
 extern "C" int bpmf_hip_side_set_ranges(bpmf_hip_side *s, const int64_t *bounds)
 {
     if (!s || !bounds) return fail(BPMF_HIP_EINVAL, "side_set_ranges: NULL");
@@ -1478,10 +1562,18 @@ extern "C" int bpmf_hip_side_set_ranges(bpmf_hip_side *s, const int64_t *bounds)
     s->bounds.assign(bounds, bounds + c->nranks + 1);
     // parts by default when the exchange is worth hiding: BPMF_HIP_OVERLAP = number of parts (0 / 1: off; unset: 4 parts
     // once a half-iteration moves >= 64 MB of fresh columns into this rank)
+    // The decision must be the same on every rank (set_overlap is collective, and the per-part messages of two
+    // ranks must pair up): it is taken from `bounds`, which every rank holds -- what the rank with the NARROWEST
+    // range receives -- not from this rank's own width.  K = 64 in fp64 keeps the uncut form unless asked: the
+    // low-rank / product-form split of a side (build_schedule) exists for the uncut item list only.
     const int want = env_int("BPMF_HIP_OVERLAP", -1);
     const size_t esz = c->dtype == BPMF_HIP_F32 ? 4 : 8;
-    const size_t incoming = (size_t)(s->ncols - (s->to - s->from)) * (size_t)c->K * esz;
-    const int nsub = want >= 0 ? want : (c->nranks > 1 && incoming >= ((size_t)64 << 20) ? 4 : 1);
+    int64_t narrowest = s->ncols;
+    for (int r = 0; r < c->nranks; ++r) narrowest = std::min(narrowest, bounds[r + 1] - bounds[r]);
+    const size_t incoming = (size_t)(s->ncols - narrowest) * (size_t)c->K * esz;
+    const size_t threshold = (size_t)std::max(1, env_int("BPMF_HIP_OVERLAP_MIN_KB", 64 << 10)) << 10;    // (the tests lower it)
+    const bool auto_ok = !(c->K == 64 && c->dtype == BPMF_HIP_F64);
+    const int nsub = want >= 0 ? want : (c->nranks > 1 && auto_ok && incoming >= threshold ? 4 : 1);
     if (nsub > 1) return bpmf_hip_side_set_overlap(s, nsub);
     return BPMF_HIP_OK;
 }

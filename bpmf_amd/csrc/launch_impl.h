@@ -215,14 +215,15 @@ int exchange(bpmf_hip_side *self, hipStream_t st, int sub)
         if (ns > 0)
             hipLaunchKernelGGL(bpmf::k_pack_cols<K>, dim3((unsigned)((ns * P + 255) / 256)), dim3(256), 0, st,
                                (const double *)self->d_items, (const int32_t *)self->d_conn_send, ns, self->d_conn_sbuf);
-        NCCL_TRY(R->GroupStart());
+        NcclGroup group(R);
+        NCCL_TRY(group.start());
         for (int r = 0; r < c->nranks; ++r) {
             const int64_t s0 = self->conn_send_ptr[(size_t)r], s1 = self->conn_send_ptr[(size_t)r + 1];
             const int64_t r0 = self->conn_recv_ptr[(size_t)r], r1 = self->conn_recv_ptr[(size_t)r + 1];
             if (s1 > s0) NCCL_TRY(R->Send(self->d_conn_sbuf + (size_t)s0 * K, (size_t)(s1 - s0) * K, ncclDouble, r, c->comm, st));
             if (r1 > r0) NCCL_TRY(R->Recv(self->d_conn_rbuf + (size_t)r0 * K, (size_t)(r1 - r0) * K, ncclDouble, r, c->comm, st));
         }
-        NCCL_TRY(R->GroupEnd());
+        NCCL_TRY(group.end());
         if (nr > 0)
             hipLaunchKernelGGL(bpmf::k_unpack_cols<K>, dim3((unsigned)((nr * P + 255) / 256)), dim3(256), 0, st,
                                (const double *)self->d_conn_rbuf, (const int32_t *)self->d_conn_recv, nr, self->d_items);
@@ -242,7 +243,8 @@ int exchange(bpmf_hip_side *self, hipStream_t st, int sub)
     static const bool want_mesh = [] { const char *e = getenv("BPMF_HIP_EXCHANGE"); return !(e && std::string(e) == "bcast"); }();
     int64_t mlo, mhi;
     range(c->rank, mlo, mhi);
-    NCCL_TRY(R->GroupStart());
+    NcclGroup group(R);
+    NCCL_TRY(group.start());
     if (want_mesh && R->Send && R->Recv) {
         for (int r = 0; r < c->nranks; ++r) {
             if (r == c->rank) continue;
@@ -261,7 +263,7 @@ int exchange(bpmf_hip_side *self, hipStream_t st, int sub)
             }
         }
     }
-    NCCL_TRY(R->GroupEnd());
+    NCCL_TRY(group.end());
     return 0;
 }
 

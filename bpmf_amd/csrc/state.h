@@ -97,6 +97,7 @@ struct Rccl {
     decltype(&ncclSend) Send = nullptr;                 // optional (connectivity-aware exchange)
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclReduce) Reduce = nullptr;             // optional (BPMF_REDUCE formulation: the parts of a side's Gram onto the owners)
+    decltype(&ncclCommCount) CommCount = nullptr;       // optional (bpmf_hip_ctx_comm_nranks)
 };
 
 Rccl *rccl();      // capi.hip
@@ -109,6 +110,17 @@ Rccl *rccl();      // capi.hip
                         (rccl() && rccl()->GetErrorString ? rccl()->GetErrorString(r_) : "RCCL error")); \
     } while (0)
 
+
+// ncclGroupStart / ncclGroupEnd as a scope: an operation that fails inside a group must not leave the group open
+// (every later collective of the thread would be queued instead of issued, and hang)
+struct NcclGroup {
+    Rccl *R;
+    bool open = false;
+    explicit NcclGroup(Rccl *r) : R(r) {}
+    ncclResult_t start() { const ncclResult_t r = R->GroupStart(); open = r == ncclSuccess; return r; }
+    ncclResult_t end() { open = false; return R->GroupEnd(); }
+    ~NcclGroup() { if (open) (void)R->GroupEnd(); }
+};
 
 struct bpmf_hip_ctx {
     int device = 0;
@@ -168,6 +180,8 @@ struct bpmf_hip_side {
     // one -- lr_n light items + hv_nwork others (the full list above stays for per-column priors etc.)
     int lr_n = 0, hv_nwork = 0;
     int lr_class[5] = {0, 0, 0, 0, 0};     // light items sorted by sweep width: class c (1..4 ratings per sweep) is [lr_class[c-1], lr_class[c])
+    int64_t pf_ratings2 = 0;
+    int64_t pf_ratings = 0;                // ratings of the product-form columns (bpmf_hip_side_schedule_info)
     int pf_class[4] = {0, 0, 0, 0};        // ahead of them: product-form items (k_sample_pf): <= 2 ratings, 3..6, 7..12 -- class c is [pf_class[c], pf_class[c+1])
     double *d_pf_q = nullptr;              // product form: R0^-T u_row for every row of the other side (nrows x K), per half-iteration
     int32_t *d_lr_col = nullptr, *d_lr_len = nullptr; int64_t *d_lr_p0 = nullptr;

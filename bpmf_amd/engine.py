@@ -71,6 +71,10 @@ class HipEngine:
         _lib.check(self.lib.bpmf_hip_ctx_comm_init(self.ctx, int(nranks), int(rank), buf))
         self.nranks, self.rank = int(nranks), int(rank)
 
+    def comm_nranks(self):
+        """Ranks of the communicator as the communication library counts them (1 without one)."""
+        return int(self.lib.bpmf_hip_ctx_comm_nranks(self.ctx))
+
     def side_set_ranges(self, side, bounds):
         b = np.ascontiguousarray(bounds, np.int64)
         _lib.check(self.lib.bpmf_hip_side_set_ranges(side.handle, _ptr(b)))
@@ -204,6 +208,19 @@ class HipEngine:
         mu = np.empty((nloc, self.K)); lam = np.empty((nloc, self.K * self.K))
         _lib.check(self.lib.bpmf_hip_side_aggr_finalize(side.handle, int(nsamples), _ptr(mu), _ptr(lam)))
         return mu, lam
+
+    def kernel_name(self, side):
+        """The kernel(s) one sampler launch of the side consists of, as a profile names them."""
+        buf = C.create_string_buffer(512)
+        _lib.check(self.lib.bpmf_hip_side_kernel_name(side.handle, buf, 512))
+        return buf.value.decode()
+
+    def schedule_info(self, side):
+        out = np.zeros(16, np.int64)
+        _lib.check(self.lib.bpmf_hip_side_schedule_info(side.handle, _ptr(out), 16))
+        keys = ("mode", "work_items", "chunks", "chunked_columns", "light_columns", "other_items", "pf_le2", "pf_3to6", "pf_7to12",
+                "lr_columns", "parts", "local_columns", "local_ratings", "pf_ratings", "pf_ratings_sq")
+        return {k: int(v) for k, v in zip(keys, out)}
 
     def kernel_ms_sum(self, side):
         """(sampler ms, statistics ms, launches) summed over the half-iterations run through sys_sample."""

@@ -95,12 +95,17 @@ BPMF_API void *bpmf_hip_ctx_stream(bpmf_hip_ctx *ctx);
  * (dlopen of librccl.so.1), single-GPU use never touches it. */
 BPMF_API int bpmf_hip_comm_unique_id(void *id128);
 BPMF_API int bpmf_hip_ctx_comm_init(bpmf_hip_ctx *ctx, int nranks, int rank, const void *id128);
+/* ranks of the context's communicator as the communication library itself counts them (ncclCommCount); 1 without one.
+ * What `nprocs` is to the reference (Sys::nprocs, c++/mpi_common.h:14-22): reports print it next to the numbers. */
+BPMF_API int bpmf_hip_ctx_comm_nranks(const bpmf_hip_ctx *ctx);
 BPMF_API int bpmf_hip_side_set_ranges(bpmf_hip_side *side, const int64_t *bounds);
 /* Overlap of exchange and sampling, the job of the reference's MPI_ISEND back-end (chunks of 100 fresh items are sent
  * while the next ones are sampled, c++/mpi_isendirecv.h:13-14,222-260): every rank's column range is cut into `nparts`
  * (1..8) parts of equal work; part c of all ranks is exchanged on a stream of its own while part c + 1 is being sampled.
  * Collective: every rank calls it with the same nparts after _side_set_ranges (which already picks 4 parts when a
- * half-iteration brings >= 64 MB of fresh columns to this rank; BPMF_HIP_OVERLAP=n overrides, 1 = off).  Same
+ * half-iteration brings >= 64 MB of fresh columns to the rank with the narrowest range -- a quantity every rank computes
+ * from the same bounds; not for K = 64 fp64, whose low-rank column forms need the uncut item list; BPMF_HIP_OVERLAP=n
+ * overrides, 1 = off).  Same
  * samples as without parts. */
 BPMF_API int bpmf_hip_side_set_overlap(bpmf_hip_side *side, int nparts);
 
@@ -271,6 +276,11 @@ BPMF_API void bpmf_randn_stream(uint32_t counter, int n, double *out);
 /* the same n draws produced by the device sampler (n <= 128) */
 BPMF_API int bpmf_hip_randn_stream(bpmf_hip_ctx *ctx, uint32_t counter, int n, double *out);
 
+/* Reporting (the reference's counters.cpp / measure_perf hooks have no numeric equivalent; these serve bench.py):
+ * the kernel(s) a sampler launch of this side consists of, by name, as a profile shows them; and the side's static
+ * schedule in numbers (16 words, see capi.hip: form, work items, chunks, columns per product-form class ...). */
+BPMF_API int bpmf_hip_side_kernel_name(const bpmf_hip_side *side, char *buf, int n);
+BPMF_API int bpmf_hip_side_schedule_info(const bpmf_hip_side *side, int64_t *out16, int n);
 /* sums of the sampler / statistics kernel times (ms, HIP events on their streams) over all
  * half-iterations of the stateful path collected so far, and their number */
 BPMF_API int bpmf_hip_side_kernel_ms_sum(bpmf_hip_side *side, double *sample_ms, double *reduce_ms, int64_t *launches);

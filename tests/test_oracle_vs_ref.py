@@ -56,3 +56,7 @@ def test_oracle_chain_equals_the_reference_dumps(oracle, name, K, data, nsims, b
     assert np.allclose([r[1] for r in rm], res["rmse_avg"], atol=6e-5, equal_nan=True)
     final = float(re.search(r"Final Avg RMSE: ([0-9.e+-]+)", out).group(1))
     assert abs(final - res["final_rmse_avg"]) < 1e-5 * max(1.0, final)
+    # the marker bench.py / smoke() report as "oracle_pinned": one file per case that passed, PINNED once all did
+    open(os.path.join(REFOUT, "..", "pinned_%s" % name), "w").write("ok\n")
+    if all(os.path.exists(os.path.join(REFOUT, "..", "pinned_%s" % c[0])) for c in CASES):
+        open(os.path.join(REFOUT, "..", "PINNED"), "w").write("oracle == reference dumps (tests/test_oracle_vs_ref.py)\n")

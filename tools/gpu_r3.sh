@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round-3 GPU session script (one gpurun call = one stage list): tools/gpu_r3.sh <stage> [<stage> ...]
+# Everything lands under gpurun_out/ (merged back by gpurun); summaries worth keeping are copied to profiles/ by hand.
+cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+for stage in "$@"; do
+  case "$stage" in
+    mr)      timeout 1500 python -m pytest tests/test_gpu_multirank.py -x -q -m gpu > gpurun_out/r3_mr.log 2>&1; tail -30 gpurun_out/r3_mr.log ;;
+    mrall)   timeout 2400 python -m pytest tests/test_gpu_multirank.py -q -m gpu > gpurun_out/r3_mr.log 2>&1; tail -40 gpurun_out/r3_mr.log ;;
+    gpu)     timeout 2400 python -m pytest tests -q -m gpu -x > gpurun_out/r3_gpu.log 2>&1; tail -15 gpurun_out/r3_gpu.log ;;
+    smoke)   python __graft_entry__.py smoke > gpurun_out/r3_smoke.log 2>&1; tail -5 gpurun_out/r3_smoke.log ;;
+    bench20) python bench.py --steps 20 --warmup 5 > gpurun_out/r3_bench20.json 2> gpurun_out/r3_bench20.err; tail -c 3000 gpurun_out/r3_bench20.json; tail -5 gpurun_out/r3_bench20.err ;;
+    bench)   python bench.py > gpurun_out/r3_bench.json 2> gpurun_out/r3_bench.err; tail -c 3000 gpurun_out/r3_bench.json; tail -5 gpurun_out/r3_bench.err ;;
+    benchall) for w in ml1m_k64 chembl ml1m_k128; do python bench.py --workload $w --no-cpu-baseline > gpurun_out/r3_bench_$w.json 2> gpurun_out/r3_bench_$w.err; tail -c 1500 gpurun_out/r3_bench_$w.json; done ;;
+    *) echo "unknown stage $stage" ;;
+  esac
+done
