@@ -185,6 +185,7 @@ def gibbs_sharded(engine, comm, M, Mt, T, nusers, nmovies, nsims=20, burnin=5, a
         movies.sample(users)
         users.sample(movies)
         movies.predict(users, True)          # all-reduced partial sums: every rank reports the global RMSE
+        movies.refresh(); users.refresh()    # (exchange inside the library: norm / cov / hp live there)
         res["rmse"].append(movies.rmse); res["rmse_avg"].append(movies.rmse_avg)
         res["norm_u"].append(float(np.sqrt(users.norm))); res["norm_m"].append(float(np.sqrt(movies.norm)))
     movies.predict(users, True)
