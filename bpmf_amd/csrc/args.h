@@ -84,6 +84,11 @@ struct SampleArgs {
     unsigned long long wait_ticks;
     unsigned long long *stamps; // profiling only (BPMF_HIP_STAMPS=1): s_memtime at phase boundaries of two probe items, or NULL
     uint32_t ablate;            // profiling only (BPMF_HIP_ABLATE): 1 = skip the factorisation, 2 = skip the Gram, 4 = gather from 64 hot rows only
+    // k_sample1q (kernels_q1.h): groups of four columns whose factorisation one wave runs in lockstep
+    const int32_t *q_col_slot;  // per LOCAL column: 4 * group + slot
+    const int32_t *q_grp_cols;  // per group: its four local columns (-1: empty slot of the last group)
+    unsigned *q_count;          // arrival counters of the groups (zero between launches)
+    double *q_scratch;          // per group: GeoQ<K>::GWORDS doubles (blocks | rhs | normals of its four columns)
 };
 
 // What else one k_sample1 launch carries besides its work items (see k_sample1 in kernels.h): the gate +

@@ -127,7 +127,11 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     else if (K == 64) { if (s->mode == 3) s->mode = 4; }
     else {
         if (s->mode == 2 || s->mode == 4) s->mode = 1;                             // (BPMF_HIP_MODE=2 / 4 exist for K >= 64 only)
+        // mode 6 (k_sample1q, kernels_q1.h): Gram per wave as in mode 1, factorisation four columns per wave as in mode 3.
+        // Its groups are built over the whole item list: a side cut into parts keeps mode 1.
+        if (s->mode == 6 && s->nsub > 1) s->mode = 1;
     }
+    if ((f32 || K == 64) && s->mode == 6) s->mode = f32 ? 5 : 4;
     const bool wg = s->mode == 2;
     int chunk = wg ? (1 << 30) : env_int("BPMF_HIP_CHUNK", 0);
     if (chunk <= 0) {
@@ -199,6 +203,24 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
             while (i < items.size() && part_of(items[i]) == c) ++i;
             s->sub_item_off.push_back((int)i);
         }
+    }
+    if (s->mode == 6) {
+        // groups of four columns in the order in which the sorted item list first mentions them: columns of similar
+        // cost, dispatched -- and therefore complete -- at about the same time
+        std::vector<int32_t> col_slot((size_t)std::max<int64_t>(nloc, 1), -1), grp_cols;
+        int32_t n = 0;
+        for (const Item &it : items)
+            if (col_slot[(size_t)it.col] < 0) { col_slot[(size_t)it.col] = n++; grp_cols.push_back(it.col); }
+        while (grp_cols.size() % 4) grp_cols.push_back(-1);
+        if (grp_cols.empty()) grp_cols.assign(4, -1);
+        s->q_ngroups = (int)(grp_cols.size() / 4);
+        int rcq;
+        std::vector<unsigned> zeros((size_t)s->q_ngroups, 0u);
+        if ((rcq = dev_upload(&s->d_q_col_slot, col_slot.data(), col_slot.size())) || (rcq = dev_upload(&s->d_q_grp_cols, grp_cols.data(), grp_cols.size())) ||
+            (rcq = dev_upload(&s->d_q_count, zeros.data(), zeros.size())) ||
+            (rcq = dev_upload<double>(&s->d_q_scratch, nullptr, (size_t)s->q_ngroups * (size_t)((K / 4) * (K / 4 + 1) / 2 + 2 * (K / 4)) * 64)))
+            return rcq;
+        HIP_TRY(hipMemset(s->d_q_scratch, 0, (size_t)s->q_ngroups * (size_t)((K / 4) * (K / 4 + 1) / 2 + 2 * (K / 4)) * 64 * sizeof(double)));
     }
     const size_t nw = items.size();
     std::vector<int32_t> wcol(nw), wlen(nw), wmc(nw), wchunk(nw);
@@ -300,7 +322,8 @@ void free_schedule(bpmf_hip_side *s)
     void **ptrs[] = {(void **)&s->d_wi_col, (void **)&s->d_wi_len, (void **)&s->d_wi_mc, (void **)&s->d_wi_chunk, (void **)&s->d_wi_p0,
                      (void **)&s->d_mc_slot0, (void **)&s->d_mc_nch, (void **)&s->d_mc_count, (void **)&s->d_partials, (void **)&s->d_stat_partials,
                      (void **)&s->d_lr_col, (void **)&s->d_lr_len, (void **)&s->d_lr_p0, (void **)&s->d_hv_col, (void **)&s->d_hv_len,
-                     (void **)&s->d_hv_mc, (void **)&s->d_hv_chunk, (void **)&s->d_hv_p0, (void **)&s->d_pf_q, (void **)&s->d_stat_list};
+                     (void **)&s->d_hv_mc, (void **)&s->d_hv_chunk, (void **)&s->d_hv_p0, (void **)&s->d_pf_q, (void **)&s->d_stat_list,
+                     (void **)&s->d_q_col_slot, (void **)&s->d_q_grp_cols, (void **)&s->d_q_count, (void **)&s->d_q_scratch};
     for (void **p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
     s->lr_n = s->hv_nwork = 0;
     s->stat_nA = s->stat_n = 0; s->stat_wgA = s->stat_wgB = 0; s->stat_a_ready = s->stat_a_done = false;
@@ -528,7 +551,8 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
     void *ptrs[] = {s->d_wi_col, s->d_wi_len, s->d_wi_mc, s->d_wi_chunk, s->d_wi_p0, s->d_mc_slot0, s->d_mc_nch, s->d_mc_count, s->d_partials, s->d_stat_partials, s->a_d_in,
                     s->d_lr_col, s->d_lr_len, s->d_lr_p0, s->d_hv_col, s->d_hv_len, s->d_hv_mc, s->d_hv_chunk, s->d_hv_p0,
                     s->d_conn_send, s->d_conn_recv, s->d_conn_sbuf, s->d_conn_rbuf, s->d_pf_q,
-                    s->d_prec, s->d_t_colptr, s->d_t_rowidx, s->d_t_vals, s->d_t_order};
+                    s->d_prec, s->d_t_colptr, s->d_t_rowidx, s->d_t_vals, s->d_t_order,
+                    s->d_q_col_slot, s->d_q_grp_cols, s->d_q_count, s->d_q_scratch};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (s->a_h_in) (void)hipHostFree(s->a_h_in);
     if (s->a_h_out) (void)hipHostFree(s->a_h_out);
@@ -1319,7 +1343,7 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     // (K = 64, slab form without low-rank columns: the same launch format, k_sample1s<64>; only the words the slab
     // form reads are staged -- the R0 / R0^-1 tail of the K = 64 blob belongs to the low-rank forms)
     const size_t stage_words = (K == 64 && self->lr_n == 0) ? (size_t)K * K + K + 2 + K : c->in_words;
-    const bool fusable_form = (K <= 32 && self->mode == 1) || (K == 64 && self->mode == 4 && self->lr_n == 0 && self->nsub <= 1);
+    const bool fusable_form = (K <= 32 && (self->mode == 1 || self->mode == 6)) || (K == 64 && self->mode == 4 && self->lr_n == 0 && self->nsub <= 1);
     const bool fused = s1 != s0 && !dist && stage_words <= 8192 && fusable_form && self->nwork > 0 && !self->reduce_on &&
                        c->dtype == BPMF_HIP_F64 && env_int("BPMF_HIP_FUSED", 1) != 0;
     bpmf::FusedArgs fz{};
@@ -1378,7 +1402,7 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     // own on S1 their 2 048 waves only got wave slots as the partner's sampler -- which fills the chip -- drained, i.e.
     // the sums of the 483 k compounds arrived when the targets' sampler ended (0.34 ms after their own sampler), and the
     // compounds' host chain (cov, Normal-Wishart draw, factor of LambdaF: 0.12 ms) started only then.
-    const bool partner_fusable = (K <= 32 && other->mode == 1) || (K == 64 && other->mode == 4 && other->lr_n == 0 && other->nsub <= 1);
+    const bool partner_fusable = (K <= 32 && (other->mode == 1 || other->mode == 6)) || (K == 64 && other->mode == 4 && other->lr_n == 0 && other->nsub <= 1);
     const bool defer = !fused && !dist && s1 != s0 && c->dtype == BPMF_HIP_F64 && partner_fusable && other->nwork > 0 && other->a_d_in &&
                        self->nwork > 0 && env_int("BPMF_HIP_FUSED", 1) != 0 && env_int("BPMF_HIP_DEFER_STATS", 0) != 0;   // (measured slower: 1.72 against 1.26 ms -- the 2 048 rider waves stream 247 MB at the head of the partner's launch; kept as a switch)
     if (fused || defer) {
@@ -1469,6 +1493,7 @@ extern "C" int bpmf_hip_side_kernel_name(const bpmf_hip_side *s, char *buf, int 
         } else name = heavy();
     } else {
         if (s->mode == 3) name = "k_sample4<" + k + ">";
+        else if (s->mode == 6) name = "k_sample1q<" + k + ">";
         else if (s->mode == 1) name = ((K == 32 || K == 16) && env_int("BPMF_HIP_SLAB32", 0) ? "k_sample1s<" : "k_sample1<") + k + ">";
         else name = "k_sample<" + k + ">";
     }

@@ -6,6 +6,7 @@
 #include "kernels_f32.h"
 #include "kernels_q4.h"
 #include "kernels_slab.h"
+#include "kernels_q1.h"
 
 namespace bpmf_launch {
 
@@ -77,6 +78,7 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
     a.tmo = self->cur_gate_flag ? tmo_word(self->a_h_out_dev, K) : nullptr; a.wait_ticks = wait_ticks();
     a.zero_row = c->d_zero;
     a.lf32 = (lf32_words(c) && !self->d_prop) ? reinterpret_cast<const float *>(d_in + c->in_words) : nullptr;
+    a.q_col_slot = self->d_q_col_slot; a.q_grp_cols = self->d_q_grp_cols; a.q_count = self->d_q_count; a.q_scratch = self->d_q_scratch;
     if constexpr (K == 128) {                                        // fp32 factors (items / other_items are float arrays)
         if (nwork > 0) {
             if (self->mode == 4) k128_slab(nwork, st, ev_start, ev_stop, a);
@@ -164,6 +166,15 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
             } else {
                 k64_slab(nwork, st, ev_start, ev_stop, a);
             }
+            return 0;
+        }
+    }
+    if constexpr (K <= 32) {
+        if (nwork > 0 && self->mode == 6) {                          // Gram one column per wave, factorisation four columns per wave
+            const FusedArgs &f = self->cur_fused;
+            const dim3 grid((unsigned)(nwork + (f.gate_host ? 1 : 0) + f.nstat));
+            if (ev_start || ev_stop) hipExtLaunchKernelGGL(k_sample1q<K>, grid, dim3(64), 0, st, ev_start, ev_stop, 0, a, f);
+            else hipLaunchKernelGGL(k_sample1q<K>, grid, dim3(64), 0, st, a, f);
             return 0;
         }
     }

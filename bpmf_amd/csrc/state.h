@@ -176,6 +176,11 @@ struct bpmf_hip_side {
     double *d_prop = nullptr;            // propagated posterior (-m / -l): K x K prior precision per local column, or NULL
     // schedule
     int nwork = 0, nmulti = 0, nslots = 0, mode = 0;
+    // mode 6 (k_sample1q): groups of four columns factorised in lockstep by the last wave to deliver its Gram
+    int32_t *d_q_col_slot = nullptr, *d_q_grp_cols = nullptr;
+    unsigned *d_q_count = nullptr;
+    double *d_q_scratch = nullptr;
+    int q_ngroups = 0;
     // K = 64: columns with a handful of ratings take the low-rank form (k_sample_lr), the rest the regular
     // one -- lr_n light items + hv_nwork others (the full list above stays for per-column priors etc.)
     int lr_n = 0, hv_nwork = 0;

@@ -13,6 +13,13 @@ for stage in "$@"; do
     bench20) python bench.py --steps 20 --warmup 5 > gpurun_out/r3_bench20.json 2> gpurun_out/r3_bench20.err; tail -c 3000 gpurun_out/r3_bench20.json; tail -5 gpurun_out/r3_bench20.err ;;
     bench)   python bench.py > gpurun_out/r3_bench.json 2> gpurun_out/r3_bench.err; tail -c 3000 gpurun_out/r3_bench.json; tail -5 gpurun_out/r3_bench.err ;;
     benchall) for w in ml1m_k64 chembl ml1m_k128; do python bench.py --workload $w --no-cpu-baseline > gpurun_out/r3_bench_$w.json 2> gpurun_out/r3_bench_$w.err; tail -c 1500 gpurun_out/r3_bench_$w.json; done ;;
+    q1)      timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "gram1 or four-columns" > gpurun_out/r3_q1.log 2>&1; tail -15 gpurun_out/r3_q1.log
+             for m in 1 6; do BPMF_HIP_MODE=$m python bench.py --no-cpu-baseline --no-strong > gpurun_out/r3_bench_mode$m.json 2> gpurun_out/r3_bench_mode$m.err; python - <<PY
+import json
+j=json.loads([l for l in open("gpurun_out/r3_bench_mode$m.json") if l.startswith("{")][-1])
+print("mode $m", j["roofline"]["kernel"], "ms/step", j["ms_per_step"], "launch", j["roofline"]["launch_ms_per_side"], "value", j["value"], "rmse", j["rmse"])
+PY
+             done ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
