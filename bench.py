@@ -470,12 +470,17 @@ def main():
     Sys.nsims, Sys.burnin, Sys.alpha = 10 ** 6, 5, 2.0
     if comm is None:
         movies = Sys("movs", eng, M, nmovies, nusers, T=T, mean_rating=mean)
-        users = Sys("users", eng, Mt, nusers, nmovies, mean_rating=mean)
+        users = Sys("users", eng, Mt, nusers, nmovies, T=Tt, mean_rating=mean)
         dom_m, dom_u = (0, nmovies), (0, nusers)
     else:
         from bpmf_amd.dist import build_sharded
-        movies, users = build_sharded(eng, comm, M, Mt, T, nusers, nmovies, mean_rating=mean)
+        movies, users = build_sharded(eng, comm, M, Mt, T, nusers, nmovies, mean_rating=mean, Tt=Tt)
         dom_m, dom_u = movies.dom, users.dom
+    # users.predict(movies) (c++/bpmf.cpp:190: inside the reference's timed region, its results never read) rides with
+    # every movies.predict(users) as the twin evaluation of the library
+    both_predicts = users.test is not None and getattr(comm, "native", True)
+    if both_predicts:
+        movies.set_twin(users)
     rccl_nranks = eng.comm_nranks() if getattr(comm, "native", False) else (world if comm is not None else 1)
     if world > 1 and getattr(comm, "native", False) and rccl_nranks != world:
         raise SystemExit("bench.py: the communicator has %d rank(s), the launcher started %d" % (rccl_nranks, world))
@@ -493,6 +498,8 @@ def main():
         if not pipelined:
             for _ in range(n):
                 movies.sample(users); users.sample(movies); movies.predict(users)
+                if both_predicts:
+                    users.predict(movies)
             return
         # the same n iterations, software-pipelined the way the `bpmf` executable runs them: the RMSE
         # of iteration i is collected after iteration i+1 has been enqueued (the evaluation runs on
@@ -502,8 +509,12 @@ def main():
             users.sample(movies)
             if i > 0:
                 movies.predict_finish()
+                if both_predicts:
+                    users.predict_finish()
             movies.predict_launch(users)
         movies.predict_finish()
+        if both_predicts:
+            users.predict_finish()
 
     # warm-up: W steps, then by TIME -- a 20-step timed region straight after start-up otherwise sits
     # on the clock ramp (round 1: 0.122 ms per step measured by the driver against 0.102 steady state)
@@ -556,6 +567,8 @@ def main():
     kernel_name = kernel_names["movs"] if kernel_names["movs"] == kernel_names["users"] else "%s | %s" % (kernel_names["movs"], kernel_names["users"])
 
     movies.predict(users, True)
+    if both_predicts:
+        users.predict(movies)
     # Which resource binds?  K = 32 on this matrix: the factors (1.5 + 0.95 MB) live in L2 / MALL -- HBM-side
     # traffic is ~0.2 x the algorithmic bytes -- and the launch is bound by instruction issue: the fp64 MFMA
     # Gram and the VALU factorisation share the SIMD.  K >= 64: the dense contraction / factorisation.
@@ -596,10 +609,11 @@ def main():
         "vs_baseline": None,
         "dtype": dtype,
         "data": "synthetic",
-        "config": {"workload": (shape_note + ", K=%d, alpha=2, full Gibbs iteration incl. host Normal-Wishart draws and RMSE "
-                                "(movies.predict(users); users.predict(movies) of c++/bpmf.cpp:190 -- same predictions into a second copy "
-                                "of Pavg that nothing reads -- is not run)")
+        "config": {"workload": (shape_note + ", K=%d, alpha=2, full Gibbs iteration of c++/bpmf.cpp:182-195: both half-iterations incl. host "
+                                "Normal-Wishart draws, movies.predict(users)" + (" and users.predict(movies)" if both_predicts else
+                                                                                 "; users.predict(movies) of c++/bpmf.cpp:190 is not run"))
                                % (nusers, nmovies, nnz + int(T[0][-1]), K),
+                   "both_predicts": bool(both_predicts),
                    "name": wl, "nnz_train": nnz, "nnz_test": int(T[0][-1]), "K": K,
                    "parallelism": "columns of U and V sharded over %d GPU(s)" % world},
         "rccl_nranks": rccl_nranks, "launcher": "self" if os.environ.get("BPMF_BENCH_SELF_LAUNCHED") else ("external" if "WORLD_SIZE" in os.environ else "none"),

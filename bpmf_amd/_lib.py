@@ -27,6 +27,7 @@ _SIGNATURES = {
     "bpmf_hip_ctx_comm_nranks": (C.c_int, [C.c_void_p]),
     "bpmf_hip_side_set_ranges": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bpmf_hip_side_set_overlap": (C.c_int, [C.c_void_p, C.c_int]),
+    "bpmf_hip_side_set_staleness": (C.c_int, [C.c_void_p, C.c_int]),
     "bpmf_hip_sys_set_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "bpmf_hip_side_set_conn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bpmf_hip_side_exchange": (C.c_int, [C.c_void_p]),
@@ -52,6 +53,7 @@ _SIGNATURES = {
     "bpmf_hip_side_aggr_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "bpmf_hip_test_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "bpmf_hip_test_destroy": (C.c_int, [C.c_void_p]),
+    "bpmf_hip_test_set_twin": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bpmf_hip_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bpmf_hip_predict_launch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "bpmf_hip_predict_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

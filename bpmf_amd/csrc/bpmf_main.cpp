@@ -182,7 +182,7 @@ void permute_columns(std::vector<double> &d, int64_t rows, const std::vector<int
 
 struct Job {
     // inputs (read-only for the ranks)
-    Csc M, Mt, T;
+    Csc M, Mt, T, Tt;                                                // Tt: the test entries by user (users.predict(movies), c++/bpmf.cpp:190)
     int K = 32, dtype = BPMF_HIP_F64, nsims = 20, burnin = 5, update_freq = 1, nthrds = -1, nranks = 1;
     double alpha = 2.0, mean_m = 0.0, mean_u = 0.0;
     bool verbose = false, redirect = false, sharded = false;
@@ -217,7 +217,7 @@ void rank_main(Job &J, int rank, std::ostream &os)
         return cp;
     };
     bpmf_hip_side *movies = nullptr, *users = nullptr;
-    bpmf_hip_test *test = nullptr;
+    bpmf_hip_test *test = nullptr, *test_u = nullptr;
     {
         const std::vector<int64_t> cp = slice_ptr(J.M, m0, m1);
         const size_t off = (size_t)J.M.colptr[(size_t)m0];
@@ -252,6 +252,19 @@ void rank_main(Job &J, int rank, std::ostream &os)
         const std::vector<int64_t> cp = slice_ptr(J.T, m0, m1);
         check(bpmf_hip_test_create(movies, cp.data(), J.T.rowidx.data() + toff, J.T.vals.data() + toff, &test));
     }
+    {   // users.predict(movies) of the reference's loop (c++/bpmf.cpp:190): the users' copy of the test entries (T = Pavg^T of
+        // the second Sys, c++/sample.cpp:132-137) is evaluated with every movies.predict(users); nothing prints its results
+        const std::vector<int64_t> cp = slice_ptr(J.Tt, u0, u1);
+        const size_t off = (size_t)J.Tt.colptr[(size_t)u0];
+        check(bpmf_hip_test_create(users, cp.data(), J.Tt.rowidx.data() + off, J.Tt.vals.data() + off, &test_u));
+        check(bpmf_hip_test_set_twin(test, test_u));
+    }
+    double se_u, se_avg_u;
+    int64_t num_u = 0;
+    auto finish_both = [&](double *se_p, double *se_avg_p, int64_t *num_p) {
+        check(bpmf_hip_predict_finish(test, se_p, se_avg_p, num_p));
+        check(bpmf_hip_predict_finish(test_u, &se_u, &se_avg_u, &num_u));
+    };
 
     char host[1024];
     gethostname(host, sizeof host);
@@ -299,7 +312,7 @@ void rank_main(Job &J, int rank, std::ostream &os)
             check(bpmf_hip_sys_sample(users, movies, alpha));   // users.sample(movies)
             if (i > 0) {
                 // the evaluation of iteration i-1 ran beside the two samplers just queued
-                check(bpmf_hip_predict_finish(test, &se, &se_avg, &num_predict));
+                finish_both(&se, &se_avg, &num_predict);
                 rmse = std::sqrt(se / (double)num_predict);
                 rmse_avg = std::sqrt(se_avg / (double)num_predict);
                 const double now = tick();
@@ -310,7 +323,7 @@ void rank_main(Job &J, int rank, std::ostream &os)
             check(bpmf_hip_predict_launch(test, movies, users, (iter < burnin) ? 0 : (iter - burnin)));
         }
         if (nsims > 0) {
-            check(bpmf_hip_predict_finish(test, &se, &se_avg, &num_predict));
+            finish_both(&se, &se_avg, &num_predict);
             rmse = std::sqrt(se / (double)num_predict);
             rmse_avg = std::sqrt(se_avg / (double)num_predict);
             check(bpmf_hip_sys_state(movies, nullptr, &norm_m, nullptr, nullptr, nullptr, nullptr));
@@ -324,7 +337,8 @@ void rank_main(Job &J, int rank, std::ostream &os)
         check(bpmf_hip_sys_sample(users, movies, alpha));       // users.sample(movies)
         iter = i;
         const int n = (iter < burnin) ? 0 : (iter - burnin);
-        check(bpmf_hip_predict(test, movies, users, n, &se, &se_avg, &num_predict));
+        check(bpmf_hip_predict_launch(test, movies, users, n));
+        finish_both(&se, &se_avg, &num_predict);
         rmse = std::sqrt(se / (double)num_predict);
         rmse_avg = std::sqrt(se_avg / (double)num_predict);
         const double stop = tick();
@@ -355,7 +369,8 @@ void rank_main(Job &J, int rank, std::ostream &os)
     // movies.predict(users, true) once more with the same iter (c++/bpmf.cpp:225,242: SURVEY Q6)
     if (nsims > 0) {
         const int n = (iter < burnin) ? 0 : (iter - burnin);
-        check(bpmf_hip_predict(test, movies, users, n, &se, &se_avg, &num_predict));
+        check(bpmf_hip_predict_launch(test, movies, users, n));
+        finish_both(&se, &se_avg, &num_predict);
         rmse_avg = std::sqrt(se_avg / (double)num_predict);
     }
     if (!J.odirname.empty()) {                                        // this rank's slice of Pavg / Pm2 and of the posterior
@@ -372,6 +387,7 @@ void rank_main(Job &J, int rank, std::ostream &os)
         J.average_items_sec = average_items_sec; J.average_ratings_sec = average_ratings_sec;
     }
     bpmf_hip_test_destroy(test);
+    bpmf_hip_test_destroy(test_u);
     bpmf_hip_side_destroy(movies);
     bpmf_hip_side_destroy(users);
     bpmf_hip_ctx_destroy(ctx);
@@ -496,6 +512,7 @@ int main(int argc, char *argv[])
         std::string tok;
         while (std::getline(ss, tok, ',')) if (!tok.empty()) J.devices.push_back(atoi(tok.c_str()));
     }
+    J.Tt = bpmf::io::transpose(J.T);
     if (J.sharded) check(bpmf_hip_comm_unique_id(J.rccl_id));      // (also loads RCCL before the rank threads start)
     if (!J.odirname.empty()) {
         J.pavg.assign(J.T.vals.size(), 0.0); J.pm2.assign(J.T.vals.size(), 0.0);

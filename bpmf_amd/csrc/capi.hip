@@ -773,9 +773,12 @@ int sample_and_exchange(bpmf_hip_side *self, const bpmf_hip_side *other, int ite
         if constexpr (K == 128) return fail(BPMF_HIP_EINVAL, "the BPMF_REDUCE formulation is fp64 only");
         else return reduce_half_iteration<K>(self, other, iter, alpha, d_in, st, ev_start, ev_stop);
     }
+    // bounded staleness: does part p travel in this half-iteration?  (iteration 0 always does, like do_comm of the
+    // reference's throttled GASPI back-end, c++/bpmf_gaspi.h:93-99)
+    auto travels = [&](int p) { return self->stale_k <= 0 || iter == 0 || ((p + iter) % (self->stale_k + 1)) == 0; };
     if (!parts) {
         int rc = launch_sampler<K>(self, other, iter, alpha, d_in, st, ev_start, ev_stop);
-        if (!rc) rc = bpmf_launch::exchange<K>(self, st, -1);
+        if (!rc && travels(0)) rc = bpmf_launch::exchange<K>(self, st, -1);
         return rc;
     }
     int rc = 0;
@@ -791,7 +794,7 @@ int sample_and_exchange(bpmf_hip_side *self, const bpmf_hip_side *other, int ite
         if (he == hipSuccess) he = hipEventRecord(self->sub_ev[p], st);
         if (he == hipSuccess) he = hipStreamWaitEvent(self->sx, self->sub_ev[p], 0);
         if (he != hipSuccess) { rc = fail(BPMF_HIP_ENODEV, std::string("sample_and_exchange: ") + hipGetErrorString(he)); break; }
-        rc = bpmf_launch::exchange<K>(self, self->sx, p);
+        if (travels(p)) rc = bpmf_launch::exchange<K>(self, self->sx, p);
     }
     self->item_off = 0; self->item_n = -1;                           // (whatever happened: later launches see the whole item list again)
     if (rc) return rc;
@@ -1599,6 +1602,7 @@ extern "C" int bpmf_hip_side_set_ranges(bpmf_hip_side *s, const int64_t *bounds)
     const size_t threshold = (size_t)std::max(1, env_int("BPMF_HIP_OVERLAP_MIN_KB", 64 << 10)) << 10;    // (the tests lower it)
     const bool auto_ok = !(c->K == 64 && c->dtype == BPMF_HIP_F64);
     const int nsub = want >= 0 ? want : (c->nranks > 1 && auto_ok && incoming >= threshold ? 4 : 1);
+    s->stale_k = std::max(0, std::min(env_int("BPMF_HIP_STALE", 0), 64));     // (bpmf_hip_side_set_staleness; `bpmf`: the environment)
     if (nsub > 1) return bpmf_hip_side_set_overlap(s, nsub);
     return BPMF_HIP_OK;
 }
@@ -1714,6 +1718,25 @@ extern "C" int bpmf_hip_side_set_overlap(bpmf_hip_side *s, int nparts)
     s->sub_bounds = nparts > 1 ? all : std::vector<int64_t>();
     free_schedule(s);
     return build_schedule(s, s->h_colptr.data());
+}
+
+// Bounded-staleness exchange: the third variant of SURVEY 8 f4.  The reference's GASPI back-end can skip sends at random
+// (`send_prob`, c++/bpmf_gaspi.h:91-104: a column then stays as the peer last saw it) and its all-reduce back-end keeps
+// blocks up to `slack` iterations old (c++/mpi_allreduce.h:134-175): relaxations for fabrics where waiting is the cost.
+// Here, deterministic and rank-invariant: part p of a side (bpmf_hip_side_set_overlap; the whole range when the side is
+// uncut) is exchanged only in the half-iterations with (p + iter) % (k + 1) == 0, and always in iteration 0 -- a
+// remote copy is at most k half-iterations of that side old, the traffic drops to 1 / (k + 1).  Columns a rank owns
+// are always current on that rank; the statistics (sum, cov, norm) are all-reduced exactly as ever.  k = 0: the exact
+// chain.  Collective in effect: every rank sets the same k.  bpmf_hip_side_exchange brings every replica up to date
+// (before outputs).  The chain is NOT the reference's NO_COMM chain any more: a property-tested relaxation
+// (tests/test_gpu_multirank.py), never a default.
+extern "C" int bpmf_hip_side_set_staleness(bpmf_hip_side *s, int k)
+{
+    if (!s || k < 0 || k > 64) return fail(BPMF_HIP_EINVAL, "side_set_staleness: k = 0 .. 64");
+    if (k > 0 && !s->conn_send_ptr.empty()) return fail(BPMF_HIP_EINVAL, "side_set_staleness: not together with the connectivity-aware exchange");
+    { const int rc = settle_async(s); if (rc) return rc; }
+    s->stale_k = k;
+    return BPMF_HIP_OK;
 }
 
 extern "C" int bpmf_hip_side_set_conn(bpmf_hip_side *s, const int64_t *send_ptr, const int32_t *send_cols,
@@ -1848,6 +1871,12 @@ extern "C" int bpmf_hip_test_destroy(bpmf_hip_test *t)
     if (!t) return BPMF_HIP_OK;
     bpmf_hip_ctx *c = t->side->ctx;
     (void)hipSetDevice(c->device);
+    if (t->owner) {                                                   // a twin: its owner's evaluation in flight reads its arrays
+        flush_deferred(t->owner);
+        (void)hipStreamSynchronize(live_pstream(t->owner));
+        t->owner->twin = nullptr; t->owner = nullptr;
+    }
+    if (t->twin) { flush_deferred(t); t->twin->owner = nullptr; t->twin->launched = false; t->twin = nullptr; }
     if (t->deferred) {                                              // never enqueued: nothing to wait for
         t->deferred = false;
         std::lock_guard<std::mutex> lk(c->launch_mutex);
@@ -1894,6 +1923,7 @@ void dispatch_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *s
 // a sampler about to overwrite a copy it reads, test_get, the destructors.
 static void flush_deferred(bpmf_hip_test *t)
 {
+    if (t && t->owner) t = t->owner;                                 // a twin is enqueued with the evaluation it belongs to
     if (!t || !t->deferred) return;
     t->deferred = false;
     bpmf_hip_side *o = t->def_other;
@@ -1903,17 +1933,40 @@ static void flush_deferred(bpmf_hip_test *t)
     trace("predict: enqueued", t->side, t->def_n);
 }
 
+// users.predict(movies) (c++/bpmf.cpp:190, inside the reference's timed region): `twin` holds the test entries by column of
+// the OTHER side (the transpose of `t`'s) and is evaluated with the roles swapped -- pred = users.col(c) . movies.col(r)
+// + mean of that side, its own Pavg / Pm2 copies and sums, as the reference's second Sys keeps them -- whenever `t` is.
+// Its sums are collected with bpmf_hip_predict_finish(twin, ...).  twin = NULL detaches.
+extern "C" int bpmf_hip_test_set_twin(bpmf_hip_test *t, bpmf_hip_test *twin)
+{
+    if (!t) return fail(BPMF_HIP_EINVAL, "test_set_twin: NULL");
+    if (t->launched || (twin && twin->launched)) return fail(BPMF_HIP_EINVAL, "test_set_twin: an evaluation is in flight");
+    if (twin && (twin == t || twin->side == t->side || twin->side->ctx != t->side->ctx || twin->side->ncols != t->side->nrows || twin->owner))
+        return fail(BPMF_HIP_EINVAL, "test_set_twin: the twin must sit on the other side of the same pair");
+    if (t->twin) t->twin->owner = nullptr;
+    t->twin = twin;
+    if (twin) twin->owner = t;
+    return BPMF_HIP_OK;
+}
+
 extern "C" int bpmf_hip_predict_launch(bpmf_hip_test *t, const bpmf_hip_side *self, const bpmf_hip_side *other_c, int n)
 {
     if (!t || !self || !other_c) return fail(BPMF_HIP_EINVAL, "predict: NULL argument");
     if (t->side != self) return fail(BPMF_HIP_EINVAL, "predict: test matrix belongs to another side");
     if (n < 0) return fail(BPMF_HIP_EINVAL, "predict: n < 0");
+    if (t->owner) return fail(BPMF_HIP_EINVAL, "predict_launch: this test matrix is a twin (it is evaluated with its owner)");
     if (t->launched) return fail(BPMF_HIP_EINVAL, "predict_launch: previous launch not finished");
+    if (t->twin && t->twin->launched) return fail(BPMF_HIP_EINVAL, "predict_launch: the twin's previous sums were not collected (bpmf_hip_predict_finish)");
     bpmf_hip_ctx *c = self->ctx;
     bpmf_hip_side *other = const_cast<bpmf_hip_side *>(other_c);
     HIP_TRY(hipSetDevice(c->device));
     const bool dist = c->comm && !self->bounds.empty();
-    if (t->nnz == 0 && !dist) { t->launched = true; return BPMF_HIP_OK; }
+    if (t->twin && t->twin->nnz == 0) t->twin->launched = true;     // (nothing to enqueue for it)
+    if (t->nnz == 0 && !dist) {
+        t->launched = true;
+        if (t->twin && t->twin->nnz > 0) return fail(BPMF_HIP_EINVAL, "predict_launch: empty test matrix with a non-empty twin");
+        return BPMF_HIP_OK;
+    }
     if (c->K != 8 && c->K != 16 && c->K != 32 && c->K != 64 && c->K != 128) return fail(BPMF_HIP_EINVAL, "predict: unsupported K");
     // (the all-reduce of the sharded form shares the main communicator: that form stays in order)
     const bool beside = t->ev_in && !dist && other->saux && !other->deferred_eval && second_copy_usable(self) && second_copy_usable(other);
@@ -1930,6 +1983,7 @@ extern "C" int bpmf_hip_predict_launch(bpmf_hip_test *t, const bpmf_hip_side *se
         other->readers[other->cur_buf].t = t; other->readers[other->cur_buf].seq = t->seq + 1;
         t->pstream = other->saux;
         t->launched = true;
+        if (t->twin) t->twin->launched = true;                        // (enqueued with this one: flush_deferred)
         trace("predict: deferred", self, n);
         return BPMF_HIP_OK;
     }
@@ -1947,6 +2001,7 @@ extern "C" int bpmf_hip_predict_finish(bpmf_hip_test *t, double *se, double *se_
     if (!t->launched) return fail(BPMF_HIP_EINVAL, "predict_finish: nothing launched");
     flush_deferred(t);
     t->launched = false;
+    if (t->owner && t->owner->cancelled) return fail(BPMF_HIP_EINVAL, "predict_finish: the evaluation this twin belongs to was cancelled");
     if (t->cancelled) { t->cancelled = false; return fail(BPMF_HIP_EINVAL, "predict_finish: the side of this test matrix was destroyed before the evaluation ran"); }
     bpmf_hip_side *self = t->side;
     bpmf_hip_ctx *c = self->ctx;

@@ -74,23 +74,27 @@ __device__ __forceinline__ void finish_group4(const SampleArgs &a, const double 
             bv[g] = lm;
         }
     }
+    // the group's blocks and rhs sums: ONE round trip (they were written through to memory: every load is a memory
+    // access), straight into the registers the factorisation keeps them in
+#pragma unroll
+    for (int t = 0; t < NB; ++t) acc[t] = __hip_atomic_load(&sc[t * 64 + lane], BPMF_RLX_AGENT);
+    double rs[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) rs[g] = __hip_atomic_load(&sc[(NB + g) * 64 + (lane & ~3)], BPMF_RLX_AGENT);
+    // LambdaF (L2 hits) one block row at a time: all NB of them in flight as well would be NB more live registers
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        double gv[NG], lf[NG];
+        double lf[NG];
 #pragma unroll
-        for (int g2 = g; g2 < NG; ++g2) {
-            gv[g2] = __hip_atomic_load(&sc[G::blk(g, g2) * 64 + lane], BPMF_RLX_AGENT);
-            lf[g2] = LF[4 * g + ii + (4 * g2 + jj) * K];
-        }
-        const double rs = __hip_atomic_load(&sc[(NB + g) * 64 + (lane & ~3)], BPMF_RLX_AGENT);
+        for (int g2 = g; g2 < NG; ++g2) lf[g2] = LF[4 * g + ii + (4 * g2 + jj) * K];
 #pragma unroll
         for (int g2 = g; g2 < NG; ++g2) {
             const int r_ = 4 * g + ii, c_ = 4 * g2 + jj;
-            double v = fma(a.alpha, alive ? gv[g2] : 0.0, lf[g2]);
+            double v = fma(a.alpha, alive ? acc[G::blk(g, g2)] : 0.0, lf[g2]);
             v = (a.diag_only && r_ != c_) ? 0.0 : v;                 // BPMF_NO_COVARIANCE (:300-304)
             acc[G::blk(g, g2)] = v;
         }
-        bv[g] = (jj == 0) ? bv[g] + (alive ? rs : 0.0) : 0.0;
+        bv[g] = (jj == 0) ? bv[g] + (alive ? rs[g] : 0.0) : 0.0;
         __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -296,6 +300,7 @@ __global__ __launch_bounds__(64, GeoQ<K>::WPS) void k_sample1q(SampleArgs a, Fus
         if ((int)t != want - 1) return;
         if (lane == 0) __hip_atomic_store(&a.q_count[grp], 0u, BPMF_RLX_AGENT);      // re-arm for the next launch
     }
+    if (a.ablate & 8u) return;                                        // (profiling switch: Gram + hand-over only)
 
     finish_group4<K>(a, sc, gcols, sw, lane);
 }

@@ -220,19 +220,27 @@ __global__ __launch_bounds__(64, Geo4<K>::WPS) void k_sample4(SampleArgs a)
         for (int g2 = g; g2 < NG; ++g2) {
             const int r_ = 4 * g + ii, c_ = 4 * g2 + jj;
             double v = fma(a.alpha, acc[G::blk(g, g2)], LF[r_ + c_ * K]);
-            if (a.diag_only && r_ != c_) v = 0.0;                    // BPMF_NO_COVARIANCE (:300-304)
+            v = (a.diag_only && r_ != c_) ? 0.0 : v;                 // BPMF_NO_COVARIANCE (:300-304)
             acc[G::blk(g, g2)] = v;
         }
     double bv[NG];                                                    // element 4 g + i of the rhs at lane (i, b, 0), zero elsewhere
+    // (per-column priors: a rolled loop of its own -- a branch between the loads of a block row and their uses makes the
+    // compiler wait for every load on the spot and keep the results in scratch across the branch: kernels_q1.h)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) bv[g] = a.Lmu[4 * g + ii];
+    if (a.prop_lambda) {                                              // rr = Lambda_i * hp.mu (:285); wave-uniform
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            double lm = 0.0;
+#pragma unroll 1
+            for (int q = 0; q < K; ++q) lm = fma(LF[4 * g + ii + q * K], a.mu[q], lm);
+            bv[g] = lm;
+        }
+    }
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const double rsel = __shfl(rr[g], (lane & ~3) | ii);          // rr of index 4 g + ii (held by the lanes x = ii of this quad)
-        double lm = a.Lmu[4 * g + ii];
-        if (a.prop_lambda) {                                          // rr = Lambda_i * hp.mu (:285)
-            lm = 0.0;
-            for (int q = 0; q < K; ++q) lm = fma(LF[4 * g + ii + q * K], a.mu[q], lm);
-        }
-        bv[g] = (jj == 0) ? lm + rsel : 0.0;
+        bv[g] = (jj == 0) ? bv[g] + rsel : 0.0;
     }
 
     // ---- blocked Cholesky Lambda* = R^T R (:306) + forward solve (:321), four columns in lockstep

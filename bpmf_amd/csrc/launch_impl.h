@@ -369,8 +369,15 @@ void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items
     const bool dist = c->comm && !self->bounds.empty();
     t->pstream = ps;
     if (beside) (void)hipStreamWaitEvent(ps, t->in_ev, 0);
+    // users.predict(movies) (c++/bpmf.cpp:190): the twin's entries with the roles of the two factor matrices swapped, on
+    // the same stream and AHEAD of this evaluation, so that the completion event below covers both
+    if (t->twin && t->twin->nnz > 0) {
+        t->twin->in_ev = t->in_ev;
+        predict<K>(t->twin, t->twin->side, other_items, self_items, n, ps, false);
+        t->twin->launched = true;
+    }
     // se | se_avg of this rank's test ratings: straight to the host, or -> all-reduce -> host
-    double *red = c->d_red + c->out_words;          // 2 spare words behind the sampler's blob
+    double *red = c->d_red + c->out_words + (t->owner ? 2 : 0);      // 2 spare words behind the sampler's blob (the twin: the next 2)
     if constexpr (K == 128) {
         hipLaunchKernelGGL(bpmf::k_predict_f32<K>, dim3((unsigned)t->nblocks), dim3(256), 0, ps,
                            (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz,

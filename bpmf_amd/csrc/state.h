@@ -209,6 +209,9 @@ struct bpmf_hip_side {
     // overlap of exchange and sampling (bpmf_hip_side_set_overlap): every rank's range is cut into nsub parts of
     // equal work; part c of every rank is exchanged on the stream `sx` while part c + 1 is being sampled
     int nsub = 1;
+    // bounded staleness (bpmf_hip_side_set_staleness): part p of this side travels only in the half-iterations with
+    // (p + iter) % (stale_k + 1) == 0 (and in iteration 0); in between the peers sample from the copy they have
+    int stale_k = 0;
     std::vector<int64_t> sub_bounds;     // nranks x (nsub + 1): global column bounds of the parts of every rank
     std::vector<int> sub_item_off;       // nsub + 1: the work items of part c are [off[c], off[c+1]) of the item arrays
     int item_off = 0, item_n = -1;       // item window of the launch being enqueued (-1: the whole list)
@@ -302,6 +305,9 @@ struct bpmf_hip_test {
     // requested, not yet enqueued (flush_deferred): the factor copies it reads, captured at the request
     bool deferred = false, cancelled = false; int def_n = 0; struct bpmf_hip_side *def_other = nullptr;
     const void *def_self_items = nullptr, *def_other_items = nullptr;
+    // users.predict(movies) of c++/bpmf.cpp:190: the test matrix of the OTHER side (transposed entries), evaluated with
+    // the roles swapped whenever this one is (bpmf_hip_test_set_twin); owner: the test matrix this one is the twin of
+    struct bpmf_hip_test *twin = nullptr, *owner = nullptr;
 };
 
 // sticky "a device-side wait timed out" word of a result blob (prod | sum | failD | fail | TMO | - | flag)

@@ -148,7 +148,7 @@ class TorchComm:
         return t.cpu().numpy()
 
 
-def build_sharded(engine, comm, M, Mt, T, nusers, nmovies, mean_rating=None, conn=True):
+def build_sharded(engine, comm, M, Mt, T, nusers, nmovies, mean_rating=None, conn=True, Tt=None):
     """Creates the two `Sys` of this rank: contiguous nnz-balanced column ranges of both sides
     (the reference's assign(), c++/assign.cpp:52-58,109-120, without the permutation), CSC
     slices of exactly those ranges, full factor replicas bound to tensors the collectives use."""
@@ -162,11 +162,12 @@ def build_sharded(engine, comm, M, Mt, T, nusers, nmovies, mean_rating=None, con
     dom_m, dom_u = (bm[rank], bm[rank + 1]), (bu[rank], bu[rank + 1])
     movies = Sys("movs", engine, synth.slice_cols(M, *dom_m), nmovies, nusers,
                  T=synth.slice_cols(T, *dom_m) if T is not None else None, dom=dom_m, mean_rating=mean_rating, comm=comm)
-    users = Sys("users", engine, synth.slice_cols(Mt, *dom_u), nusers, nmovies, dom=dom_u, mean_rating=mean_rating, comm=comm)
+    users = Sys("users", engine, synth.slice_cols(Mt, *dom_u), nusers, nmovies,
+                T=synth.slice_cols(Tt, *dom_u) if Tt is not None else None, dom=dom_u, mean_rating=mean_rating, comm=comm)
     # who reads what (c++/assign.cpp:204-241): sampling the movies of rank r reads the users rated in
     # them, predict() of rank r reads the users of its test entries; sampling users reads movies
     conn_u = conn_lists(connectivity(M, bm, T), bu, rank)            # exchange of the USERS' columns
-    conn_m = conn_lists(connectivity(Mt, bu), bm, rank)              # exchange of the MOVIES' columns
+    conn_m = conn_lists(connectivity(Mt, bu, Tt), bm, rank)          # exchange of the MOVIES' columns (users.predict(movies) reads them too)
     movies.conn_used = bool(conn and conn_pays(conn_m, bm, rank))
     users.conn_used = bool(conn and conn_pays(conn_u, bu, rank))
     movies.conn_lists, users.conn_lists = conn_m, conn_u
@@ -192,9 +193,11 @@ def gibbs_sharded(engine, comm, M, Mt, T, nusers, nmovies, nsims=20, burnin=5, a
     res["final_rmse_avg"] = movies.rmse_avg
     # replicas as the loop leaves them (with the connectivity-aware exchange: only the columns this rank reads are current)
     res["U_replica"] = users.items(); res["V_replica"] = movies.items()
-    if movies.conn_used:
+    import os
+    stale = int(os.environ.get("BPMF_HIP_STALE", "0") or 0) > 0       # bounded-staleness exchange: replicas may lag behind
+    if movies.conn_used or stale:
         comm.full_gather(movies)
-    if users.conn_used:
+    if users.conn_used or stale:
         comm.full_gather(users)
     res["U"] = users.items(); res["V"] = movies.items()
     res["conn_used"] = (movies.conn_used, users.conn_used)

@@ -83,6 +83,10 @@ class HipEngine:
         """Cut every rank's range into `nparts` parts: part c is exchanged while part c + 1 is sampled (collective)."""
         _lib.check(self.lib.bpmf_hip_side_set_overlap(side.handle, int(nparts)))
 
+    def side_set_staleness(self, side, k):
+        """Bounded-staleness exchange: a part of the side travels every (k + 1)-th half-iteration only (include/bpmf_hip.h)."""
+        _lib.check(self.lib.bpmf_hip_side_set_staleness(side.handle, int(k)))
+
     def sys_set_reduce(self, a, b, on=True):
         """BPMF_REDUCE formulation for the pair of sides (preComputeMuLambda + reduce onto the owners; include/bpmf_hip.h)."""
         _lib.check(self.lib.bpmf_hip_sys_set_reduce(a.handle, b.handle, 1 if on else 0))
@@ -245,6 +249,10 @@ class HipEngine:
             self._tests = []
         self._tests.append(t)
         return t
+
+    def test_set_twin(self, test, twin):
+        """users.predict(movies): `twin` (a test matrix of the other side) is evaluated whenever `test` is."""
+        _lib.check(self.lib.bpmf_hip_test_set_twin(test[0], twin[0] if twin is not None else None))
 
     def test_destroy(self, test):
         if test[0]:

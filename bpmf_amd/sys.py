@@ -137,6 +137,9 @@ class Sys:
         n = 0 if self.iter < Sys.burnin else self.iter - Sys.burnin          # :50
         if self.test is None:
             return
+        if getattr(self, "_twin_of", None) is not None:                    # evaluated with its owner: only the sums are collected here
+            self.predict_finish()
+            return
         se, se_avg, nump = self.engine.predict(self.test, self.side, other.side, n)
         if self.comm is not None and not getattr(self.comm, "native", False) and all:
             red = self.comm.allreduce(np.array([se, se_avg, float(nump)]))
@@ -144,6 +147,13 @@ class Sys:
         self.num_predict = nump
         self.rmse = math.sqrt(se / nump) if nump else float("nan")
         self.rmse_avg = math.sqrt(se_avg / nump) if nump else float("nan")
+
+    def set_twin(self, other):
+        """`other.predict(self)` of the reference's loop (c++/bpmf.cpp:190) rides with every self.predict(other): `other`
+        must hold the transposed test entries (its own T).  Its sums: other.predict_finish() after self's."""
+        self.engine.test_set_twin(self.test, other.test)
+        self._twin = other
+        other._twin_of = self
 
     def predict_launch(self, other):
         """First half of predict(): enqueue the evaluation behind the samplers.  The caller may start
@@ -167,14 +177,16 @@ class Sys:
             Sys.procid, phase, self.iter, self.rmse, self.rmse_avg, norm_u, norm_m, items_per_sec, ratings_per_sec / 1e6)
 
 
-def gibbs(engine, M, Mt, T, nusers, nmovies, nsims=20, burnin=5, alpha=2.0, out=None, keep_samples=False):
+def gibbs(engine, M, Mt, T, nusers, nmovies, nsims=20, burnin=5, alpha=2.0, out=None, keep_samples=False, Tt=None):
     """The loop of main() (c++/bpmf.cpp:131-253) in NO_COMM mode.  M / T: CSC
     with one column per movie (rows = users); Mt its transpose.  Returns a dict
     with the per-iteration trace; `out` (a file object) receives the reference's
     stdout lines."""
     Sys.nsims, Sys.burnin, Sys.alpha = nsims, burnin, alpha
     movies = Sys("movs", engine, M, nmovies, nusers, T=T)
-    users = Sys("users", engine, Mt, nusers, nmovies)
+    users = Sys("users", engine, Mt, nusers, nmovies, T=Tt)
+    if Tt is not None:
+        movies.set_twin(users)                       # users.predict(movies) rides with movies.predict(users)
     res = dict(rmse=[], rmse_avg=[], norm_u=[], norm_m=[], secs=[], samples=[])
     nnz = movies.local_nnz
     avg_items = 0.0
@@ -182,7 +194,9 @@ def gibbs(engine, M, Mt, T, nusers, nmovies, nsims=20, burnin=5, alpha=2.0, out=
         start = time.perf_counter()
         movies.sample(users)
         users.sample(movies)
-        movies.predict(users)                        # users.predict(movies) has no observable effect: see DESIGN.md
+        movies.predict(users)
+        if Tt is not None:
+            users.predict(movies)                    # c++/bpmf.cpp:190 (nothing reads its results; Tt = None leaves it out)
         stop = time.perf_counter()
         movies.refresh(); users.refresh()
         ips = (users.num() + movies.num()) / (stop - start)
@@ -196,6 +210,8 @@ def gibbs(engine, M, Mt, T, nusers, nmovies, nsims=20, burnin=5, alpha=2.0, out=
         if keep_samples:
             res["samples"].append((users.items(), movies.items()))
     movies.predict(users, True)                      # c++/bpmf.cpp:242 (the extra call of Q6)
+    if Tt is not None:
+        users.predict(movies)                        # (the twin was evaluated with it: collect its sums)
     res["final_rmse_avg"] = movies.rmse_avg
     res["num_predict"] = movies.num_predict
     res["U"] = users.items(); res["V"] = movies.items()

@@ -109,6 +109,15 @@ BPMF_API int bpmf_hip_side_set_ranges(bpmf_hip_side *side, const int64_t *bounds
  * samples as without parts. */
 BPMF_API int bpmf_hip_side_set_overlap(bpmf_hip_side *side, int nparts);
 
+/* Bounded-staleness exchange (third variant; the reference's relaxations: random send throttling of the
+ * GASPI back-end, `send_prob`, c++/bpmf_gaspi.h:91-104, and the blocks up to `slack` iterations old of
+ * c++/mpi_allreduce.h:134-175).  Part p of the side (the whole range if uncut) travels only in the half-iterations with
+ * (p + iter) % (k + 1) == 0 and in iteration 0; in between the peers sample from the copy they have: at most k
+ * half-iterations old, 1 / (k + 1) of the traffic.  Own columns and the all-reduced statistics stay exact.  k = 0
+ * (default): the exact chain.  Every rank sets the same k (or BPMF_HIP_STALE=k in the environment of all ranks).
+ * bpmf_hip_side_exchange brings the replicas up to date.  A relaxation: results differ from the reference's. */
+BPMF_API int bpmf_hip_side_set_staleness(bpmf_hip_side *side, int k);
+
 /* The BPMF_REDUCE formulation of the reference (`Sys::preComputeMuLambda`, c++/sample.cpp:234-246; the
  * sampler reading precMu / precLambda, :289-291; `other.preComputeMuLambda(*this)` after a side's columns, :375-377; the
  * per-owner MPI_Reduce of c++/mpi_reduce.h:24-47).  For a pair of sides: after side S has been sampled, the Gram and rhs
@@ -246,6 +255,11 @@ BPMF_API int bpmf_hip_predict(bpmf_hip_test *test, const bpmf_hip_side *self, co
  * beside them.  Otherwise it runs in order on the main stream.  Same results either way. */
 BPMF_API int bpmf_hip_predict_launch(bpmf_hip_test *test, const bpmf_hip_side *self, const bpmf_hip_side *other, int n);
 BPMF_API int bpmf_hip_predict_finish(bpmf_hip_test *test, double *se, double *se_avg, int64_t *count);
+/* `users.predict(movies)` of the reference's loop (c++/bpmf.cpp:190; inside its timed region, its results never
+ * printed): `twin` is a test matrix created on the OTHER side from the transposed test entries; it is evaluated with
+ * the roles of the two factor matrices swapped whenever `test` is (same launch sequence, its own Pavg / Pm2 and sums).
+ * Collect its sums with bpmf_hip_predict_finish(twin, ...) after those of `test`.  twin = NULL detaches. */
+BPMF_API int bpmf_hip_test_set_twin(bpmf_hip_test *test, bpmf_hip_test *twin);
 /* Pavg / Pm2 in the nnz order of the slice passed to _test_create (Pavg.sdm /
  * Pm2.sdm outputs, c++/bpmf.cpp:229-230) */
 BPMF_API int bpmf_hip_test_get(bpmf_hip_test *test, double *pavg_host, double *pm2_host);

@@ -339,6 +339,51 @@ def test_fused_launch_is_the_same_chain(hip_engine_factory, monkeypatch, K):
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_users_predict_rides_with_movies_predict(hip_engine_factory, pipelined):
+    """users.predict(movies) of the reference's loop (c++/bpmf.cpp:190): the twin evaluation (bpmf_hip_test_set_twin) runs
+    with every movies.predict(users), roles swapped, its own Pavg / Pm2 (Q6's running mean included).  Same predictions
+    as the movies side, entry for entry, hence the same sums; and the chain itself is untouched."""
+    import scipy.sparse as sp
+    from bpmf_amd.sys import Sys
+    K = 16
+    M, Mt, T, Tt, nu, nm = util.ml100k()
+    eng = hip_engine_factory(K)
+    Sys.nsims, Sys.burnin, Sys.alpha = 7, 2, 2.0
+    movies = Sys("movs", eng, M, nm, nu, T=T); users = Sys("users", eng, Mt, nu, nm, T=Tt)
+    movies.set_twin(users)
+    plain_m = Sys("movs", eng, M, nm, nu, T=T); plain_u = Sys("users", eng, Mt, nu, nm)
+    tr = []
+    for i in range(7):
+        movies.sample(users); users.sample(movies)
+        plain_m.sample(plain_u); plain_u.sample(plain_m); plain_m.predict(plain_u)
+        if pipelined:
+            if i > 0:
+                movies.predict_finish(); users.predict_finish()
+                tr.append((movies.rmse, movies.rmse_avg, users.rmse, users.rmse_avg))
+            movies.predict_launch(users)
+        else:
+            movies.predict(users); users.predict(movies)
+            tr.append((movies.rmse, movies.rmse_avg, users.rmse, users.rmse_avg))
+            assert movies.rmse == plain_m.rmse and movies.rmse_avg == plain_m.rmse_avg
+    if pipelined:
+        movies.predict_finish(); users.predict_finish()
+        tr.append((movies.rmse, movies.rmse_avg, users.rmse, users.rmse_avg))
+    tr = np.asarray(tr)
+    assert len(tr) == 7 and np.all(np.isfinite(tr))
+    assert np.allclose(tr[:, 0], tr[:, 2], rtol=1e-12) and np.allclose(tr[:, 1], tr[:, 3], rtol=1e-12)
+    assert users.num_predict == movies.num_predict == int(T[0][-1])
+    # entry for entry: Pavg / Pm2 of the users' copy are those of the movies' copy, transposed
+    pm, qm = eng.test_get(movies.test); pu, qu = eng.test_get(users.test)
+    A = sp.csc_matrix((np.arange(len(T[2]), dtype=np.float64) + 1.0, T[1], T[0]), shape=(nu, nm))
+    At = A.T.tocsc(); At.sort_indices()
+    perm = At.data.astype(np.int64) - 1                     # entry e of Tt is entry perm[e] of T
+    assert np.allclose(pu, pm[perm], rtol=1e-13, atol=1e-13) and np.allclose(qu, qm[perm], rtol=1e-12, atol=1e-12)
+    assert np.array_equal(movies.items(), plain_m.items()) and np.array_equal(users.items(), plain_u.items())
+    for sd in (movies, users, plain_m, plain_u):
+        eng.side_destroy(sd.side)
+
+
 def test_posterior_moments_of_one_column(hip_engine_factory):
     """Statistical check that does not involve the oracle: many draws of the same column
     (different iter => different streams) have mean Lambda*^-1 b and covariance Lambda*^-1."""

@@ -20,6 +20,14 @@ j=json.loads([l for l in open("gpurun_out/r3_bench_mode$m.json") if l.startswith
 print("mode $m", j["roofline"]["kernel"], "ms/step", j["ms_per_step"], "launch", j["roofline"]["launch_ms_per_side"], "value", j["value"], "rmse", j["rmse"])
 PY
              done ;;
+    q1ab)    for ab in 1 8 0; do BPMF_HIP_MODE=6 python bench.py --no-cpu-baseline --no-strong --ablate $ab --steps 200 > gpurun_out/r3_q1ab$ab.json 2> gpurun_out/r3_q1ab$ab.err; python - <<PY
+import json
+j=json.loads([l for l in open("gpurun_out/r3_q1ab$ab.json") if l.startswith("{")][-1])
+print("mode 6 ablate $ab", j["roofline"]["kernel"], "ms/step", j["ms_per_step"], "launch", j["roofline"]["launch_ms_per_side"])
+PY
+             done ;;
+    q1shapes) for shape in "32 24000 14800 4000000" "32 60400 37060 10000000" "32 300000 100000 20000000" "16 60400 37060 10000000"; do for m in 1 3 6; do
+               echo "shape $shape mode $m: $(BPMF_HIP_MODE=$m python tools/shape_bench.py $shape 20 2>&1 | tail -1)"; done; done > gpurun_out/r3_q1shapes.log 2>&1; cat gpurun_out/r3_q1shapes.log ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
