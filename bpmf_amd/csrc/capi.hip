@@ -1961,7 +1961,7 @@ extern "C" int bpmf_hip_predict_launch(bpmf_hip_test *t, const bpmf_hip_side *se
     bpmf_hip_side *other = const_cast<bpmf_hip_side *>(other_c);
     HIP_TRY(hipSetDevice(c->device));
     const bool dist = c->comm && !self->bounds.empty();
-    if (t->twin && t->twin->nnz == 0) t->twin->launched = true;     // (nothing to enqueue for it)
+    if (t->twin && t->twin->nnz == 0 && !dist) t->twin->launched = true;     // (nothing to enqueue for it)
     if (t->nnz == 0 && !dist) {
         t->launched = true;
         if (t->twin && t->twin->nnz > 0) return fail(BPMF_HIP_EINVAL, "predict_launch: empty test matrix with a non-empty twin");

@@ -371,7 +371,7 @@ void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items
     if (beside) (void)hipStreamWaitEvent(ps, t->in_ev, 0);
     // users.predict(movies) (c++/bpmf.cpp:190): the twin's entries with the roles of the two factor matrices swapped, on
     // the same stream and AHEAD of this evaluation, so that the completion event below covers both
-    if (t->twin && t->twin->nnz > 0) {
+    if (t->twin && (t->twin->nnz > 0 || dist)) {                     // (sharded: its all-reduce is collective, entries or not)
         t->twin->in_ev = t->in_ev;
         predict<K>(t->twin, t->twin->side, other_items, self_items, n, ps, false);
         t->twin->launched = true;
