@@ -100,6 +100,17 @@ struct FusedArgs {
     unsigned long long *st_tmo;        // sticky time-out word of the side the statistics belong to
 };
 
+// users.predict(movies) fused into movies.predict(users) (k_predict): the same prediction goes into the other side's copy
+// of the test entries as well -- entry q of this test matrix is entry perm[q] of the twin (its transpose).  perm = NULL: none.
+struct TwinArgs {
+    const int32_t *perm;
+    double *pavg, *pm2;         // the twin's running mean / M2 (its own entry order)
+    double mean;                // the twin side's mean_rating (c++/sample.cpp:78 adds the predicting Sys's own)
+    double *partial;            // block partials of the twin's two sums
+    double *out;                // the twin's pinned se | se_avg | flag
+    unsigned *flag; unsigned seq;
+};
+
 // one workgroup per column (kernels_f32.h): the fp32 large-K path, and K = 64 in fp64 behind BPMF_HIP_MODE=2
 template <typename T>
 struct SampleArgsW {

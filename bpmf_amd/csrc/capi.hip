@@ -1823,6 +1823,8 @@ extern "C" int bpmf_hip_test_create(bpmf_hip_side *side, const int64_t *tcolptr,
     bpmf_hip_test *t = new (std::nothrow) bpmf_hip_test();
     if (!t) return fail(BPMF_HIP_ENOMEM, "test_create: out of host memory");
     t->side = side; t->nnz = nnz;
+    t->h_col.resize((size_t)nnz); t->h_row.assign(trowidx, trowidx + nnz);
+    for (int64_t p = 0; p < nnz; ++p) t->h_col[(size_t)p] = (int32_t)(side->from + tcol[(size_t)p]);
     if (hipHostMalloc((void **)&t->h_res, 4 * sizeof(double), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **)&t->h_res_dev, t->h_res, 0) != hipSuccess) {
         delete t;
@@ -1874,6 +1876,7 @@ extern "C" int bpmf_hip_test_destroy(bpmf_hip_test *t)
     if (t->owner) {                                                   // a twin: its owner's evaluation in flight reads its arrays
         flush_deferred(t->owner);
         (void)hipStreamSynchronize(live_pstream(t->owner));
+        if (t->owner->d_twin_perm) { (void)hipFree(t->owner->d_twin_perm); t->owner->d_twin_perm = nullptr; }
         t->owner->twin = nullptr; t->owner = nullptr;
     }
     if (t->twin) { flush_deferred(t); t->twin->owner = nullptr; t->twin->launched = false; t->twin = nullptr; }
@@ -1892,7 +1895,7 @@ extern "C" int bpmf_hip_test_destroy(bpmf_hip_test *t)
     }
     if (t->ev_in) (void)hipEventDestroy(t->ev_in);
     for (hipEvent_t e : t->ev_done) if (e) (void)hipEventDestroy(e);
-    void *ptrs[] = {t->d_tcol, t->d_trow, t->d_tval, t->d_pavg, t->d_pm2, t->d_partial, t->d_ticket};
+    void *ptrs[] = {t->d_tcol, t->d_trow, t->d_tval, t->d_pavg, t->d_pm2, t->d_partial, t->d_ticket, t->d_twin_perm};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (t->h_res) (void)hipHostFree(t->h_res);
     delete t;
@@ -1943,9 +1946,43 @@ extern "C" int bpmf_hip_test_set_twin(bpmf_hip_test *t, bpmf_hip_test *twin)
     if (t->launched || (twin && twin->launched)) return fail(BPMF_HIP_EINVAL, "test_set_twin: an evaluation is in flight");
     if (twin && (twin == t || twin->side == t->side || twin->side->ctx != t->side->ctx || twin->side->ncols != t->side->nrows || twin->owner))
         return fail(BPMF_HIP_EINVAL, "test_set_twin: the twin must sit on the other side of the same pair");
+    HIP_TRY(hipSetDevice(t->side->ctx->device));
     if (t->twin) t->twin->owner = nullptr;
+    if (t->d_twin_perm) { (void)hipFree(t->d_twin_perm); t->d_twin_perm = nullptr; }
     t->twin = twin;
-    if (twin) twin->owner = t;
+    if (!twin) return BPMF_HIP_OK;
+    twin->owner = t;
+    // Same entries, transposed?  Then one kernel serves both copies: entry q of `t` is entry perm[q] of the twin.
+    // (Otherwise -- shards of different column ranges -- the twin keeps a kernel of its own.)
+    bpmf_hip_ctx *c = t->side->ctx;
+    const bool whole = t->side->to - t->side->from == t->side->ncols && twin->side->to - twin->side->from == twin->side->ncols;
+    if (whole && c->dtype == BPMF_HIP_F64 && t->nnz == twin->nnz && t->nnz > 0 && t->nnz < ((int64_t)1 << 31)) {
+        const int64_t n = t->nnz, ncm = t->side->ncols;
+        std::vector<int64_t> ka((size_t)n), kb((size_t)n);
+        std::vector<int32_t> ia((size_t)n), ib((size_t)n);
+        for (int64_t q = 0; q < n; ++q) {
+            ka[(size_t)q] = (int64_t)t->h_row[(size_t)q] * ncm + t->h_col[(size_t)q];           // (user, movie) of t's entry
+            kb[(size_t)q] = (int64_t)twin->h_col[(size_t)q] * ncm + twin->h_row[(size_t)q];     // ... of the twin's
+            ia[(size_t)q] = ib[(size_t)q] = (int32_t)q;
+        }
+        std::sort(ia.begin(), ia.end(), [&](int32_t x, int32_t y) { return ka[(size_t)x] < ka[(size_t)y]; });
+        std::sort(ib.begin(), ib.end(), [&](int32_t x, int32_t y) { return kb[(size_t)x] < kb[(size_t)y]; });
+        std::vector<int32_t> perm((size_t)n);
+        bool ok = true;
+        for (int64_t q = 0; q < n && ok; ++q) {
+            ok = ka[(size_t)ia[(size_t)q]] == kb[(size_t)ib[(size_t)q]] && (q == 0 || ka[(size_t)ia[(size_t)q]] != ka[(size_t)ia[(size_t)q - 1]]);
+            perm[(size_t)ia[(size_t)q]] = ib[(size_t)q];
+        }
+        if (ok) {
+            int rc;
+            if ((rc = dev_upload(&t->d_twin_perm, perm.data(), perm.size()))) return rc;
+            // the fused kernel writes the twin's block partials with the OWNER's grid
+            if (twin->nblocks < t->nblocks) {
+                if (twin->d_partial) (void)hipFree(twin->d_partial);
+                if ((rc = dev_upload<double>(&twin->d_partial, nullptr, (size_t)t->nblocks * 2))) return rc;
+            }
+        }
+    }
     return BPMF_HIP_OK;
 }
 

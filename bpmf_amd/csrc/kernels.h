@@ -1439,13 +1439,13 @@ __global__ __launch_bounds__(256) void k_predict(const int32_t *__restrict__ tco
                                                  const double *__restrict__ items, const double *__restrict__ other,
                                                  int64_t col_from, double mean, int n, double *__restrict__ pavg,
                                                  double *__restrict__ pm2, double *partial, double *__restrict__ out,
-                                                 unsigned *ticket, unsigned *flag, unsigned seq)
+                                                 unsigned *ticket, unsigned *flag, unsigned seq, TwinArgs tw)
 {
-    __shared__ double red[2][4];
-    __shared__ double fin[2][256];
+    __shared__ double red[4][4];
+    __shared__ double fin[4][256];
     __shared__ unsigned last;
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    double se = 0.0, se_avg = 0.0;
+    double se = 0.0, se_avg = 0.0, se_t = 0.0, se_avg_t = 0.0;
     if (q < nnz) {
         const double2 *m = reinterpret_cast<const double2 *>(items + (size_t)(col_from + tcol[q]) * K);
         const double2 *u = reinterpret_cast<const double2 *>(other + (size_t)trow[q] * K);
@@ -1465,18 +1465,37 @@ __global__ __launch_bounds__(256) void k_predict(const int32_t *__restrict__ tco
         pavg[q] = avg;
         pm2[q] = (n == 0) ? 0.0 : pm2[q] + delta * (pred - avg);    // :86
         se_avg = (v - avg) * (v - avg);
+        if (tw.perm) {
+            // users.predict(movies), c++/bpmf.cpp:190: the same dot product (the two sides' roles swapped), plus THAT
+            // side's mean, into ITS copy of the entry (Pavg / Pm2 of the second Sys, c++/sample.cpp:132-137)
+            const int qt = tw.perm[q];
+            const double pred_t = (d0 + d1) + tw.mean;
+            se_t = (v - pred_t) * (v - pred_t);
+            double avg_t = tw.pavg[qt];
+            const double delta_t = pred_t - avg_t;
+            avg_t = (n == 0) ? pred_t : (avg_t + delta_t / n);
+            tw.pavg[qt] = avg_t;
+            tw.pm2[qt] = (n == 0) ? 0.0 : tw.pm2[qt] + delta_t * (pred_t - avg_t);
+            se_avg_t = (v - avg_t) * (v - avg_t);
+        }
     }
 #pragma unroll
     for (int sh = 32; sh >= 1; sh >>= 1) {
         se += __shfl_xor(se, sh);
         se_avg += __shfl_xor(se_avg, sh);
+        se_t += __shfl_xor(se_t, sh);
+        se_avg_t += __shfl_xor(se_avg_t, sh);
     }
     const int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[0][wv] = se; red[1][wv] = se_avg; }
+    if ((threadIdx.x & 63) == 0) { red[0][wv] = se; red[1][wv] = se_avg; red[2][wv] = se_t; red[3][wv] = se_avg_t; }
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_store(&partial[2 * blockIdx.x], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), BPMF_RLX_AGENT);
         __hip_atomic_store(&partial[2 * blockIdx.x + 1], (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]), BPMF_RLX_AGENT);
+        if (tw.perm) {
+            __hip_atomic_store(&tw.partial[2 * blockIdx.x], (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]), BPMF_RLX_AGENT);
+            __hip_atomic_store(&tw.partial[2 * blockIdx.x + 1], (red[3][0] + red[3][1]) + (red[3][2] + red[3][3]), BPMF_RLX_AGENT);
+        }
         // the last block to arrive adds the block partials up (fixed-shape tree: the result does
         // not depend on which block that is) and publishes the two sums
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1487,23 +1506,35 @@ __global__ __launch_bounds__(256) void k_predict(const int32_t *__restrict__ tco
     if (!last) return;
     {
         const int64_t nblocks = gridDim.x;
-        double a = 0.0, b = 0.0;
+        double a = 0.0, b = 0.0, at = 0.0, bt = 0.0;
         for (int64_t w = threadIdx.x; w < nblocks; w += 256) {
             a += __hip_atomic_load(&partial[2 * w], BPMF_RLX_AGENT);
             b += __hip_atomic_load(&partial[2 * w + 1], BPMF_RLX_AGENT);
+            if (tw.perm) {
+                at += __hip_atomic_load(&tw.partial[2 * w], BPMF_RLX_AGENT);
+                bt += __hip_atomic_load(&tw.partial[2 * w + 1], BPMF_RLX_AGENT);
+            }
         }
-        fin[0][threadIdx.x] = a; fin[1][threadIdx.x] = b;
+        fin[0][threadIdx.x] = a; fin[1][threadIdx.x] = b; fin[2][threadIdx.x] = at; fin[3][threadIdx.x] = bt;
         __syncthreads();
         for (int st = 128; st >= 1; st >>= 1) {
-            if ((int)threadIdx.x < st) { fin[0][threadIdx.x] += fin[0][threadIdx.x + st]; fin[1][threadIdx.x] += fin[1][threadIdx.x + st]; }
+            if ((int)threadIdx.x < st) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) fin[c][threadIdx.x] += fin[c][threadIdx.x + st];
+            }
             __syncthreads();
         }
         if (threadIdx.x == 0) {
             __hip_atomic_store(&out[0], fin[0][0], BPMF_RLX_SYSTEM);
             __hip_atomic_store(&out[1], fin[1][0], BPMF_RLX_SYSTEM);
+            if (tw.perm) {
+                __hip_atomic_store(&tw.out[0], fin[2][0], BPMF_RLX_SYSTEM);
+                __hip_atomic_store(&tw.out[1], fin[3][0], BPMF_RLX_SYSTEM);
+            }
             __hip_atomic_store(ticket, 0u, BPMF_RLX_AGENT);          // re-arm
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(flag, seq, BPMF_RLX_SYSTEM);
+            if (tw.perm) __hip_atomic_store(tw.flag, tw.seq, BPMF_RLX_SYSTEM);
         }
     }
 }

@@ -371,7 +371,8 @@ void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items
     if (beside) (void)hipStreamWaitEvent(ps, t->in_ev, 0);
     // users.predict(movies) (c++/bpmf.cpp:190): the twin's entries with the roles of the two factor matrices swapped, on
     // the same stream and AHEAD of this evaluation, so that the completion event below covers both
-    if (t->twin && (t->twin->nnz > 0 || dist)) {                     // (sharded: its all-reduce is collective, entries or not)
+    const bool fused_twin = t->twin && t->d_twin_perm && !dist && K != 128;
+    if (t->twin && !fused_twin && (t->twin->nnz > 0 || dist)) {      // (sharded: its all-reduce is collective, entries or not)
         t->twin->in_ev = t->in_ev;
         predict<K>(t->twin, t->twin->side, other_items, self_items, n, ps, false);
         t->twin->launched = true;
@@ -389,11 +390,18 @@ void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items
             publish(red, t->h_res_dev, 2, flag, ++t->seq, -1, c->stream);
         }
     } else {
+    bpmf::TwinArgs tw{};
+    if (fused_twin) {                                                 // one kernel, both copies of the test entries
+        bpmf_hip_test *u = t->twin;
+        tw.perm = t->d_twin_perm; tw.pavg = u->d_pavg; tw.pm2 = u->d_pm2; tw.mean = u->side->mean_rating;
+        tw.partial = u->d_partial; tw.out = u->h_res_dev; tw.flag = reinterpret_cast<unsigned *>(u->h_res_dev + 2); tw.seq = ++u->seq;
+        u->pstream = ps; u->launched = true;
+    }
     hipLaunchKernelGGL(bpmf::k_predict<K>, dim3((unsigned)t->nblocks), dim3(256), 0, ps,
                        (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz,
                        (const double *)self_items, (const double *)other_items, self->from, self->mean_rating, n,
                        t->d_pavg, t->d_pm2, t->d_partial, dist ? red : t->h_res_dev, t->d_ticket,
-                       dist ? t->d_ticket + 8 : flag, dist ? 0u : ++t->seq);
+                       dist ? t->d_ticket + 8 : flag, dist ? 0u : ++t->seq, tw);
     if (dist) {
         if (rccl()->AllReduce(red, red, 2, ncclDouble, ncclSum, c->comm, c->stream) != ncclSuccess) return;
         publish(red, t->h_res_dev, 2, flag, ++t->seq, -1, c->stream);

@@ -308,6 +308,10 @@ struct bpmf_hip_test {
     // users.predict(movies) of c++/bpmf.cpp:190: the test matrix of the OTHER side (transposed entries), evaluated with
     // the roles swapped whenever this one is (bpmf_hip_test_set_twin); owner: the test matrix this one is the twin of
     struct bpmf_hip_test *twin = nullptr, *owner = nullptr;
+    // single GPU, fp64: the twin's entries are this matrix's, transposed -- entry q here is entry twin_perm[q] there, and
+    // ONE kernel writes both copies (k_predict's TwinArgs).  NULL: the twin runs as a kernel of its own (sharded, fp32).
+    int32_t *d_twin_perm = nullptr;
+    std::vector<int32_t> h_col, h_row;   // global column / row of every entry (kept for the matching)
 };
 
 // sticky "a device-side wait timed out" word of a result blob (prod | sum | failD | fail | TMO | - | flag)

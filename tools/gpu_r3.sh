@@ -28,6 +28,7 @@ PY
              done ;;
     q1shapes) for shape in "32 24000 14800 4000000" "32 60400 37060 10000000" "32 300000 100000 20000000" "16 60400 37060 10000000"; do for m in 1 3 6; do
                echo "shape $shape mode $m: $(BPMF_HIP_MODE=$m python tools/shape_bench.py $shape 20 2>&1 | tail -1)"; done; done > gpurun_out/r3_q1shapes.log 2>&1; cat gpurun_out/r3_q1shapes.log ;;
+    twin)    timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_cli.py -x -q -m gpu -k "twin or rides or cli or g1 or bpmf" > gpurun_out/r3_twin.log 2>&1; tail -5 gpurun_out/r3_twin.log ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
