@@ -1260,6 +1260,7 @@ int flush_pending_stats(bpmf_hip_ctx *c)
     bpmf_hip_side *P = c->pending_stats;
     if (!P) return 0;
     c->pending_stats = nullptr;
+    c->pending_inorder = false;
     const int K = c->K;
     HIP_TRY(hipSetDevice(c->device));
     hipEvent_t *ev = P->evs[c->pending_evset];
@@ -1271,6 +1272,34 @@ int flush_pending_stats(bpmf_hip_ctx *c)
     HIP_TRY(hipEventRecord(ev[2], P->saux));
     P->stats_ev[c->pending_evset].store(ev[2], std::memory_order_release);
     trace("statistics flushed (no launch to ride in)", P, P->iter);
+    return 0;
+}
+
+// "In-order head start": the pending statistics pass goes onto the MAIN stream, directly ahead of the sampler launch the
+// caller is about to enqueue there, and that launch is flagged hipExtAnyOrderLaunch: its dispatch packet carries no
+// barrier bit, so the command processor hands out its workgroups as soon as the statistics kernel has been LAUNCHED,
+// not finished.  The pass gets what the cross-queue head start bought it -- its workgroups are dispatched first and keep
+// their slots beside a sampler that fills the chip -- without the two event hops that cost (S0 -> S1: the pass waits for
+// the sampler's end; S1 -> S0: the next sampler waits for the marker ahead of the pass; ~30 us per half-iteration in the
+// K = 128 timeline, profiles/r03_timeline_ml1m_k128.txt).  Ordering: the pass is a normal packet behind P's sampler on
+// the same queue; the any-order launch is consumed in queue order behind it, i.e. after P's sampler has completed too.
+int flush_pending_stats_inorder(bpmf_hip_ctx *c)
+{
+    bpmf_hip_side *P = c->pending_stats;
+    if (!P) return 0;
+    c->pending_stats = nullptr;
+    c->pending_inorder = false;
+    const int K = c->K;
+    hipEvent_t *ev = P->evs[c->pending_evset];
+    unsigned *flag = reinterpret_cast<unsigned *>(P->a_h_out_dev + c->out_words - 1);
+    P->stat_a_ready = false;
+    // (completion event on the pass's own dispatch packet: a marker packet behind it would carry a barrier bit and hold the
+    // any-order launch back until the pass has FINISHED)
+    const int rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK>(P, c->stream, P->a_d_in, P->a_h_out_dev, flag, c->pending_seq, P->a_ticket, ev[2]));
+    if (rc) return rc;
+    P->stats_ev[c->pending_evset].store(ev[2], std::memory_order_release);
+    bpmf_launch::next_flags() = hipExtAnyOrderLaunch;                // consumed by the first kernel of the sampler sequence that follows
+    trace("statistics in order ahead of the next sampler", P, P->iter);
     return 0;
 }
 
@@ -1350,7 +1379,8 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     const bool fused = s1 != s0 && !dist && stage_words <= 8192 && fusable_form && self->nwork > 0 && !self->reduce_on &&
                        c->dtype == BPMF_HIP_F64 && env_int("BPMF_HIP_FUSED", 1) != 0;
     bpmf::FusedArgs fz{};
-    bpmf_hip_side *P = c->pending_stats;
+    bool inorder_flush = c->pending_stats != nullptr && c->pending_inorder;   // the partner's pass goes ahead of this launch, on S0
+    bpmf_hip_side *P = inorder_flush ? nullptr : c->pending_stats;
     // statistics waiting for a carrier: they ride here, unless this launch cannot take them, or would
     // overwrite in place the very columns they read (the same side twice in a row without a second copy)
     bool carry = fused && P != nullptr;
@@ -1386,12 +1416,14 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     const bool timed = every > 0 && seq % (unsigned)every == 0;
     const bool ride = s1 != s0 && self->nwork > 0 && env_int("BPMF_HIP_EXT_EVENTS", 1) != 0;   // events on the sampler's own packet
     if (timed && !ride) HIP_TRY(hipEventRecord(ev[0], s0));
+    if (inorder_flush) { if ((rc = flush_pending_stats_inorder(c))) return rc; }
     self->cur_fused = fz;
     self->cur_gate_flag = fused ? self->a_dflag : nullptr; self->cur_gate_want = seq;
     rc = BPMF_DISPATCH_K(K, sample_and_exchange<KK>(self, other, iter, alpha, self->a_d_in, s0, (ride && timed) ? ev[0] : nullptr,
                                                     ride ? ev[1] : nullptr));
     self->cur_gate_flag = nullptr;
     self->cur_fused = bpmf::FusedArgs{};
+    bpmf_launch::next_flags() = 0;                                    // (a sampler sequence without a kernel leaves it pending)
     if (rc) return rc;
     if (!ride) HIP_TRY(hipEventRecord(ev[1], s0));
     c->last_sampler_done = (env_int("BPMF_HIP_EVAL_MARKER", 0) == 0) ? ev[1] : nullptr;   // an evaluation requested next waits for this: no marker of its own on S0
@@ -1408,8 +1440,16 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     const bool partner_fusable = (K <= 32 && (other->mode == 1 || other->mode == 6)) || (K == 64 && other->mode == 4 && other->lr_n == 0 && other->nsub <= 1);
     const bool defer = !fused && !dist && s1 != s0 && c->dtype == BPMF_HIP_F64 && partner_fusable && other->nwork > 0 && other->a_d_in &&
                        self->nwork > 0 && env_int("BPMF_HIP_FUSED", 1) != 0 && env_int("BPMF_HIP_DEFER_STATS", 0) != 0;   // (measured slower: 1.72 against 1.26 ms -- the 2 048 rider waves stream 247 MB at the head of the partner's launch; kept as a switch)
-    if (fused || defer) {
-        c->pending_stats = self; c->pending_seq = seq; c->pending_evset = evset;     // ride in the next launch
+    // unfused side with a stand-alone pass that wants a head start (big side: k_colstats_wg; fp32 path): in order on S0,
+    // ahead of the next sampler launch, which is launched any-order (flush_pending_stats_inorder)
+    // MEASURED SLOWER, off: the queue still ran pass and sampler one after the other (rocprofv3 timeline: the any-order launch
+    // started ~5 us after the pass's last kernel ENDED) -- K = 128 0.857 against 0.818 ms, ChEMBL shape 1.35 against 1.07.
+    static const int stats_inorder = env_int("BPMF_HIP_STATS_INORDER", 0);
+    const bool inorder = stats_inorder && !fused && !defer && !dist && s1 != s0 && self->nwork > 0 && !self->reduce_on && !self->d_stat_list &&
+                         (self->nstat_wg > 0 || c->dtype == BPMF_HIP_F32);
+    if (fused || defer || inorder) {
+        c->pending_stats = self; c->pending_seq = seq; c->pending_evset = evset;     // ride in / go ahead of the next launch
+        c->pending_inorder = inorder;
     } else {
         // (fp32 path: the statistics used to take 0.2 ms from the end of the sampler to the sums, on the critical path of
         // the side's host chain: their 256-thread workgroups had to find room beside the NEXT side's sampler, whose

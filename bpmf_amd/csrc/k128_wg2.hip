@@ -17,11 +17,9 @@ void k128_wg2(int grid, int nwaves, hipStream_t st, hipEvent_t e0, hipEvent_t e1
         }
     }
     if (nwaves == 4) {
-        if (e0 || e1) hipExtLaunchKernelGGL((bpmf::k_sample_wg2<128, 4>), dim3(grid), dim3(256), 0, st, e0, e1, 0, a);
-        else hipLaunchKernelGGL((bpmf::k_sample_wg2<128, 4>), dim3(grid), dim3(256), 0, st, a);
+        BPMF_LAUNCH((bpmf::k_sample_wg2<128, 4>), dim3(grid), dim3(256), st, e0, e1, a);
     } else {
-        if (e0 || e1) hipExtLaunchKernelGGL((bpmf::k_sample_wg2<128, 2>), dim3(grid), dim3(128), 0, st, e0, e1, 0, a);
-        else hipLaunchKernelGGL((bpmf::k_sample_wg2<128, 2>), dim3(grid), dim3(128), 0, st, a);
+        BPMF_LAUNCH((bpmf::k_sample_wg2<128, 2>), dim3(grid), dim3(128), st, e0, e1, a);
     }
 }
 

@@ -7,8 +7,7 @@ namespace bpmf_launch {
 template <typename Kern, typename Args>
 static void go(Kern kernel, int grid, int block, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const Args &a)
 {
-    if (e0 || e1) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, st, e0, e1, 0, a);
-    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, st, a);
+    BPMF_LAUNCH(kernel, dim3(grid), dim3(block), st, e0, e1, a);
 }
 
 void k64_pf(int cls, int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::LrArgs &a)
@@ -22,8 +21,7 @@ void k64_pf(int cls, int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, con
 
 void k64_pf_prepare(int grid, hipStream_t st, hipEvent_t e0, const double *S0t, const double *other_items, int64_t nrows, double *Q)
 {
-    if (e0) hipExtLaunchKernelGGL(bpmf::k_pf_prepare<64>, dim3(grid), dim3(512), 0, st, e0, nullptr, 0, S0t, other_items, nrows, Q);
-    else hipLaunchKernelGGL(bpmf::k_pf_prepare<64>, dim3(grid), dim3(512), 0, st, S0t, other_items, nrows, Q);
+    BPMF_LAUNCH(bpmf::k_pf_prepare<64>, dim3(grid), dim3(512), st, e0, (hipEvent_t) nullptr, S0t, other_items, nrows, Q);
 }
 
 }  // namespace bpmf_launch

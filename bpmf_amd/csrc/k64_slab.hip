@@ -6,8 +6,7 @@ namespace bpmf_launch {
 
 void k64_slab(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a)
 {
-    if (e0 || e1) hipExtLaunchKernelGGL((bpmf::k_sample_slab<64, double>), dim3(grid), dim3(64), 0, st, e0, e1, 0, a);
-    else hipLaunchKernelGGL((bpmf::k_sample_slab<64, double>), dim3(grid), dim3(64), 0, st, a);
+    BPMF_LAUNCH((bpmf::k_sample_slab<64, double>), dim3(grid), dim3(64), st, e0, e1, a);
 }
 
 }  // namespace bpmf_launch

@@ -7,8 +7,7 @@ namespace bpmf_launch {
 template <typename Kern, typename Args>
 static void go(Kern kernel, int grid, int block, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const Args &a)
 {
-    if (e0 || e1) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, st, e0, e1, 0, a);
-    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, st, a);
+    BPMF_LAUNCH(kernel, dim3(grid), dim3(block), st, e0, e1, a);
 }
 
 void k64_wg(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgsW<double> &a)

@@ -4,7 +4,22 @@
 #pragma once
 #include "state.h"
 
+// one kernel launch of a sampler sequence: events ride on the dispatch packet when given, the pending launch flags are consumed
+#define BPMF_LAUNCH(kernel, grid, block, st, e0, e1, ...)                                                         \
+    do {                                                                                                          \
+        const unsigned fl_ = bpmf_launch::take_flags();                                                           \
+        hipEvent_t e0_ = (e0), e1_ = (e1);                                                                        \
+        if (e0_ || e1_ || fl_) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, e0_, e1_, fl_, __VA_ARGS__);    \
+        else hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                                         \
+    } while (0)
+
 namespace bpmf_launch {
+
+// hipExtAnyOrderLaunch for the NEXT sampler launch of this thread, consumed by the first kernel of its sequence: that
+// launch may start while the packet ahead of it in the queue -- the statistics pass of the other side -- is still
+// running (see bpmf_hip_sys_sample: "in-order head start").
+inline unsigned &next_flags() { static thread_local unsigned f = 0; return f; }
+inline unsigned take_flags() { unsigned &f = next_flags(); const unsigned v = f; f = 0; return v; }
 
 // the per-column update of `self` into `out_items`, reading the parameter blob `d_in`
 template <int K>
@@ -17,7 +32,8 @@ template <int K>
 int exchange(bpmf_hip_side *self, hipStream_t st, int sub);
 // sum x / sum x x^T of this rank's columns (+ all-reduce), published to `out_host_dev`
 template <int K>
-int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_host_dev, unsigned *flag, unsigned seq, unsigned *ticket);
+int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_host_dev, unsigned *flag, unsigned seq, unsigned *ticket,
+          hipEvent_t ev_done = nullptr);     // ev_done: rides on the dispatch packet of the pass's last kernel (single GPU; no marker packet behind it)
 // group A of a split statistics pass (see bpmf_hip_side::d_stat_list): partials only, behind the side's ev_stat_a
 template <int K>
 int stats_a(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_host_dev, unsigned *ticket);

@@ -26,8 +26,7 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
     using namespace bpmf;
     bpmf_hip_ctx *c = self->ctx;
     auto launch = [&](auto kernel, dim3 grid, dim3 block, auto args) {
-        if (ev_start || ev_stop) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, ev_start, ev_stop, 0, args);
-        else hipLaunchKernelGGL(kernel, grid, block, 0, st, args);
+        BPMF_LAUNCH(kernel, grid, block, st, ev_start, ev_stop, args);
     };
     // one workgroup per column (k_sample_wg): the fp32 large-K path, and K = 64 in fp64
     auto launch_wg = [&](auto zero) {
@@ -102,8 +101,7 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
                     k64_slab(self->hv_nwork, st, ev_start, nullptr, a);
                 } else if (self->mode == 1) {
                     const FusedArgs f0{};
-                    if (ev_start) hipExtLaunchKernelGGL(k_sample1<K>, dim3(self->hv_nwork), dim3(64), 0, st, ev_start, nullptr, 0, a, f0);
-                    else hipLaunchKernelGGL(k_sample1<K>, dim3(self->hv_nwork), dim3(64), 0, st, a, f0);
+                    BPMF_LAUNCH(k_sample1<K>, dim3(self->hv_nwork), dim3(64), st, ev_start, (hipEvent_t) nullptr, a, f0);
                 } else {
                     const int grid = std::min(self->hv_nwork, env_int("BPMF_HIP_GRID", c->num_cu * 4 * Geo<K>::WPS));
                     k64_persistent(grid, st, ev_start, nullptr, a);
@@ -161,8 +159,7 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
             const FusedArgs &f = self->cur_fused;                    // (all zero outside the fused stateful path)
             if (f.gate_host || f.nstat) {                            // gate workgroup + statistics riders + items in one launch
                 const dim3 grid((unsigned)(nwork + (f.gate_host ? 1 : 0) + f.nstat));
-                if (ev_start || ev_stop) hipExtLaunchKernelGGL(k_sample1s<K>, grid, dim3(64), 0, st, ev_start, ev_stop, 0, a, f);
-                else hipLaunchKernelGGL(k_sample1s<K>, grid, dim3(64), 0, st, a, f);
+                BPMF_LAUNCH(k_sample1s<K>, grid, dim3(64), st, ev_start, ev_stop, a, f);
             } else {
                 k64_slab(nwork, st, ev_start, ev_stop, a);
             }
@@ -173,8 +170,7 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
         if (nwork > 0 && self->mode == 6) {                          // Gram one column per wave, factorisation four columns per wave
             const FusedArgs &f = self->cur_fused;
             const dim3 grid((unsigned)(nwork + (f.gate_host ? 1 : 0) + f.nstat));
-            if (ev_start || ev_stop) hipExtLaunchKernelGGL(k_sample1q<K>, grid, dim3(64), 0, st, ev_start, ev_stop, 0, a, f);
-            else hipLaunchKernelGGL(k_sample1q<K>, grid, dim3(64), 0, st, a, f);
+            BPMF_LAUNCH(k_sample1q<K>, grid, dim3(64), st, ev_start, ev_stop, a, f);
             return 0;
         }
     }
@@ -185,13 +181,11 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
             // the slab form of the item body (kernels_slab.h) behind the same launch format: BPMF_HIP_SLAB32
             static const int slab = env_int("BPMF_HIP_SLAB32", 0);
             if (slab) {
-                if (ev_start || ev_stop) hipExtLaunchKernelGGL(k_sample1s<K>, grid, dim3(64), 0, st, ev_start, ev_stop, 0, a, f);
-                else hipLaunchKernelGGL(k_sample1s<K>, grid, dim3(64), 0, st, a, f);
+                BPMF_LAUNCH(k_sample1s<K>, grid, dim3(64), st, ev_start, ev_stop, a, f);
                 return 0;
             }
         }
-        if (ev_start || ev_stop) hipExtLaunchKernelGGL(k_sample1<K>, grid, dim3(64), 0, st, ev_start, ev_stop, 0, a, f);
-        else hipLaunchKernelGGL(k_sample1<K>, grid, dim3(64), 0, st, a, f);
+        BPMF_LAUNCH(k_sample1<K>, grid, dim3(64), st, ev_start, ev_stop, a, f);
     } else if (nwork > 0) {
         // persistent waves: as many single-wave workgroups as the chip holds at this kernel's occupancy
         const int resident = c->num_cu * 4 * Geo<K>::WPS;
@@ -279,7 +273,8 @@ int exchange(bpmf_hip_side *self, hipStream_t st, int sub)
 }
 
 template <int K>
-int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_host_dev, unsigned *flag, unsigned seq, unsigned *ticket)
+int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_host_dev, unsigned *flag, unsigned seq, unsigned *ticket,
+          hipEvent_t ev_done)
 {
     using namespace bpmf;
     bpmf_hip_ctx *c = self->ctx;
@@ -291,6 +286,10 @@ int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_h
         hipLaunchKernelGGL(k_colstats_f32<K>, dim3(self->nstat_waves * (K / 16) * (K / 16 + 1) / 2), dim3(64), 0, st, reinterpret_cast<const float *>(self->d_items),
                            self->from, self->to, self->nstat_waves, self->d_stat_partials);
         // single GPU: the sums go straight to the pinned blob; sharded: into a device blob, all-reduced, then published
+        if (ev_done && !dist)
+            hipExtLaunchKernelGGL(k_colstats_f32_final<K>, dim3((K * K + K + 255) / 256), dim3(256), 0, st, nullptr, ev_done, 0,
+                                  (const double *)self->d_stat_partials, self->nstat_waves, failp, out_host_dev, ticket, flag, seq);
+        else
         hipLaunchKernelGGL(k_colstats_f32_final<K>, dim3((K * K + K + 255) / 256), dim3(256), 0, st,
                            (const double *)self->d_stat_partials, self->nstat_waves, failp, dist ? red : out_host_dev, ticket,
                            dist ? ticket + 8 : flag, dist ? 0u : seq);
@@ -307,15 +306,27 @@ int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_h
                                (const double *)self->d_items + (size_t)self->from * K, self->stat_nA, self->stat_n, self->stat_wgB, self->d_stat_partials,
                                failp, out_host_dev, ticket, flag, seq, tmo_word(out_host_dev, K), wait_ticks(),
                                (const int32_t *)self->d_stat_list, self->stat_wgA, self->stat_wgA + self->stat_wgB, 1);
-        } else if (self->nstat_wg > 0)
+        } else if (self->nstat_wg > 0) {
+            if (ev_done)
+                hipExtLaunchKernelGGL(k_colstats_wg<K>, dim3(self->nstat_wg), dim3(256), 0, st, nullptr, ev_done, 0,
+                                      (const double *)self->d_items, self->from, self->to, self->nstat_wg, self->d_stat_partials,
+                                      failp, out_host_dev, ticket, flag, seq, tmo_word(out_host_dev, K), wait_ticks(),
+                                      (const int32_t *)nullptr, 0, self->nstat_wg, 1);
+            else
             hipLaunchKernelGGL(k_colstats_wg<K>, dim3(self->nstat_wg), dim3(256), 0, st,
                                (const double *)self->d_items, self->from, self->to, self->nstat_wg, self->d_stat_partials,
                                failp, out_host_dev, ticket, flag, seq, tmo_word(out_host_dev, K), wait_ticks(),
                                (const int32_t *)nullptr, 0, self->nstat_wg, 1);
-        else
+        } else {
+            if (ev_done)
+                hipExtLaunchKernelGGL(k_colstats<K>, dim3(self->nstat_waves), dim3(64), 0, st, nullptr, ev_done, 0,
+                                      (const double *)self->d_items, self->from, self->to, self->nstat_waves, self->d_stat_partials,
+                                      failp, out_host_dev, ticket, flag, seq, tmo_word(out_host_dev, K), wait_ticks());
+            else
         hipLaunchKernelGGL(k_colstats<K>, dim3(self->nstat_waves), dim3(64), 0, st,
                            (const double *)self->d_items, self->from, self->to, self->nstat_waves, self->d_stat_partials,
                            failp, out_host_dev, ticket, flag, seq, tmo_word(out_host_dev, K), wait_ticks());
+        }
     } else {
         // local sums into a device blob, all-reduce them (cov is then formed once from the GLOBAL
         // sums: SURVEY Q19) together with the failed-column word, publish to the host
@@ -416,6 +427,6 @@ void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items
     template int bpmf_launch::sampler_into<KK>(bpmf_hip_side *, double *, const bpmf_hip_side *, int, double, double *, hipStream_t, \
                                                hipEvent_t, hipEvent_t);                                                          \
     template int bpmf_launch::exchange<KK>(bpmf_hip_side *, hipStream_t, int);                                                        \
-    template int bpmf_launch::stats<KK>(bpmf_hip_side *, hipStream_t, const double *, double *, unsigned *, unsigned, unsigned *); \
+    template int bpmf_launch::stats<KK>(bpmf_hip_side *, hipStream_t, const double *, double *, unsigned *, unsigned, unsigned *, hipEvent_t); \
     template int bpmf_launch::stats_a<KK>(bpmf_hip_side *, hipStream_t, const double *, double *, unsigned *);                       \
     template void bpmf_launch::predict<KK>(bpmf_hip_test *, const bpmf_hip_side *, const void *, const void *, int, hipStream_t, bool);

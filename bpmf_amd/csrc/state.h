@@ -131,6 +131,9 @@ struct bpmf_hip_ctx {
     // fused stateful path: the side whose newest half-iteration still has its statistics to run (they
     // ride in the next k_sample1 launch; flush_pending_stats launches them alone if none comes)
     struct bpmf_hip_side *pending_stats = nullptr; unsigned pending_seq = 0; int pending_evset = 0;
+    // ... or, unfused sides with a stand-alone statistics pass (big sides, the fp32 path): the pass goes onto S0 itself just
+    // ahead of the NEXT sampler launch, which is then launched "any order" (no barrier bit): see bpmf_hip_sys_sample
+    bool pending_inorder = false;
     std::vector<bpmf_hip_side *> sides;  // stateful sides with a statistics stream of their own (for ctx_sync)
     bool own_stream = false;
     int num_cu = 256;

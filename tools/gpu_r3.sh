@@ -29,6 +29,14 @@ PY
     q1shapes) for shape in "32 24000 14800 4000000" "32 60400 37060 10000000" "32 300000 100000 20000000" "16 60400 37060 10000000"; do for m in 1 3 6; do
                echo "shape $shape mode $m: $(BPMF_HIP_MODE=$m python tools/shape_bench.py $shape 20 2>&1 | tail -1)"; done; done > gpurun_out/r3_q1shapes.log 2>&1; cat gpurun_out/r3_q1shapes.log ;;
     twin)    timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_cli.py -x -q -m gpu -k "twin or rides or cli or g1 or bpmf" > gpurun_out/r3_twin.log 2>&1; tail -5 gpurun_out/r3_twin.log ;;
+    inorder) timeout 1500 python -m pytest tests/test_gpu_f32.py tests/test_gpu_fullsize.py tests/test_gpu_waits.py -x -q -m gpu > gpurun_out/r3_inorder.log 2>&1; tail -5 gpurun_out/r3_inorder.log
+             for w in ml1m_k128 chembl ml1m_k64; do for io in 1 0; do BPMF_HIP_STATS_INORDER=$io python bench.py --workload $w --no-cpu-baseline --no-strong > gpurun_out/r3_io_${w}_$io.json 2> gpurun_out/r3_io_${w}_$io.err; python - <<PY
+import json
+j=json.loads([l for l in open("gpurun_out/r3_io_${w}_$io.json") if l.startswith("{")][-1])
+print("$w inorder=$io", "ms/step", round(j["ms_per_step"],4), "launch", j["roofline"]["launch_ms_per_side"], "value", round(j["value"]), "rmse", j["rmse"])
+PY
+             done; done
+             bash tools/trace_timeline.sh ml1m_k128 > gpurun_out/r3_tl_k128_inorder.txt 2>&1; head -24 gpurun_out/r3_tl_k128_inorder.txt ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
