@@ -5,6 +5,9 @@
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 R=${1:-r02}; W=${2:-ml1m}; PMC=${3:-1}
 O=gpurun_out/profiles; mkdir -p $O; rm -f $O/${R}_pmc_$W.txt
+# the kernel sources these counters belong to (bench.py reports figures of a profile of OTHER sources as stale)
+echo "# kernel-source-sha: $(python -c 'import bench; print(bench.kernel_source_sha())')" > $O/${R}_pmc_$W.txt
+echo "# rocprofv3 --pmc <one group per pass> --kernel-trace -- python bench.py --workload $W --steps 10 --warmup 2 --repeats 1 --prewarm-ms 0 --no-cpu-baseline --no-strong   (per-launch averages of the sampler kernels)" >> $O/${R}_pmc_$W.txt
 CMD="python bench.py --workload $W --no-cpu-baseline --no-strong"
 rm -rf /tmp/prof_kt; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o kt -- $CMD > $O/${R}_bench_under_rocprof_$W.json 2> /tmp/prof_kt.err
 find /tmp/prof_kt -name "*kernel_stats.csv" -exec cp {} $O/${R}_kernel_stats_$W.csv \;
