@@ -92,7 +92,9 @@ def kernel_source_sha():
     with, and figures of a profile of OTHER code are reported as stale, not as this run's."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "bpmf_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "bpmf_amd", "csrc", "*.hip"))):
+    # (device code only: the kernel headers -- host-side files of csrc/ do not change what a counter sees)
+    for f in sorted(glob.glob(os.path.join(ROOT, "bpmf_amd", "csrc", "kernels*.h")) +
+                    [os.path.join(ROOT, "bpmf_amd", "csrc", n) for n in ("philox.h", "args.h")]):
         h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
@@ -410,6 +412,7 @@ def main():
     ap.add_argument("--no-strong", action="store_true", help="skip the strong_10Mx1M sub-record")
     ap.add_argument("--strong-steps", type=int, default=8, help="timed steps of the strong_10Mx1M record (>= 8: the library times every 8th launch of a side)")
     ap.add_argument("--strong-scale", type=float, default=float(os.environ.get("BPMF_BENCH_STRONG_SCALE", "1.0")))
+    ap.add_argument("--no-users-predict", action="store_true", help="A/B: leave users.predict(movies) (c++/bpmf.cpp:190) out of the step; the line says so")
     ap.add_argument("--ablate", type=int, default=None, help="profiling only: run with BPMF_HIP_ABLATE=<bits> (phases of the sampler skipped, samples WRONG); the line is marked invalid")
     args = ap.parse_args()
     wl = args.workload or {None: "ml1m", 32: "ml1m", 64: "ml1m_k64", 128: "ml1m_k128"}.get(args.K)
@@ -478,7 +481,7 @@ def main():
         dom_m, dom_u = movies.dom, users.dom
     # users.predict(movies) (c++/bpmf.cpp:190: inside the reference's timed region, its results never read) rides with
     # every movies.predict(users) as the twin evaluation of the library
-    both_predicts = users.test is not None and getattr(comm, "native", True)
+    both_predicts = users.test is not None and getattr(comm, "native", True) and not args.no_users_predict
     if both_predicts:
         movies.set_twin(users)
     rccl_nranks = eng.comm_nranks() if getattr(comm, "native", False) else (world if comm is not None else 1)

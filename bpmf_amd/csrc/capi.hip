@@ -1555,9 +1555,9 @@ extern "C" int bpmf_hip_side_schedule_info(const bpmf_hip_side *s, int64_t *out,
     for (int i = 0; i < n; ++i) out[i] = 0;
     out[0] = s->mode; out[1] = s->nwork; out[2] = s->nslots; out[3] = s->nmulti;
     out[4] = s->lr_n; out[5] = s->lr_n > 0 ? s->hv_nwork : s->nwork;
-    for (int pc = 0; pc < 3; ++pc) out[6 + pc] = s->pf_class[pc + 1] - s->pf_class[pc];
+    for (int pc = 0; pc < 3; ++pc) out[6 + pc] = s->lr_n > 0 ? s->pf_class[pc + 1] - s->pf_class[pc] : 0;    // (the classes are only in use when the side is split)
     out[9] = s->lr_n > 0 ? s->lr_class[4] - s->lr_class[0] : 0;
-    out[10] = s->nsub; out[11] = s->to - s->from; out[12] = s->nnz; out[13] = s->pf_ratings; out[14] = s->pf_ratings2;
+    out[10] = s->nsub; out[11] = s->to - s->from; out[12] = s->nnz; out[13] = s->lr_n > 0 ? s->pf_ratings : 0; out[14] = s->lr_n > 0 ? s->pf_ratings2 : 0;
     return BPMF_HIP_OK;
 }
 

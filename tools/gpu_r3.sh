@@ -37,6 +37,12 @@ print("$w inorder=$io", "ms/step", round(j["ms_per_step"],4), "launch", j["roofl
 PY
              done; done
              bash tools/trace_timeline.sh ml1m_k128 > gpurun_out/r3_tl_k128_inorder.txt 2>&1; head -24 gpurun_out/r3_tl_k128_inorder.txt ;;
+    twinab)  for w in ml1m ml1m_k64 chembl ml1m_k128; do for fl in "" "--no-users-predict"; do python bench.py --workload $w --no-cpu-baseline --no-strong $fl > gpurun_out/r3_tw.json 2> gpurun_out/r3_tw.err; python - <<PY
+import json
+j=json.loads([l for l in open("gpurun_out/r3_tw.json") if l.startswith("{")][-1])
+print("$w '$fl'", "ms/step", round(j["ms_per_step"],4), "launch", {k: round(v,4) for k,v in j["roofline"]["launch_ms_per_side"].items()}, "value", round(j["value"]), "current", j["roofline"]["profiled"]["current"], "traffic", j["roofline"]["traffic"])
+PY
+             done; done ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
