@@ -111,6 +111,16 @@ struct TwinArgs {
     unsigned *flag; unsigned seq;
 };
 
+// fp32 path (K = 128): the column statistics of the PREVIOUS launch's side as the first workgroups of a k_sample_wg2 launch
+// (colstats_f32_rider, kernels_f32.h) -- what FusedArgs' st_* fields are to k_sample1.  nblocks = 0: none.
+struct StatRiders {
+    int nblocks;                       // rider workgroups at the head of the grid
+    const float *items; int64_t c0, c1; int nsl;
+    double *partials; const unsigned long long *fail_in; double *out;
+    unsigned *ticket; unsigned *flag; unsigned seq;
+    unsigned long long *tmo; unsigned long long wait_ticks;
+};
+
 // one workgroup per column (kernels_f32.h): the fp32 large-K path, and K = 64 in fp64 behind BPMF_HIP_MODE=2
 template <typename T>
 struct SampleArgsW {

@@ -47,6 +47,7 @@ Rccl *rccl()
 static int settle_async(struct bpmf_hip_side *s);      // waits until the worker is done with `s`; returns its deferred error
 static void flush_deferred(struct bpmf_hip_test *t);   // enqueues an evaluation whose launch was put off
 namespace { void predraw_stop(struct bpmf_hip_side *s); }   // joins the side's pre-draw helper threads
+namespace { int flush_pending_stats(struct bpmf_hip_ctx *c); }   // statistics without a launch to ride in: a kernel of their own
 
 struct bpmf_hip_side;
 // host-side timeline for BPMF_HIP_TRACE=1: (time, tag, side) records, printed when the context dies
@@ -441,6 +442,7 @@ extern "C" int bpmf_hip_ctx_sync(bpmf_hip_ctx *c)
     std::vector<bpmf_hip_side *> sides;
     { std::lock_guard<std::mutex> lk(c->launch_mutex); sides = c->sides; }
     int rc = 0;
+    if (c->pending_stats) { HIP_TRY(hipSetDevice(c->device)); rc = flush_pending_stats(c); }   // (start them before waiting for the other side's collection)
     for (bpmf_hip_side *s : sides) { const int r = settle_async(s); if (r && !rc) rc = r; }
     for (bpmf_hip_side *s : sides) flush_deferred(s->deferred_eval);
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1260,7 +1262,7 @@ int flush_pending_stats(bpmf_hip_ctx *c)
     bpmf_hip_side *P = c->pending_stats;
     if (!P) return 0;
     c->pending_stats = nullptr;
-    c->pending_inorder = false;
+    c->pending_inorder = false; c->pending_riders = false;
     const int K = c->K;
     HIP_TRY(hipSetDevice(c->device));
     hipEvent_t *ev = P->evs[c->pending_evset];
@@ -1288,7 +1290,7 @@ int flush_pending_stats_inorder(bpmf_hip_ctx *c)
     bpmf_hip_side *P = c->pending_stats;
     if (!P) return 0;
     c->pending_stats = nullptr;
-    c->pending_inorder = false;
+    c->pending_inorder = false; c->pending_riders = false;
     const int K = c->K;
     hipEvent_t *ev = P->evs[c->pending_evset];
     unsigned *flag = reinterpret_cast<unsigned *>(P->a_h_out_dev + c->out_words - 1);
@@ -1383,13 +1385,28 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     bpmf_hip_side *P = inorder_flush ? nullptr : c->pending_stats;
     // statistics waiting for a carrier: they ride here, unless this launch cannot take them, or would
     // overwrite in place the very columns they read (the same side twice in a row without a second copy)
-    bool carry = fused && P != nullptr;
+    bool carry = fused && P != nullptr && !c->pending_riders;
+    // fp32 path: P's pass as the first workgroups of this side's k_sample_wg2 launch (StatRiders)
+    const bool ride_f32 = P != nullptr && c->pending_riders && c->dtype == BPMF_HIP_F32 && self->mode == 5 && self->nwork > 0 && !dist && self->nsub <= 1;
+    if (ride_f32) carry = true;
     if (carry && P == self && !second_copy_usable(self)) carry = false;
     if (P && !carry) { if ((rc = flush_pending_stats(c))) return rc; }
+    bpmf::StatRiders riders{};
+    if (carry && ride_f32) {
+        const int nw = env_int("BPMF_HIP_WG_WAVES", 2) == 4 ? 4 : 2;
+        const int njobs = P->nstat_waves * (K / 16) * (K / 16 + 1) / 2;
+        riders.nblocks = (njobs + nw - 1) / nw;
+        riders.items = reinterpret_cast<const float *>(P->d_items); riders.c0 = P->from; riders.c1 = P->to; riders.nsl = P->nstat_waves;
+        riders.partials = P->d_stat_partials;
+        riders.fail_in = (const unsigned long long *)(P->a_d_in + (size_t)K * K + K);
+        riders.out = P->a_h_out_dev; riders.ticket = P->a_ticket;
+        riders.flag = reinterpret_cast<unsigned *>(P->a_h_out_dev + c->out_words - 1); riders.seq = c->pending_seq;
+        riders.tmo = tmo_word(P->a_h_out_dev, K); riders.wait_ticks = wait_ticks();
+    }
     if (fused) {
         fz.gate_host = self->a_gate_dev; fz.gate_want = (unsigned)(iter + 1); fz.src_host = self->a_h_in_dev;
         fz.dst = self->a_d_in; fz.n = (int)stage_words; fz.dflag = self->a_dflag; fz.dval = seq;
-        if (carry) {
+        if (carry && !ride_f32) {
             fz.nstat = P->nstat_waves; fz.st_items = P->d_items; fz.st_c0 = P->from; fz.st_c1 = P->to;
             fz.st_partials = P->d_stat_partials;
             fz.st_fail = (const unsigned long long *)(P->a_d_in + (size_t)K * K + K);
@@ -1418,11 +1435,13 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     if (timed && !ride) HIP_TRY(hipEventRecord(ev[0], s0));
     if (inorder_flush) { if ((rc = flush_pending_stats_inorder(c))) return rc; }
     self->cur_fused = fz;
+    self->cur_riders = riders;
     self->cur_gate_flag = fused ? self->a_dflag : nullptr; self->cur_gate_want = seq;
     rc = BPMF_DISPATCH_K(K, sample_and_exchange<KK>(self, other, iter, alpha, self->a_d_in, s0, (ride && timed) ? ev[0] : nullptr,
                                                     ride ? ev[1] : nullptr));
     self->cur_gate_flag = nullptr;
     self->cur_fused = bpmf::FusedArgs{};
+    self->cur_riders = bpmf::StatRiders{};
     bpmf_launch::next_flags() = 0;                                    // (a sampler sequence without a kernel leaves it pending)
     if (rc) return rc;
     if (!ride) HIP_TRY(hipEventRecord(ev[1], s0));
@@ -1430,6 +1449,7 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     if (carry) {                                                      // P's statistics are inside this launch: complete behind ev[1]
         P->stats_ev[c->pending_evset].store(ev[1], std::memory_order_release);
         c->pending_stats = nullptr;
+        c->pending_riders = false;
     }
     self->stats_ev[evset].store(nullptr, std::memory_order_release);
     // An unfused side whose partner launches in the fused format (ChEMBL shape: the compounds side runs the low-rank
@@ -1447,9 +1467,19 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     static const int stats_inorder = env_int("BPMF_HIP_STATS_INORDER", 0);
     const bool inorder = stats_inorder && !fused && !defer && !dist && s1 != s0 && self->nwork > 0 && !self->reduce_on && !self->d_stat_list &&
                          (self->nstat_wg > 0 || c->dtype == BPMF_HIP_F32);
-    if (fused || defer || inorder) {
+    // fp32 path (workgroup-per-item form, single GPU): the pass rides at the head of the next k_sample_wg2 launch of the
+    // context -- no stream of its own, no head start to buy with event hops (BPMF_HIP_F32_RIDERS=0: the two kernels on S1)
+    // MEASURED: no gain, off.  The two 30-us gaps go (rocprofv3 timeline: 9 / 14 us between the samplers), but the riders
+    // -- 576 two-wave workgroups that each hold the kernel's 40 KB of LDS -- lengthen the launches by ~23 us per iteration, and
+    // with the gaps gone the host chain (sums -> cov -> 230 us Normal-Wishart finish -> staging) becomes the critical path of
+    // one side: 0.806 / 0.864 against 0.810 / 0.833 ms in interleaved runs.
+    static const int f32_riders = env_int("BPMF_HIP_F32_RIDERS", 0);
+    const bool riders_next = f32_riders && !fused && !defer && !inorder && !dist && s1 != s0 && c->dtype == BPMF_HIP_F32 && self->mode == 5 &&
+                             other->mode == 5 && self->nwork > 0 && other->nwork > 0 && self->nsub <= 1;
+    if (fused || defer || inorder || riders_next) {
         c->pending_stats = self; c->pending_seq = seq; c->pending_evset = evset;     // ride in / go ahead of the next launch
         c->pending_inorder = inorder;
+        c->pending_riders = riders_next;
     } else {
         // (fp32 path: the statistics used to take 0.2 ms from the end of the sampler to the sums, on the critical path of
         // the side's host chain: their 256-thread workgroups had to find room beside the NEXT side's sampler, whose
@@ -2076,7 +2106,12 @@ extern "C" int bpmf_hip_predict_finish(bpmf_hip_test *t, double *se, double *se_
 {
     if (!t || !se || !se_avg || !count) return fail(BPMF_HIP_EINVAL, "predict_finish: NULL argument");
     if (!t->launched) return fail(BPMF_HIP_EINVAL, "predict_finish: nothing launched");
+    // Still not enqueued?  Then no sampler launch has come since it was requested: the end of a run of iterations.  The
+    // statistics of the newest half-iteration have no launch to ride in either: they start now, beside the evaluation,
+    // instead of when somebody finally asks for the side's state (a 20-step block of bench.py ended ~20 us later).
+    const bool tail = (t->owner ? t->owner : t)->deferred;
     flush_deferred(t);
+    if (tail && t->side->ctx->pending_stats) (void)flush_pending_stats(t->side->ctx);
     t->launched = false;
     if (t->owner && t->owner->cancelled) return fail(BPMF_HIP_EINVAL, "predict_finish: the evaluation this twin belongs to was cancelled");
     if (t->cancelled) { t->cancelled = false; return fail(BPMF_HIP_EINVAL, "predict_finish: the side of this test matrix was destroyed before the evaluation ran"); }

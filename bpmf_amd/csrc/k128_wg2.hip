@@ -5,8 +5,9 @@
 
 namespace bpmf_launch {
 
-void k128_wg2(int grid, int nwaves, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a)
+void k128_wg2(int grid, int nwaves, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a, const bpmf::StatRiders &r)
 {
+    grid += r.nblocks;                                              // (riders first: they are dispatched ahead of the items)
     if (a.stamps) {                                                 // profiling: what the runtime says about residency
         static bool said = false;
         if (!said) {
@@ -17,9 +18,9 @@ void k128_wg2(int grid, int nwaves, hipStream_t st, hipEvent_t e0, hipEvent_t e1
         }
     }
     if (nwaves == 4) {
-        BPMF_LAUNCH((bpmf::k_sample_wg2<128, 4>), dim3(grid), dim3(256), st, e0, e1, a);
+        BPMF_LAUNCH((bpmf::k_sample_wg2<128, 4>), dim3(grid), dim3(256), st, e0, e1, a, r);
     } else {
-        BPMF_LAUNCH((bpmf::k_sample_wg2<128, 2>), dim3(grid), dim3(128), st, e0, e1, a);
+        BPMF_LAUNCH((bpmf::k_sample_wg2<128, 2>), dim3(grid), dim3(128), st, e0, e1, a, r);
     }
 }
 

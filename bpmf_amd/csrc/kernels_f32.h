@@ -448,6 +448,107 @@ __global__ __launch_bounds__(256) void k_colstats_f32_final(const double *__rest
     publish_when_last(ticket, gridDim.x, flag, seq);
 }
 
+// The same pass as RIDERS at the head of the next sampler launch (k_sample_wg2, workgroups of NW waves): job = (slice, tile)
+// per wave as in k_colstats_f32, partials written through, a ticket per workgroup; the last arrivers wait until every
+// partial has landed (every workgroup takes its ticket before it waits: the count completes as soon as all riders have
+// run, and they are the first workgroups of the grid) and add the slices in order, one output per thread -- the sums of
+// k_colstats_f32_final, bit for bit.  Why: as kernels of their own on the side's stream the pass needed a head start over
+// the partner's sampler, bought with two cross-queue event hops of ~15 us each per half-iteration (DESIGN.md section 4,
+// "what the K = 128 iteration is made of"); as riders the partner's launch follows its predecessor on ONE queue.
+template <int K, int NW>
+__device__ __forceinline__ void colstats_f32_rider(const StatRiders &r, int rb, int tid)
+{
+    constexpr int NT = K / 16, NTRI = NT * (NT + 1) / 2, PARTW = NTRI * 256 + K, NOUT = K * K + K, NTH = 64 * NW;
+    __shared__ unsigned stk;
+    const int wave = tid >> 6, lane = tid & 63, kq = lane >> 4, li = lane & 15;
+    const int job = rb * NW + wave;
+    if (job < r.nsl * NTRI) {                                         // wave-uniform
+        const int tri = job % NTRI, sl = job / NTRI;
+        int I = 0, t = tri;
+        while (t >= NT - I) { t -= NT - I; ++I; }
+        const int J = I + t;
+        const int64_t n = r.c1 - r.c0;
+        const int64_t per = ((n + r.nsl - 1) / r.nsl + 3) / 4 * 4;
+        const int64_t b = r.c0 + sl * per, e = (b + per < r.c1) ? b + per : r.c1;
+        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+        double rs = 0.0;
+        const float *xi = r.items + 16 * I + li, *xj = r.items + 16 * J + li;
+        float fa[4], fb[4], na[4], nb[4];
+        auto fetch = [&](int64_t c, float (&a4)[4], float (&b4)[4]) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t cc = c + 4 * u + kq;
+                const size_t at = (size_t)((cc < e) ? cc : b) * K;
+                a4[u] = xi[at];
+                b4[u] = xj[at];
+            }
+        };
+        if (b < e) fetch(b, fa, fb);
+        for (int64_t c = b; c < e; c += 16) {
+            fetch(c + 16 < e ? c + 16 : b, na, nb);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = c + 4 * u + kq < e;
+                const double ya = ok ? (double)fa[u] : 0.0, yb = ok ? (double)fb[u] : 0.0;
+                acc = mfma16(ya, yb, acc);
+                rs += ya;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { fa[u] = na[u]; fb[u] = nb[u]; }
+        }
+        double *p = r.partials + (size_t)sl * PARTW;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) __hip_atomic_store(&p[tri * 256 + reg * 64 + lane], acc[reg], BPMF_RLX_AGENT);
+        if (I == J) {
+            rs += __shfl_xor(rs, 16);
+            rs += __shfl_xor(rs, 32);
+            if (kq == 0) __hip_atomic_store(&p[NTRI * 256 + 16 * I + li], rs, BPMF_RLX_AGENT);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's partial has landed
+    __syncthreads();
+    if (tid == 0) stk = __hip_atomic_fetch_add(r.ticket, 1u, BPMF_RLX_AGENT);
+    __syncthreads();
+    const int tk = (int)stk;
+    const int nfin = r.nblocks < (NOUT + NTH - 1) / NTH ? r.nblocks : (NOUT + NTH - 1) / NTH;
+    if (tk < r.nblocks - nfin) return;
+    const int f = tk - (r.nblocks - nfin);                            // finisher 0 .. nfin-1
+    if (tid == 0) {
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(r.ticket, BPMF_RLX_AGENT) < (unsigned)r.nblocks) {
+            __builtin_amdgcn_s_sleep(1);
+            if (r.wait_ticks && wall_clock64() - t0 > r.wait_ticks) { flag_timeout(r.tmo, BPMF_TMO_STATS); break; }
+        }
+    }
+    __syncthreads();
+    for (int o = f * NTH + tid; o < NOUT; o += nfin * NTH) {
+        int at;
+        if (o < K * K) {                                              // prod(gi, gj) at gi + gj K: from tile (min, max) of the block pair
+            int gi = o % K, gj = o / K;
+            if (gi / 16 > gj / 16) { const int x = gi; gi = gj; gj = x; }
+            const int I = gi / 16, J = gj / 16, ii = gi % 16;
+            at = (I * NT - (I * (I - 1)) / 2 + (J - I)) * 256 + (ii >> 2) * 64 + (ii & 3) * 16 + (gj % 16);
+        } else {
+            at = NTRI * 256 + (o - K * K);
+        }
+        double s = 0.0;
+        for (int q0 = 0; q0 < r.nsl; q0 += 8) {                       // eight loads in flight, added in slice order (as k_colstats_f32_final)
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = __hip_atomic_load(&r.partials[(size_t)((q0 + u < r.nsl) ? q0 + u : q0) * PARTW + at], BPMF_RLX_AGENT);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (q0 + u < r.nsl) ? v[u] : 0.0;
+        }
+        __hip_atomic_store(&r.out[o], s, BPMF_RLX_SYSTEM);
+    }
+    if (f == 0 && tid == 0) {
+        const unsigned long long fw = *r.fail_in;
+        __hip_atomic_store(&r.out[NOUT], (fw == ~0ull) ? 0.0 : (double)(fw + 1ull), BPMF_RLX_SYSTEM);
+        __hip_atomic_store(&reinterpret_cast<unsigned long long *>(r.out)[NOUT + 1], fw, BPMF_RLX_SYSTEM);
+    }
+    publish_when_last(r.ticket + 1, (unsigned)nfin, r.flag, r.seq, r.ticket);
+}
+
 // ---------------------------------------------------------------------------
 // Sys::predict (c++/sample.cpp:48-96) on fp32 factors: fp64 accumulation of the dot product and
 // of everything behind it; same partial / publish scheme as k_predict.

@@ -415,11 +415,13 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
 }
 
 template <int K, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void k_sample_wg2(SampleArgs a)
+__global__ __launch_bounds__(64 * NW, 2) void k_sample_wg2(SampleArgs a, StatRiders r)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[GeoW2<K>::lds_bytes()];
     const int tid = threadIdx.x, wave = tid >> 6;
-    const int w = blockIdx.x;
+    // the column statistics of the previous launch's side ride as the first workgroups (colstats_f32_rider)
+    if ((int)blockIdx.x < r.nblocks) { colstats_f32_rider<K, NW>(r, (int)blockIdx.x, tid); return; }
+    const int w = (int)blockIdx.x - r.nblocks;
     const unsigned long long t_begin = a.stamps ? wall_clock64() : 0ull;
     if constexpr (NW == 2) {
         if (wave == 0) wg2_column<K, 2, 0>(a, w, smem, tid);

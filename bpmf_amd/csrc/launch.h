@@ -52,7 +52,8 @@ void k64_pf_prepare(int grid, hipStream_t st, hipEvent_t e0, const double *S0t, 
 void k64_slab(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a);
 void k128_slab(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a);
 // K = 128 fp32: workgroup of 2 / 4 waves per item, second form (kernels_wg2.h)
-void k128_wg2(int grid, int nwaves, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a);
+// (r: column statistics of another side as rider workgroups at the head of the grid, or r.nblocks == 0)
+void k128_wg2(int grid, int nwaves, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a, const bpmf::StatRiders &r);
 
 // BPMF_REDUCE formulation (kernels_reduce.h, kreduce.hip): fp64, K = 8 .. 64
 int reduce_part_words(int K);                  // doubles per column of a side's `prec` array (0: K not supported)

@@ -81,7 +81,7 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
     if constexpr (K == 128) {                                        // fp32 factors (items / other_items are float arrays)
         if (nwork > 0) {
             if (self->mode == 4) k128_slab(nwork, st, ev_start, ev_stop, a);
-            else k128_wg2(nwork, env_int("BPMF_HIP_WG_WAVES", 2) == 4 ? 4 : 2, st, ev_start, ev_stop, a);
+            else k128_wg2(nwork, env_int("BPMF_HIP_WG_WAVES", 2) == 4 ? 4 : 2, st, ev_start, ev_stop, a, self->cur_riders);
         }
         return 0;
     } else {

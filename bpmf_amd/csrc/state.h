@@ -134,6 +134,8 @@ struct bpmf_hip_ctx {
     // ... or, unfused sides with a stand-alone statistics pass (big sides, the fp32 path): the pass goes onto S0 itself just
     // ahead of the NEXT sampler launch, which is then launched "any order" (no barrier bit): see bpmf_hip_sys_sample
     bool pending_inorder = false;
+    // ... or, fp32 path: as rider workgroups at the head of the next k_sample_wg2 launch (StatRiders, args.h)
+    bool pending_riders = false;
     std::vector<bpmf_hip_side *> sides;  // stateful sides with a statistics stream of their own (for ctx_sync)
     bool own_stream = false;
     int num_cu = 256;
@@ -240,6 +242,7 @@ struct bpmf_hip_side {
     double *a_h_in = nullptr, *a_h_in_dev = nullptr, *a_d_in = nullptr;
     double *a_h_out = nullptr, *a_h_out_dev = nullptr;
     bpmf::FusedArgs cur_fused{};         // gate + statistics riders of the k_sample1 launch being enqueued (fused stateful path)
+    bpmf::StatRiders cur_riders{};       // fp32 path: statistics riders of the k_sample_wg2 launch being enqueued
     // the event behind which this side's statistics of the job with event set 0 / 1 are complete, once they
     // have been enqueued (inside the next sampler launch, or as a kernel of their own): the collector's blocking wait
     std::atomic<hipEvent_t> stats_ev[2] = {{nullptr}, {nullptr}};

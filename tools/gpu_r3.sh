@@ -43,6 +43,15 @@ j=json.loads([l for l in open("gpurun_out/r3_tw.json") if l.startswith("{")][-1]
 print("$w '$fl'", "ms/step", round(j["ms_per_step"],4), "launch", {k: round(v,4) for k,v in j["roofline"]["launch_ms_per_side"].items()}, "value", round(j["value"]), "current", j["roofline"]["profiled"]["current"], "traffic", j["roofline"]["traffic"])
 PY
              done; done ;;
+    riders)  timeout 1500 python -m pytest tests/test_gpu_f32.py tests/test_gpu_fullsize.py tests/test_gpu_waits.py -x -q -m gpu > gpurun_out/r3_riders.log 2>&1; tail -5 gpurun_out/r3_riders.log
+             timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_multirank.py -x -q -m gpu -k "128 or fp32 or f32 or parts_single" >> gpurun_out/r3_riders.log 2>&1; tail -3 gpurun_out/r3_riders.log
+             for io in 1 0 1 0; do BPMF_HIP_F32_RIDERS=$io python bench.py --workload ml1m_k128 --no-cpu-baseline --no-strong > gpurun_out/r3_rd_$io.json 2> gpurun_out/r3_rd_$io.err; python - <<PY
+import json
+j=json.loads([l for l in open("gpurun_out/r3_rd_$io.json") if l.startswith("{")][-1])
+print("ml1m_k128 riders=$io", "ms/step", round(j["ms_per_step"],4), "launch", j["roofline"]["launch_ms_per_side"], "value", round(j["value"]), "rmse", j["rmse"])
+PY
+             done
+             bash tools/trace_timeline.sh ml1m_k128 > gpurun_out/r3_tl_k128_riders.txt 2>&1; head -22 gpurun_out/r3_tl_k128_riders.txt ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
