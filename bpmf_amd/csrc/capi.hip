@@ -45,9 +45,9 @@ Rccl *rccl()
 
 
 static int settle_async(struct bpmf_hip_side *s);      // waits until the worker is done with `s`; returns its deferred error
-static void flush_deferred(struct bpmf_hip_test *t);   // enqueues an evaluation whose launch was put off
+static void flush_deferred(struct bpmf_hip_test *t, bool on_main = false);   // enqueues an evaluation whose launch was put off
 namespace { void predraw_stop(struct bpmf_hip_side *s); }   // joins the side's pre-draw helper threads
-namespace { int flush_pending_stats(struct bpmf_hip_ctx *c); }   // statistics without a launch to ride in: a kernel of their own
+namespace { int flush_pending_stats(struct bpmf_hip_ctx *c, bool on_main = false); }   // statistics without a launch to ride in: a kernel of their own
 
 struct bpmf_hip_side;
 // host-side timeline for BPMF_HIP_TRACE=1: (time, tag, side) records, printed when the context dies
@@ -1257,7 +1257,9 @@ void post_collect(bpmf_hip_side *s, const bpmf_hip_side::Job &job)
 
 // fused stateful path: the statistics of the newest half-iteration ride in the NEXT sampler launch;
 // when somebody needs them and no launch has come, they run as a kernel of their own on the side's stream
-int flush_pending_stats(bpmf_hip_ctx *c)
+// on_main: on the main stream, in order behind P's sampler (end of a run: nothing else is coming on that stream, and a
+// kernel on the side's stream would first pay the cross-queue hop -- ~40 us on a queue that has gone idle)
+int flush_pending_stats(bpmf_hip_ctx *c, bool on_main)
 {
     bpmf_hip_side *P = c->pending_stats;
     if (!P) return 0;
@@ -1266,12 +1268,14 @@ int flush_pending_stats(bpmf_hip_ctx *c)
     const int K = c->K;
     HIP_TRY(hipSetDevice(c->device));
     hipEvent_t *ev = P->evs[c->pending_evset];
-    HIP_TRY(hipStreamWaitEvent(P->saux, ev[1], 0));                  // (ev[1]: recorded with / behind P's sampler)
+    hipStream_t sst = on_main ? c->stream : P->saux;
+    if (!on_main) HIP_TRY(hipStreamWaitEvent(sst, ev[1], 0));        // (ev[1]: recorded with / behind P's sampler)
+    else c->last_sampler_done = nullptr;                              // (the newest thing on S0 is no longer a sampler)
     unsigned *flag = reinterpret_cast<unsigned *>(P->a_h_out_dev + c->out_words - 1);
     P->stat_a_ready = false;
-    const int rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK>(P, P->saux, P->a_d_in, P->a_h_out_dev, flag, c->pending_seq, P->a_ticket));
+    const int rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK>(P, sst, P->a_d_in, P->a_h_out_dev, flag, c->pending_seq, P->a_ticket));
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(ev[2], P->saux));
+    HIP_TRY(hipEventRecord(ev[2], sst));
     P->stats_ev[c->pending_evset].store(ev[2], std::memory_order_release);
     trace("statistics flushed (no launch to ride in)", P, P->iter);
     return 0;
@@ -1994,7 +1998,7 @@ void dispatch_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *s
 // one of the other four, and behind a gate kernel that polls the host everything on that queue
 // stalls: 0.13 -> 0.34 ms per iteration.)  Whoever needs it earlier flushes it: predict_finish,
 // a sampler about to overwrite a copy it reads, test_get, the destructors.
-static void flush_deferred(bpmf_hip_test *t)
+static void flush_deferred(bpmf_hip_test *t, bool on_main)
 {
     if (t && t->owner) t = t->owner;                                 // a twin is enqueued with the evaluation it belongs to
     if (!t || !t->deferred) return;
@@ -2002,7 +2006,9 @@ static void flush_deferred(bpmf_hip_test *t)
     bpmf_hip_side *o = t->def_other;
     if (o && o->deferred_eval == t) o->deferred_eval = nullptr;
     (void)hipSetDevice(t->side->ctx->device);
-    dispatch_predict(t, t->side, t->def_self_items, t->def_other_items, t->def_n, o->saux, true);
+    // (on_main: the end of a run -- behind the last sampler on its own stream, no cross-queue hop)
+    if (on_main) t->side->ctx->last_sampler_done = nullptr;
+    dispatch_predict(t, t->side, t->def_self_items, t->def_other_items, t->def_n, on_main ? t->side->ctx->stream : o->saux, true);
     trace("predict: enqueued", t->side, t->def_n);
 }
 
@@ -2110,8 +2116,8 @@ extern "C" int bpmf_hip_predict_finish(bpmf_hip_test *t, double *se, double *se_
     // statistics of the newest half-iteration have no launch to ride in either: they start now, beside the evaluation,
     // instead of when somebody finally asks for the side's state (a 20-step block of bench.py ended ~20 us later).
     const bool tail = (t->owner ? t->owner : t)->deferred;
-    flush_deferred(t);
-    if (tail && t->side->ctx->pending_stats) (void)flush_pending_stats(t->side->ctx);
+    if (tail && t->side->ctx->pending_stats) (void)flush_pending_stats(t->side->ctx, true);   // (first: its host chain is the longer one)
+    flush_deferred(t, tail);
     t->launched = false;
     if (t->owner && t->owner->cancelled) return fail(BPMF_HIP_EINVAL, "predict_finish: the evaluation this twin belongs to was cancelled");
     if (t->cancelled) { t->cancelled = false; return fail(BPMF_HIP_EINVAL, "predict_finish: the side of this test matrix was destroyed before the evaluation ran"); }
