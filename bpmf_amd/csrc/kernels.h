@@ -276,8 +276,10 @@ __device__ __forceinline__ double row_ror_add(double x)
 {
     const long long v = __builtin_bit_cast(long long, x);
     const int lo = (int)v, hi = (int)(v >> 32);
-    const int rlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-    const int rhi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    // (bound_ctrl set: every lane of a rotate has a source, and with all rows / banks enabled the compiler then
+    // knows the old value of the destination is dead -- otherwise it zeroes both halves ahead of every move)
+    const int rlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    const int rhi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     const long long rv = ((long long)rhi << 32) | (unsigned int)rlo;
     return x + __builtin_bit_cast(double, rv);
 }
@@ -371,29 +373,50 @@ __device__ __forceinline__ void gram_chunk44(const int32_t *__restrict__ rowidx,
     }
 }
 
-// The four b of every accumulator are added (fixed order: (b + b^2) + the same of b^1), then the
-// lanes b = 0 write the full symmetric G into the K x LD LDS matrix finish_single reads, and
-// the rhs sums (also over the four k) into sb.
+// The four b of every accumulator are added (fixed order: (b + b^2) + the same of b^1; every lane ends up with the
+// total), then the full symmetric G goes into the K x LD LDS matrix finish_single reads: the lanes b = 0 write the
+// upper blocks, the lanes b = 1 their mirror images, two block rows (g, g + 1) at a time -- two exec regions per row
+// pair instead of one per block, 16-byte stores wherever two blocks are neighbours in a row (idx(g, x) and
+// idx(g + 1, x) are adjacent for even g: 36 LDS stores for K = 32 instead of 64), and the accumulators of a row pair
+// are dead once it is written (all 36 sums live at once spill).  The rhs sums (also over the four k) go into sb.
 template <int K>
 __device__ __forceinline__ void assemble44(double (&acc)[Geo44<K>::NB], double (&rr)[Geo44<K>::NG], double *sA, double *sb,
                                            int LD, int lane)
 {
     using G = Geo44<K>;
     constexpr int NG = G::NG;
+    static_assert(NG % 2 == 0, "block rows are written in pairs");
     const int i = lane >> 4, b = (lane >> 2) & 3, j = lane & 3;
-    int blk = 0;
+    auto blk = [](int g, int g2) constexpr { return g * NG - (g * (g - 1)) / 2 + (g2 - g); };
+    double *up = sA + (2 * i) * LD + 2 * j;      // entry (idx(g, i), idx(g2, j)) of block (g, g2): lane base + compile-time offset
+    double *lo = sA + (2 * j) * LD + 2 * i;      // its mirror image (idx(g2, j), idx(g, i))
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
+    for (int g = 0; g < NG; g += 2) {
 #pragma unroll
-        for (int g2 = g; g2 < NG; ++g2, ++blk) {
-            double v = row_ror_add<0x128>(acc[blk]);                              // row_ror:8
-            v = row_ror_add<0x124>(v);                                            // row_ror:4
-            if (b == 0) {
-                const int gi = G::idx(g, i), gj = G::idx(g2, j);
-                sA[gi * LD + gj] = v;
-                if (g != g2) sA[gj * LD + gi] = v;
+        for (int t = blk(g, g); t < blk(g + 1, NG - 1) + 1; ++t) {
+            const double v = row_ror_add<0x128>(acc[t]);                          // row_ror:8
+            acc[t] = row_ror_add<0x124>(v);                                       // row_ror:4
+        }
+        if (b == 0) {
+            up[G::idx(g + 1, 0) * LD + G::idx(g + 1, 0)] = acc[blk(g + 1, g + 1)];
+#pragma unroll
+            for (int g2 = g; g2 < NG; g2 += 2) {
+                double2 v; v.x = acc[blk(g, g2)]; v.y = acc[blk(g, g2 + 1)];
+                *reinterpret_cast<double2 *>(&up[G::idx(g, 0) * LD + G::idx(g2, 0)]) = v;
+                if (g2 > g) {
+                    double2 w; w.x = acc[blk(g + 1, g2)]; w.y = acc[blk(g + 1, g2 + 1)];
+                    *reinterpret_cast<double2 *>(&up[G::idx(g + 1, 0) * LD + G::idx(g2, 0)]) = w;
+                }
+            }
+        } else if (b == 1) {
+            lo[G::idx(g + 1, 0) * LD + G::idx(g, 0)] = acc[blk(g, g + 1)];
+#pragma unroll
+            for (int g2 = g + 2; g2 < NG; ++g2) {
+                double2 v; v.x = acc[blk(g, g2)]; v.y = acc[blk(g + 1, g2)];
+                *reinterpret_cast<double2 *>(&lo[G::idx(g2, 0) * LD + G::idx(g, 0)]) = v;
             }
         }
+    }
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         double v = row_ror_add<0x128>(rr[g]);

@@ -44,14 +44,14 @@ __device__ __forceinline__ double mfma44n(double a, double b, double c)   // c -
 template <int T>
 __device__ __forceinline__ int quad_bcast_i(int v)
 {
-    return __builtin_amdgcn_update_dpp(0, v, T * 0x55, 0xF, 0xF, false);
+    return __builtin_amdgcn_update_dpp(0, v, T * 0x55, 0xF, 0xF, true);
 }
 template <int T>
 __device__ __forceinline__ double quad_bcast_d(double v)
 {
     const long long w = __builtin_bit_cast(long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)w, T * 0x55, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(w >> 32), T * 0x55, 0xF, 0xF, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)w, T * 0x55, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(w >> 32), T * 0x55, 0xF, 0xF, true);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 

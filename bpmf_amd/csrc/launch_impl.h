@@ -7,6 +7,7 @@
 #include "kernels_q4.h"
 #include "kernels_slab.h"
 #include "kernels_q1.h"
+#include "kernels_x4.h"
 
 namespace bpmf_launch {
 
@@ -171,6 +172,19 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
             const FusedArgs &f = self->cur_fused;
             const dim3 grid((unsigned)(nwork + (f.gate_host ? 1 : 0) + f.nstat));
             BPMF_LAUNCH(k_sample1q<K>, grid, dim3(64), st, ev_start, ev_stop, a, f);
+            return 0;
+        }
+    }
+    if constexpr (K <= 32) {
+        if (nwork > 0 && self->mode == 7) {                          // up to four items per wave one after the other, factorised in lockstep
+            const FusedArgs &f = self->cur_fused;
+            // as many waves as the chip holds at this kernel's occupancy (every wave then walks nwork / nwaves items of
+            // about the same total length), more only when that would be more than four items per wave
+            static const int waves_env = env_int("BPMF_HIP_X4_WAVES", 0);
+            const int slots = waves_env > 0 ? waves_env : c->num_cu * 4 * GeoX<K>::WPS;
+            const int nwaves = std::max(std::min(nwork, slots), (nwork + GeoX<K>::NITEM - 1) / GeoX<K>::NITEM);
+            const dim3 grid((unsigned)(nwaves + (f.gate_host ? 1 : 0) + f.nstat));
+            BPMF_LAUNCH(k_sample1x<K>, grid, dim3(64), st, ev_start, ev_stop, a, f, nwaves);
             return 0;
         }
     }

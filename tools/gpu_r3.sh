@@ -52,6 +52,33 @@ print("ml1m_k128 riders=$io", "ms/step", round(j["ms_per_step"],4), "launch", j[
 PY
              done
              bash tools/trace_timeline.sh ml1m_k128 > gpurun_out/r3_tl_k128_riders.txt 2>&1; head -22 gpurun_out/r3_tl_k128_riders.txt ;;
+    m3)      # k_sample4 on the ML-1M shape: chunk sizes and phase switches (is it slots / latency or instructions?)
+             pr() { python - "$1" "$2" <<PY
+import json, sys
+try:
+    j=json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
+    print(sys.argv[1], j["roofline"]["kernel"], "ms/step", round(j["ms_per_step"],4), "launch", {k: round(v*1e3,1) for k,v in j["roofline"]["launch_ms_per_side"].items()}, "rmse", round(j["rmse"],4))
+except Exception as e: print(sys.argv[1], "failed", e)
+PY
+             }
+             for cfg in "BPMF_HIP_MODE=1" "BPMF_HIP_MODE=1 BPMF_HIP_FUSED=0" "BPMF_HIP_MODE=3" "BPMF_HIP_MODE=3 BPMF_HIP_CHUNK=64" "BPMF_HIP_MODE=3 BPMF_HIP_CHUNK=96" "BPMF_HIP_MODE=3 BPMF_HIP_CHUNK=128" "BPMF_HIP_MODE=3 BPMF_HIP_CHUNK=256" "BPMF_HIP_MODE=3 BPMF_HIP_CHUNK=640"; do
+               env $cfg python bench.py --no-cpu-baseline --no-strong --steps 200 > gpurun_out/r3_m3.json 2> gpurun_out/r3_m3.err; pr "$cfg" gpurun_out/r3_m3.json; done
+             for ab in 1 2 3; do for cfg in "BPMF_HIP_MODE=1 BPMF_HIP_FUSED=0" "BPMF_HIP_MODE=3" "BPMF_HIP_MODE=3 BPMF_HIP_CHUNK=96"; do
+               env $cfg python bench.py --no-cpu-baseline --no-strong --steps 200 --ablate $ab > gpurun_out/r3_m3.json 2> gpurun_out/r3_m3.err; pr "ablate=$ab $cfg" gpurun_out/r3_m3.json; done; done ;;
+    x4)      # k_sample1x (mode 7): parity, then A/B against the committed build and mode 1
+             timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "four-in-a-row or per-item or auto" > gpurun_out/r3_x4.log 2>&1; tail -8 gpurun_out/r3_x4.log
+             pr() { python - "$1" "$2" <<PY
+import json, sys
+try:
+    j=json.loads([l for l in open(sys.argv[2]) if l.startswith("{")][-1])
+    print(sys.argv[1], j["roofline"]["kernel"], "ms/step", round(j["ms_per_step"],4), "launch", {k: round(v*1e3,1) for k,v in j["roofline"]["launch_ms_per_side"].items()}, "rmse", round(j["rmse"],4), "value", round(j["value"]/1e6,1))
+except Exception as e: print(sys.argv[1], "failed", e)
+PY
+             }
+             for rep in 1 2; do for cfg in "BPMF_HIP_LIBRARY=$PWD/bpmf_amd/csrc/variants/base.so" "BPMF_HIP_MODE=1" "BPMF_HIP_MODE=7" "BPMF_HIP_MODE=7 BPMF_HIP_CHUNK=768" "BPMF_HIP_MODE=7 BPMF_HIP_CHUNK=1280" "BPMF_HIP_MODE=7 BPMF_HIP_CHUNK=1536" "BPMF_HIP_MODE=7 BPMF_HIP_CHUNK=2048" "BPMF_HIP_MODE=7 BPMF_HIP_X4_WAVES=1792" "BPMF_HIP_MODE=7 BPMF_HIP_X4_WAVES=2560"; do
+               env $cfg python bench.py --no-cpu-baseline --no-strong --steps 200 > gpurun_out/r3_x4.json 2> gpurun_out/r3_x4.err; pr "$cfg" gpurun_out/r3_x4.json; done; done
+             for ab in 1 2 3; do for cfg in "BPMF_HIP_MODE=7"; do
+               env $cfg python bench.py --no-cpu-baseline --no-strong --steps 200 --ablate $ab > gpurun_out/r3_x4.json 2> gpurun_out/r3_x4.err; pr "ablate=$ab $cfg" gpurun_out/r3_x4.json; done; done ;;
     *) echo "unknown stage $stage" ;;
   esac
 done
