@@ -139,11 +139,11 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     int chunk = wg ? (1 << 30) : env_int("BPMF_HIP_CHUNK", 0);
     if (chunk <= 0) {
         const int64_t simds = (int64_t)s->ctx->num_cu * 4;
-        // mode 1: ~1.5 chunks of work per SIMD (measured best on the ML-1M shape: 512-768);
+        // mode 1: ~one chunk of work per SIMD (ML-1M shape, round 3: 896 ratings 0.1011 ms per iteration, 640: 0.1025, 1 280: 0.1047);
         // mode 0: >= 8 work items per SIMD so the tail of the launch stays short.  Lower bound
         // 16 K: a chunk's partial tiles are ~1.3 K^2 doubles written and read back, against 8 K
         // bytes gathered per rating, so shorter chunks make the partials a first-order traffic term.
-        int64_t c = (s->mode == 0) ? s->nnz / (simds * 8) : (s->mode == 4 ? s->nnz / (simds * 3) : (s->mode == 5 ? (s->nnz * 3) / (simds * 7) : (s->mode == 7 ? (s->nnz * 9) / (simds * 8) : (s->nnz * 2) / (simds * 3))));   // (mode 7: a wave walks several items anyway; every chunk is a hand-over through memory: ML-1M shape 1 024 against 640: 48 / 53 us against 55 / 53)
+        int64_t c = (s->mode == 0) ? s->nnz / (simds * 8) : (s->mode == 4 ? s->nnz / (simds * 3) : (s->mode == 5 ? (s->nnz * 3) / (simds * 7) : (s->mode == 7 ? (s->nnz * 9) / (simds * 8) : s->nnz / simds)));   // (mode 7: a wave walks several items anyway; every chunk is a hand-over through memory: ML-1M shape 1 024 against 640: 48 / 53 us against 55 / 53)
         c = (c + 63) / 64 * 64;
         // slab form: ONE wave walks an item, and a rating costs 36 (K = 128) / 10 (K = 64) tile MFMAs per 4
         // ratings: a launch lasts (average load of a wave slot) + (longest item), so items must stay short (ML-1M shape,
@@ -307,6 +307,10 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     // column statistics: one wave per 64+ columns, at most 2 waves per CU
     // (sides with hundreds of thousands of columns: the pass is a 8 K-byte-per-column stream, four times the waves)
     s->nstat_waves = (int)std::max<int64_t>(1, std::min<int64_t>((nloc + 31) / 32, (int64_t)s->ctx->num_cu * (nloc > 100000 ? 8 : 2)));
+    // sides of the one-item-per-wave forms (their statistics ride at the head of the partner's launch): ~160 columns per
+    // rider -- every rider is a wave slot the launch's first items do not get (ML-1M shape: 24-40 riders 0.0996 ms per
+    // iteration, 189 / 116 riders 0.1011, 16: 0.107)
+    if (nloc < 20000) s->nstat_waves = (int)std::max<int64_t>(1, std::min<int64_t>(s->nstat_waves, std::max<int64_t>((nloc + 159) / 160, 24)));
     if (env_int("BPMF_HIP_NSTAT", 0) > 0) s->nstat_waves = (int)std::min<int64_t>(env_int("BPMF_HIP_NSTAT", 0), std::max<int64_t>(1, (nloc + 31) / 32));   // (experiments)
     // big sides: four-wave workgroups with a finisher that reads the partials contiguously (k_colstats_wg)
     s->nstat_wg = (nloc > 100000 && env_int("BPMF_HIP_STATS_WG", 1) != 0) ? (int)std::min<int64_t>((nloc + 127) / 128, (int64_t)s->ctx->num_cu * 2) : 0;
@@ -444,11 +448,22 @@ extern "C" int bpmf_hip_ctx_sync(bpmf_hip_ctx *c)
     std::vector<bpmf_hip_side *> sides;
     { std::lock_guard<std::mutex> lk(c->launch_mutex); sides = c->sides; }
     int rc = 0;
+    trace("ctx_sync: enter", nullptr, 0);
     if (c->pending_stats) { HIP_TRY(hipSetDevice(c->device)); rc = flush_pending_stats(c); }   // (start them before waiting for the other side's collection)
     for (bpmf_hip_side *s : sides) { const int r = settle_async(s); if (r && !rc) rc = r; }
     for (bpmf_hip_side *s : sides) flush_deferred(s->deferred_eval);
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    for (bpmf_hip_side *s : sides) HIP_TRY(hipStreamSynchronize(s->saux));
+    // (a query first: after the collections above the streams are usually idle already, and a blocking
+    // synchronize of an idle stream still costs ~10 us each -- 30 us per fence of a 2 ms block of bench.py)
+    auto sync_stream = [](hipStream_t st) -> hipError_t {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return hipSuccess;
+        if (q != hipErrorNotReady) return q;
+        (void)hipGetLastError();                                      // ("not ready" is no error: do not leave it for a later hipGetLastError())
+        return hipStreamSynchronize(st);
+    };
+    HIP_TRY(sync_stream(c->stream));
+    for (bpmf_hip_side *s : sides) HIP_TRY(sync_stream(s->saux));
+    trace("ctx_sync: done", nullptr, 0);
     return rc;
 }
 

@@ -42,7 +42,7 @@ template <int K>
 struct GeoX {
     static constexpr int NG = K / 4;
     static constexpr int NB = NG * (NG + 1) / 2;
-    static constexpr int WPS = K == 32 ? 2 : 4;           // (3: the registers of k_sample1, but the compiler spills inside the Gram loop and the factorisation)
+    static constexpr int WPS = K == 32 ? 2 : 4;           // (3 -- the registers of k_sample1 -- spills inside the Gram loop and the factorisation: 80 / 80 us per launch against 48 / 54)
     static constexpr int NITEM = 3;                       // work items per wave: two stashed in LDS + one in the accumulators
     static constexpr int SWORDS = NB * 16;                // doubles of one stashed column (result layout of its 16 lanes)
     __host__ __device__ static constexpr int blk(int g, int g2) { return g * NG - (g * (g - 1)) / 2 + (g2 - g); }
@@ -61,10 +61,14 @@ __device__ __forceinline__ void gram_chunk44n(const int32_t *__restrict__ rowidx
     using G = GeoX<K>;
     constexpr int NG = G::NG;
     const int slot = lane >> 2, x = lane & 3;
+    // (one address register for the four groups of a block: the group's 64 bytes go into the offset field of ds_bpermute)
+    const int perm_base = slot * 4;
     auto gather = [&](const IdxBlock &ib, int gg, double (&R)[NG], double &ww) {
         const int src = gg * 16 + slot;
-        const int row = __shfl(ib.ri, src);
-        ww = (__shfl(ib.v, src) - mean) * alpha;                                  // c++/sample.cpp:256 (padding slots: times a row of zeros)
+        const int row = __builtin_amdgcn_ds_bpermute(perm_base + gg * 64, ib.ri);
+        const double v = __hiloint2double(__builtin_amdgcn_ds_bpermute(perm_base + gg * 64, __double2hiint(ib.v)),
+                                          __builtin_amdgcn_ds_bpermute(perm_base + gg * 64, __double2loint(ib.v)));
+        ww = (v - mean) * alpha;                                                  // c++/sample.cpp:256 (padding slots: times a row of zeros)
         const double *p = ((ib.base + src < len) ? other + (size_t)(row & rowmask) * K : zero_row) + x;
 #pragma unroll
         for (int g = 0; g < NG; ++g) R[g] = p[4 * g];
@@ -84,7 +88,6 @@ __device__ __forceinline__ void gram_chunk44n(const int32_t *__restrict__ rowidx
     gather(cur, 0, yA, wA);
     int b0 = 0;
     for (; b0 + 64 < len; b0 += 64) {
-        const IdxBlock nn = load_idx_block(rowidx, vals, b0 + 128, lane, len, zero_row);   // index block after the next one
         gather(cur, 1, yB, wB);
         contract(yA, wA);
         gather(cur, 2, yA, wA);
@@ -92,9 +95,11 @@ __device__ __forceinline__ void gram_chunk44n(const int32_t *__restrict__ rowidx
         gather(cur, 3, yB, wB);
         contract(yA, wA);
         gather(nxt, 0, yA, wA);                                                  // first group of the next block
-        contract(yB, wB);
+        // the index block after the next one: requested here, a whole block (144 MFMAs) ahead of its first use --
+        // and not a block earlier, where it would be three more live registers through the loop
         cur = nxt;
-        nxt = nn;
+        nxt = load_idx_block(rowidx, vals, b0 + 128, lane, len, zero_row);
+        contract(yB, wB);
     }
     const int ng = (len - b0 + 15) >> 4;                                         // last block: 1..4 groups
     if (ng > 1) gather(cur, 1, yB, wB);
