@@ -143,7 +143,7 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
         // mode 0: >= 8 work items per SIMD so the tail of the launch stays short.  Lower bound
         // 16 K: a chunk's partial tiles are ~1.3 K^2 doubles written and read back, against 8 K
         // bytes gathered per rating, so shorter chunks make the partials a first-order traffic term.
-        int64_t c = (s->mode == 0) ? s->nnz / (simds * 8) : (s->mode == 4 ? s->nnz / (simds * 3) : (s->mode == 5 ? (s->nnz * 3) / (simds * 7) : (s->mode == 7 ? (s->nnz * 9) / (simds * 8) : s->nnz / simds)));   // (mode 7: a wave walks several items anyway; every chunk is a hand-over through memory: ML-1M shape 1 024 against 640: 48 / 53 us against 55 / 53)
+        int64_t c = (s->mode == 0) ? s->nnz / (simds * 8) : (s->mode == 4 ? (s->nnz * 9) / (simds * 16) : (s->mode == 5 ? (s->nnz * 3) / (simds * 7) : (s->mode == 7 ? (s->nnz * 9) / (simds * 8) : s->nnz / simds)));   // (mode 7: a wave walks several items anyway; every chunk is a hand-over through memory: ML-1M shape 1 024 against 640: 48 / 53 us against 55 / 53)
         c = (c + 63) / 64 * 64;
         // slab form: ONE wave walks an item, and a rating costs 36 (K = 128) / 10 (K = 64) tile MFMAs per 4
         // ratings: a launch lasts (average load of a wave slot) + (longest item), so items must stay short (ML-1M shape,
@@ -160,7 +160,13 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     std::vector<Item> items;
     items.reserve((size_t)nloc + (size_t)(s->nnz / chunk) + 16);
     std::vector<int32_t> mc_slot0, mc_nch;
-    const int64_t fin_cost = (int64_t)K * K / 4 + 64;     // factorisation etc., in units of "ratings"
+    // The sort key of the item list: ratings + a SMALL constant for everything after the Gram.  The chunks of the heavy
+    // columns -- whose last arriver still has a chunk sum and a factorisation ahead of it -- must start before whole
+    // columns of similar length: with the factorisation priced at what it costs (K^2 / 4 + 64 "ratings": rounds 1-2)
+    // whole columns overtook them and every launch ended on the heavy columns' last arrivers.  Round 3, ML-1M shape:
+    // K = 64 0.3645 -> 0.3045 ms per iteration, K = 128 0.822 -> 0.752, K = 32 0.0993 -> 0.0985; ChEMBL shape
+    // 1.065 -> 1.031.  Flat between 1 and ~K^2 / 16; chunks ahead of ALL whole columns measured the same.
+    const int64_t fin_cost = env_int("BPMF_HIP_FINCOST", 0) > 0 ? env_int("BPMF_HIP_FINCOST", 0) : 32;     // (BPMF_HIP_FINCOST: experiments)
     int32_t slots = 0;
     for (int64_t c = 0; c < nloc; ++c) {
         const int64_t p0 = colptr[c], n = colptr[c + 1] - colptr[c];
