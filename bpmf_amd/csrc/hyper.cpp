@@ -126,18 +126,48 @@ bool inverse_factor_spd(int K, const double *X_in, double *L_out)
     static thread_local std::vector<double> ux;
     ux.assign(X_in, X_in + (size_t)K * K);
     Mat U{ux.data(), K};
-    for (int c = K - 1; c >= 0; --c) {                   // right-looking from the last column: contiguous inner loops
+    // right-looking from the last column, contiguous inner loops.  Four pivot columns at a time: they are finished
+    // among themselves first (each takes the rank-one updates of the ones before it), then every column to their left
+    // takes the four updates in ONE pass -- per entry the same subtractions in the same order (c descending) as one
+    // pivot column after the other, with its running value in a register across the four.
+    auto finish_column = [&](int c) -> bool {            // sqrt of the pivot, scale the column above it
         double *uc = &U(0, c);
         const double d = uc[c];
         if (!(d > 0.0)) return false;
         const double sd = std::sqrt(d);
         uc[c] = sd;
         for (int r = 0; r < c; ++r) uc[r] /= sd;
-        for (int j = 0; j < c; ++j) {                     // X(0..j, j) -= Ux(0..j, c) Ux(j, c)
+        return true;
+    };
+    auto update_column = [&](int j, int c) {              // X(0..j, j) -= Ux(0..j, c) Ux(j, c)
+        double *uj = &U(0, j);
+        const double *uc = &U(0, c);
+        const double f = uc[j];
+        for (int r = 0; r <= j; ++r) uj[r] -= uc[r] * f;
+    };
+    int c = K - 1;
+    for (; c >= 3; c -= 4) {
+        if (!finish_column(c)) return false;
+        update_column(c - 1, c); update_column(c - 2, c); update_column(c - 3, c);
+        if (!finish_column(c - 1)) return false;
+        update_column(c - 2, c - 1); update_column(c - 3, c - 1);
+        if (!finish_column(c - 2)) return false;
+        update_column(c - 3, c - 2);
+        if (!finish_column(c - 3)) return false;
+        const double *u0 = &U(0, c), *u1 = &U(0, c - 1), *u2 = &U(0, c - 2), *u3 = &U(0, c - 3);
+        for (int j = 0; j < c - 3; ++j) {
             double *uj = &U(0, j);
-            const double f = uc[j];
-            for (int r = 0; r <= j; ++r) uj[r] -= uc[r] * f;
+            const double f0 = u0[j], f1 = u1[j], f2 = u2[j], f3 = u3[j];
+            for (int r = 0; r <= j; ++r) {
+                double t = uj[r];
+                t -= u0[r] * f0; t -= u1[r] * f1; t -= u2[r] * f2; t -= u3[r] * f3;
+                uj[r] = t;
+            }
         }
+    }
+    for (; c >= 0; --c) {
+        if (!finish_column(c)) return false;
+        for (int j = 0; j < c; ++j) update_column(j, c);
     }
     std::memset(L_out, 0, sizeof(double) * K * K);
     static thread_local std::vector<double> x;
@@ -145,7 +175,23 @@ bool inverse_factor_spd(int K, const double *X_in, double *L_out)
     for (int c = 0; c < K; ++c) {                         // column c of R = Ux^-1: Ux x = e_c, x_r = 0 for r > c
         for (int r = 0; r < c; ++r) x[r] = 0.0;
         x[c] = 1.0;
-        for (int j = c; j >= 0; --j) {
+        int j = c;
+        for (; j >= 3; j -= 4) {                          // four steps of the back substitution at a time (same order per entry)
+            const double *u0 = &U(0, j), *u1 = &U(0, j - 1), *u2 = &U(0, j - 2), *u3 = &U(0, j - 3);
+            const double x0 = (x[j] /= u0[j]);
+            x[j - 1] -= u0[j - 1] * x0;
+            const double x1 = (x[j - 1] /= u1[j - 1]);
+            x[j - 2] -= u0[j - 2] * x0; x[j - 2] -= u1[j - 2] * x1;
+            const double x2 = (x[j - 2] /= u2[j - 2]);
+            x[j - 3] -= u0[j - 3] * x0; x[j - 3] -= u1[j - 3] * x1; x[j - 3] -= u2[j - 3] * x2;
+            const double x3 = (x[j - 3] /= u3[j - 3]);
+            for (int r = 0; r < j - 3; ++r) {
+                double t = x[r];
+                t -= u0[r] * x0; t -= u1[r] * x1; t -= u2[r] * x2; t -= u3[r] * x3;
+                x[r] = t;
+            }
+        }
+        for (; j >= 0; --j) {
             const double *uj = &U(0, j);
             const double xj = (x[j] /= uj[j]);
             for (int r = 0; r < j; ++r) x[r] -= uj[r] * xj;
@@ -228,10 +274,27 @@ extern "C" int bpmf_hyper_finish(int K, int64_t N, const double *cov, const doub
     // U(0..k, j) += au(0..k, k) * R(j,k), k ascending: every entry still adds its terms in the order
     // k = i, i+1, ..., j (bit-identical to the dot-product form) but the inner loop runs down a
     // contiguous column and vectorises without re-association.
+    // Four k at a time: an entry keeps its running sum in a register across the four terms instead of going through
+    // memory after each -- the same additions in the same order (mul and add are separate roundings here), a quarter of
+    // the loads / stores and loop set-ups of the accumulator column.
     std::memset(LambdaU, 0, sizeof(double) * KK);
     for (int j = 0; j < K; ++j) {
         double *uj = &U(0, j);
-        for (int k = 0; k <= j; ++k) {
+        int k = 0;
+        for (; k + 3 <= j; k += 4) {
+            const double f0 = R[(size_t)k * K + j], f1 = R[(size_t)(k + 1) * K + j], f2 = R[(size_t)(k + 2) * K + j], f3 = R[(size_t)(k + 3) * K + j];
+            const double *a0 = au + (size_t)k * K, *a1 = a0 + K, *a2 = a1 + K, *a3 = a2 + K;
+            for (int i = 0; i <= k; ++i) {
+                double t = uj[i];
+                t += a0[i] * f0; t += a1[i] * f1; t += a2[i] * f2; t += a3[i] * f3;
+                uj[i] = t;
+            }
+            // ragged ends: i = k + 1 .. k + 3 take the terms of the k' >= i only
+            uj[k + 1] = ((uj[k + 1] + a1[k + 1] * f1) + a2[k + 1] * f2) + a3[k + 1] * f3;
+            uj[k + 2] = (uj[k + 2] + a2[k + 2] * f2) + a3[k + 2] * f3;
+            uj[k + 3] = uj[k + 3] + a3[k + 3] * f3;
+        }
+        for (; k <= j; ++k) {
             const double f = R[(size_t)k * K + j];
             const double *ak = au + (size_t)k * K;
             for (int i = 0; i <= k; ++i) uj[i] += ak[i] * f;
@@ -249,15 +312,33 @@ extern "C" int bpmf_hyper_finish(int K, int64_t N, const double *cov, const doub
         // column updates F(k.., j) += W(k.., k) * U(k,j) with W = U^T (row k of U made contiguous), k ascending
         for (int c = 0; c < K; ++c)
             for (int r = 0; r < K; ++r) W[(size_t)r * K + c] = U(r, c);      // W(c, r) = U(r, c): column r of W = row r of U
+        // Only the lower triangle (i >= j) is accumulated: F(i,j) and F(j,i) are sums of the same products in the
+        // same order (k ascending), i.e. bit-identical -- the upper triangle is a copy.  Half the multiply-adds of this
+        // product.  (Round 3 also tried helper threads for the three stages of the draw whose result columns are
+        // independent -- R = Ux^-1, U = au R^T, F -- with a spinning fork / join: bit-identical, but on the GPU boxes'
+        // EPYC 259 us with one thread, 256 with three, 230-244 with six at K = 128: the 128 KB operands produced on one
+        // core are cache misses on the others.  tools/probes/hyper_bench.cpp is the micro-benchmark.)
         std::memset(LambdaF, 0, sizeof(double) * KK);
         for (int j = 0; j < K; ++j) {
             double *fj = &F(0, j);
-            for (int k = 0; k <= j; ++k) {
+            int k = 0;
+            for (; k + 3 <= j; k += 4) {                      // four k at a time (see LambdaU above): same sums, same order
+                const double f0 = U(k, j), f1 = U(k + 1, j), f2 = U(k + 2, j), f3 = U(k + 3, j);
+                const double *w0 = &W[(size_t)k * K], *w1 = w0 + K, *w2 = w1 + K, *w3 = w2 + K;
+                for (int i = j; i < K; ++i) {
+                    double t = fj[i];
+                    t += w0[i] * f0; t += w1[i] * f1; t += w2[i] * f2; t += w3[i] * f3;
+                    fj[i] = t;
+                }
+            }
+            for (; k <= j; ++k) {
                 const double f = U(k, j);
                 const double *wk = &W[(size_t)k * K];
-                for (int i = k; i < K; ++i) fj[i] += wk[i] * f;
+                for (int i = j; i < K; ++i) fj[i] += wk[i] * f;
             }
         }
+        for (int j = 0; j < K; ++j)
+            for (int i = j + 1; i < K; ++i) F(j, i) = F(i, j);
     }
     return BPMF_HIP_OK;
 }
