@@ -195,6 +195,57 @@ __device__ __forceinline__ void draw_normals_deferred(uint32_t counter, int n, d
     }
 }
 
+// The same streams for TWO columns at once.  n = 64 normals need ~82 attempts: a second round of 64 attempts uses a
+// fifth of its lanes.  Here every column gets its first 64 attempts in a round of its own and the later rounds are
+// SHARED: lanes 0..31 try the next 32 blocks of column A, lanes 32..63 the next 32 of column B (96 attempts are enough in
+// 99.8 % of the cases: three Philox rounds per pair instead of four).  Attempt n is still block n of its column's stream
+// and the j-th normal its j-th accepted attempt, so every normal is the one draw_normals_deferred produces.
+template <int NMAX>
+__device__ __forceinline__ void draw_normals_pair(uint32_t counterA, uint32_t counterB, int n, double *outA, double *outB,
+                                                  double *r2A, double *r2B, int lane)
+{
+    auto attempt = [&](uint32_t counter, uint32_t block, double &y, double &r2) -> bool {
+        const Philox4 b = stream_block(counter, block);
+        const double x = 2.0 * canonical53(b.w[3], b.w[2]) - 1.0;   // URNG order: w3, w2, w1, w0
+        y = 2.0 * canonical53(b.w[1], b.w[0]) - 1.0;
+        r2 = polar_r2(x, y);
+        return !(r2 > 1.0 || r2 == 0.0);
+    };
+    int prodA, prodB;
+    {   // first 64 attempts of A, then of B
+        double y, r2;
+        bool acc = attempt(counterA, (uint32_t)lane, y, r2);
+        unsigned long long m = __ballot(acc);
+        int rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (acc && rank < n) { outA[rank] = y; r2A[rank] = r2; }
+        prodA = __popcll(m);
+        acc = attempt(counterB, (uint32_t)lane, y, r2);
+        m = __ballot(acc);
+        rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (acc && rank < n) { outB[rank] = y; r2B[rank] = r2; }
+        prodB = __popcll(m);
+    }
+    const bool hi = lane >= 32;
+    const int l32 = lane & 31;
+    uint32_t base = 64u;                                              // next unused block (the same for both columns)
+    while (prodA < n || prodB < n) {                                  // wave-uniform
+        double y, r2;
+        const bool acc = attempt(hi ? counterB : counterA, base + (uint32_t)l32, y, r2);
+        const unsigned long long m = __ballot(acc);
+        const unsigned mA = (unsigned)m, mB = (unsigned)(m >> 32);
+        const int rank = (hi ? prodB : prodA) + __popc((hi ? mB : mA) & ((1u << l32) - 1u));
+        if (acc && rank < n) { (hi ? outB : outA)[rank] = y; (hi ? r2B : r2A)[rank] = r2; }
+        prodA += __popc(mA); prodB += __popc(mB);                     // (a column that is complete just drops its extra attempts)
+        base += 32u;
+    }
+    for (int i = lane; i < n; i += 64) {
+        const double ra = r2A[i], rb = r2B[i];
+        const double multA = sqrt(-2 * log(ra) / ra), multB = sqrt(-2 * log(rb) / rb);
+        outA[i] = outA[i] * multA;
+        outB[i] = outB[i] * multB;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Gram accumulation over one chunk of a column's ratings.
 // ---------------------------------------------------------------------------

@@ -284,9 +284,8 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
     static_assert(K == 64, "one lane per latent index");
     constexpr int LD = K + 1, NW = 8, NB = 4;                         // NB columns per wave and pass: their final products x = R0^-1 v run as ONE MFMA GEMM
     __shared__ double S0[K * LD];                                     // S0[i * LD + j] = (R0^-1)[i][j]
-    __shared__ double sz[NW][K];
-    __shared__ double sr[NW][K];                                      // r2 of the accepted polar attempts (draw_normals_deferred)
-    __shared__ double sv[NW][NB][K];                                  // v of the NB columns of a pass (then their x)
+    __shared__ double sr[NW][2][K];                                   // r2 of the accepted polar attempts of a pair of columns (draw_normals_pair)
+    __shared__ double sv[NW][NB][K];                                  // per column of a pass: its normals z, then v, then x
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int q = tid; q < K * K; q += 64 * NW) {                       // a.S0t[j * K + i] = (R0^-1)[i][j]
         const int j = q / K, i = q % K;
@@ -297,6 +296,20 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
     const int kq = lane >> 4, bq = (lane >> 2) & 3, xq = lane & 3;      // operand view of v_mfma_f64_4x4x4_4b_f64: lane (k, b, x)
 
     for (int w0 = ((int)blockIdx.x * NW + wave) * NB; w0 < a.nitems; w0 += (int)gridDim.x * NW * NB) {
+        // z ~ N(0, I) of the pass's columns, two columns at a time (the later Philox rounds of a pair are shared), straight
+        // into their slots of sv
+#pragma unroll 1
+        for (int cb = 0; cb < NB; cb += 2) {
+            const int w = w0 + cb;
+            if (w >= a.nitems) break;                                 // wave-uniform
+            const uint32_t cA = sample_counter<K>(a.col_from + a.col[w], a.iter_plus_1);
+            if (w + 1 < a.nitems) {
+                const uint32_t cB = sample_counter<K>(a.col_from + a.col[w + 1], a.iter_plus_1);
+                draw_normals_pair<K>(cA, cB, K, sv[wave][cb], sv[wave][cb + 1], sr[wave][0], sr[wave][1], lane);
+            } else {
+                draw_normals_deferred<K>(cA, K, sv[wave][cb], sr[wave][0], lane);
+            }
+        }
 #pragma unroll 1
         for (int cb = 0; cb < NB; ++cb) {
             const int w = w0 + cb;
@@ -304,7 +317,6 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
             const int col = a.col[w];
             const int64_t p0 = a.p0[w];
             const int len = a.len[w];
-            draw_normals_deferred<K>(sample_counter<K>(a.col_from + col, a.iter_plus_1), K, sz[wave], sr[wave], lane);
 
             PfFactor f[NCAP];
             double c = y0;                                            // R0^-T b = y0 + sum_m kappa_m R0^-T x_m
@@ -325,7 +337,7 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
 #pragma unroll
             for (int m = 0; m < NCAP; ++m)
                 if (m < len) t = pf_solve_t(f[m], t, lane);
-            double v = t + sz[wave][lane];                            // :322 (same wave wrote the normals)
+            double v = t + sv[wave][cb][lane];                        // :322 (same wave wrote the normals)
 #pragma unroll
             for (int m = NCAP - 1; m >= 0; --m)
                 if (m < len) v = pf_solve(f[m], v, lane);
