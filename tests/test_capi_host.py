@@ -61,7 +61,7 @@ def test_host_randn_stream_equals_oracle(oracle):
         assert np.array_equal(engine.randn_host(c, 500), oracle.randn(c, 500))
 
 
-@pytest.mark.parametrize("K,N", [(8, 2), (8, 4), (16, 50), (32, 943), (32, 1682), (64, 300)])
+@pytest.mark.parametrize("K,N", [(8, 2), (8, 4), (16, 50), (32, 943), (32, 1682), (64, 300), (5, 30), (13, 100), (35, 500), (128, 6040), (128, 3706)])   # (odd K: the ragged ends of the four-at-a-time loops; K = 128: the inverse-free factor)
 def test_hyper_sample_matches_oracle(oracle, K, N):
     rng = np.random.default_rng(K * 1000 + N)
     A = rng.standard_normal((K, max(N, K + 3)))
