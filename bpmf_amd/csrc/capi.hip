@@ -1619,6 +1619,19 @@ extern "C" int bpmf_hip_side_schedule_info(const bpmf_hip_side *s, int64_t *out,
     return BPMF_HIP_OK;
 }
 
+extern "C" int bpmf_hip_side_schedule_items(const bpmf_hip_side *s, int32_t *col, int32_t *len, int32_t *heavy, int64_t n, int64_t *nitems)
+{
+    if (!s || n < 0) return fail(BPMF_HIP_EINVAL, "side_schedule_items: bad argument");
+    if (nitems) *nitems = s->nwork;
+    const size_t m = (size_t)std::min<int64_t>(n, s->nwork);
+    if (m == 0) return BPMF_HIP_OK;
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    if (col) HIP_TRY(hipMemcpy(col, s->d_wi_col, m * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (len) HIP_TRY(hipMemcpy(len, s->d_wi_len, m * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (heavy) HIP_TRY(hipMemcpy(heavy, s->d_wi_mc, m * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return BPMF_HIP_OK;
+}
+
 // sum of the sampler / statistics kernel times over all collected launches of the stateful path
 extern "C" int bpmf_hip_side_kernel_ms_sum(bpmf_hip_side *s, double *sample_ms, double *reduce_ms, int64_t *launches)
 {

@@ -314,7 +314,6 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
         for (int cb = 0; cb < NB; ++cb) {
             const int w = w0 + cb;
             if (w >= a.nitems) { sv[wave][cb][lane] = 0.0; continue; }    // wave-uniform
-            const int col = a.col[w];
             const int64_t p0 = a.p0[w];
             const int len = a.len[w];
 

@@ -226,6 +226,15 @@ class HipEngine:
                 "lr_columns", "parts", "local_columns", "local_ratings", "pf_ratings", "pf_ratings_sq")
         return {k: int(v) for k, v in zip(keys, out)}
 
+    def schedule_items(self, side):
+        """The side's work items in launch order: (local column, ratings, heavy-column ordinal or -1) arrays."""
+        n = C.c_int64()
+        _lib.check(self.lib.bpmf_hip_side_schedule_items(side.handle, None, None, None, 0, C.byref(n)))
+        col = np.zeros(n.value, np.int32); ln = np.zeros(n.value, np.int32); heavy = np.zeros(n.value, np.int32)
+        if n.value:
+            _lib.check(self.lib.bpmf_hip_side_schedule_items(side.handle, _ptr(col), _ptr(ln), _ptr(heavy), n.value, None))
+        return col, ln, heavy
+
     def kernel_ms_sum(self, side):
         """(sampler ms, statistics ms, launches) summed over the half-iterations run through sys_sample."""
         a = C.c_double(); b = C.c_double(); n = C.c_int64()

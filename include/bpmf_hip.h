@@ -295,6 +295,10 @@ BPMF_API int bpmf_hip_randn_stream(bpmf_hip_ctx *ctx, uint32_t counter, int n, d
  * schedule in numbers (16 words, see capi.hip: form, work items, chunks, columns per product-form class ...). */
 BPMF_API int bpmf_hip_side_kernel_name(const bpmf_hip_side *side, char *buf, int n);
 BPMF_API int bpmf_hip_side_schedule_info(const bpmf_hip_side *side, int64_t *out16, int n);
+/* the side's work items in launch order (what replaces the `#pragma omp parallel for schedule(guided)` over the columns,
+ * c++/sample.cpp:353-356): local column, number of ratings, and the ordinal of the item's heavy column (-1: the item is
+ * a whole column).  Copies min(n, work items) entries; returns the number of work items through *nitems. */
+BPMF_API int bpmf_hip_side_schedule_items(const bpmf_hip_side *side, int32_t *col, int32_t *len, int32_t *heavy, int64_t n, int64_t *nitems);
 /* sums of the sampler / statistics kernel times (ms, HIP events on their streams) over all
  * half-iterations of the stateful path collected so far, and their number */
 BPMF_API int bpmf_hip_side_kernel_ms_sum(bpmf_hip_side *side, double *sample_ms, double *reduce_ms, int64_t *launches);
