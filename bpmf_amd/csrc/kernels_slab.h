@@ -192,7 +192,10 @@ __device__ __forceinline__ void slab_cholesky_solve(double (&A)[GeoS<K>::NREG], 
                      d22 = bcast(dblk, 32 + 4 * b0 + 2), d23 = bcast(dblk, 32 + 4 * b0 + 3), d33 = bcast(dblk, 48 + 4 * b0 + 3);
         double WA, WB;
         factor_block44(d00, d01, d02, d03, d11, d12, d13, d22, d23, d33, kq, x, WA, WB);
-        if (b == 0) sw[16 * s + 4 * kq + x] = WB;                     // W_s as the A operand of the backward solve
+        // W_s as the A operand of the backward solve: entry [kq][x] of the tile has to hold W[x][kq] -- the lane writes
+        // ITS W[kq][x] to [x][kq] instead of selecting the transposed entry from the ten candidates a second time
+        (void)WB;
+        if (b == 0) sw[16 * s + 4 * x + kq] = WA;
         // forward solve of this block row: y_s = W^T b_s (block b0 of bv[q0]); y_s in every b as a B operand
         const double ys_all = mfma44(WA, bv[q0], 0.0);
         bv[q0] = (b == b0) ? ys_all : bv[q0];
