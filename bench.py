@@ -546,7 +546,7 @@ def main():
     # what the launches execute: differs from the algorithmic count where columns take the product form (ChEMBL shape)
     flops_launch = 0.5 * (executed_flops(info_m, nnz_m, dom_m[1] - dom_m[0], K) + executed_flops(info_u, nnz_u, dom_u[1] - dom_u[0], K))
     # HIP-event times of the sampler / statistics kernels on their streams, summed by the library
-    # over the timed steps (events ride on every 8th launch of a side: BPMF_HIP_TIMING_EVERY)
+    # over the timed steps (events ride on every 8th launch of a side, every 32nd after its first 64: BPMF_HIP_TIMING_EVERY)
     kern_ms, red_ms, nl, per_side = 0.0, 0.0, 0, {}
     for sd in (movies, users):
         a1 = eng.kernel_ms_sum(sd.side); a0 = base[sd.name]

@@ -1456,8 +1456,11 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     flush_deferred(self->deferred_eval);
     // kernel times come from events around every n-th launch of the side (BPMF_HIP_TIMING_EVERY,
     // default 8; 1 = every launch; 0 = never): the start marker costs a few microseconds on S0
+    // A timed launch costs ~8 us (ML-1M shape: every 2nd launch 0.1015 ms per iteration, every 8th 0.0985, every 32nd
+    // 0.0975): every n-th launch for the first 64 launches of a side (short records: the 8-step strong-scaling one), every
+    // 4 n-th from then on.
     static const int every = env_int("BPMF_HIP_TIMING_EVERY", 8);
-    const bool timed = every > 0 && seq % (unsigned)every == 0;
+    const bool timed = every > 0 && seq % (unsigned)(seq <= 64u ? every : 4 * every) == 0;
     const bool ride = s1 != s0 && self->nwork > 0 && env_int("BPMF_HIP_EXT_EVENTS", 1) != 0;   // events on the sampler's own packet
     if (timed && !ride) HIP_TRY(hipEventRecord(ev[0], s0));
     if (inorder_flush) { if ((rc = flush_pending_stats_inorder(c))) return rc; }
