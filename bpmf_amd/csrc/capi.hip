@@ -130,11 +130,11 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
         if (s->mode == 2 || s->mode == 4) s->mode = 1;                             // (BPMF_HIP_MODE=2 / 4 exist for K >= 64 only)
         // mode 6 (k_sample1q, kernels_q1.h): Gram per wave as in mode 1, factorisation four columns per wave as in mode 3.
         // Its groups are built over the whole item list: a side cut into parts keeps mode 1.
-        if (s->mode == 6 && s->nsub > 1) s->mode = 1;
+        if ((s->mode == 6 || s->mode == 8) && s->nsub > 1) s->mode = 1;   // (8: mode 6 in two launches, see kernels_q1.h)
         // mode 7 (k_sample1x, kernels_x4.h): up to four items per wave one after the other (Gram as in mode 1 on natural
         // blocks), their columns factorised in lockstep as in mode 3; item list and chunks as mode 1
     }
-    if ((f32 || K == 64) && (s->mode == 6 || s->mode == 7)) s->mode = f32 ? 5 : 4;
+    if ((f32 || K == 64) && (s->mode == 6 || s->mode == 7 || s->mode == 8)) s->mode = f32 ? 5 : 4;
     const bool wg = s->mode == 2;
     int chunk = wg ? (1 << 30) : env_int("BPMF_HIP_CHUNK", 0);
     if (chunk <= 0) {
@@ -213,7 +213,7 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
             s->sub_item_off.push_back((int)i);
         }
     }
-    if (s->mode == 6) {
+    if (s->mode == 6 || s->mode == 8) {
         // groups of four columns in the order in which the sorted item list first mentions them: columns of similar
         // cost, dispatched -- and therefore complete -- at about the same time
         std::vector<int32_t> col_slot((size_t)std::max<int64_t>(nloc, 1), -1), grp_cols;
@@ -1404,7 +1404,7 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     // (K = 64, slab form without low-rank columns: the same launch format, k_sample1s<64>; only the words the slab
     // form reads are staged -- the R0 / R0^-1 tail of the K = 64 blob belongs to the low-rank forms)
     const size_t stage_words = (K == 64 && self->lr_n == 0) ? (size_t)K * K + K + 2 + K : c->in_words;
-    const bool fusable_form = (K <= 32 && (self->mode == 1 || self->mode == 6 || self->mode == 7)) || (K == 64 && self->mode == 4 && self->lr_n == 0 && self->nsub <= 1);
+    const bool fusable_form = (K <= 32 && (self->mode == 1 || self->mode == 6 || self->mode == 7 || self->mode == 8)) || (K == 64 && self->mode == 4 && self->lr_n == 0 && self->nsub <= 1);
     const bool fused = s1 != s0 && !dist && stage_words <= 8192 && fusable_form && self->nwork > 0 && !self->reduce_on &&
                        c->dtype == BPMF_HIP_F64 && env_int("BPMF_HIP_FUSED", 1) != 0;
     bpmf::FusedArgs fz{};
@@ -1487,7 +1487,7 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     // own on S1 their 2 048 waves only got wave slots as the partner's sampler -- which fills the chip -- drained, i.e.
     // the sums of the 483 k compounds arrived when the targets' sampler ended (0.34 ms after their own sampler), and the
     // compounds' host chain (cov, Normal-Wishart draw, factor of LambdaF: 0.12 ms) started only then.
-    const bool partner_fusable = (K <= 32 && (other->mode == 1 || other->mode == 6 || other->mode == 7)) || (K == 64 && other->mode == 4 && other->lr_n == 0 && other->nsub <= 1);
+    const bool partner_fusable = (K <= 32 && (other->mode == 1 || other->mode == 6 || other->mode == 7 || other->mode == 8)) || (K == 64 && other->mode == 4 && other->lr_n == 0 && other->nsub <= 1);
     const bool defer = !fused && !dist && s1 != s0 && c->dtype == BPMF_HIP_F64 && partner_fusable && other->nwork > 0 && other->a_d_in &&
                        self->nwork > 0 && env_int("BPMF_HIP_FUSED", 1) != 0 && env_int("BPMF_HIP_DEFER_STATS", 0) != 0;   // (measured slower: 1.72 against 1.26 ms -- the 2 048 rider waves stream 247 MB at the head of the partner's launch; kept as a switch)
     // unfused side with a stand-alone pass that wants a head start (big side: k_colstats_wg; fp32 path): in order on S0,
@@ -1598,6 +1598,7 @@ extern "C" int bpmf_hip_side_kernel_name(const bpmf_hip_side *s, char *buf, int 
         if (s->mode == 3) name = "k_sample4<" + k + ">";
         else if (s->mode == 6) name = "k_sample1q<" + k + ">";
         else if (s->mode == 7) name = "k_sample1x<" + k + ">";
+        else if (s->mode == 8) name = "k_sample1q<" + k + ",split> + k_finish_groups<" + k + ">";
         else if (s->mode == 1) name = ((K == 32 || K == 16) && env_int("BPMF_HIP_SLAB32", 0) ? "k_sample1s<" : "k_sample1<") + k + ">";
         else name = "k_sample<" + k + ">";
     }

@@ -172,7 +172,10 @@ __device__ __forceinline__ void finish_group4(const SampleArgs &a, const double 
     if (bad) atomicMin(a.fail, (unsigned long long)(a.col_from + fcol));
 }
 
-template <int K>
+// SPLIT (BPMF_HIP_MODE=8): the kernel ends when the column's slot is written -- plain visibility through the kernel
+// boundary, no write-through wait, no ticket -- and k_finish_groups, the next launch on the same stream, factorises every
+// group: all groups' lockstep chains run side by side instead of each at the end of its last column's wave.
+template <int K, bool SPLIT = false>
 __global__ __launch_bounds__(64, GeoQ<K>::WPS) void k_sample1q(SampleArgs a, FusedArgs f)
 {
     using GQ = GeoQ<K>;
@@ -253,6 +256,11 @@ __global__ __launch_bounds__(64, GeoQ<K>::WPS) void k_sample1q(SampleArgs a, Fus
     const int gs = a.q_col_slot[col];
     const int grp = gs >> 2, slot = gs & 3;
     double *sc = a.q_scratch + (size_t)grp * GQ::GWORDS;
+    // (split form: plain stores -- the kernel boundary makes them visible; fused form: write-through for the ticket)
+    auto put = [](double *p, double v) {
+        if constexpr (SPLIT) *p = v;
+        else __hip_atomic_store(p, v, BPMF_RLX_AGENT);
+    };
     {
         const int i = lane >> 4, b = (lane >> 2) & 3, j = lane & 3;
         const int ih = i >> 1, jh = j >> 1, i1 = i & 1, j1 = j & 1;
@@ -268,13 +276,13 @@ __global__ __launch_bounds__(64, GeoQ<K>::WPS) void k_sample1q(SampleArgs a, Fus
                 // lane (i, b, j) holds G[r][c], r = idx(g, i), c = idx(g2, j) (gram_chunk44's permuted blocks)
                 const int R = 2 * (g >> 1) + ih, C = 2 * (g2 >> 1) + jh, ri = 2 * i1 + (g & 1), ci = 2 * j1 + (g2 & 1);
                 if ((g >> 1) < (g2 >> 1)) {                          // strictly upper natural block
-                    if (b == 0) __hip_atomic_store(&sc[word(R, C, ri, ci)], v, BPMF_RLX_AGENT);
+                    if (b == 0) put(&sc[word(R, C, ri, ci)], v);
                 } else if (g == g2) {                                 // both orientations exist among the lanes: each writes the upper one
-                    if (b == 0 && R <= C) __hip_atomic_store(&sc[word(R, C, ri, ci)], v, BPMF_RLX_AGENT);
+                    if (b == 0 && R <= C) put(&sc[word(R, C, ri, ci)], v);
                 } else {                                              // g = 2 h, g2 = 2 h + 1: one orientation only
                     const bool up = R <= C;
-                    if (b == 0) __hip_atomic_store(&sc[up ? word(R, C, ri, ci) : word(C, R, ci, ri)], v, BPMF_RLX_AGENT);
-                    if (b == 0 && R == C) __hip_atomic_store(&sc[word(R, R, ci, ri)], v, BPMF_RLX_AGENT);      // mirror inside the diagonal block
+                    if (b == 0) put(&sc[up ? word(R, C, ri, ci) : word(C, R, ci, ri)], v);
+                    if (b == 0 && R == C) put(&sc[word(R, R, ci, ri)], v);      // mirror inside the diagonal block
                 }
             }
         // rhs sums: over the four b and the four k; element e = idx(g, x) by the lanes x = 0..3 of quad 0
@@ -285,11 +293,12 @@ __global__ __launch_bounds__(64, GeoQ<K>::WPS) void k_sample1q(SampleArgs a, Fus
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
             const int e = G4::idx(g, lane & 3);
-            if (lane < 4) __hip_atomic_store(&sc[(NB + (e >> 2)) * 64 + 16 * (e & 3) + 4 * slot], v, BPMF_RLX_AGENT);
+            if (lane < 4) put(&sc[(NB + (e >> 2)) * 64 + 16 * (e & 3) + 4 * slot], v);
         }
         __syncthreads();                                              // (single wave: the normals are in LDS)
-        if (lane < K) __hip_atomic_store(&sc[(NB + NG + (lane >> 2)) * 64 + 16 * (lane & 3) + 4 * slot], sz[lane], BPMF_RLX_AGENT);
+        if (lane < K) put(&sc[(NB + NG + (lane >> 2)) * 64 + 16 * (lane & 3) + 4 * slot], sz[lane]);
     }
+    if constexpr (SPLIT) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int4 gcols = *reinterpret_cast<const int4 *>(a.q_grp_cols + 4 * grp);
     const int want = (gcols.x >= 0) + (gcols.y >= 0) + (gcols.z >= 0) + (gcols.w >= 0);
@@ -303,6 +312,17 @@ __global__ __launch_bounds__(64, GeoQ<K>::WPS) void k_sample1q(SampleArgs a, Fus
     if (a.ablate & 8u) return;                                        // (profiling switch: Gram + hand-over only)
 
     finish_group4<K>(a, sc, gcols, sw, lane);
+}
+
+// second launch of the split form: one wave per group of four columns
+template <int K>
+__global__ __launch_bounds__(64, GeoQ<K>::WPS) void k_finish_groups(SampleArgs a, int ngroups)
+{
+    __shared__ double sw[GeoQ<K>::NG * 64];
+    const int grp = blockIdx.x;
+    if (grp >= ngroups) return;
+    const int4 gcols = *reinterpret_cast<const int4 *>(a.q_grp_cols + 4 * grp);
+    finish_group4<K>(a, a.q_scratch + (size_t)grp * GeoQ<K>::GWORDS, gcols, sw, threadIdx.x);
 }
 
 }  // namespace bpmf

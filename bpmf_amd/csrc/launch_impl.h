@@ -174,6 +174,13 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
             BPMF_LAUNCH(k_sample1q<K>, grid, dim3(64), st, ev_start, ev_stop, a, f);
             return 0;
         }
+        if (nwork > 0 && self->mode == 8) {                          // the same in two launches: Grams, then every group's factorisation side by side
+            const FusedArgs &f = self->cur_fused;
+            const dim3 grid((unsigned)(nwork + (f.gate_host ? 1 : 0) + f.nstat));
+            BPMF_LAUNCH((k_sample1q<K, true>), grid, dim3(64), st, ev_start, (hipEvent_t) nullptr, a, f);
+            BPMF_LAUNCH(k_finish_groups<K>, dim3((unsigned)self->q_ngroups), dim3(64), st, (hipEvent_t) nullptr, ev_stop, a, self->q_ngroups);
+            return 0;
+        }
     }
     if constexpr (K <= 32) {
         if (nwork > 0 && self->mode == 7) {                          // up to four items per wave one after the other, factorised in lockstep

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-9
 
 
-@pytest.fixture(params=[None, 0, 1, 2, 3, 6, 7], ids=["auto", "persistent", "per-item", "workgroup", "four-columns", "gram1-finish4", "four-in-a-row"])
+@pytest.fixture(params=[None, 0, 1, 2, 3, 6, 7, 8], ids=["auto", "persistent", "per-item", "workgroup", "four-columns", "gram1-finish4", "four-in-a-row", "gram1-then-finish4"])
 def sampler_mode(request):
     """The forms of the sampler (BPMF_HIP_MODE, read when a side is created): 0 = persistent
     waves with C = 64/K columns factorised side by side, 1 = one work item per single-wave
@@ -23,7 +23,8 @@ def sampler_mode(request):
     3 = four columns per wave, factorisation on the 4x4x4 MFMA shape (K <= 32), 6 = the Gram of a column by one wave, the
     factorisation of four columns by the last wave of their group to deliver (k_sample1q, K <= 32; other K: auto),
     7 = a wave forms the Grams of up to four work items one after the other and factorises their columns in lockstep
-    (k_sample1x, K <= 32; other K: auto)."""
+    (k_sample1x, K <= 32; other K: auto), 8 = form 6 in two launches: the Grams, then one wave per group of four columns
+    (k_sample1q<K, split> + k_finish_groups, K <= 32; other K: auto)."""
     import os
     old = os.environ.get("BPMF_HIP_MODE")
     if request.param is None:
