@@ -7,13 +7,15 @@ movies.predict(users) -- both host hyper-parameter draws, the device->host
 reductions and the RMSE evaluation are inside the timed region, exactly what the
 reference's `items/sec` covers.  value = (N_users + N_movies) * steps / seconds.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ml1m|ml1m_k64|chembl|ml1m_k128]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload ml1m|ml1m_k64|chembl|ml1m_k128|ml1m_k128_f64|ml1m_k100]
 
 Workloads (BASELINE.json configs; synthetic stand-ins, the reference ships only ML-100K):
   ml1m        configs[1]  6040 x 3706, 1 000 209 ratings (90/10 split), K = 32 fp64   <- the headline / default
   ml1m_k64                the same matrix, K = 64 fp64
   chembl      configs[2]  483 500 x 5 775, 1 023 952 real-valued activities, K = 64 fp64
-  ml1m_k128   configs[4]  the ML-1M shape, K = 128, fp32 factors (mixed-precision path)
+  ml1m_k128   configs[4]  the ML-1M shape, K = 128, fp32 factors (mixed-precision path; an explicit opt-in everywhere)
+  ml1m_k128_f64           the ML-1M shape, K = 128 in the reference's fp64 (what `bpmf -d 128` / bpmf-128 of ci/multilatent.sh:5 runs)
+  ml1m_k100               the ML-1M shape, K = 100 fp64 (BASELINE.md's "industrial" num_latent) on the K = 128 kernels, 28 padded dimensions
 N > 1: one rank per GPU, RCCL inside the library.  Under a launcher (WORLD_SIZE / RANK / LOCAL_RANK set, e.g.
 `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) this process is one of the N ranks; without one,
 `bench.py --gpus N` starts the N ranks itself (the job of `mpirun -np N` for the reference, c++/mpi_common.h:11-50) and
@@ -59,6 +61,8 @@ WORKLOADS = {
     "ml1m_k64":  (64, "f64", None, None),
     "chembl":    (64, "f64", None, None),
     "ml1m_k128": (128, "f32", None, None),
+    "ml1m_k128_f64": (128, "f64", None, None),
+    "ml1m_k100": (100, "f64", None, None),
 }
 
 
@@ -92,9 +96,12 @@ def kernel_source_sha():
     with, and figures of a profile of OTHER code are reported as stale, not as this run's."""
     import hashlib
     h = hashlib.sha256()
-    # (device code only: the kernel headers -- host-side files of csrc/ do not change what a counter sees)
+    # (everything device code is compiled from or launched with: the kernel headers, the per-K translation units --
+    # launch bounds and template instantiations live there -- and launch_impl.h, which holds the grids and launch shapes;
+    # capi.hip / hyper.cpp / io.cpp are host-only and do not change what a counter sees)
     for f in sorted(glob.glob(os.path.join(ROOT, "bpmf_amd", "csrc", "kernels*.h")) +
-                    [os.path.join(ROOT, "bpmf_amd", "csrc", n) for n in ("philox.h", "args.h")]):
+                    glob.glob(os.path.join(ROOT, "bpmf_amd", "csrc", "k*.hip")) +
+                    [os.path.join(ROOT, "bpmf_amd", "csrc", n) for n in ("philox.h", "args.h", "launch_impl.h", "launch.h")]):
         h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 

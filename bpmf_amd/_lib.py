@@ -16,6 +16,10 @@ _SIGNATURES = {
     "bpmf_hip_abi_version": (C.c_int, []),
     "bpmf_hip_supports_k": (C.c_int, [C.c_int]),
     "bpmf_hip_supports": (C.c_int, [C.c_int, C.c_int]),
+    "bpmf_hip_kernel_k": (C.c_int, [C.c_int, C.c_int]),
+    "bpmf_hip_ctx_num_latent": (C.c_int, [C.c_void_p]),
+    "bpmf_hip_ctx_dtype": (C.c_int, [C.c_void_p]),
+    "bpmf_hip_ctx_ld": (C.c_int, [C.c_void_p]),
     "bpmf_hip_ctx_create_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "bpmf_hip_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     "bpmf_hip_ctx_set_no_covariance": (C.c_int, [C.c_void_p, C.c_int]),

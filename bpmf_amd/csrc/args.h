@@ -73,6 +73,7 @@ struct SampleArgs {
     double mean_rating;
     double alpha;
     uint32_t iter_plus_1;
+    int ktrue;                  // the caller's num_latent (<= the K the kernel is instantiated for): RNG stream id and number of normals per column
     // in-kernel gate (NULL: the launch itself was ordered behind the staging kernel): the word
     // k_gate_stage sets to `gate_want` once LambdaF | Lmu | fail | mu are in device memory
     const unsigned *gate_flag;
@@ -141,6 +142,7 @@ struct SampleArgsW {
     double mean_rating;
     double alpha;
     uint32_t iter_plus_1;
+    int ktrue;                  // (see SampleArgs)
 };
 
 // columns with a handful of ratings at K = 64 (kernels_lr.h)
@@ -157,6 +159,7 @@ struct LrArgs {
     unsigned long long *fail;
     double mean_rating, alpha, sqrt_alpha;
     uint32_t iter_plus_1;
+    int ktrue;                 // (see SampleArgs)
 };
 
 // BPMF_REDUCE formulation (kernels_reduce.h): the pass that computes the other side's precomputed Gram parts

@@ -3,13 +3,15 @@
 //
 // Host C++ only: it reads the matrices (io.cpp), mirrors them to the device through the C ABI of
 // include/bpmf_hip.h and runs main()'s Gibbs loop; every column update happens in the HIP kernels.
-// Flags: -n TRAIN -p TEST [-o DIR] [-i N] [-b N] [-a F] [-d K] [-t N] [-f N] [-k] [-r] [-v] [-g N]
+// Flags: -n TRAIN -p TEST [-o DIR] [-i N] [-b N] [-a F] [-d K] [-t N] [-f N] [-k] [-r] [-v] [-g N] [--fp32]
 // -g N (or BPMF_NGPU=N): N GPUs of this node, the job of `mpirun -np N bpmf` (c++/bpmf.cpp:111-117, c++/mpi_common.h:14-50):
 // one host thread + one context per GPU in this process, RCCL id shared in memory, columns of both sides sharded,
 // `nprocs: N`, every rank writes bpmf_<rank>.out like the reference's ranks do.
 // -m / -l "MU_FILE,LAMBDA_FILE": propagated posteriors of a previous run (c++/bpmf.cpp:134-135).
-// K (the reference's compile-time BPMF_NUMLATENT) is chosen at run time: -d K, else the
-// environment variable BPMF_NUMLATENT, else 32.
+// K (the reference's compile-time BPMF_NUMLATENT, c++/bpmf.h:22-24; ci/multilatent.sh:5 builds bpmf-8 ... bpmf-128 incl. 10, 20 ...
+// 100) is chosen at run time: -d K, else the environment variable BPMF_NUMLATENT, else 32.  Any 1 <= K <= 128, always in the
+// reference's fp64 arithmetic.  --fp32 (or BPMF_HIP_F32=1; K > 64 only) opts into the library's mixed-precision large-K path
+// and says so on stdout: never chosen silently.
 #include <getopt.h>
 #include <unistd.h>
 
@@ -45,7 +47,7 @@ double tick()
 
 void usage()
 {
-    std::cout << "Usage: bpmf -n <MTX> -p <MTX> [-o DIR/] [-i N] [-b N] [-f N] [-a F] [-d K] [-krv] [-t N] [-m MTX,MTX] [-l MTX,MTX] [-g N]\n"
+    std::cout << "Usage: bpmf -n <MTX> -p <MTX> [-o DIR/] [-i N] [-b N] [-f N] [-a F] [-d K] [-krv] [-t N] [-m MTX,MTX] [-l MTX,MTX] [-g N] [--fp32]\n"
               << "\n"
               << "Parameters:\n"
               << "  -n MTX: training matrix (rows = users, columns = items)\n"
@@ -55,7 +57,8 @@ void usage()
               << "  [-b N]: number of burn-in iterations (5)\n"
               << "  [-f N]: update frequency (accepted, unused)\n"
               << "  [-a F]: noise precision alpha (2.0)\n"
-              << "  [-d K]: number of latent dimensions: 8, 16, 32, 64 in fp64, 128 in fp32 (32, or $BPMF_NUMLATENT)\n"
+              << "  [-d K]: number of latent dimensions, 1 .. 128, fp64 (32, or $BPMF_NUMLATENT)\n"
+              << "  [--fp32]: mixed-precision column update (fp32 factors / Gram / factorisation; K > 64 only; or BPMF_HIP_F32=1)\n"
               << "\n"
               << "  [-l MTX,MTX]: propagated posterior mu and Lambda matrices for U\n"
               << "  [-m MTX,MTX]: propagated posterior mu and Lambda matrices for V\n"
@@ -79,11 +82,18 @@ void usage()
 // (c++/mpi_common.h:28-31): the message, then the process ends at once.
 std::atomic<bool> g_rank_threads{false};
 std::mutex g_die_mutex;
+std::vector<std::ostream *> g_rank_streams;                          // bpmf_<rank>.out of every rank (-g N / -r): flushed before the process ends
 
 [[noreturn]] void die(const std::string &msg)
 {
     if (g_rank_threads.load()) {
-        { std::lock_guard<std::mutex> lk(g_die_mutex); std::cerr << "bpmf: " << msg << std::endl; fflush(nullptr); }
+        {   // _Exit runs no destructors: the rank logs' buffered lines (the diagnostics of the failing run) go out here.  A rank
+            // that is writing its log right now may interleave with this flush; losing the lines would be worse.
+            std::lock_guard<std::mutex> lk(g_die_mutex);
+            std::cerr << "bpmf: " << msg << std::endl;
+            for (std::ostream *o : g_rank_streams) if (o) { *o << "bpmf: " << msg << std::endl; o->flush(); }
+            fflush(nullptr);
+        }
         std::_Exit(1);
     }
     std::cerr << "bpmf: " << msg << std::endl;
@@ -272,6 +282,8 @@ void rank_main(Job &J, int rank, std::ostream &os)
     os << "pid: " << getpid() << std::endl;
     if (getenv("PBS_JOBID")) os << "jobid: " << getenv("PBS_JOBID") << std::endl;
     os << "num_latent: " << K << std::endl;
+    if (J.dtype == BPMF_HIP_F32) os << "arithmetic: fp32 factors / Gram / factorisation (--fp32), fp64 hyper-parameters and sums" << std::endl;
+    if (bpmf_hip_kernel_k(K, J.dtype) != K) os << "kernels: num_latent " << bpmf_hip_kernel_k(K, J.dtype) << ", " << bpmf_hip_kernel_k(K, J.dtype) - K << " padded dimensions" << std::endl;
     os << "nprocs: " << J.nranks << std::endl;
     os << "nthrds: " << (J.nthrds > 0 ? J.nthrds : 1) << std::endl;
     os << "nsims: " << J.nsims << std::endl;
@@ -403,9 +415,12 @@ int main(int argc, char *argv[])
     int K = 32, ngpu = getenv("BPMF_NGPU") ? atoi(getenv("BPMF_NGPU")) : 0;
     if (const char *e = getenv("BPMF_NUMLATENT")) K = atoi(e);
 
+    bool fp32 = getenv("BPMF_HIP_F32") && atoi(getenv("BPMF_HIP_F32")) != 0;
+    static const struct option long_opts[] = {{"fp32", no_argument, nullptr, 1000}, {nullptr, 0, nullptr, 0}};
     int ch;
-    while ((ch = getopt(argc, argv, "krvn:t:p:i:b:f:o:m:l:a:d:g:h")) != -1) {
+    while ((ch = getopt_long(argc, argv, "krvn:t:p:i:b:f:o:m:l:a:d:g:h", long_opts, nullptr)) != -1) {
         switch (ch) {
+        case 1000: fp32 = true; break;
         case 'i': J.nsims = atoi(optarg); break;
         case 'b': J.burnin = atoi(optarg); break;
         case 'f': J.update_freq = atoi(optarg); break;
@@ -425,10 +440,11 @@ int main(int argc, char *argv[])
         }
     }
     if (fname.empty() || probename.empty()) { usage(); return 1; }
-    // fp64 like the reference for 8..64 latent dimensions; 128 selects the fp32 large-K path of the library
+    // fp64 like the reference (c++/bpmf.h:55-58) for every num_latent; the fp32 large-K path only when asked for
     J.K = K;
-    J.dtype = (K == 128) ? BPMF_HIP_F32 : BPMF_HIP_F64;
-    if (!bpmf_hip_supports(K, J.dtype)) die("unsupported number of latent dimensions " + std::to_string(K) + " (8, 16, 32, 64; 128 in fp32)");
+    J.dtype = fp32 ? BPMF_HIP_F32 : BPMF_HIP_F64;
+    if (!bpmf_hip_supports(K, J.dtype))
+        die("unsupported number of latent dimensions " + std::to_string(K) + (fp32 ? " with --fp32 (65 .. 128)" : " (1 .. 128)"));
     if (J.verbose && J.odirname.empty()) die("-v needs -o DIR");   // the reference would write to "/U-0.ddm" 
     // -g N: the sharded path (N = 1 too: one rank with a communicator -- what the tests can run on one GPU); no -g: NO_COMM
     J.sharded = ngpu >= 1;
@@ -528,7 +544,10 @@ int main(int argc, char *argv[])
         if (!to_files) return std::cout;
         return *files[(size_t)r];
     };
-    if (to_files) for (int r = 0; r < J.nranks; ++r) files.emplace_back(new std::ofstream("bpmf_" + std::to_string(r) + ".out"));
+    if (to_files) for (int r = 0; r < J.nranks; ++r) {
+        files.emplace_back(new std::ofstream("bpmf_" + std::to_string(r) + ".out"));
+        g_rank_streams.push_back(files.back().get());
+    }
 
     if (J.nranks == 1) {
         rank_main(J, 0, rank_os(0));

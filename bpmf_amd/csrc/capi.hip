@@ -124,7 +124,9 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     // K = 128: the slab form measured slower than the workgroup form (one wave per SIMD cannot hide the gather
     // latency of a 36-tile Gram, and its 120 KB of straight-line code thrash the instruction cache): opt-in
     // the default: workgroup per item, second form (kernels_wg2.h, mode 5); 2 = the first workgroup form (no chunking)
-    if (f32) s->mode = (mode_env == 4) ? 4 : (mode_env == 2 ? 2 : 5);
+    // (K = 128 in fp64 -- num_latent 65 .. 128 in the reference's arithmetic: the same workgroup form with fp64 factors, mode 5 only)
+    const bool big = K == 128;
+    if (big) s->mode = f32 ? ((mode_env == 4) ? 4 : (mode_env == 2 ? 2 : 5)) : 5;
     else if (K == 64) { if (s->mode == 3) s->mode = 4; }
     else {
         if (s->mode == 2 || s->mode == 4) s->mode = 1;                             // (BPMF_HIP_MODE=2 / 4 exist for K >= 64 only)
@@ -134,7 +136,7 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
         // mode 7 (k_sample1x, kernels_x4.h): up to four items per wave one after the other (Gram as in mode 1 on natural
         // blocks), their columns factorised in lockstep as in mode 3; item list and chunks as mode 1
     }
-    if ((f32 || K == 64) && (s->mode == 6 || s->mode == 7 || s->mode == 8)) s->mode = f32 ? 5 : 4;
+    if ((big || K == 64) && (s->mode == 6 || s->mode == 7 || s->mode == 8)) s->mode = big ? 5 : 4;
     const bool wg = s->mode == 2;
     int chunk = wg ? (1 << 30) : env_int("BPMF_HIP_CHUNK", 0);
     if (chunk <= 0) {
@@ -303,15 +305,15 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
         std::vector<unsigned> zeros(std::max<size_t>(mc_slot0.size(), 8 * 32), 0u);
         if ((rc = dev_upload(&s->d_mc_count, zeros.data(), std::max<size_t>(mc_slot0.size(), 1)))) return rc;
     }
-    if (f32) {
+    if (big) {
         // column statistics: <= 32 slices of columns x 36 tiles (k_colstats_f32), one partial (tiles | sum) per slice
         // (128 partials of 132 KB were 17 MB written and read back per half-iteration: the two kernels took 55 us alone)
         s->nstat_waves = (int)std::max<int64_t>(1, std::min<int64_t>((nloc + 63) / 64, 32));
         if ((rc = dev_upload<double>(&s->d_stat_partials, nullptr, (size_t)s->nstat_waves * ((size_t)K * K + K)))) return rc;
-        if ((rc = dev_upload<double>(&s->d_partials, nullptr, (size_t)slots * part_words_rt(K)))) return rc;     // chunks of heavy columns (slab form)
+        if ((rc = dev_upload<double>(&s->d_partials, nullptr, (size_t)slots * part_words_rt(K, f32)))) return rc;     // chunks of heavy columns
         return 0;
     }
-    const size_t pw = part_words_rt(K);
+    const size_t pw = part_words_rt(K, false);
     if ((rc = dev_upload<double>(&s->d_partials, nullptr, (size_t)slots * pw))) return rc;
     // column statistics: one wave per 64+ columns, at most 2 waves per CU
     // (sides with hundreds of thousands of columns: the pass is a 8 K-byte-per-column stream, four times the waves)
@@ -350,14 +352,26 @@ void free_schedule(bpmf_hip_side *s)
 // ---------------------------------------------------------------------------
 extern "C" const char *bpmf_hip_last_error(void) { return g_err.c_str(); }
 extern "C" int bpmf_hip_abi_version(void) { return BPMF_HIP_ABI_VERSION; }
-extern "C" int bpmf_hip_supports_k(int K) { return K == 8 || K == 16 || K == 32 || K == 64; }
+extern "C" int bpmf_hip_supports_k(int K) { return K >= 1 && K <= 128; }
 
 extern "C" int bpmf_hip_supports(int K, int dtype)
 {
     if (dtype == BPMF_HIP_F64) return bpmf_hip_supports_k(K);
-    if (dtype == BPMF_HIP_F32) return K == 128;
+    if (dtype == BPMF_HIP_F32) return K > 64 && K <= 128;
     return 0;
 }
+
+// the instantiated num_latent a context of (K, dtype) runs on: 8, 16, 32, 64, 128 (0: unsupported)
+extern "C" int bpmf_hip_kernel_k(int K, int dtype)
+{
+    if (!bpmf_hip_supports(K, dtype)) return 0;
+    if (dtype == BPMF_HIP_F32) return 128;
+    return K <= 8 ? 8 : K <= 16 ? 16 : K <= 32 ? 32 : K <= 64 ? 64 : 128;
+}
+
+extern "C" int bpmf_hip_ctx_ld(const bpmf_hip_ctx *c) { return c ? c->K : 0; }
+extern "C" int bpmf_hip_ctx_num_latent(const bpmf_hip_ctx *c) { return c ? c->Kt : 0; }
+extern "C" int bpmf_hip_ctx_dtype(const bpmf_hip_ctx *c) { return c ? c->dtype : -1; }
 
 static int ctx_create_impl(int device, int K, int dtype, void *stream, bpmf_hip_ctx **out);
 
@@ -371,13 +385,14 @@ extern "C" int bpmf_hip_ctx_create_ex(int device, int K, int dtype, void *stream
     return ctx_create_impl(device, K, dtype, stream, out);
 }
 
-static int ctx_create_impl(int device, int K, int dtype, void *stream, bpmf_hip_ctx **out)
+static int ctx_create_impl(int device, int Ktrue, int dtype, void *stream, bpmf_hip_ctx **out)
 {
     if (!out) return fail(BPMF_HIP_EINVAL, "ctx_create: out is NULL");
     *out = nullptr;
-    if (!bpmf_hip_supports(K, dtype))
-        return fail(BPMF_HIP_EINVAL, "ctx_create: unsupported num_latent / dtype " + std::to_string(K) + " / " + std::to_string(dtype) +
-                                         " (fp64: 8, 16, 32, 64; fp32: 128)");
+    if (!bpmf_hip_supports(Ktrue, dtype))
+        return fail(BPMF_HIP_EINVAL, "ctx_create: unsupported num_latent / dtype " + std::to_string(Ktrue) + " / " + std::to_string(dtype) +
+                                         " (fp64: 1 .. 128; fp32: 65 .. 128)");
+    const int K = bpmf_hip_kernel_k(Ktrue, dtype);                  // what the kernels are instantiated for (>= Ktrue)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(BPMF_HIP_ENODEV, "no HIP device available (the BPMF hot path has no CPU fallback)");
@@ -385,7 +400,7 @@ static int ctx_create_impl(int device, int K, int dtype, void *stream, bpmf_hip_
     HIP_TRY(hipSetDevice(device));
     bpmf_hip_ctx *c = new (std::nothrow) bpmf_hip_ctx();
     if (!c) return fail(BPMF_HIP_ENOMEM, "ctx_create: out of host memory");
-    c->device = device; c->K = K; c->dtype = dtype;
+    c->device = device; c->K = K; c->Kt = Ktrue; c->dtype = dtype;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -593,6 +608,22 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
     return BPMF_HIP_OK;
 }
 
+// ---- padded num_latent (ctx->Kt < ctx->K) -----------------------------------------------------
+// Everything that crosses the C ABI has the caller's size Kt; the device side has the instantiated size K.
+namespace {
+// Kt x Kt column-major -> K x K column-major, `diag` on the extra diagonal, zeros elsewhere
+void pad_square(int Kt, int K, const double *src, double *dst, double diag)
+{
+    for (int j = 0; j < K; ++j)
+        for (int i = 0; i < K; ++i)
+            dst[(size_t)j * K + i] = (i < Kt && j < Kt) ? src[(size_t)j * Kt + i] : ((i == j) ? diag : 0.0);
+}
+void unpad_square(int Kt, int K, const double *src, double *dst)
+{
+    for (int j = 0; j < Kt; ++j) memcpy(dst + (size_t)j * Kt, src + (size_t)j * K, sizeof(double) * Kt);
+}
+}  // namespace
+
 // Sys::add_prop_posterior (c++/sample.cpp:157-174): per-column priors from a previous run's
 // *-mu.ddm / *-Lambda.ddm.  Like the reference, only Lambda takes part in the update (the loaded
 // mu is never used: rr = hp_LambdaF * hp.mu, c++/sample.cpp:285).
@@ -605,10 +636,22 @@ extern "C" int bpmf_hip_side_set_prop_posterior(bpmf_hip_side *s, const double *
     HIP_TRY(hipStreamSynchronize(s->ctx->stream));
     if (s->d_prop) { (void)hipFree(s->d_prop); s->d_prop = nullptr; }
     if (!Lambda) return BPMF_HIP_OK;
-    const size_t words = (size_t)s->ctx->K * s->ctx->K * (size_t)(s->to - s->from);
-    if (hipMalloc((void **)&s->d_prop, words * sizeof(double)) != hipSuccess)
+    const int K = s->ctx->K, Kt = s->ctx->Kt;
+    const size_t nloc = (size_t)(s->to - s->from), words = (size_t)K * K * nloc;
+    if (hipMalloc((void **)&s->d_prop, std::max<size_t>(words, 1) * sizeof(double)) != hipSuccess)
         return fail(BPMF_HIP_ENOMEM, "set_prop_posterior: device allocation failed");
-    HIP_TRY(hipMemcpy(s->d_prop, Lambda, words * sizeof(double), hipMemcpyHostToDevice));
+    if (Kt == K) {
+        HIP_TRY(hipMemcpy(s->d_prop, Lambda, words * sizeof(double), hipMemcpyHostToDevice));
+        return BPMF_HIP_OK;
+    }
+    // padded num_latent: identity in the extra dimensions of every column's prior, a few thousand columns at a time
+    const size_t per = std::max<size_t>(1, ((size_t)32 << 20) / ((size_t)K * K * sizeof(double)));
+    std::vector<double> buf(std::min(per, std::max<size_t>(nloc, 1)) * (size_t)K * K);
+    for (size_t c0 = 0; c0 < nloc; c0 += per) {
+        const size_t n = std::min(per, nloc - c0);
+        for (size_t c = 0; c < n; ++c) pad_square(Kt, K, Lambda + (c0 + c) * (size_t)Kt * Kt, buf.data() + c * (size_t)K * K, 1.0);
+        HIP_TRY(hipMemcpy(s->d_prop + c0 * (size_t)K * K, buf.data(), n * (size_t)K * K * sizeof(double), hipMemcpyHostToDevice));
+    }
     return BPMF_HIP_OK;
 }
 
@@ -665,14 +708,17 @@ extern "C" int bpmf_hip_side_get_items(bpmf_hip_side *s, double *h)
     if (!s || !h) return fail(BPMF_HIP_EINVAL, "get_items: NULL");
     HIP_TRY(hipSetDevice(s->ctx->device));
     HIP_TRY(hipStreamSynchronize(s->ctx->stream));
-    const size_t words = (size_t)s->ctx->K * s->ncols;
+    const size_t K = (size_t)s->ctx->K, Kt = (size_t)s->ctx->Kt, n = (size_t)s->ncols;     // (device leading dimension K, the caller's rows Kt)
+    const size_t words = K * n;
     if (s->ctx->dtype == BPMF_HIP_F32) {                            // fp32 factors: widen on the host
         std::vector<float> tmp(words);
         HIP_TRY(hipMemcpy(tmp.data(), s->d_items, words * sizeof(float), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < words; ++i) h[i] = (double)tmp[i];
+        for (size_t c = 0; c < n; ++c)
+            for (size_t i = 0; i < Kt; ++i) h[c * Kt + i] = (double)tmp[c * K + i];
         return BPMF_HIP_OK;
     }
-    HIP_TRY(hipMemcpy(h, s->d_items, words * sizeof(double), hipMemcpyDeviceToHost));
+    if (Kt == K) HIP_TRY(hipMemcpy(h, s->d_items, words * sizeof(double), hipMemcpyDeviceToHost));
+    else HIP_TRY(hipMemcpy2D(h, Kt * sizeof(double), s->d_items, K * sizeof(double), Kt * sizeof(double), n, hipMemcpyDeviceToHost));
     return BPMF_HIP_OK;
 }
 
@@ -683,14 +729,20 @@ extern "C" int bpmf_hip_side_set_items(bpmf_hip_side *s, const double *h)
     { const int rc = settle_async(s); if (rc) return rc; }
     flush_evals_touching(s);
     HIP_TRY(hipDeviceSynchronize());                                // (an evaluation beside the samplers may still read the factors)
-    const size_t words = (size_t)s->ctx->K * s->ncols;
+    const size_t K = (size_t)s->ctx->K, Kt = (size_t)s->ctx->Kt, n = (size_t)s->ncols;     // (rows Kt .. K - 1 of every column stay zero)
+    const size_t words = K * n;
     if (s->ctx->dtype == BPMF_HIP_F32) {
-        std::vector<float> tmp(words);
-        for (size_t i = 0; i < words; ++i) tmp[i] = (float)h[i];
+        std::vector<float> tmp(words, 0.0f);
+        for (size_t c = 0; c < n; ++c)
+            for (size_t i = 0; i < Kt; ++i) tmp[c * K + i] = (float)h[c * Kt + i];
         HIP_TRY(hipMemcpy(s->d_items, tmp.data(), words * sizeof(float), hipMemcpyHostToDevice));
         return BPMF_HIP_OK;
     }
-    HIP_TRY(hipMemcpy(s->d_items, h, words * sizeof(double), hipMemcpyHostToDevice));
+    if (Kt == K) HIP_TRY(hipMemcpy(s->d_items, h, words * sizeof(double), hipMemcpyHostToDevice));
+    else {
+        HIP_TRY(hipMemset(s->d_items, 0, words * sizeof(double)));
+        HIP_TRY(hipMemcpy2D(s->d_items, K * sizeof(double), h, Kt * sizeof(double), Kt * sizeof(double), n, hipMemcpyHostToDevice));
+    }
     return BPMF_HIP_OK;
 }
 
@@ -698,11 +750,11 @@ namespace {
 
 using bpmf_launch::sampler_into;
 
-template <int K>
+template <int K, bool F32>
 int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double alpha, double *d_in, hipStream_t st,
                    hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr)
 {
-    if (!second_copy_usable(self)) return sampler_into<K>(self, self->d_items, other, iter, alpha, d_in, st, ev_start, ev_stop);
+    if (!second_copy_usable(self)) return sampler_into<K, F32>(self, self->d_items, other, iter, alpha, d_in, st, ev_start, ev_stop);
     // the copy about to be overwritten may still be read by an evaluation that has not been collected
     const int tgt = self->cur_buf ^ 1;
     bpmf_hip_side::Reader &rd = self->readers[tgt];
@@ -711,7 +763,7 @@ int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, do
         if (rd.t->done_seq < rd.seq) HIP_TRY(hipStreamWaitEvent(st, rd.t->ev_done[rd.seq & 1u], 0));
     }
     rd.t = nullptr;
-    const int rc = sampler_into<K>(self, self->d_items_alt, other, iter, alpha, d_in, st, ev_start, ev_stop);
+    const int rc = sampler_into<K, F32>(self, self->d_items_alt, other, iter, alpha, d_in, st, ev_start, ev_stop);
     if (rc) return rc;
     std::swap(self->d_items, self->d_items_alt);                    // everything enqueued from here on sees the new factors
     self->cur_buf = tgt;
@@ -727,7 +779,7 @@ int launch_sampler(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, do
 // The factors themselves are still exchanged afterwards: the sampler no longer needs them, but the evaluation over
 // the whole test set and the outputs do (the reference's predict is restricted to local rows in this mode, with a
 // warning: c++/sample.cpp:59-61,71-74).
-template <int K>
+template <int K, bool F32>
 int reduce_half_iteration(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double alpha, double *d_in, hipStream_t st,
                           hipEvent_t ev_start, hipEvent_t ev_stop)
 {
@@ -769,7 +821,7 @@ int reduce_half_iteration(bpmf_hip_side *self, const bpmf_hip_side *other, int i
     a.LambdaF = d_in; a.Lmu = d_in + (size_t)K * K;
     a.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
     a.mu = d_in + (size_t)K * K + K + 2; a.prop_lambda = self->d_prop; a.diag_only = c->diag_only;
-    a.mean_rating = self->mean_rating; a.alpha = alpha; a.iter_plus_1 = (uint32_t)(iter + 1);
+    a.mean_rating = self->mean_rating; a.alpha = alpha; a.iter_plus_1 = (uint32_t)(iter + 1); a.ktrue = c->Kt;
     const int resident = c->num_cu * 4 * bpmf_launch::reduce_waves_per_simd(K);
     const int C = 64 / K;
     const int grid = std::max(1, std::min((a.nwork + C - 1) / C, resident));
@@ -783,14 +835,14 @@ int reduce_half_iteration(bpmf_hip_side *self, const bpmf_hip_side *other, int i
     p.mean_rating = other->mean_rating; p.alpha = alpha;
     bpmf_launch::reduce_precompute(K, st, nullptr, ev_stop, p);
     HIP_TRY(hipGetLastError());
-    return bpmf_launch::exchange<K>(self, st, -1);
+    return bpmf_launch::exchange<K, F32>(self, st, -1);
 }
 
 // Sampler + exchange of one half-iteration on stream `st`.  Sharded side with parts (bpmf_hip_side_set_overlap):
 // part c is sampled on `st`, then exchanged on the side's exchange stream `sx` while part c + 1 is being
 // sampled -- what the reference's MPI_ISEND back-end does with its chunks of 100 items sent during compute
 // (c++/mpi_isendirecv.h:222-260); `st` continues behind the last exchange.
-template <int K>
+template <int K, bool F32>
 int sample_and_exchange(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double alpha, double *d_in, hipStream_t st,
                         hipEvent_t ev_start, hipEvent_t ev_stop)
 {
@@ -798,15 +850,18 @@ int sample_and_exchange(bpmf_hip_side *self, const bpmf_hip_side *other, int ite
     const bool dist = c->comm != nullptr && !self->bounds.empty();
     const bool parts = dist && self->nsub > 1 && self->sx && self->conn_send_ptr.empty() && (int)self->sub_item_off.size() == self->nsub + 1;
     if (self->reduce_on) {
-        if constexpr (K == 128) return fail(BPMF_HIP_EINVAL, "the BPMF_REDUCE formulation is fp64 only");
-        else return reduce_half_iteration<K>(self, other, iter, alpha, d_in, st, ev_start, ev_stop);
+        if constexpr (K == 128) return fail(BPMF_HIP_EINVAL, "the BPMF_REDUCE formulation exists for num_latent <= 64 in fp64");
+        else return reduce_half_iteration<K, F32>(self, other, iter, alpha, d_in, st, ev_start, ev_stop);
     }
-    // bounded staleness: does part p travel in this half-iteration?  (iteration 0 always does, like do_comm of the
-    // reference's throttled GASPI back-end, c++/bpmf_gaspi.h:93-99)
-    auto travels = [&](int p) { return self->stale_k <= 0 || iter == 0 || ((p + iter) % (self->stale_k + 1)) == 0; };
+    // bounded staleness: does part p travel in this half-iteration?  (the side's first half-iteration under a k > 0
+    // always exchanges everything, like do_comm of the reference's throttled GASPI back-end, c++/bpmf_gaspi.h:93-99:
+    // keyed on the side, not on the iteration number -- a k set in the middle of a chain starts from current replicas too)
+    const bool prime = self->stale_k > 0 && !self->stale_primed;
+    self->stale_primed = true;
+    auto travels = [&](int p) { return self->stale_k <= 0 || prime || ((p + iter) % (self->stale_k + 1)) == 0; };
     if (!parts) {
-        int rc = launch_sampler<K>(self, other, iter, alpha, d_in, st, ev_start, ev_stop);
-        if (!rc && travels(0)) rc = bpmf_launch::exchange<K>(self, st, -1);
+        int rc = launch_sampler<K, F32>(self, other, iter, alpha, d_in, st, ev_start, ev_stop);
+        if (!rc && travels(0)) rc = bpmf_launch::exchange<K, F32>(self, st, -1);
         return rc;
     }
     int rc = 0;
@@ -814,15 +869,15 @@ int sample_and_exchange(bpmf_hip_side *self, const bpmf_hip_side *other, int ite
     for (int p = 0; p < self->nsub && !rc; ++p) {
         self->item_off = self->sub_item_off[(size_t)p];
         self->item_n = self->sub_item_off[(size_t)p + 1] - self->item_off;
-        if (p == 0) rc = launch_sampler<K>(self, other, iter, alpha, d_in, st, nullptr, nullptr);       // (chooses / swaps the factor copy)
-        else rc = sampler_into<K>(self, self->d_items, other, iter, alpha, d_in, st, nullptr, nullptr);
+        if (p == 0) rc = launch_sampler<K, F32>(self, other, iter, alpha, d_in, st, nullptr, nullptr);       // (chooses / swaps the factor copy)
+        else rc = sampler_into<K, F32>(self, self->d_items, other, iter, alpha, d_in, st, nullptr, nullptr);
         if (rc) break;
         hipError_t he = hipSuccess;
         if (p == self->nsub - 1 && ev_stop) he = hipEventRecord(ev_stop, st);
         if (he == hipSuccess) he = hipEventRecord(self->sub_ev[p], st);
         if (he == hipSuccess) he = hipStreamWaitEvent(self->sx, self->sub_ev[p], 0);
         if (he != hipSuccess) { rc = fail(BPMF_HIP_ENODEV, std::string("sample_and_exchange: ") + hipGetErrorString(he)); break; }
-        if (travels(p)) rc = bpmf_launch::exchange<K>(self, self->sx, p);
+        if (travels(p)) rc = bpmf_launch::exchange<K, F32>(self, self->sx, p);
     }
     self->item_off = 0; self->item_n = -1;                           // (whatever happened: later launches see the whole item list again)
     if (rc) return rc;
@@ -831,14 +886,17 @@ int sample_and_exchange(bpmf_hip_side *self, const bpmf_hip_side *other, int ite
     return 0;
 }
 
-#define BPMF_DISPATCH_K(K_, CALL)                                                    \
+// KK: the instantiated num_latent; FF: the fp32 context (K = 128 only).  Uses the context `c` of the caller.
+#define BPMF_DISPATCH_K(K_, ...)                                                     \
     [&]() -> int {                                                                   \
         switch (K_) {                                                                \
-        case 8: { constexpr int KK = 8; return CALL; }                               \
-        case 16: { constexpr int KK = 16; return CALL; }                             \
-        case 32: { constexpr int KK = 32; return CALL; }                             \
-        case 64: { constexpr int KK = 64; return CALL; }                             \
-        case 128: { constexpr int KK = 128; return CALL; }                           \
+        case 8: { constexpr int KK = 8; constexpr bool FF = false; return __VA_ARGS__; }    \
+        case 16: { constexpr int KK = 16; constexpr bool FF = false; return __VA_ARGS__; }  \
+        case 32: { constexpr int KK = 32; constexpr bool FF = false; return __VA_ARGS__; }  \
+        case 64: { constexpr int KK = 64; constexpr bool FF = false; return __VA_ARGS__; }  \
+        case 128:                                                                    \
+            if (c->dtype == BPMF_HIP_F32) { constexpr int KK = 128; constexpr bool FF = true; return __VA_ARGS__; } \
+            else { constexpr int KK = 128; constexpr bool FF = false; return __VA_ARGS__; } \
         default: return fail(BPMF_HIP_EINVAL, "unsupported K");                     \
         }                                                                            \
     }()
@@ -907,6 +965,21 @@ void fill_blob(int K, const double *mu, const double *LambdaF, double *h_in, boo
     }
 }
 
+// the same from hyper-parameters of the caller's size Kt: identity precision / zero mean in the extra dimensions
+// (their factor rows are zero, their rhs is zero, they draw no normals: x stays exactly 0 there and the leading
+// Kt x Kt arithmetic of every column is the unpadded one -- c++/sample.cpp:297-323 with num_latent = Kt)
+void fill_blob_ctx(const bpmf_hip_ctx *c, const double *mu, const double *LambdaF, double *h_in, bool with_factor, const double *LambdaU = nullptr)
+{
+    const int K = c->K, Kt = c->Kt;
+    if (Kt == K) { fill_blob(K, mu, LambdaF, h_in, with_factor, LambdaU); return; }
+    static thread_local std::vector<double> pm, pf, pu;
+    pm.assign((size_t)K, 0.0); pf.resize((size_t)K * K);
+    memcpy(pm.data(), mu, sizeof(double) * Kt);
+    pad_square(Kt, K, LambdaF, pf.data(), 1.0);
+    if (LambdaU) { pu.resize((size_t)K * K); pad_square(Kt, K, LambdaU, pu.data(), 1.0); }
+    fill_blob(K, pm.data(), pf.data(), h_in, with_factor, LambdaU ? pu.data() : nullptr);
+}
+
 }  // namespace
 
 extern "C" int bpmf_hip_sample_side_launch(bpmf_hip_side *self, const bpmf_hip_side *other, int iter, double alpha,
@@ -922,17 +995,17 @@ extern "C" int bpmf_hip_sample_side_launch(bpmf_hip_side *self, const bpmf_hip_s
     HIP_TRY(hipSetDevice(c->device));
     { const int rs = settle_async(self); if (rs) return rs; }
     if (self->saux) HIP_TRY(hipStreamSynchronize(self->saux));
-    fill_blob(K, mu, LambdaF, c->h_in, K == 64 && c->dtype == BPMF_HIP_F64 && self->lr_n > 0);
+    fill_blob_ctx(c, mu, LambdaF, c->h_in, K == 64 && c->dtype == BPMF_HIP_F64 && self->lr_n > 0);
     bpmf_launch::stage(c->h_in_dev, c->d_in, (int)c->in_words, c->stream);
     if (lf32_words(c)) bpmf_launch::lf32_tiles(c->d_in, reinterpret_cast<float *>(c->d_in + c->in_words), K, c->stream);
     HIP_TRY(hipEventRecord(c->ev[0], c->stream));
     c->last_sampler_done = nullptr;
-    int rc = BPMF_DISPATCH_K(K, sample_and_exchange<KK>(self, other, iter, alpha, c->d_in, c->stream, nullptr, nullptr));
+    int rc = BPMF_DISPATCH_K(K, sample_and_exchange<KK, FF>(self, other, iter, alpha, c->d_in, c->stream, nullptr, nullptr));
     if (rc) return rc;
     self->stat_a_ready = false;                                     // (the split statistics pass belongs to the asynchronous path)
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     unsigned *flag = reinterpret_cast<unsigned *>(c->h_out_dev + c->out_words - 1);
-    rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK>(self, c->stream, c->d_in, c->h_out_dev, flag, ++c->seq, c->d_ticket));
+    rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK, FF>(self, c->stream, c->d_in, c->h_out_dev, flag, ++c->seq, c->d_ticket));
     if (rc) return rc;
     HIP_TRY(hipEventRecord(c->ev[2], c->stream));
     // prod | sum | - | fail word land in the pinned result blob; the last wave of k_colstats
@@ -952,11 +1025,12 @@ extern "C" int bpmf_hip_sample_side_finish(bpmf_hip_side *self, double *sum_out,
     self->pending = false;
     { const int rcw = wait_host(c); if (rcw) return rcw; }
     { std::string m; if (check_timeout(c->h_out, K, &m)) return fail(BPMF_HIP_ENODEV, m); }
-    memcpy(prod_out, c->h_out, sizeof(double) * K * K);
-    memcpy(sum_out, c->h_out + (size_t)K * K, sizeof(double) * K);
+    const int Kt = c->Kt;                                           // (the caller's size; the extra rows / columns of the sums are zero)
+    unpad_square(Kt, K, c->h_out, prod_out);
+    memcpy(sum_out, c->h_out + (size_t)K * K, sizeof(double) * Kt);
     {   // sum |x|^2 = trace(sum x x^T)
         double nn = 0.0;
-        for (int i = 0; i < K; ++i) nn += c->h_out[(size_t)i * K + i];
+        for (int i = 0; i < Kt; ++i) nn += c->h_out[(size_t)i * K + i];
         *norm_out = nn;
     }
     unsigned long long f;
@@ -988,7 +1062,7 @@ extern "C" int bpmf_hip_side_aggr_add(bpmf_hip_side *s)
     bpmf_hip_ctx *c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
     { const int rc = settle_async(s); if (rc) return rc; }
-    const size_t K = (size_t)c->K, nloc = (size_t)(s->to - s->from);
+    const size_t K = (size_t)c->Kt, nloc = (size_t)(s->to - s->from);      // (aggrMu / aggrLambda have the caller's size)
     if (!s->d_aggr_mu || !s->d_aggr_lambda) {
         if (s->d_aggr_mu) { (void)hipFree(s->d_aggr_mu); s->d_aggr_mu = nullptr; }
         if (hipMalloc((void **)&s->d_aggr_mu, std::max<size_t>(K * nloc, 1) * sizeof(double)) != hipSuccess ||
@@ -1001,7 +1075,7 @@ extern "C" int bpmf_hip_side_aggr_add(bpmf_hip_side *s)
         HIP_TRY(hipMemsetAsync(s->d_aggr_mu, 0, K * nloc * sizeof(double), c->stream));
         HIP_TRY(hipMemsetAsync(s->d_aggr_lambda, 0, K * K * nloc * sizeof(double), c->stream));
     }
-    bpmf_launch::aggr_add(s->d_items, c->dtype == BPMF_HIP_F32, c->K, s->from, (int64_t)nloc, s->d_aggr_mu, s->d_aggr_lambda, c->stream);
+    bpmf_launch::aggr_add(s->d_items, c->dtype == BPMF_HIP_F32, c->K, c->Kt, s->from, (int64_t)nloc, s->d_aggr_mu, s->d_aggr_lambda, c->stream);
     HIP_TRY(hipGetLastError());
     c->last_sampler_done = nullptr;
     return BPMF_HIP_OK;
@@ -1014,8 +1088,8 @@ extern "C" int bpmf_hip_side_aggr_finalize(bpmf_hip_side *s, int nsamples, doubl
     if (!s->d_aggr_mu || !s->d_aggr_lambda) return fail(BPMF_HIP_EINVAL, "aggr_finalize: nothing was aggregated");
     bpmf_hip_ctx *c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    const size_t K = (size_t)c->K, nloc = (size_t)(s->to - s->from);
-    bpmf_launch::aggr_finalize(c->K, nsamples, (int64_t)nloc, s->d_aggr_mu, s->d_aggr_lambda, c->stream);
+    const size_t K = (size_t)c->Kt, nloc = (size_t)(s->to - s->from);
+    bpmf_launch::aggr_finalize(c->Kt, nsamples, (int64_t)nloc, s->d_aggr_mu, s->d_aggr_lambda, c->stream);
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(mu_host, s->d_aggr_mu, K * nloc * sizeof(double), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(lambda_host, s->d_aggr_lambda, K * K * nloc * sizeof(double), hipMemcpyDeviceToHost));
@@ -1066,7 +1140,7 @@ namespace {
 int ensure_state(bpmf_hip_side *s)
 {
     bpmf_hip_ctx *c = s->ctx;
-    const size_t K = (size_t)c->K;
+    const size_t K = (size_t)c->Kt;                                  // (the Sys state -- cov, hp -- has the caller's size)
     if (s->cov.size() == K * K) return 0;
     HIP_TRY(hipHostMalloc((void **)&s->a_h_in, c->in_words * sizeof(double), hipHostMallocMapped));
     HIP_TRY(hipHostMalloc((void **)&s->a_h_out, c->out_words * sizeof(double), hipHostMallocMapped));
@@ -1097,7 +1171,7 @@ int ensure_state(bpmf_hip_side *s)
 void predraw_main(bpmf_hip_side *s)
 {
     auto &P = s->predraw;
-    const int K = s->ctx->K;
+    const int K = s->ctx->Kt;
     std::unique_lock<std::mutex> lk(P.m);
     for (;;) {
         P.cv.wait(lk, [&] { return P.stop || P.next <= P.consumed + bpmf_hip_side::Predraw::DEPTH; });
@@ -1117,7 +1191,7 @@ void predraw_main(bpmf_hip_side *s)
 int predraw_get(bpmf_hip_side *s, int iter)
 {
     auto &P = s->predraw;
-    const int K = s->ctx->K;
+    const int K = s->ctx->Kt;
     if (P.threads.empty()) {
         const int n = std::max(1, env_int("BPMF_HIP_PREDRAW_THREADS", K >= 128 ? 3 : 1));
         { std::lock_guard<std::mutex> lk(P.m); P.next = iter; P.consumed = iter - 1; }
@@ -1161,13 +1235,13 @@ void predraw_stop(bpmf_hip_side *s)
 int draw_and_release(bpmf_hip_side *s, int iter, double *mu, double *LU, double *LF)
 {
     bpmf_hip_ctx *c = s->ctx;
-    const int K = c->K;
+    const int K = c->Kt;
     // rng_set_pos(iter); hp.sample(num(), sum = 0, cov)  (c++/sample.cpp:349-350); the random part
     // may have been drawn ahead of time (it does not depend on cov)
     int rc = 0;
     if (s->rd_iter != iter) rc = predraw_get(s, iter);
     if (!rc) rc = bpmf_hyper_finish(K, s->ncols, s->cov.data(), nullptr, s->rd_au.data(), s->rd_z.data(), mu, LU, LF);
-    if (!rc) fill_blob(K, mu, LF, s->a_h_in, K == 64 && s->ctx->dtype == BPMF_HIP_F64 && s->lr_n > 0, LU);   // (R0, R0^-1: only the low-rank forms read them)
+    if (!rc) fill_blob_ctx(c, mu, LF, s->a_h_in, c->K == 64 && c->dtype == BPMF_HIP_F64 && s->lr_n > 0, LU);   // (R0, R0^-1: only the low-rank forms read them)
     // the gate is opened even after an error: a sampler may already be queued behind it and must
     // not be left spinning (its results are never looked at: the error is reported first)
     {   // test hook: a host worker that is descheduled for a while (SIGSTOP, debugger, oversubscription)
@@ -1229,10 +1303,17 @@ void collect(bpmf_hip_side *s, const bpmf_hip_side::Job &job)
             rc = BPMF_HIP_ECHOL; msg = "Cholesky failed in column " + std::to_string((long long)f);
         } else {
             s->failed_column = -1;
+            const int Kt = c->Kt;
             double nn = 0.0;                                          // sum |x|^2 = trace(sum x x^T)  (:381)
-            for (int i = 0; i < K; ++i) nn += prod[(size_t)i * K + i];
+            for (int i = 0; i < Kt; ++i) nn += prod[(size_t)i * K + i];
             s->norm = nn;
-            bpmf_cov_from_sums(K, s->ncols, sum, prod, s->cov.data());   // :383-384
+            if (Kt == K) bpmf_cov_from_sums(K, s->ncols, sum, prod, s->cov.data());   // :383-384
+            else {                                                    // padded num_latent: the leading Kt x Kt block of the sums
+                static thread_local std::vector<double> pc;
+                pc.resize((size_t)Kt * Kt);
+                unpad_square(Kt, K, prod, pc.data());
+                bpmf_cov_from_sums(Kt, s->ncols, sum, pc.data(), s->cov.data());
+            }
         }
     }
     // the next half-iteration of this side: parameters + gate (opened in every case, see above)
@@ -1299,7 +1380,7 @@ int flush_pending_stats(bpmf_hip_ctx *c, bool on_main)
     else c->last_sampler_done = nullptr;                              // (the newest thing on S0 is no longer a sampler)
     unsigned *flag = reinterpret_cast<unsigned *>(P->a_h_out_dev + c->out_words - 1);
     P->stat_a_ready = false;
-    const int rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK>(P, sst, P->a_d_in, P->a_h_out_dev, flag, c->pending_seq, P->a_ticket));
+    const int rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK, FF>(P, sst, P->a_d_in, P->a_h_out_dev, flag, c->pending_seq, P->a_ticket));
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ev[2], sst));
     P->stats_ev[c->pending_evset].store(ev[2], std::memory_order_release);
@@ -1327,7 +1408,7 @@ int flush_pending_stats_inorder(bpmf_hip_ctx *c)
     P->stat_a_ready = false;
     // (completion event on the pass's own dispatch packet: a marker packet behind it would carry a barrier bit and hold the
     // any-order launch back until the pass has FINISHED)
-    const int rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK>(P, c->stream, P->a_d_in, P->a_h_out_dev, flag, c->pending_seq, P->a_ticket, ev[2]));
+    const int rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK, FF>(P, c->stream, P->a_d_in, P->a_h_out_dev, flag, c->pending_seq, P->a_ticket, ev[2]));
     if (rc) return rc;
     P->stats_ev[c->pending_evset].store(ev[2], std::memory_order_release);
     bpmf_launch::next_flags() = hipExtAnyOrderLaunch;                // consumed by the first kernel of the sampler sequence that follows
@@ -1470,7 +1551,7 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     self->cur_fused = fz;
     self->cur_riders = riders;
     self->cur_gate_flag = fused ? self->a_dflag : nullptr; self->cur_gate_want = seq;
-    rc = BPMF_DISPATCH_K(K, sample_and_exchange<KK>(self, other, iter, alpha, self->a_d_in, s0, (ride && timed) ? ev[0] : nullptr,
+    rc = BPMF_DISPATCH_K(K, sample_and_exchange<KK, FF>(self, other, iter, alpha, self->a_d_in, s0, (ride && timed) ? ev[0] : nullptr,
                                                     ride ? ev[1] : nullptr));
     self->cur_gate_flag = nullptr;
     self->cur_fused = bpmf::FusedArgs{};
@@ -1499,7 +1580,7 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     // started ~5 us after the pass's last kernel ENDED) -- K = 128 0.857 against 0.818 ms, ChEMBL shape 1.35 against 1.07.
     static const int stats_inorder = env_int("BPMF_HIP_STATS_INORDER", 0);
     const bool inorder = stats_inorder && !fused && !defer && !dist && s1 != s0 && self->nwork > 0 && !self->reduce_on && !self->d_stat_list &&
-                         (self->nstat_wg > 0 || c->dtype == BPMF_HIP_F32);
+                         (self->nstat_wg > 0 || K == 128);
     // fp32 path (workgroup-per-item form, single GPU): the pass rides at the head of the next k_sample_wg2 launch of the
     // context -- no stream of its own, no head start to buy with event hops (BPMF_HIP_F32_RIDERS=0: the two kernels on S1)
     // MEASURED: no gain, off.  The two 30-us gaps go (rocprofv3 timeline: 9 / 14 us between the samplers), but the riders
@@ -1521,7 +1602,7 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
         hipStream_t sst = (stats_s0 && !dist && s1 != s0 && self->nstat_waves >= 1024) ? s0 : s1;
         if (self->stat_a_ready && sst != s0) {                        // group A of a split pass: behind the launch of its columns
             HIP_TRY(hipStreamWaitEvent(sst, self->ev_stat_a, 0));
-            rc = BPMF_DISPATCH_K(K, bpmf_launch::stats_a<KK>(self, sst, self->a_d_in, self->a_h_out_dev, self->a_ticket));
+            rc = BPMF_DISPATCH_K(K, bpmf_launch::stats_a<KK, FF>(self, sst, self->a_d_in, self->a_h_out_dev, self->a_ticket));
             if (rc) return rc;
         }
         self->stat_a_ready = false;
@@ -1532,13 +1613,13 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
         // S1 passes just ahead of the statistics kernel: the pass (0.1 ms alone) starts a hop ahead of the sampler, keeps
         // its slots, and the side's host chain is done before the partner's sampler is.
         static const int head_start = env_int("BPMF_HIP_STATS_HEADSTART", 1);
-        if (head_start && sst != s0 && !dist && (self->nstat_wg > 0 || c->dtype == BPMF_HIP_F32)) {   // (fp32 path: 1 152 single-wave tile workgroups, same reasoning: 0.84 -> 0.81 ms)
+        if (head_start && sst != s0 && !dist && (self->nstat_wg > 0 || K == 128)) {   // (fp32 path: 1 152 single-wave tile workgroups, same reasoning: 0.84 -> 0.81 ms)
             if (!self->ev_stat_go) HIP_TRY(hipEventCreateWithFlags(&self->ev_stat_go, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(self->ev_stat_go, sst));
             HIP_TRY(hipStreamWaitEvent(s0, self->ev_stat_go, 0));
         }
         unsigned *flag = reinterpret_cast<unsigned *>(self->a_h_out_dev + c->out_words - 1);
-        rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK>(self, sst, self->a_d_in, self->a_h_out_dev, flag, seq, self->a_ticket));
+        rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK, FF>(self, sst, self->a_d_in, self->a_h_out_dev, flag, seq, self->a_ticket));
         if (rc) return rc;
         HIP_TRY(hipEventRecord(ev[2], sst));
         self->stats_ev[evset].store(ev[2], std::memory_order_release);
@@ -1557,7 +1638,7 @@ extern "C" int bpmf_hip_sys_state(const bpmf_hip_side *cs, int *iter, double *no
     if (!cs) return fail(BPMF_HIP_EINVAL, "sys_state: NULL");
     bpmf_hip_side *s = const_cast<bpmf_hip_side *>(cs);
     { const int rc = settle_async(s); if (rc) return rc; }
-    const size_t K = (size_t)s->ctx->K;
+    const size_t K = (size_t)s->ctx->Kt;
     if (iter) *iter = s->iter;
     if (norm) *norm = s->norm;
     const bool have = s->cov.size() == K * K;
@@ -1583,6 +1664,8 @@ extern "C" int bpmf_hip_side_kernel_name(const bpmf_hip_side *s, char *buf, int 
     else if (c->dtype == BPMF_HIP_F32) {
         const std::string w = env_int("BPMF_HIP_WG_WAVES", 2) == 4 ? "4" : "2";
         name = s->mode == 4 ? "k_sample_slab<128>" : s->mode == 2 ? "k_sample_wg<128,float," + w + ">" : "k_sample_wg2<128," + w + ">";
+    } else if (K == 128) {
+        name = std::string("k_sample_wg2<128,") + (env_int("BPMF_HIP_WG_WAVES_F64", 4) == 2 ? "2" : "4") + ",double>";
     } else if (K == 64) {
         auto heavy = [&]() -> std::string {
             if (s->mode == 2) return "k_sample_wg<64,double,1>";
@@ -1720,7 +1803,13 @@ extern "C" int bpmf_hip_side_set_ranges(bpmf_hip_side *s, const int64_t *bounds)
     const size_t threshold = (size_t)std::max(1, env_int("BPMF_HIP_OVERLAP_MIN_KB", 64 << 10)) << 10;    // (the tests lower it)
     const bool auto_ok = !(c->K == 64 && c->dtype == BPMF_HIP_F64);
     const int nsub = want >= 0 ? want : (c->nranks > 1 && auto_ok && incoming >= threshold ? 4 : 1);
-    s->stale_k = std::max(0, std::min(env_int("BPMF_HIP_STALE", 0), 64));     // (bpmf_hip_side_set_staleness; `bpmf`: the environment)
+    // BPMF_HIP_STALE (`bpmf`, the tests): only when set, and never over a k given through bpmf_hip_side_set_staleness
+    if (getenv("BPMF_HIP_STALE") && !s->stale_explicit) {
+        const int k = std::max(0, std::min(env_int("BPMF_HIP_STALE", 0), 64));
+        if (k > 0 && !s->conn_send_ptr.empty()) return fail(BPMF_HIP_EINVAL, "side_set_ranges: BPMF_HIP_STALE cannot be combined with the connectivity-aware exchange");
+        if (k != s->stale_k) s->stale_primed = false;
+        s->stale_k = k;
+    }
     if (nsub > 1) return bpmf_hip_side_set_overlap(s, nsub);
     return BPMF_HIP_OK;
 }
@@ -1853,7 +1942,8 @@ extern "C" int bpmf_hip_side_set_staleness(bpmf_hip_side *s, int k)
     if (!s || k < 0 || k > 64) return fail(BPMF_HIP_EINVAL, "side_set_staleness: k = 0 .. 64");
     if (k > 0 && !s->conn_send_ptr.empty()) return fail(BPMF_HIP_EINVAL, "side_set_staleness: not together with the connectivity-aware exchange");
     { const int rc = settle_async(s); if (rc) return rc; }
-    s->stale_k = k;
+    if (k != s->stale_k) s->stale_primed = false;                      // the next half-iteration exchanges every part
+    s->stale_k = k; s->stale_explicit = true;
     return BPMF_HIP_OK;
 }
 
@@ -1864,6 +1954,7 @@ extern "C" int bpmf_hip_side_set_conn(bpmf_hip_side *s, const int64_t *send_ptr,
     bpmf_hip_ctx *c = s->ctx;
     if (!c->comm || s->bounds.empty()) return fail(BPMF_HIP_EINVAL, "side_set_conn: set the communicator and the ranges first");
     if (c->dtype != BPMF_HIP_F64) return fail(BPMF_HIP_EINVAL, "side_set_conn: the packed exchange is fp64 only (the fp32 context uses the all-gather form)");
+    if (s->stale_k > 0 && (send_ptr || recv_ptr)) return fail(BPMF_HIP_EINVAL, "side_set_conn: not together with the bounded-staleness exchange");
     int rc;
     if ((rc = settle_async(s))) return rc;
     HIP_TRY(hipSetDevice(c->device));
@@ -1907,12 +1998,7 @@ extern "C" int bpmf_hip_side_exchange(bpmf_hip_side *s)
     if ((rc = settle_async(s))) return rc;
     HIP_TRY(hipSetDevice(c->device));
     c->last_sampler_done = nullptr;
-    switch (c->K) {
-#define BPMF_CASE(KK) case KK: rc = bpmf_launch::exchange<KK>(s, c->stream, -1); break;
-        BPMF_CASE(8) BPMF_CASE(16) BPMF_CASE(32) BPMF_CASE(64) BPMF_CASE(128)
-#undef BPMF_CASE
-        default: return fail(BPMF_HIP_EINVAL, "unsupported K");
-    }
+    rc = BPMF_DISPATCH_K(c->K, (bpmf_launch::exchange<KK, FF>(s, c->stream, -1)));
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return BPMF_HIP_OK;
@@ -2024,11 +2110,14 @@ void dispatch_predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *s
                       hipStream_t ps, bool beside)
 {
     switch (self->ctx->K) {
-    case 8: bpmf_launch::predict<8>(t, self, self_items, other_items, n, ps, beside); break;
-    case 16: bpmf_launch::predict<16>(t, self, self_items, other_items, n, ps, beside); break;
-    case 32: bpmf_launch::predict<32>(t, self, self_items, other_items, n, ps, beside); break;
-    case 64: bpmf_launch::predict<64>(t, self, self_items, other_items, n, ps, beside); break;
-    case 128: bpmf_launch::predict<128>(t, self, self_items, other_items, n, ps, beside); break;
+    case 8: bpmf_launch::predict<8, false>(t, self, self_items, other_items, n, ps, beside); break;
+    case 16: bpmf_launch::predict<16, false>(t, self, self_items, other_items, n, ps, beside); break;
+    case 32: bpmf_launch::predict<32, false>(t, self, self_items, other_items, n, ps, beside); break;
+    case 64: bpmf_launch::predict<64, false>(t, self, self_items, other_items, n, ps, beside); break;
+    case 128:
+        if (self->ctx->dtype == BPMF_HIP_F32) bpmf_launch::predict<128, true>(t, self, self_items, other_items, n, ps, beside);
+        else bpmf_launch::predict<128, false>(t, self, self_items, other_items, n, ps, beside);
+        break;
     default: break;
     }
 }

@@ -31,11 +31,11 @@ void randn_probe(uint32_t counter, int n, double *out_dev, hipStream_t st)
     hipLaunchKernelGGL(bpmf::k_randn_probe, dim3(1), dim3(64), 0, st, counter, n, out_dev);
 }
 
-void aggr_add(const void *items, bool f32, int K, int64_t c0, int64_t ncols, double *mu, double *lambda, hipStream_t st)
+void aggr_add(const void *items, bool f32, int ld, int K, int64_t c0, int64_t ncols, double *mu, double *lambda, hipStream_t st)
 {
     if (ncols <= 0) return;
-    if (f32) hipLaunchKernelGGL(bpmf::k_aggr_add<float>, dim3((unsigned)ncols), dim3(256), 0, st, (const float *)items, K, c0, mu, lambda);
-    else hipLaunchKernelGGL(bpmf::k_aggr_add<double>, dim3((unsigned)ncols), dim3(256), 0, st, (const double *)items, K, c0, mu, lambda);
+    if (f32) hipLaunchKernelGGL(bpmf::k_aggr_add<float>, dim3((unsigned)ncols), dim3(256), 0, st, (const float *)items, ld, K, c0, mu, lambda);
+    else hipLaunchKernelGGL(bpmf::k_aggr_add<double>, dim3((unsigned)ncols), dim3(256), 0, st, (const double *)items, ld, K, c0, mu, lambda);
 }
 
 void aggr_finalize(int K, int nsamples, int64_t ncols, double *mu, double *lambda, hipStream_t st)

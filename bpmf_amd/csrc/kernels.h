@@ -98,11 +98,13 @@ __device__ __forceinline__ double polar_r2(double x, double y)
     return x * x + y * y;      // two roundings + add, as the un-fused x86 reference build evaluates it
 }
 
-// stream id of a column: (idx+1)*K*(iter+1) truncated to 32 bits (c++/sample.cpp:266, c++/bpmf.h:67)
-template <int K>
-__device__ __forceinline__ uint32_t sample_counter(int64_t idx, uint32_t iter_plus_1)
+// stream id of a column: (idx+1)*K*(iter+1) truncated to 32 bits (c++/sample.cpp:266, c++/bpmf.h:67).  K is the
+// reference's num_latent -- the caller's (`ktrue` of the argument blocks), not the K the kernel is instantiated for:
+// a num_latent between two instantiated sizes runs on the next one with zero factor rows / identity precision in the
+// extra dimensions, and takes its stream id and its number of normals from the true K (c++/sample.cpp:266,322)
+__device__ __forceinline__ uint32_t sample_counter(int64_t idx, int ktrue, uint32_t iter_plus_1)
 {
-    return (uint32_t)((uint64_t)(idx + 1) * (uint64_t)K * (uint64_t)iter_plus_1);
+    return (uint32_t)((uint64_t)(idx + 1) * (uint64_t)ktrue * (uint64_t)iter_plus_1);
 }
 
 // The hyper-parameters of this half-iteration may still be on their way (the host's Normal-Wishart
@@ -146,9 +148,11 @@ __device__ __forceinline__ void stamp(const SampleArgs &a, int w, int slot)
     if (probe >= 0 && slot < 64) a.stamps[probe * 64 + slot] = wall_clock64();
 }
 
+// pad_to > n: out_lds[n .. pad_to) = 0 (the extra dimensions of a padded num_latent draw nothing: x stays 0 there)
 template <int NMAX>
-__device__ __forceinline__ void draw_normals(uint32_t counter, int n, double *out_lds, int lane)
+__device__ __forceinline__ void draw_normals(uint32_t counter, int n, double *out_lds, int lane, int pad_to = 0)
 {
+    for (int i = n + lane; i < pad_to; i += 64) out_lds[i] = 0.0;
     int produced = 0;
     uint32_t base = 0;
     while (produced < n) {                                         // wave-uniform
@@ -172,8 +176,9 @@ __device__ __forceinline__ void draw_normals(uint32_t counter, int n, double *ou
 // only park (y, r2) of the accepted attempts by rank; log / sqrt / divide -- a third of a round --
 // run once at the end, one lane per normal.  Same expression on the same inputs: bit-identical.
 template <int NMAX>
-__device__ __forceinline__ void draw_normals_deferred(uint32_t counter, int n, double *out_lds, double *r2_lds, int lane)
+__device__ __forceinline__ void draw_normals_deferred(uint32_t counter, int n, double *out_lds, double *r2_lds, int lane, int pad_to = 0)
 {
+    for (int i = n + lane; i < pad_to; i += 64) out_lds[i] = 0.0;
     int produced = 0;
     uint32_t base = 0;
     while (produced < n) {                                         // wave-uniform
@@ -202,8 +207,9 @@ __device__ __forceinline__ void draw_normals_deferred(uint32_t counter, int n, d
 // and the j-th normal its j-th accepted attempt, so every normal is the one draw_normals_deferred produces.
 template <int NMAX>
 __device__ __forceinline__ void draw_normals_pair(uint32_t counterA, uint32_t counterB, int n, double *outA, double *outB,
-                                                  double *r2A, double *r2B, int lane)
+                                                  double *r2A, double *r2B, int lane, int pad_to = 0)
 {
+    for (int i = n + lane; i < pad_to; i += 64) { outA[i] = 0.0; outB[i] = 0.0; }
     auto attempt = [&](uint32_t counter, uint32_t block, double &y, double &r2) -> bool {
         const Philox4 b = stream_block(counter, block);
         const double x = 2.0 * canonical53(b.w[3], b.w[2]) - 1.0;   // URNG order: w3, w2, w1, w0
@@ -505,7 +511,7 @@ __device__ __forceinline__ void deposit_column(const SampleArgs &a, int64_t idx,
     const int kq = lane >> 4, li = lane & 15;
     double *sL = lds + slot * G::SLOT, *sY = sL + G::PLEN, *sZ = sY + K;
 
-    draw_normals<K>(sample_counter<K>(idx, a.iter_plus_1), K, sZ, lane);
+    draw_normals<K>(sample_counter(idx, a.ktrue, a.iter_plus_1), a.ktrue, sZ, lane, K);
     const double *LF = a.prop_lambda ? a.prop_lambda + (size_t)(idx - a.col_from) * K * K : a.LambdaF;
 
     int tri = 0;
@@ -843,7 +849,7 @@ __device__ __forceinline__ void finish_single(const SampleArgs &a, int col_local
     const int64_t idx = a.col_from + col_local;
 
     // z ~ N(0, I) from stream (idx+1)*K*(iter+1) truncated to 32 bits (c++/sample.cpp:266, c++/bpmf.h:67)
-    if (!have_z) draw_normals<K>(sample_counter<K>(idx, a.iter_plus_1), K, sz, lane);
+    if (!have_z) draw_normals<K>(sample_counter(idx, a.ktrue, a.iter_plus_1), a.ktrue, sz, lane, K);
 
     const int l = lane & (G::LANES - 1);                           // K=8: the upper half-wave mirrors the lower
     const int h = l / K, i = l % K;
@@ -1045,7 +1051,7 @@ __global__ __launch_bounds__(64, Geo1<K>::WPS) void k_sample1(SampleArgs a, Fuse
     // whole column in one item: its normals do not depend on the Gram -- draw them first so that
     // the Philox / log / sqrt chain is off the critical path between the last MFMA and the factorisation
     if (mc < 0 && !(a.ablate & 1u))
-        draw_normals<K>(sample_counter<K>(a.col_from + col, a.iter_plus_1), K, lds + Geo1<K>::AWORDS + K, lane);
+        draw_normals<K>(sample_counter(a.col_from + col, a.ktrue, a.iter_plus_1), a.ktrue, lds + Geo1<K>::AWORDS + K, lane, K);
 
     if constexpr (K <= 32) {
         // Gram on the 4x4x4 MFMA shape: NB block accumulators + NG rhs sums per lane

@@ -69,10 +69,11 @@ __global__ __launch_bounds__(64) void k_randn_probe(uint32_t counter, int n, dou
 // K x K covariance per column at the end.  One workgroup per column; K is a run-time argument.
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_aggr_add(const T *__restrict__ items, int K, int64_t c0, double *__restrict__ mu, double *__restrict__ lambda)
+__global__ __launch_bounds__(256) void k_aggr_add(const T *__restrict__ items, int ld, int K, int64_t c0, double *__restrict__ mu, double *__restrict__ lambda)
 {
+    // (ld: leading dimension of the factor matrix on the device -- the instantiated K; K: the caller's num_latent)
     const int64_t c = blockIdx.x;                                   // local column
-    const T *x = items + (size_t)(c0 + c) * K;
+    const T *x = items + (size_t)(c0 + c) * ld;
     double *l = lambda + (size_t)c * K * K;
     for (int e = threadIdx.x; e < K * K; e += 256) l[e] += (double)x[e % K] * (double)x[e / K];     // column-major K x K: (i, j) at i + j K
     if ((int)threadIdx.x < K) mu[(size_t)c * K + threadIdx.x] += (double)x[threadIdx.x];

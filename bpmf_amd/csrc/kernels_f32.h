@@ -271,7 +271,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sample_wg(SampleArgsW<T> a)
     const int64_t idx = a.col_from + col;
 
     // z ~ N(0, I): stream (idx+1)*K*(iter+1) mod 2^32 (c++/sample.cpp:266); the last wave has the fewest tiles
-    if (wave == NW - 1) draw_normals<K>(sample_counter<K>(idx, a.iter_plus_1), K, zs, lane);
+    if (wave == NW - 1) draw_normals<K>(sample_counter(idx, a.ktrue, a.iter_plus_1), a.ktrue, zs, lane, K);
     bool bad;
     if constexpr (NW == 1) {
         bad = wg_column<K, T, 1, 0>(a, col, p0, len, R, dinv, bv, tid);
@@ -363,8 +363,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sample_wg(SampleArgsW<T> a)
 // slice: the tiles in accumulator layout | sum[K]; k_colstats_f32_final adds the slices in order and un-tiles.
 // (First form: one output per thread and column on the VALU, 128 partials of 132 KB: 55 us alone, 0.2 ms beside the
 // next sampler.  With the select wrapped around each load the loads of a k-step were serialised: see kernels_wg2.h.)
-template <int K>
-__global__ __launch_bounds__(64) void k_colstats_f32(const float *__restrict__ items, int64_t c0, int64_t c1, int nsl,
+// (T = double: the fp64 K = 128 context -- the same pass over fp64 columns)
+template <int K, typename T = float>
+__global__ __launch_bounds__(64) void k_colstats_f32(const T *__restrict__ items, int64_t c0, int64_t c1, int nsl,
                                                      double *__restrict__ partials)
 {
     constexpr int NT = K / 16, NTRI = NT * (NT + 1) / 2, PARTW = NTRI * 256 + K;
@@ -378,10 +379,10 @@ __global__ __launch_bounds__(64) void k_colstats_f32(const float *__restrict__ i
     const int64_t b = c0 + sl * per, e = (b + per < c1) ? b + per : c1;
     d4 acc = d4{0.0, 0.0, 0.0, 0.0};
     double r = 0.0;
-    const float *xi = items + 16 * I + li, *xj = items + 16 * J + li;
+    const T *xi = items + 16 * I + li, *xj = items + 16 * J + li;
     // 16 columns per trip; the loads of the next trip are issued before the MFMAs of the current one
-    float fa[4], fb[4], na[4], nb[4];
-    auto fetch = [&](int64_t c, float (&a4)[4], float (&b4)[4]) {
+    T fa[4], fb[4], na[4], nb[4];
+    auto fetch = [&](int64_t c, T (&a4)[4], T (&b4)[4]) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t cc = c + 4 * u + kq;

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64, 3) void k_sample_lr(LrArgs a)
     const int len = a.len[w];
 
     // (the normal draw first: its Philox / log / sqrt temporaries are dead before R occupies 128 registers)
-    draw_normals<K>(sample_counter<K>(a.col_from + col, a.iter_plus_1), K, sz, lane);
+    draw_normals<K>(sample_counter(a.col_from + col, a.ktrue, a.iter_plus_1), a.ktrue, sz, lane, K);
     __builtin_amdgcn_sched_barrier(0);
 
     if (len == 0) {
@@ -302,12 +302,12 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
         for (int cb = 0; cb < NB; cb += 2) {
             const int w = w0 + cb;
             if (w >= a.nitems) break;                                 // wave-uniform
-            const uint32_t cA = sample_counter<K>(a.col_from + a.col[w], a.iter_plus_1);
+            const uint32_t cA = sample_counter(a.col_from + a.col[w], a.ktrue, a.iter_plus_1);
             if (w + 1 < a.nitems) {
-                const uint32_t cB = sample_counter<K>(a.col_from + a.col[w + 1], a.iter_plus_1);
-                draw_normals_pair<K>(cA, cB, K, sv[wave][cb], sv[wave][cb + 1], sr[wave][0], sr[wave][1], lane);
+                const uint32_t cB = sample_counter(a.col_from + a.col[w + 1], a.ktrue, a.iter_plus_1);
+                draw_normals_pair<K>(cA, cB, a.ktrue, sv[wave][cb], sv[wave][cb + 1], sr[wave][0], sr[wave][1], lane, K);
             } else {
-                draw_normals_deferred<K>(cA, K, sv[wave][cb], sr[wave][0], lane);
+                draw_normals_deferred<K>(cA, a.ktrue, sv[wave][cb], sr[wave][0], lane, K);
             }
         }
 #pragma unroll 1

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64, GeoQ<K>::WPS) void k_sample1q(SampleArgs a, Fus
     const int glen = (a.ablate & 2u) ? 0 : len;
     const IdxBlock ib0 = load_idx_block(a.rowidx + p0, a.vals + p0, 0, lane, glen, a.zero_row);
     const IdxBlock ib1 = load_idx_block(a.rowidx + p0, a.vals + p0, 64, lane, glen, a.zero_row);
-    if (mc < 0) draw_normals<K>(sample_counter<K>(a.col_from + col, a.iter_plus_1), K, sz, lane);
+    if (mc < 0) draw_normals<K>(sample_counter(a.col_from + col, a.ktrue, a.iter_plus_1), a.ktrue, sz, lane, K);
     double acc[NB], rr[NG];
 #pragma unroll
     for (int t = 0; t < NB; ++t) acc[t] = 0.0;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64, GeoQ<K>::WPS) void k_sample1q(SampleArgs a, Fus
         if ((int)t != nch - 1) return;
         if (lane == 0) __hip_atomic_store(&a.mc_count[mc], 0u, BPMF_RLX_AGENT);
         // (the normals now, while no accumulator is live: log / sqrt want ~60 registers of their own)
-        draw_normals<K>(sample_counter<K>(a.col_from + col, a.iter_plus_1), K, sz, lane);
+        draw_normals<K>(sample_counter(a.col_from + col, a.ktrue, a.iter_plus_1), a.ktrue, sz, lane, K);
 #pragma unroll
         for (int t2 = 0; t2 < NB; ++t2) acc[t2] = 0.0;
 #pragma unroll

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64, Geo4<K>::WPS) void k_sample4(SampleArgs a)
     for (int sb = 0; sb < 4; ++sb) {
         const int c = __builtin_amdgcn_readfirstlane(__shfl(col, 4 * sb));
         const int m = __builtin_amdgcn_readfirstlane(__shfl(mc, 4 * sb));
-        if (c >= 0 && m < 0) draw_normals<K>(sample_counter<K>(a.col_from + c, a.iter_plus_1), K, sz[sb], lane);
+        if (c >= 0 && m < 0) draw_normals<K>(sample_counter(a.col_from + c, a.ktrue, a.iter_plus_1), a.ktrue, sz[sb], lane, K);
     }
 
     // ---- Gram: block b of every instruction takes 4 ratings of column b
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64, Geo4<K>::WPS) void k_sample4(SampleArgs a)
         const int c = __builtin_amdgcn_readfirstlane(__shfl(col, 4 * sb));
         const int m = __builtin_amdgcn_readfirstlane(__shfl(mc, 4 * sb));
         const int al = __builtin_amdgcn_readfirstlane(__shfl((int)alive, 4 * sb));
-        if (c >= 0 && m >= 0 && al) draw_normals<K>(sample_counter<K>(a.col_from + c, a.iter_plus_1), K, sz[sb], lane);
+        if (c >= 0 && m >= 0 && al) draw_normals<K>(sample_counter(a.col_from + c, a.ktrue, a.iter_plus_1), a.ktrue, sz[sb], lane, K);
     }
     if (a.ablate & 1u) {
         double v = rr[0];

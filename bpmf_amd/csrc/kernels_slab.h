@@ -270,7 +270,7 @@ __device__ __forceinline__ void slab_item(const SampleArgs &a, int w, double *ld
 
     stamp(a, w, 0);
     // whole column in one item: its normals do not depend on the Gram -- drawn first, in the shadow of the first loads
-    if (mc < 0) draw_normals_deferred<K>(sample_counter<K>(idx, a.iter_plus_1), K, sz, srow, lane);
+    if (mc < 0) draw_normals_deferred<K>(sample_counter(idx, a.ktrue, a.iter_plus_1), a.ktrue, sz, srow, lane, K);
 
     stamp(a, w, 1);
     double A[NREG];
@@ -313,7 +313,7 @@ __device__ __forceinline__ void slab_item(const SampleArgs &a, int w, double *ld
 #pragma unroll
                 for (int t = 0; t < NT; ++t) rsum[t] += __hip_atomic_load(&pc[NREG * 64 + t * 16 + li], BPMF_RLX_AGENT);
             }
-            draw_normals_deferred<K>(sample_counter<K>(idx, a.iter_plus_1), K, sz, srow, lane);
+            draw_normals_deferred<K>(sample_counter(idx, a.ktrue, a.iter_plus_1), a.ktrue, sz, srow, lane, K);
         }
     } else {
         // fp32 Gram on v_mfma_f32_16x16x4_f32: D[i = 4 (lane / 16) + reg][j = lane % 16]
@@ -414,7 +414,7 @@ __device__ __forceinline__ void slab_item(const SampleArgs &a, int w, double *ld
 #pragma unroll
                 for (int t = 0; t < NT; ++t) r[t] += __hip_atomic_load(&pc[NTRI * 256 + t * 16 + li], BPMF_RLX_AGENT);
             }
-            draw_normals_deferred<K>(sample_counter<K>(idx, a.iter_plus_1), K, sz, srow, lane);
+            draw_normals_deferred<K>(sample_counter(idx, a.ktrue, a.iter_plus_1), a.ktrue, sz, srow, lane, K);
         }
         // widen: tile element (4 kq + reg, li) -> slab m lane (kq', li) = tile element (4 m + kq', li), through a 16 x 17 LDS tile
         float *stile = reinterpret_cast<float *>(sw + 16 * NG);

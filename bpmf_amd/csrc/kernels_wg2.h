@@ -1,4 +1,6 @@
-// kernels_wg2.h -- k_sample_wg2<K, NW>: the fp32 large-K column update (K = 128, BASELINE configs[4]), second form.
+// kernels_wg2.h -- k_sample_wg2<K, NW, T>: the large-K column update (K = 128), second form.  T = float: the fp32
+// mixed-precision path (BASELINE configs[4]); T = double: the reference's own fp64 arithmetic at num_latent 65 .. 128
+// (`bpmf-128`, `bpmf-100` ... of ci/multilatent.sh:5) -- same frame, fp64 factors, Gram on v_mfma_f64_16x16x4_f64.
 //
 // Reference: Sys::sample(long idx, Sys&) + computeMuLambda, c++/sample.cpp:248-336.
 //
@@ -30,8 +32,9 @@ struct GeoW2 {
     // LDS (floats unless noted): zs [K doubles] | R by block rows | b / y, later x [K] | t [16] | ticket.  W_s^T = R_ss^-T takes
     // the place of the diagonal block R_ss in block row s (nothing reads R_ss once it is inverted), and x_s overwrites
     // y_s in the backward solve: 40 528 B, FOUR workgroups per CU (with W^T and x on their own: 49 232 B, three)
-    static constexpr size_t lds_bytes() { return (size_t)K * 8 + ((size_t)F::RWORDS + K + 16 + 4) * 4; }
-    static constexpr int PART_FLOATS = F::NTRI * 256 + NT * 16;   // partial of one chunk: all tiles + rhs
+    // (T = double: 80 032 B, two workgroups per CU)
+    template <typename T = float> static constexpr size_t lds_bytes() { return (size_t)K * 8 + ((size_t)F::RWORDS + K + 16 + 4) * sizeof(T); }
+    static constexpr int PART_FLOATS = F::NTRI * 256 + NT * 16;   // partial of one chunk: all tiles + rhs (elements of T)
 };
 
 // 16 x 16 SPD block (upper part used), given as four fp64 slabs A[I]: lane (kq, c) <-> D[4 I + kq][c].
@@ -65,11 +68,13 @@ __device__ __forceinline__ void diag16_factor_invert(double (&A)[4], double (&E)
 }
 
 // per-wave part of one work item: Gram of the wave's tiles, then (whole column / last chunk) the factorisation
-template <int K, int NW, int W>
+template <int K, int NW, int W, typename T = float>
 __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned char *smem, int tid)
 {
     using G = GeoF<K>;
-    typedef float T;
+    using X = WgTraits<T>;
+    typedef typename X::acc_t acc_t;
+    constexpr bool F32 = sizeof(T) == 4;
     constexpr int NT = G::NT, TPW = (G::NTRI + NW - 1) / NW;
     double *zs = reinterpret_cast<double *>(smem);
     T *R = reinterpret_cast<T *>(zs + K);
@@ -86,10 +91,10 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
 
     stamp(a, w, 0);
 
-    f4 acc[TPW];
+    acc_t acc[TPW];
     T r[NT];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[t] = f4{0, 0, 0, 0};
+    for (int t = 0; t < TPW; ++t) acc[t] = acc_t{0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < NT; ++t) r[t] = 0;
     {
@@ -124,7 +129,7 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
             for (int st = 0; st < 4; ++st) {
                 if (W == 0 || no_mfma) {
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) r[t] = fmaf(yy[st][t], w1[st], r[t]);
+                    for (int t = 0; t < NT; ++t) r[t] = fma(yy[st][t], w1[st], r[t]);
                 }
                 if (no_mfma) continue;
 #pragma unroll
@@ -132,7 +137,7 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
 #pragma unroll
                     for (int J = I; J < NT; ++J)
                         if ((G::tri(I, J) % NW) == W)
-                            acc[G::tri(I, J) / NW] = __builtin_amdgcn_mfma_f32_16x16x4f32(yy[st][I], yy[st][J], acc[G::tri(I, J) / NW], 0, 0, 0);
+                            acc[G::tri(I, J) / NW] = X::mfma(yy[st][I], yy[st][J], acc[G::tri(I, J) / NW]);
             }
         };
         if (len > 0) gather(0, yA, wA);
@@ -168,8 +173,8 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
         // the workgroup that draws the last ticket adds the partials in chunk order
         constexpr int PF = GeoW2<K>::PART_FLOATS;
         const int nch = a.mc_nchunks[mc];
-        float *pbase = reinterpret_cast<float *>(a.partials) + (size_t)a.mc_slot0[mc] * PF;
-        float *p = pbase + (size_t)a.wi_chunk[w] * PF;
+        T *pbase = reinterpret_cast<T *>(a.partials) + (size_t)a.mc_slot0[mc] * PF;
+        T *p = pbase + (size_t)a.wi_chunk[w] * PF;
 #pragma unroll
         for (int I = 0; I < NT; ++I)
 #pragma unroll
@@ -190,11 +195,11 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
         if ((int)tk != nch - 1) return;                               // (the whole workgroup)
         if (tid == 0) __hip_atomic_store(&a.mc_count[mc], 0u, BPMF_RLX_AGENT);
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) acc[t] = f4{0, 0, 0, 0};
+        for (int t = 0; t < TPW; ++t) acc[t] = acc_t{0, 0, 0, 0};
 #pragma unroll
         for (int t = 0; t < NT; ++t) r[t] = 0;
         for (int ch = 0; ch < nch; ++ch) {                            // fixed chunk order: deterministic
-            const float *pc = pbase + (size_t)ch * PF;
+            const T *pc = pbase + (size_t)ch * PF;
 #pragma unroll
             for (int I = 0; I < NT; ++I)
 #pragma unroll
@@ -219,7 +224,9 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
     }
     // Lambda* = LambdaF + alpha G in the register tiles (:297-298); b = LambdaF mu + rr (:285,:256)
     const double *LF = a.prop_lambda ? a.prop_lambda + (size_t)col * K * K : a.LambdaF;
-    if (a.lf32) {                                                     // (workgroup-uniform) the prior as fp32 tiles: one 16-byte load per tile
+    bool lf_tiles = false;
+    if constexpr (F32) lf_tiles = a.lf32 != nullptr;
+    if constexpr (F32) if (lf_tiles) {                                // (workgroup-uniform) the prior as fp32 tiles: one 16-byte load per tile
         const f4 *lt = reinterpret_cast<const f4 *>(a.lf32);
         const T alpha_f = (T)a.alpha;
         f4 lf[TPW];
@@ -239,7 +246,8 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
                         acc[G::tri(I, J) / NW][reg] = (a.diag_only && (16 * I + 4 * kq + reg) != (16 * J + li)) ? (T)0 : v;
                     }
                 }
-    } else {
+    }
+    if (!lf_tiles) {
         // LambdaF(gj, gi): the lower triangle, which is what LLT reads (:306); 16 lanes = one 128-byte line.  The loads of
         // a batch of tiles are issued together and without control flow around them (with the diag_only select wrapped
         // around each load they were 72 serialised L2 round trips: 14.6 of the ~50 us a mid-size column lived)
@@ -253,7 +261,7 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
                 if (t0 + u < TPW && tri < G::NTRI) {
                     const int I = G::tile_i(tri), J = G::tile_j(tri);
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) lf[u][reg] = LF[(16 * J + li) + (size_t)(16 * I + 4 * kq + reg) * K];
+                    for (int reg = 0; reg < 4; ++reg) lf[u][reg] = LF[(16 * J + li) + (size_t)(16 * I + X::drow(kq, reg)) * K];
                 }
             }
 #pragma unroll
@@ -264,7 +272,7 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         const T v = (T)fma(a.alpha, (double)acc[t0 + u][reg], lf[u][reg]);
-                        acc[t0 + u][reg] = (a.diag_only && (16 * I + 4 * kq + reg) != (16 * J + li)) ? (T)0 : v;
+                        acc[t0 + u][reg] = (a.diag_only && (16 * I + X::drow(kq, reg)) != (16 * J + li)) ? (T)0 : v;
                     }
                 }
             }
@@ -292,13 +300,13 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
         for (int J = s; J < NT; ++J)
             if ((G::tri(s, J) % NW) == W) {
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) Rs[(4 * kq + reg) * LDs + 16 * (J - s) + li] = acc[G::tri(s, J) / NW][reg];
+                for (int reg = 0; reg < 4; ++reg) Rs[X::drow(kq, reg) * LDs + 16 * (J - s) + li] = acc[G::tri(s, J) / NW][reg];
             }
         __syncthreads();
         stamp(a, w, 2 + 4 * s);
         // z ~ N(0, I): stream (idx+1)*K*(iter+1) mod 2^32 (c++/sample.cpp:266) -- by the last wave while wave 0 factors the
         // first diagonal block (it would idle at the next barrier otherwise; the backward solve is what reads z)
-        if (s == 0 && W == NW - 1) draw_normals<K>(sample_counter<K>(idx, a.iter_plus_1), K, zs, lane);
+        if (s == 0 && W == NW - 1) draw_normals<K>(sample_counter(idx, a.ktrue, a.iter_plus_1), a.ktrue, zs, lane, K);
         // B: diagonal block in fp64 on the 4x4x4 shape: R_ss (upper) and W_s^T = R_ss^-T; then y_s = W_s^T b_s
         if (W == 0) {
             double A16[4], E[4];
@@ -315,7 +323,7 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
             T ysum = 0;
             if (lane < 16) {
 #pragma unroll
-                for (int k = 0; k < 16; ++k) ysum = fmaf(Rs[lane * LDs + k], bv[16 * s + k], ysum);
+                for (int k = 0; k < 16; ++k) ysum = fma(Rs[lane * LDs + k], bv[16 * s + k], ysum);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane < 16) bv[16 * s + lane] = ysum;
@@ -334,11 +342,11 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
                     T opB[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) opB[q] = Rs[(4 * q + kq) * LDs + 16 * (J - s) + li];
-                    f4 t4 = f4{0, 0, 0, 0};
+                    acc_t t4 = acc_t{0, 0, 0, 0};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) t4 = __builtin_amdgcn_mfma_f32_16x16x4f32(opA[q], opB[q], t4, 0, 0, 0);
+                    for (int q = 0; q < 4; ++q) t4 = X::mfma(opA[q], opB[q], t4);
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) Rs[(4 * kq + reg) * LDs + 16 * (J - s) + li] = t4[reg];
+                    for (int reg = 0; reg < 4; ++reg) Rs[X::drow(kq, reg) * LDs + 16 * (J - s) + li] = t4[reg];
                 }
             __syncthreads();
             stamp(a, w, 5 + 4 * s);
@@ -346,7 +354,7 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
             for (int cc = tid; cc < Ws - 16; cc += 64 * NW) {
                 T sacc = 0;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) sacc = fmaf(Rs[k * LDs + 16 + cc], bv[16 * s + k], sacc);
+                for (int k = 0; k < 16; ++k) sacc = fma(Rs[k * LDs + 16 + cc], bv[16 * s + k], sacc);
                 bv[16 * (s + 1) + cc] -= sacc;
             }
             // D: trailing update of this wave's tiles  A_IJ -= R_sI^T R_sJ
@@ -367,7 +375,7 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
                         for (int q = 0; q < 4; ++q) opJ[q] = Rs[(4 * q + kq) * LDs + 16 * (J - s) + li];
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            acc[G::tri(I, J) / NW] = __builtin_amdgcn_mfma_f32_16x16x4f32(opI[q], opJ[q], acc[G::tri(I, J) / NW], 0, 0, 0);
+                            acc[G::tri(I, J) / NW] = X::mfma(opI[q], opJ[q], acc[G::tri(I, J) / NW]);
                     }
             }
         }
@@ -385,8 +393,8 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
             T t = 0, t2 = 0;                                          // (fp32 products and sums: half the issue slots of the widened form)
 #pragma unroll
             for (int j = 16; j < Ws; j += 8) {
-                t = fmaf(Rs[li * LDs + j + kq], xs[16 * s + j + kq], t);
-                if (j + 4 < Ws) t2 = fmaf(Rs[li * LDs + j + 4 + kq], xs[16 * s + j + 4 + kq], t2);
+                t = fma(Rs[li * LDs + j + kq], xs[16 * s + j + kq], t);
+                if (j + 4 < Ws) t2 = fma(Rs[li * LDs + j + 4 + kq], xs[16 * s + j + 4 + kq], t2);
             }
             t += t2;
             t += __shfl_xor(t, 16);
@@ -397,7 +405,7 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
             // x_s = W_s t: x_i = sum_k W_s[i][k] t_k = sum_k Wt_s[k][i] t_k
             T xsum = 0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) xsum = fmaf(Rs[k * LDs + li], ts[k], xsum);
+            for (int k = 0; k < 16; ++k) xsum = fma(Rs[k * LDs + li], ts[k], xsum);
             if (kq == 0) xs[16 * s + li] = xsum;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -406,7 +414,7 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
         for (int i = lane; i < K; i += 64) {
             const T v = xs[i];
             dst[i] = v;
-            nf |= !(fabsf(v) <= 3.0e38f);
+            nf |= F32 ? !(fabsf((float)v) <= 3.0e38f) : !(fabs((double)v) <= 1.7e308);
         }
         // a non-positive pivot turns into NaN / inf and reaches the sample: "Cholesky failed" (:308)
         if (__any(nf) && lane == 0) atomicMin(a.fail, (unsigned long long)idx);
@@ -414,24 +422,26 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
     }
 }
 
-template <int K, int NW>
+template <int K, int NW, typename T = float>
 __global__ __launch_bounds__(64 * NW, 2) void k_sample_wg2(SampleArgs a, StatRiders r)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[GeoW2<K>::lds_bytes()];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[GeoW2<K>::template lds_bytes<T>()];
     const int tid = threadIdx.x, wave = tid >> 6;
-    // the column statistics of the previous launch's side ride as the first workgroups (colstats_f32_rider)
-    if ((int)blockIdx.x < r.nblocks) { colstats_f32_rider<K, NW>(r, (int)blockIdx.x, tid); return; }
+    // the column statistics of the previous launch's side ride as the first workgroups (colstats_f32_rider; fp32 path only)
+    if constexpr (sizeof(T) == 4) {
+        if ((int)blockIdx.x < r.nblocks) { colstats_f32_rider<K, NW>(r, (int)blockIdx.x, tid); return; }
+    }
     const int w = (int)blockIdx.x - r.nblocks;
     const unsigned long long t_begin = a.stamps ? wall_clock64() : 0ull;
     if constexpr (NW == 2) {
-        if (wave == 0) wg2_column<K, 2, 0>(a, w, smem, tid);
-        else wg2_column<K, 2, 1>(a, w, smem, tid);
+        if (wave == 0) wg2_column<K, 2, 0, T>(a, w, smem, tid);
+        else wg2_column<K, 2, 1, T>(a, w, smem, tid);
     } else {
         switch (wave) {
-        case 0: wg2_column<K, 4, 0>(a, w, smem, tid); break;
-        case 1: wg2_column<K, 4, 1>(a, w, smem, tid); break;
-        case 2: wg2_column<K, 4, 2>(a, w, smem, tid); break;
-        default: wg2_column<K, 4, 3>(a, w, smem, tid); break;
+        case 0: wg2_column<K, 4, 0, T>(a, w, smem, tid); break;
+        case 1: wg2_column<K, 4, 1, T>(a, w, smem, tid); break;
+        case 2: wg2_column<K, 4, 2, T>(a, w, smem, tid); break;
+        default: wg2_column<K, 4, 3, T>(a, w, smem, tid); break;
         }
     }
     if (a.stamps && tid == 0) {                                        // profiling: sum of the items' lifetimes (wave 0), their number, first start / last end

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64, GeoX<K>::WPS) void k_sample1x(SampleArgs a, Fus
         asm volatile("" : "+v"(lane));
         const int glen = (a.ablate & 2u) ? 0 : len;
         // whole column in one item: its normals in the shadow of the index loads
-        if (mc < 0) draw_normals<K>(sample_counter<K>(a.col_from + col, a.iter_plus_1), K, sz + c * K, lane);
+        if (mc < 0) draw_normals<K>(sample_counter(a.col_from + col, a.ktrue, a.iter_plus_1), a.ktrue, sz + c * K, lane, K);
 #pragma unroll
         for (int t = 0; t < NB; ++t) acc[t] = 0.0;
 #pragma unroll
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(64, GeoX<K>::WPS) void k_sample1x(SampleArgs a, Fus
             tk = __builtin_amdgcn_readfirstlane(tk);
             if ((int)tk != nch - 1) continue;                         // (this slot of the wave stays empty)
             if (lane == 0) __hip_atomic_store(&a.mc_count[mc], 0u, BPMF_RLX_AGENT);
-            draw_normals<K>(sample_counter<K>(a.col_from + col, a.iter_plus_1), K, sz + c * K, lane);
+            draw_normals<K>(sample_counter(a.col_from + col, a.ktrue, a.iter_plus_1), a.ktrue, sz + c * K, lane, K);
 #pragma unroll
             for (int t2 = 0; t2 < NB; ++t2) acc[t2] = 0.0;
 #pragma unroll

@@ -22,22 +22,22 @@ inline unsigned &next_flags() { static thread_local unsigned f = 0; return f; }
 inline unsigned take_flags() { unsigned &f = next_flags(); const unsigned v = f; f = 0; return v; }
 
 // the per-column update of `self` into `out_items`, reading the parameter blob `d_in`
-template <int K>
+template <int K, bool F32>
 int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *other, int iter, double alpha, double *d_in, hipStream_t st,
                  hipEvent_t ev_start, hipEvent_t ev_stop);
 // multi-GPU: every rank's fresh columns travel to the others, in place in the replicated factor matrix.
 // sub < 0: the whole range of every rank; sub >= 0: sub-range `sub` of every rank (bpmf_hip_side_set_overlap:
 // the exchange of one part of a side's columns runs on a stream of its own beside the sampling of the next part)
-template <int K>
+template <int K, bool F32>
 int exchange(bpmf_hip_side *self, hipStream_t st, int sub);
 // sum x / sum x x^T of this rank's columns (+ all-reduce), published to `out_host_dev`
-template <int K>
+template <int K, bool F32>
 int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_host_dev, unsigned *flag, unsigned seq, unsigned *ticket,
           hipEvent_t ev_done = nullptr);     // ev_done: rides on the dispatch packet of the pass's last kernel (single GPU; no marker packet behind it)
 // group A of a split statistics pass (see bpmf_hip_side::d_stat_list): partials only, behind the side's ev_stat_a
-template <int K>
+template <int K, bool F32>
 int stats_a(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_host_dev, unsigned *ticket);
-template <int K>
+template <int K, bool F32>
 void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items, const void *other_items, int n, hipStream_t ps, bool beside);
 
 // K = 64: every kernel family but k_sample1 sits in a unit of its own (k64_*.hip) -- the instantiations
@@ -54,6 +54,8 @@ void k128_slab(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpm
 // K = 128 fp32: workgroup of 2 / 4 waves per item, second form (kernels_wg2.h)
 // (r: column statistics of another side as rider workgroups at the head of the grid, or r.nblocks == 0)
 void k128_wg2(int grid, int nwaves, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a, const bpmf::StatRiders &r);
+// K = 128 fp64 (num_latent 65 .. 128 in the reference's arithmetic): the same form with fp64 factors (k128_f64.hip)
+void k128_wg2_f64(int grid, int nwaves, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a);
 
 // BPMF_REDUCE formulation (kernels_reduce.h, kreduce.hip): fp64, K = 8 .. 64
 int reduce_part_words(int K);                  // doubles per column of a side's `prec` array (0: K not supported)
@@ -68,7 +70,7 @@ void gate_stage(int nblocks, const unsigned *gate_host_dev, unsigned want, const
 void lf32_tiles(const double *LambdaF_dev, float *out, int K, hipStream_t st);    // fp32 path: LambdaF in tile layout behind the blob
 void publish(const double *src, double *dst_host_dev, int n, unsigned *flag_host_dev, unsigned seq, int fail_at, hipStream_t st);
 void randn_probe(uint32_t counter, int n, double *out_dev, hipStream_t st);
-void aggr_add(const void *items, bool f32, int K, int64_t c0, int64_t ncols, double *mu, double *lambda, hipStream_t st);
+void aggr_add(const void *items, bool f32, int ld, int K, int64_t c0, int64_t ncols, double *mu, double *lambda, hipStream_t st);   // ld: device leading dimension, K: the caller's num_latent
 void aggr_finalize(int K, int nsamples, int64_t ncols, double *mu, double *lambda, hipStream_t st);
 
 }  // namespace bpmf_launch

@@ -17,7 +17,8 @@ namespace bpmf_launch {
 //   launch_sampler: the per-column update, reading the parameter blob `d_in`
 //   launch_exchange: multi-GPU only, in-place broadcast of every rank's fresh column range
 //   launch_stats: sum x / sum x x^T of this rank's columns (+ all-reduce), published to `out_host_dev`
-template <int K>
+// F32: the fp32 context (K = 128 only).  K = 128 with F32 = false is the reference's fp64 arithmetic at num_latent 65 .. 128.
+template <int K, bool F32>
 // ev_start / ev_stop (optional): recorded by the dispatch packet of the sampler itself
 // (hipExtLaunchKernel) instead of by marker packets before and after it -- every marker is a few
 // microseconds on the stream between two samplers.
@@ -41,12 +42,12 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
         f.LambdaF = d_in; f.Lmu = d_in + (size_t)K * K;
         f.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
         f.mu = d_in + (size_t)K * K + K + 2; f.prop_lambda = self->d_prop; f.diag_only = c->diag_only;
-        f.mean_rating = self->mean_rating; f.alpha = alpha; f.iter_plus_1 = (uint32_t)(iter + 1);
+        f.mean_rating = self->mean_rating; f.alpha = alpha; f.iter_plus_1 = (uint32_t)(iter + 1); f.ktrue = c->Kt;
         // four waves per column at K = 128; one wave owning all tiles at K = 64 (no idle waves in the
         // serial phases of the factorisation: the column-dominated shapes are what K = 64 is run on)
         const int fnw = self->item_n >= 0 ? self->item_n : self->nwork;
         if (fnw > 0) {
-            if constexpr (K == 128) {
+            if constexpr (F32) {
                 // two waves per column (18 tiles each) by default: three columns in flight per CU instead of two,
                 // and one idle wave instead of three through the serial phases (0.66 -> 0.58 ms per launch)
                 if (env_int("BPMF_HIP_WG_WAVES", 2) == 4) launch(k_sample_wg<K, T, 4>, dim3(fnw), dim3(256), f);
@@ -55,7 +56,7 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
             else if constexpr (K == 64) k64_wg(fnw, st, ev_start, ev_stop, f);
         }
     };
-    if constexpr (K == 128) {
+    if constexpr (F32) {
         if (self->mode == 2) { launch_wg(0.0f); return 0; }
     }
     if constexpr (K == 64) {
@@ -72,18 +73,21 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
     a.LambdaF = d_in; a.Lmu = d_in + (size_t)K * K;
     a.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
     a.mu = d_in + (size_t)K * K + K + 2; a.prop_lambda = self->d_prop; a.diag_only = c->diag_only;
-    a.mean_rating = self->mean_rating; a.alpha = alpha; a.iter_plus_1 = (uint32_t)(iter + 1);
+    a.mean_rating = self->mean_rating; a.alpha = alpha; a.iter_plus_1 = (uint32_t)(iter + 1); a.ktrue = c->Kt;
     a.ablate = c->ablate; a.stamps = c->d_stamps;
     a.gate_flag = self->cur_gate_flag; a.gate_want = self->cur_gate_want;
     a.tmo = self->cur_gate_flag ? tmo_word(self->a_h_out_dev, K) : nullptr; a.wait_ticks = wait_ticks();
     a.zero_row = c->d_zero;
     a.lf32 = (lf32_words(c) && !self->d_prop) ? reinterpret_cast<const float *>(d_in + c->in_words) : nullptr;
     a.q_col_slot = self->d_q_col_slot; a.q_grp_cols = self->d_q_grp_cols; a.q_count = self->d_q_count; a.q_scratch = self->d_q_scratch;
-    if constexpr (K == 128) {                                        // fp32 factors (items / other_items are float arrays)
+    if constexpr (F32) {                                             // fp32 factors (items / other_items are float arrays)
         if (nwork > 0) {
             if (self->mode == 4) k128_slab(nwork, st, ev_start, ev_stop, a);
             else k128_wg2(nwork, env_int("BPMF_HIP_WG_WAVES", 2) == 4 ? 4 : 2, st, ev_start, ev_stop, a, self->cur_riders);
         }
+        return 0;
+    } else if constexpr (K == 128) {                                 // fp64 factors, workgroup of four waves per item (kernels_wg2.h, T = double)
+        if (nwork > 0) k128_wg2_f64(nwork, env_int("BPMF_HIP_WG_WAVES_F64", 4) == 2 ? 2 : 4, st, ev_start, ev_stop, a);
         return 0;
     } else {
     if constexpr (K <= 32) {
@@ -113,7 +117,7 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
             l.nitems = self->lr_n; l.other_items = other->d_items; l.items = out_items; l.col_from = self->from;
             l.R0 = d_in + (size_t)K * K + K + 2 + K; l.S0t = l.R0 + (size_t)K * K; l.y0 = l.S0t + (size_t)K * K;
             l.Lmu = a.Lmu; l.fail = a.fail;
-            l.mean_rating = self->mean_rating; l.alpha = alpha; l.sqrt_alpha = std::sqrt(alpha); l.iter_plus_1 = (uint32_t)(iter + 1);
+            l.mean_rating = self->mean_rating; l.alpha = alpha; l.sqrt_alpha = std::sqrt(alpha); l.iter_plus_1 = (uint32_t)(iter + 1); l.ktrue = c->Kt;
             // product form for the columns with <= 6 ratings: two instantiations (<= 2, <= 6), persistent workgroups
             // of eight waves with R0^-1 in LDS; then one launch per sweep width for the rest (the events ride on
             // the first / last launch of the side)
@@ -218,7 +222,7 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
     }
 }
 
-template <int K>
+template <int K, bool F32>
 int exchange(bpmf_hip_side *self, hipStream_t st, int sub)
 {
     bpmf_hip_ctx *c = self->ctx;
@@ -230,7 +234,7 @@ int exchange(bpmf_hip_side *self, hipStream_t st, int sub)
     char *items = reinterpret_cast<char *>(self->d_items);
     Rccl *R = rccl();
     if (!self->conn_send_ptr.empty()) {
-        if constexpr (K == 128) return fail(BPMF_HIP_EINVAL, "the connectivity-aware exchange is fp64 only");
+        if constexpr (F32) return fail(BPMF_HIP_EINVAL, "the connectivity-aware exchange is fp64 only");
         else {
         // connectivity-aware form (c++/assign.cpp:204-241 conn_map + send_item, c++/sample.cpp:370): a column
         // only travels to the ranks whose ratings / test entries reference it.  Pack the columns of
@@ -293,18 +297,19 @@ int exchange(bpmf_hip_side *self, hipStream_t st, int sub)
     return 0;
 }
 
-template <int K>
+template <int K, bool F32>
 int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_host_dev, unsigned *flag, unsigned seq, unsigned *ticket,
           hipEvent_t ev_done)
 {
     using namespace bpmf;
     bpmf_hip_ctx *c = self->ctx;
     const unsigned long long *failp = (const unsigned long long *)(d_in + (size_t)K * K + K);
-    if constexpr (K == 128) {                           // fp32 factors, fp64 sums
+    if constexpr (K == 128) {                           // one wave per (slice of columns, 16 x 16 tile): fp32 or fp64 factors, fp64 sums
+        typedef typename std::conditional<F32, float, double>::type T;
         const bool dist = c->comm != nullptr && !self->bounds.empty();
         const bool own = st != c->stream && c->comm2 && self->a_d_red;
         double *red = own ? self->a_d_red : c->d_red;
-        hipLaunchKernelGGL(k_colstats_f32<K>, dim3(self->nstat_waves * (K / 16) * (K / 16 + 1) / 2), dim3(64), 0, st, reinterpret_cast<const float *>(self->d_items),
+        hipLaunchKernelGGL((k_colstats_f32<K, T>), dim3(self->nstat_waves * (K / 16) * (K / 16 + 1) / 2), dim3(64), 0, st, reinterpret_cast<const T *>(self->d_items),
                            self->from, self->to, self->nstat_waves, self->d_stat_partials);
         // single GPU: the sums go straight to the pinned blob; sharded: into a device blob, all-reduced, then published
         if (ev_done && !dist)
@@ -371,7 +376,7 @@ int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_h
     }
 }
 
-template <int K>
+template <int K, bool F32>
 int stats_a(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_host_dev, unsigned *ticket)
 {
     using namespace bpmf;
@@ -392,7 +397,7 @@ int stats_a(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out
 // k_predict on stream `ps` over explicit factor pointers.  in_order: on the main stream behind the
 // samplers.  Otherwise (`beside`): behind ev_in (everything that was on the main stream when the
 // evaluation was requested), with ev_done recorded after it for launch_sampler's hazard check.
-template <int K>
+template <int K, bool F32>
 void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items, const void *other_items, int n,
                     hipStream_t ps, bool beside)
 {
@@ -403,15 +408,15 @@ void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items
     if (beside) (void)hipStreamWaitEvent(ps, t->in_ev, 0);
     // users.predict(movies) (c++/bpmf.cpp:190): the twin's entries with the roles of the two factor matrices swapped, on
     // the same stream and AHEAD of this evaluation, so that the completion event below covers both
-    const bool fused_twin = t->twin && t->d_twin_perm && !dist && K != 128;
+    const bool fused_twin = t->twin && t->d_twin_perm && !dist && !F32;
     if (t->twin && !fused_twin && (t->twin->nnz > 0 || dist)) {      // (sharded: its all-reduce is collective, entries or not)
         t->twin->in_ev = t->in_ev;
-        predict<K>(t->twin, t->twin->side, other_items, self_items, n, ps, false);
+        predict<K, F32>(t->twin, t->twin->side, other_items, self_items, n, ps, false);
         t->twin->launched = true;
     }
     // se | se_avg of this rank's test ratings: straight to the host, or -> all-reduce -> host
     double *red = c->d_red + c->out_words + (t->owner ? 2 : 0);      // 2 spare words behind the sampler's blob (the twin: the next 2)
-    if constexpr (K == 128) {
+    if constexpr (F32) {
         hipLaunchKernelGGL(bpmf::k_predict_f32<K>, dim3((unsigned)t->nblocks), dim3(256), 0, ps,
                            (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz,
                            reinterpret_cast<const float *>(self_items), reinterpret_cast<const float *>(other_items), self->from,
@@ -444,10 +449,10 @@ void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items
 
 }  // namespace bpmf_launch
 
-#define BPMF_INSTANTIATE_K(KK)                                                                                                   \
-    template int bpmf_launch::sampler_into<KK>(bpmf_hip_side *, double *, const bpmf_hip_side *, int, double, double *, hipStream_t, \
+#define BPMF_INSTANTIATE_K(KK, FF)                                                                                               \
+    template int bpmf_launch::sampler_into<KK, FF>(bpmf_hip_side *, double *, const bpmf_hip_side *, int, double, double *, hipStream_t, \
                                                hipEvent_t, hipEvent_t);                                                          \
-    template int bpmf_launch::exchange<KK>(bpmf_hip_side *, hipStream_t, int);                                                        \
-    template int bpmf_launch::stats<KK>(bpmf_hip_side *, hipStream_t, const double *, double *, unsigned *, unsigned, unsigned *, hipEvent_t); \
-    template int bpmf_launch::stats_a<KK>(bpmf_hip_side *, hipStream_t, const double *, double *, unsigned *);                       \
-    template void bpmf_launch::predict<KK>(bpmf_hip_test *, const bpmf_hip_side *, const void *, const void *, int, hipStream_t, bool);
+    template int bpmf_launch::exchange<KK, FF>(bpmf_hip_side *, hipStream_t, int);                                                        \
+    template int bpmf_launch::stats<KK, FF>(bpmf_hip_side *, hipStream_t, const double *, double *, unsigned *, unsigned, unsigned *, hipEvent_t); \
+    template int bpmf_launch::stats_a<KK, FF>(bpmf_hip_side *, hipStream_t, const double *, double *, unsigned *);                       \
+    template void bpmf_launch::predict<KK, FF>(bpmf_hip_test *, const bpmf_hip_side *, const void *, const void *, int, hipStream_t, bool);

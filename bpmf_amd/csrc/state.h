@@ -124,7 +124,11 @@ struct NcclGroup {
 
 struct bpmf_hip_ctx {
     int device = 0;
-    int K = 0;
+    // K: the num_latent the kernels are instantiated for -- the leading dimension of EVERY device array and blob (factors,
+    // LambdaF, sums).  Kt <= K: the caller's num_latent (c++/bpmf.h:22-24 BPMF_NUMLATENT), the size of everything that crosses
+    // the C ABI.  Kt < K: the extra dimensions carry zero factor rows and an identity block of the prior precision, draw no
+    // normals and stay exactly zero; RNG stream ids use Kt (c++/sample.cpp:266).
+    int K = 0, Kt = 0;
     int dtype = BPMF_HIP_F64;            // arithmetic of the column loop and storage of the factors (BPMF_HIP_F32: K = 128)
     hipStream_t stream = nullptr;        // S0: samplers, exchange, predict
     hipEvent_t last_sampler_done = nullptr;   // stop event of the newest thing on S0 when that is a stateful sampler (+ exchange), else NULL
@@ -217,6 +221,8 @@ struct bpmf_hip_side {
     // bounded staleness (bpmf_hip_side_set_staleness): part p of this side travels only in the half-iterations with
     // (p + iter) % (stale_k + 1) == 0 (and in iteration 0); in between the peers sample from the copy they have
     int stale_k = 0;
+    bool stale_explicit = false;         // k came through bpmf_hip_side_set_staleness (the environment then does not override it)
+    bool stale_primed = false;           // every part has travelled once since k was set (the first half-iteration always exchanges everything)
     std::vector<int64_t> sub_bounds;     // nranks x (nsub + 1): global column bounds of the parts of every rank
     std::vector<int> sub_item_off;       // nsub + 1: the work items of part c are [off[c], off[c+1]) of the item arrays
     int item_off = 0, item_n = -1;       // item window of the launch being enqueued (-1: the whole list)
@@ -342,14 +348,14 @@ inline size_t part_words()
     return w;
 }
 
-inline size_t part_words_rt(int K)
+inline size_t part_words_rt(int K, bool f32)
 {
     switch (K) {
     case 8: return part_words<8>();
     case 16: return part_words<16>();
     case 32: return part_words<32>();
     case 64: return part_words<64>();
-    case 128: return (size_t)(36 * 256 + 8 * 16) / 2;       // fp32 tiles + rhs of the slab form (GeoS<128>::PART)
+    case 128: return (size_t)(36 * 256 + 8 * 16) / (f32 ? 2 : 1);       // 36 tiles + rhs in the element type of the factors (GeoW2<128>::PART_FLOATS, GeoS<128>::PART)
     }
     return 0;
 }
@@ -363,6 +369,10 @@ inline size_t lf32_words(const bpmf_hip_ctx *c) { return c->dtype == BPMF_HIP_F3
 inline bool second_copy_usable(const bpmf_hip_side *s)
 {
     if (!s->d_items_alt || !s->own_items || s->items_exposed || s->nwork <= 0) return false;
+    // bounded staleness: a part that does not travel must keep the value the peer LAST RECEIVED, and that sits in the
+    // current copy only -- with two copies a skipped part would fall back to what the other copy held two
+    // half-iterations earlier: the samplers of such a side write in place
+    if (s->stale_k > 0) return false;
     const bool dist = s->ctx->comm != nullptr && !s->bounds.empty();
     return dist || (s->from == 0 && s->to == s->ncols);
 }

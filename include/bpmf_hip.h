@@ -58,7 +58,12 @@ typedef struct bpmf_hip_test bpmf_hip_test;   /* test matrix T with Pavg / Pm2  
 /* message of the last failing call on this thread */
 BPMF_API const char *bpmf_hip_last_error(void);
 BPMF_API int bpmf_hip_abi_version(void);
-/* 1 if K (BPMF_NUMLATENT, c++/bpmf.h:22-24,53) has an instantiated kernel: 8,16,32,64 */
+/* 1 if a context of num_latent K (BPMF_NUMLATENT, c++/bpmf.h:22-24,53: the reference ships bpmf-8 ... bpmf-128 incl. 10, 20 ... 100,
+ * ci/multilatent.sh:5) can be created in fp64: 1 <= K <= 128.  The kernels are instantiated for 8, 16, 32, 64, 128; any other K
+ * runs on the next instantiated size (bpmf_hip_kernel_k) with zero factor rows and an identity block of the prior precision in
+ * the extra dimensions, which draw no normals and stay exactly zero: the per-column RNG stream id (idx+1)*K*(iter+1) and the
+ * number of normals per column are taken from the caller's K (c++/sample.cpp:266,322), the hyper-parameter draw runs at K, and
+ * everything that crosses this interface (items, sums, cov, priors, outputs) has the caller's K x ... sizes. */
 BPMF_API int bpmf_hip_supports_k(int K);
 /* arithmetic of the column loop / storage type of the factors on the device.  The reference is
  * fp64 throughout (c++/bpmf.h:55-58); BPMF_HIP_F32 is the large-K mixed-precision path (K = 128:
@@ -66,7 +71,9 @@ BPMF_API int bpmf_hip_supports_k(int K);
  * normal draws).  The host-side interface (items, sums) stays double in both cases. */
 #define BPMF_HIP_F64 0
 #define BPMF_HIP_F32 1
-BPMF_API int bpmf_hip_supports(int K, int dtype);
+BPMF_API int bpmf_hip_supports(int K, int dtype);    /* fp64: 1 .. 128; fp32: 65 .. 128 (opt-in, never chosen silently) */
+/* the instantiated size a context of (K, dtype) runs on (8, 16, 32, 64 or 128; 0: unsupported) */
+BPMF_API int bpmf_hip_kernel_k(int K, int dtype);
 
 /* ---- context --------------------------------------------------------------
  * Replaces Sys::Init / Sys::Finalize (c++/nocomm.h:19-27).  `stream` is a
@@ -77,6 +84,12 @@ BPMF_API int bpmf_hip_ctx_create_ex(int device, int K, int dtype, void *stream, 
 /* run-time form of the reference's BPMF_NO_COVARIANCE build (c++/sample.cpp:300-304): only the
  * diagonal of Lambda* = LambdaF + alpha G enters the factorisation of every column */
 BPMF_API int bpmf_hip_ctx_set_no_covariance(bpmf_hip_ctx *ctx, int on);
+/* what the context was created with, and the leading dimension of its DEVICE arrays (= bpmf_hip_kernel_k): a factor matrix
+ * handed out / bound as a raw device pointer (bpmf_hip_side_items_dev, _bind_items) is ld x N column-major with rows
+ * num_latent .. ld-1 zero.  ld == num_latent for 8, 16, 32, 64, 128: byte-compatible with the reference's items(). */
+BPMF_API int bpmf_hip_ctx_num_latent(const bpmf_hip_ctx *ctx);
+BPMF_API int bpmf_hip_ctx_dtype(const bpmf_hip_ctx *ctx);
+BPMF_API int bpmf_hip_ctx_ld(const bpmf_hip_ctx *ctx);
 BPMF_API int bpmf_hip_ctx_destroy(bpmf_hip_ctx *ctx);
 BPMF_API int bpmf_hip_ctx_sync(bpmf_hip_ctx *ctx);
 BPMF_API void *bpmf_hip_ctx_stream(bpmf_hip_ctx *ctx);

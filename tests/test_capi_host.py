@@ -34,7 +34,12 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_k_support():
     lib = bpmf_amd.load_library()
     assert lib.bpmf_hip_abi_version() == 1
-    assert [k for k in (4, 8, 16, 32, 64, 100, 128) if lib.bpmf_hip_supports_k(k)] == [8, 16, 32, 64]
+    # every num_latent the reference ships a binary for (ci/multilatent.sh:5: 8 16 32 64 128 10 20 ... 100) runs in fp64,
+    # on the next instantiated size; fp32 is an explicit opt-in for the large sizes only
+    assert [k for k in (0, 1, 4, 8, 10, 16, 32, 50, 64, 100, 128, 129, 256) if lib.bpmf_hip_supports_k(k)] == [1, 4, 8, 10, 16, 32, 50, 64, 100, 128]
+    assert [lib.bpmf_hip_kernel_k(k, 0) for k in (1, 8, 9, 10, 16, 20, 32, 40, 50, 64, 70, 100, 128, 129)] == [8, 8, 16, 16, 16, 32, 32, 64, 64, 64, 128, 128, 128, 0]
+    assert [lib.bpmf_hip_kernel_k(k, 1) for k in (32, 64, 65, 100, 128)] == [0, 0, 128, 128, 128]
+    assert lib.bpmf_hip_supports(128, 0) == 1 and lib.bpmf_hip_supports(128, 1) == 1 and lib.bpmf_hip_supports(32, 1) == 0
 
 
 def test_no_silent_cpu_fallback():

@@ -34,8 +34,9 @@ def test_no_arguments_prints_usage_and_fails(tmp_path):
 def test_missing_file_and_bad_k(tmp_path):
     r = run(["-n", "nope.mtx", "-p", os.path.join(G, "tiny-test.mtx")], tmp_path)
     assert r.returncode != 0 and "File 'nope.mtx' not found" in r.stderr
-    r = run(["-n", os.path.join(G, "tiny-train.mtx"), "-p", os.path.join(G, "tiny-test.mtx"), "-d", "12"], tmp_path)
-    assert r.returncode != 0 and "unsupported number of latent dimensions" in r.stderr
+    for bad in (["-d", "0"], ["-d", "129"], ["-d", "32", "--fp32"]):          # (every 1 .. 128 runs, in fp64; fp32 is for K > 64 and opt-in)
+        r = run(["-n", os.path.join(G, "tiny-train.mtx"), "-p", os.path.join(G, "tiny-test.mtx")] + bad, tmp_path)
+        assert r.returncode != 0 and "unsupported number of latent dimensions" in r.stderr, bad
 
 
 @pytest.mark.gpu
@@ -125,13 +126,47 @@ def test_propagated_posterior_workflow(hip_engine_factory, tmp_path):
 
 
 @pytest.mark.gpu
-def test_k128_selects_the_fp32_path(tmp_path):
-    """-d 128: the fp32 large-K path of the library behind the same command line."""
-    r = run(["-i", "4", "-b", "1", "-d", "128", "-n", os.path.join(G, "ml100k-train.mtx.gz"), "-p", os.path.join(G, "ml100k-test.mtx.gz")], tmp_path)
+def test_d128_is_fp64_and_fp32_is_an_explicit_opt_in(oracle, tmp_path):
+    """-d 128 means what it means in the reference (`bpmf-128` of ci/multilatent.sh:5: fp64, c++/bpmf.h:55-58): the chain of
+    the oracle to the printed digits.  --fp32 / BPMF_HIP_F32=1 select the mixed-precision path and say so on stdout."""
+    args = ["-i", "4", "-b", "1", "-d", "128", "-n", os.path.join(G, "ml100k-train.mtx.gz"), "-p", os.path.join(G, "ml100k-test.mtx.gz")]
+    r = run(args, tmp_path)
     assert r.returncode == 0, r.stderr
-    assert "num_latent: 128" in r.stdout
-    final = float(re.search(r"Final Avg RMSE: (\S+)", r.stdout).group(1))
-    assert 0.9 < final < 1.3
+    assert "num_latent: 128" in r.stdout and "fp32" not in r.stdout
+    M, Mt, T, Tt, nu, nm = util.ml100k()
+    ref = oracle.gibbs(128, M, Mt, T, Tt, nsims=4, burnin=1, nthreads=8)
+    pick = lambda text: [float(m.group(1)) for m in re.finditer(r"\t RMSE: (\S+)", text)]
+    assert np.allclose(pick(r.stdout), ref["rmse"], atol=1e-4)                # (4 printed decimals)
+    assert abs(float(re.search(r"Final Avg RMSE: (\S+)", r.stdout).group(1)) - ref["final_rmse_avg"]) < 1e-5
+    for extra, env in ((["--fp32"], {}), ([], {"BPMF_HIP_F32": "1"})):
+        r32 = subprocess.run([BPMF] + args + extra, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r32.returncode == 0, r32.stderr
+        assert "arithmetic: fp32" in r32.stdout
+        assert np.allclose(pick(r32.stdout), ref["rmse"], atol=2e-3)          # the fp32 study's tolerance (tests/test_gpu_f32.py)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [10, 100])
+def test_d_any_num_latent_of_the_reference_builds(oracle, tmp_path, K):
+    """ci/multilatent.sh:5 ships bpmf-10 ... bpmf-100; BASELINE.md's "industrial" run is K = 100.  `bpmf -d K` runs them on
+    the next instantiated kernel size, with the RNG streams and the sizes of every output taken from the true K: RMSE lines and
+    the -o / -v files against the oracle at that K."""
+    (tmp_path / "o").mkdir()
+    r = run(["-i", "5", "-b", "2", "-d", str(K), "-v", "-o", "o/", "-n", os.path.join(G, "ml100k-train.mtx.gz"), "-p", os.path.join(G, "ml100k-test.mtx.gz")], tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert ("num_latent: %d" % K) in r.stdout and "padded dimensions" in r.stdout
+    M, Mt, T, Tt, nu, nm = util.ml100k()
+    ref = oracle.gibbs(K, M, Mt, T, Tt, nsims=5, burnin=2, nthreads=8)
+    pick = lambda text: [float(m.group(1)) for m in re.finditer(r"\t RMSE: (\S+)", text)]
+    assert np.allclose(pick(r.stdout), ref["rmse"], atol=1e-4)
+    assert abs(float(re.search(r"Final Avg RMSE: (\S+)", r.stdout).group(1)) - ref["final_rmse_avg"]) < 1e-5
+    U = bio.read_dense(tmp_path / "o" / "U-4.ddm"); V = bio.read_dense(tmp_path / "o" / "V-4.ddm")
+    assert U.shape == (K, nu) and V.shape == (K, nm)
+    assert np.allclose(U.T, ref["U"], rtol=1e-7, atol=1e-9) and np.allclose(V.T, ref["V"], rtol=1e-7, atol=1e-9)
+    samples = np.stack([bio.read_dense(tmp_path / "o" / ("U-%d.ddm" % i)) for i in range(2, 5)])
+    assert np.allclose(bio.read_dense(tmp_path / "o" / "U-mu.ddm"), samples.mean(0), rtol=1e-10, atol=1e-12)
+    assert bio.read_dense(tmp_path / "o" / "U-Lambda.ddm").shape == (K * K, nu)
+    assert np.allclose(bio.read_sparse(tmp_path / "o" / "Pavg.sdm")[2][2], ref["Pavg"], rtol=1e-8)
 
 
 @pytest.mark.gpu

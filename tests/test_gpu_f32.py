@@ -21,11 +21,14 @@ K = 128
 def test_f32_context_and_bad_combinations(hip_engine_factory):
     import bpmf_amd
     lib = bpmf_amd._lib.load_library()
-    assert lib.bpmf_hip_supports(128, 1) == 1 and lib.bpmf_hip_supports(128, 0) == 0 and lib.bpmf_hip_supports(32, 1) == 0
+    assert lib.bpmf_hip_supports(128, 1) == 1 and lib.bpmf_hip_supports(128, 0) == 1 and lib.bpmf_hip_supports(32, 1) == 0
     with pytest.raises(RuntimeError):
         bpmf_amd.HipEngine(32, dtype="f32")
-    with pytest.raises(RuntimeError):
-        bpmf_amd.HipEngine(128, dtype="f64")
+    # fp32 is what the caller asks for, never what num_latent = 128 silently means: the default context is the reference's fp64
+    eng = hip_engine_factory(128)
+    assert eng.dtype == "f64" and lib.bpmf_hip_ctx_dtype(eng.ctx) == 0 and lib.bpmf_hip_ctx_num_latent(eng.ctx) == 128
+    eng32 = hip_engine_factory(128, "f32")
+    assert lib.bpmf_hip_ctx_dtype(eng32.ctx) == 1 and lib.bpmf_hip_ctx_ld(eng32.ctx) == 128
 
 
 def test_f32_half_iterations_against_fp64_oracle(oracle, hip_engine_factory):
