@@ -7,7 +7,9 @@ Gram -- is exercised on real numbers at the size the bench is quoted on
   * configs[1]  exactly bench.py's `synth.ml1m_shaped(seed=42)` (6040 x 3706, 1 000 209 ratings), K = 32 fp64
   * configs[2]  ChEMBL-shaped 483 500 x 5 775 x 1 023 952 real-valued activities, K = 64 fp64, default
                 schedule (k_sample_pf<64,2|6|12> for the light compounds, k_sample1<64> for the rest)
-  * configs[4]  ML-1M shape, K = 128, fp32 (k_sample_wg<128,float>), tolerance 2e-3 of max|U|
+  * configs[4]  ML-1M shape, K = 128, fp32 (k_sample_wg2<128,2,float>), tolerance 2e-3 of max|U|
+  * the same shape at K = 128 and K = 100 in the reference's fp64 (k_sample_wg2<128,4,double>; what `bpmf-128` / `bpmf-100` of
+                ci/multilatent.sh:5 compute), fp64 tolerance
   * configs[3]  one rank's share of 10M x 1M x 200 per user, K = 32: test_gpu_shard.py
 
 The oracle runs its OpenMP column loop on the box's host cores (an ML-1M iteration is ~0.1 s on one
@@ -91,3 +93,12 @@ def test_ml1m_k128_f32_every_column_within_2e3_of_the_fp64_oracle(oracle, hip_en
     from bpmf_amd import synth
     w = _both_sides(oracle, hip_engine_factory(128, "f32"), 128, synth.ml1m_shaped(seed=42), 2e-3, 1e-3, seed=14, f32=True)
     print("ML-1M K=128 fp32 worst column error / max|U|:", w)
+
+
+@pytest.mark.parametrize("K", [128, 100])
+def test_ml1m_k128_fp64_every_column_matches_the_oracle(oracle, hip_engine_factory, K):
+    """num_latent 128 (and 100: the K = 128 kernels with 28 padded dimensions, RNG streams of K = 100) in fp64, the
+    arithmetic the reference's bpmf-128 / bpmf-100 use (c++/bpmf.h:55-58): every column of both sides at the ML-1M size."""
+    from bpmf_amd import synth
+    w = _both_sides(oracle, hip_engine_factory(K), K, synth.ml1m_shaped(seed=42), 1e-9, 1e-8, seed=15)
+    print("ML-1M K=%d fp64 worst column error / max|U|:" % K, w)

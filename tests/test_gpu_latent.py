@@ -139,7 +139,7 @@ def test_state_and_raw_layout_of_a_padded_context(oracle, hip_engine_factory):
         movies.sample(users); users.sample(movies); movies.predict(users)
     it, nrm, cov, mu, LF, LU = eng.sys_state(users.side)
     ref = oracle.gibbs(K, M, Mt, T, Tt, nsims=3, burnin=0)
-    assert it == 2 and cov.shape == (K, K) and mu.shape == (K,) and abs(nrm - ref["norm_u"][-1]) < 1e-8 * max(1.0, ref["norm_u"][-1])
+    assert it == 2 and cov.shape == (K, K) and mu.shape == (K,) and abs(np.sqrt(nrm) - ref["norm_u"][-1]) < 1e-8 * max(1.0, ref["norm_u"][-1])
     assert np.allclose(LF, LU.T @ LU, rtol=1e-10, atol=1e-12)
     X = users.items()
     assert X.shape == (nu, K) and rel_err(X, ref["U"]) < 1e-8
