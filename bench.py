@@ -181,6 +181,148 @@ def timed_blocks(step_block, fence, steps, dist_max, min_blocks=5, max_blocks=25
             return times
 
 
+METRIC = "user+item column samples/sec per Gibbs iter; test RMSE vs reference"
+
+
+def error_line(msg, **extra):
+    """The line of a run that could not be measured: same keys, value null, the reason under "error" (never silence)."""
+    out = {"metric": METRIC, "value": None, "unit": "samples/s", "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "data": "synthetic", "error": str(msg)[:1500]}
+    out.update(extra)
+    return json.dumps(out)
+
+
+class Watchdog:
+    """Wall-clock bound on every stage of the run (first contact with N real GPUs must not be able to hang): a daemon
+    thread; when the stage in progress outlives its limit, rank 0 prints an error line and EVERY rank ends at once
+    (os._exit: a rank stuck inside a collective cannot be unwound) -- the launcher then reaps the others.  The reference
+    ends a job whose collective fails (c++/mpi_common.h:16 MPI_ERRORS_ARE_FATAL, c++/bpmf_gaspi.h:26-64 SUCCESS_OR_DIE);
+    this is the same for a collective that never returns.  BPMF_BENCH_WATCHDOG_S: default limit per stage (120 s)."""
+
+    def __init__(self, rank, extra=None):
+        import threading
+        self.rank, self.extra = rank, (extra if extra is not None else {})
+        self.default = float(os.environ.get("BPMF_BENCH_WATCHDOG_S", "120"))
+        self.name, self.deadline, self.t0 = "start-up", time.time() + self.default, time.time()
+        self.lock = threading.Lock()
+        self.done = False
+        threading.Thread(target=self._run, daemon=True).start()
+
+    def stage(self, name, limit=None):
+        with self.lock:
+            self.name, self.t0 = name, time.time()
+            self.deadline = self.t0 + (limit if limit is not None else self.default)
+
+    def stop(self):
+        self.done = True
+
+    def _run(self):
+        while not self.done:
+            time.sleep(0.25)
+            with self.lock:
+                late, name, dt = time.time() > self.deadline, self.name, time.time() - self.t0
+            if late and not self.done:
+                msg = "watchdog: stage '%s' did not finish within %.0f s on rank %d (a rank stalled or died, or a collective never returned)" % (name, dt, self.rank)
+                sys.stderr.write("bench.py: " + msg + "\n"); sys.stderr.flush()
+                if self.rank == 0:
+                    sys.stdout.write(error_line(msg, stage=name, **self.extra) + "\n"); sys.stdout.flush()
+                os._exit(3)
+
+
+# The exchange configurations a sharded run may use, most aggressive first (DESIGN.md section 6).  `env`: what the run itself is
+# given; `preflight`: what the 4-iteration trial adds so that its small matrix takes the same code path (parts are automatic
+# only above 64 MB of fresh columns per half-iteration).
+LADDER = [
+    {"name": "mesh+parts+2comms", "env": {}, "preflight": {"BPMF_HIP_OVERLAP": "4"}},
+    {"name": "mesh+1comm", "env": {"BPMF_HIP_COMM_STREAMS": "1", "BPMF_HIP_OVERLAP": "1"}, "preflight": {}},
+    {"name": "bcast+1comm", "env": {"BPMF_HIP_EXCHANGE": "bcast", "BPMF_HIP_COMM_STREAMS": "1", "BPMF_HIP_OVERLAP": "1"}, "preflight": {}},
+]
+LADDER_VARS = ("BPMF_HIP_EXCHANGE", "BPMF_HIP_COMM_STREAMS", "BPMF_HIP_OVERLAP")
+
+
+def preflight_child():
+    """One rank of a 4-iteration trial of ONE exchange configuration (the environment says which): a small sharded K = 32
+    problem through the library's own RCCL path; every replica must hold the same bits afterwards.  Prints PREFLIGHT-OK."""
+    import torch
+    import torch.distributed as dist
+    import bpmf_amd
+    from bpmf_amd import synth
+    from bpmf_amd.dist import NativeComm, build_sharded
+    from bpmf_amd.sys import Sys
+    R = Ranks()
+    hang = os.environ.get("BPMF_BENCH_TEST_HANG_RUNG", "")           # test hook "rung-name:rank": that rank's trial of that rung never ends
+    if hang and hang.split(":")[0] == os.environ.get("BPMF_BENCH_PREFLIGHT_RUNG") and int(hang.split(":")[1]) == R.rank:
+        time.sleep(3600)
+    torch.cuda.set_device(R.local_rank)
+    dist.init_process_group("gloo")
+    eng = bpmf_amd.HipEngine(32, device=R.local_rank)
+    comm = NativeComm(eng)
+    M, Mt, T, Tt, nu, nm = synth.ratings(4000 * R.world, 2000, 160000 * R.world, seed=7)
+    Sys.nsims, Sys.burnin, Sys.alpha = 4, 1, 2.0
+    movies, users = build_sharded(eng, comm, M, Mt, T, nu, nm, Tt=None, conn=False)
+    for _ in range(4):
+        movies.sample(users); users.sample(movies); movies.predict(users, True)
+    eng.sync()
+    U, V = users.items(), movies.items()
+    if not (np.isfinite(movies.rmse) and np.isfinite(U).all() and np.isfinite(V).all()):
+        raise SystemExit("preflight: non-finite results")
+    sums = [None] * R.world
+    dist.all_gather_object(sums, (float(U.sum()), float(np.abs(V).sum()), float(movies.rmse)))
+    if any(x != sums[0] for x in sums):
+        raise SystemExit("preflight: the ranks' replicas differ: %r" % (sums,))
+    eng.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    print("PREFLIGHT-OK rank %d rmse %.6f" % (R.rank, movies.rmse), flush=True)
+
+
+def preflight_ladder(R, wd):
+    """Every rank starts a child that is ITS rank of a trial job (own rendez-vous port, own communicators), waits for it with
+    a wall-clock limit (kill + reap), and the ranks agree on the outcome; the first configuration that every rank completed is
+    the one the run uses.  Returns (record for the JSON line, None) or (record, error message)."""
+    import torch.distributed as dist
+    user_set = {k: os.environ[k] for k in LADDER_VARS if k in os.environ}
+    if os.environ.get("BPMF_BENCH_PREFLIGHT", "1") == "0":
+        return {"chosen": "environment" if user_set else LADDER[0]["name"], "env": user_set, "ladder": [], "preflight": "skipped (BPMF_BENCH_PREFLIGHT=0)"}, None
+    rungs = [{"name": "environment", "env": {}, "preflight": {}}] if user_set else LADDER
+    limit = float(os.environ.get("BPMF_BENCH_PREFLIGHT_TIMEOUT_S", "75"))
+    record = []
+    for idx, rung in enumerate(rungs):
+        wd.stage("preflight of exchange configuration '%s'" % rung["name"], limit + 45)
+        box = [None]
+        if R.rank == 0:
+            import socket
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); box[0] = s.getsockname()[1]; s.close()
+        dist.broadcast_object_list(box, src=0)
+        env = dict(os.environ, MASTER_PORT=str(box[0]), BPMF_BENCH_PREFLIGHT_CHILD="1", BPMF_BENCH_PREFLIGHT_RUNG=rung["name"])
+        env.setdefault("BPMF_HIP_COMM_TIMEOUT_MS", str(int(limit * 1000 * 0.4)))      # the library gives up (with a message) before the child is killed
+        env.update(rung["env"]); env.update(rung["preflight"])
+        t0 = time.time()
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--preflight-child"], env=env, stdout=subprocess.PIPE,
+                                 stderr=subprocess.PIPE, text=True)
+        try:
+            so, se = child.communicate(timeout=limit)
+            ok, why = (child.returncode == 0 and "PREFLIGHT-OK" in so), ""
+            if not ok:
+                tail = [l for l in (se or so).strip().splitlines() if l.strip()][-3:]
+                why = "rank %d: exit code %s: %s" % (R.rank, child.returncode, " | ".join(tail)[-400:])
+        except subprocess.TimeoutExpired:
+            child.kill()
+            try:
+                so, se = child.communicate(timeout=10)
+            except subprocess.TimeoutExpired:
+                so, se = "", ""
+            ok, why = False, "rank %d: no result within %.0f s (killed)" % (R.rank, limit)
+        res = R.gather({"ok": ok, "why": why})
+        all_ok = all(r["ok"] for r in res)
+        record.append({"config": rung["name"], "ok": all_ok, "seconds": round(time.time() - t0, 2),
+                       "why": "; ".join(r["why"] for r in res if r["why"])[:800] or None})
+        if all_ok:
+            os.environ.update(rung["env"])
+            return {"chosen": rung["name"], "env": dict(rung["env"], **user_set), "ladder": record}, None
+    return {"chosen": None, "env": user_set, "ladder": record}, "no exchange configuration completed its 4-iteration preflight on every rank"
+
+
 class Ranks:
     """The launcher side of a run: who am I, how do the ranks talk (torch.distributed is only the launcher and the
     clock here: barriers, the max of the block times, gathering the per-rank records; the data path is RCCL inside the
@@ -372,6 +514,7 @@ def strong_10Mx1M(R, steps, scale=1.0, check=True):
                                   "against": "host solve + bpmf_randn_stream (no oracle)", "seconds": time.perf_counter() - t_chk}
     ranks = R.gather(mine)
     out.update({k: v for k, v in ranks[0].items() if k != "rank"})          # rank 0's figures at top level (as before)
+    out["model"] = strong_model(big.NU, big.NI, K, world, ranks, dt / steps * 1e3)
     if world > 1:
         out["per_rank"] = ranks
         errs = [r.get("spot_check", {}).get("max_err") for r in ranks]
@@ -379,6 +522,34 @@ def strong_10Mx1M(R, steps, scale=1.0, check=True):
             out["spot_check"] = dict(ranks[0]["spot_check"], max_err=max(errs), ok=bool(max(errs) < 1e-9))
     eng.close()
     return out
+
+
+def strong_model(NU, NI, K, world, ranks, ms_per_step):
+    """The predicted 1 -> 8 curve of the strong-scaling record, so that the first measured SCALE record can be read against
+    it.  Ingredients: the sampler time of the whole matrix (sum over the ranks of their two launches -- at N = 1 the measured
+    launches themselves), divided by N (columns are cut at equal work); the fresh columns every rank must receive per
+    iteration, (NU + NI) K 8 (N - 1) / N bytes, arriving over N - 1 point-to-point xGMI links at 153 GB/s each (the mesh
+    exchange puts one peer on one link: per-link bytes = (NU + NI) K 8 / N), of which only the last of 4 parts is not
+    hidden behind sampling; two all-reduces of K^2 + K + 1 doubles (~30 us each); and what one iteration spends outside
+    the samplers on one GPU (statistics, host draws, RMSE; measured at N = 1, else the 0.7 ms of the round-3 N = 1 record)."""
+    link_gbs, allreduce_ms, parts = 153.0, 0.03, 4
+    samp = [sum(r["sampler_ms"].values()) for r in ranks if r.get("sampler_ms")]
+    if len(samp) != len(ranks):
+        return {"error": "no sampler times"}
+    s_total = float(sum(samp))
+    rest = (ms_per_step - s_total) if world == 1 else float(os.environ.get("BPMF_BENCH_MODEL_REST_MS", "0.7"))
+    per_n, base = {}, None
+    for n in (1, 2, 4, 8):
+        link_bytes = (NU + NI) * K * 8.0 / n if n > 1 else 0.0
+        ex = link_bytes / (link_gbs * 1e9) * 1e3
+        ms = s_total / n + rest + (ex / parts if n > 1 else 0.0) + (2 * allreduce_ms if n > 1 else 0.0)
+        base = ms if n == 1 else base
+        per_n[str(n)] = {"sampler_ms": s_total / n, "exchange_bytes_per_link": link_bytes, "exchange_ms_if_exposed": ex,
+                         "exchange_ms_exposed_with_%d_parts" % parts: ex / parts if n > 1 else 0.0, "allreduce_ms": 2 * allreduce_ms if n > 1 else 0.0,
+                         "ms_per_step": ms, "samples_per_s": (NU + NI) / ms * 1e3, "speedup_vs_1": base / ms}
+    return {"sampler_ms_whole_matrix": s_total, "rest_ms": rest, "rest_is": "measured at N = 1" if world == 1 else "assumed (BPMF_BENCH_MODEL_REST_MS)",
+            "xgmi_link_gbs": link_gbs, "per_n": per_n, "this_run": {"n_gpus": world, "ms_per_step": ms_per_step,
+                                                                   "over_model": ms_per_step / per_n[str(world)]["ms_per_step"] if str(world) in per_n else None}}
 
 
 def self_launch(n):
@@ -395,14 +566,44 @@ def self_launch(n):
     procs = []
     for r in range(n):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
-                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r))))
-    rc = 0
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE if r == 0 else None, text=True))
+    # Reap with a wall-clock limit: a rank that dies takes the others down (they would wait for it in a collective), a job
+    # that outlives BPMF_BENCH_TOTAL_TIMEOUT_S is killed, and if rank 0 never printed its line this process prints one.
+    import threading
+    seen = {"line": False}
+
+    def relay():
+        for line in procs[0].stdout:
+            if line.startswith('{"metric"'):
+                seen["line"] = True
+            sys.stdout.write(line); sys.stdout.flush()
+    th = threading.Thread(target=relay, daemon=True); th.start()
+    limit = float(os.environ.get("BPMF_BENCH_TOTAL_TIMEOUT_S", "1500"))
+    t0, rc, why = time.time(), 0, None
+    while True:
+        codes = [pr.poll() for pr in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            rc, why = bad[0][1], "rank %d exited with code %d" % bad[0]
+            time.sleep(2.0)                                             # (its peers' watchdogs / error paths get to print first)
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() - t0 > limit:
+            rc, why = 124, "the job did not finish within %.0f s" % limit
+            break
+        time.sleep(0.2)
     for pr in procs:
-        rc = pr.wait() or rc
-    if rc:
-        for pr in procs:
-            if pr.poll() is None:
-                pr.kill()
+        if pr.poll() is None:
+            pr.kill()
+    for pr in procs:
+        try:
+            pr.wait(timeout=15)
+        except subprocess.TimeoutExpired:
+            pass
+    th.join(timeout=5)
+    if rc and not seen["line"]:
+        print(error_line("bench.py --gpus %d: %s" % (n, why), launcher="self"), flush=True)
     raise SystemExit(rc)
 
 
@@ -420,8 +621,12 @@ def main():
     ap.add_argument("--strong-steps", type=int, default=8, help="timed steps of the strong_10Mx1M record (>= 8: the library times every 8th launch of a side)")
     ap.add_argument("--strong-scale", type=float, default=float(os.environ.get("BPMF_BENCH_STRONG_SCALE", "1.0")))
     ap.add_argument("--no-users-predict", action="store_true", help="A/B: leave users.predict(movies) (c++/bpmf.cpp:190) out of the step; the line says so")
+    ap.add_argument("--preflight-child", action="store_true", help="internal: one rank of a 4-iteration trial of an exchange configuration")
     ap.add_argument("--ablate", type=int, default=None, help="profiling only: run with BPMF_HIP_ABLATE=<bits> (phases of the sampler skipped, samples WRONG); the line is marked invalid")
     args = ap.parse_args()
+    if args.preflight_child:
+        preflight_child()
+        return
     wl = args.workload or {None: "ml1m", 32: "ml1m", 64: "ml1m_k64", 128: "ml1m_k128"}.get(args.K)
     if wl is None:
         raise SystemExit("bench.py: --K must be 32, 64 or 128 (or use --workload)")
@@ -438,6 +643,22 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args.gpus)                                         # (does not return)
     R = Ranks()
+    wd = Watchdog(R.rank, {"steps": args.steps, "warmup": args.warmup})
+    try:
+        run(args, wl, R, wd)
+    except SystemExit:
+        raise
+    except BaseException as e:                                        # a rank that fails says so in the line's own format
+        import traceback
+        traceback.print_exc()
+        if R.rank == 0:
+            print(error_line("rank 0: %r" % (e,), stage=wd.name, steps=args.steps, warmup=args.warmup), flush=True)
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(4)                                                   # (not sys.exit: worker threads / a wedged collective must not hold the exit)
+    wd.stop()
+
+
+def run(args, wl, R, wd):
     if R.world != args.gpus and not R.force_dist:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): the two must agree" % (args.gpus, R.world))
     K, dtype, lds_wg, wg_per_cu = WORKLOADS[wl]
@@ -453,9 +674,20 @@ def main():
         raise SystemExit("bench.py needs a HIP device (bpmf_amd has no CPU fallback)")
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: rank %d wants device %d, %d visible" % (rank, local_rank, torch.cuda.device_count()))
+    wd.stage("process group")
     R.init()
     comm = None
     force_dist = R.force_dist
+    exchange_config = None
+    if world > 1:
+        exchange_config, err = preflight_ladder(R, wd)
+        if err:
+            if rank == 0:
+                print(error_line(err, exchange_config=exchange_config, steps=args.steps, warmup=args.warmup), flush=True)
+            R.finish()
+            raise SystemExit(2)
+        wd.extra["exchange_config"] = exchange_config
+    wd.stage("matrices + engine + communicator")
 
     mult = world if (world > 1 or force_dist) else 1
     if wl == "chembl":
@@ -526,6 +758,7 @@ def main():
         if both_predicts:
             users.predict_finish()
 
+    wd.stage("warm-up")
     # warm-up: W steps, then by TIME -- a 20-step timed region straight after start-up otherwise sits
     # on the clock ramp (round 1: 0.122 ms per step measured by the driver against 0.102 steady state)
     t_warm = time.perf_counter()
@@ -538,6 +771,7 @@ def main():
         fence()
     prewarm_ms = (time.perf_counter() - t_warm) * 1e3
     base = {sd.name: eng.kernel_ms_sum(sd.side) for sd in (movies, users)}
+    wd.stage("timed blocks", wd.default + 30)
     if args.repeats > 0:
         times = timed_blocks(step_block, fence, args.steps, dist_max, min_blocks=args.repeats, max_blocks=args.repeats)
     else:
@@ -609,7 +843,7 @@ def main():
                            "bank_conflict_rate": p_conflict if pmc_current else None}
     bpmf_env = {k: v for k, v in sorted(os.environ.items()) if k.startswith("BPMF_") and k != "BPMF_BENCH_SELF_LAUNCHED"}
     out = {
-        "metric": "user+item column samples/sec per Gibbs iter; test RMSE vs reference",
+        "metric": METRIC,
         "value": (nusers + nmovies) * args.steps / dt,
         "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -626,6 +860,7 @@ def main():
                    "both_predicts": bool(both_predicts),
                    "name": wl, "nnz_train": nnz, "nnz_test": int(T[0][-1]), "K": K,
                    "parallelism": "columns of U and V sharded over %d GPU(s)" % world},
+        "exchange_config": exchange_config,
         "rccl_nranks": rccl_nranks, "launcher": "self" if os.environ.get("BPMF_BENCH_SELF_LAUNCHED") else ("external" if "WORLD_SIZE" in os.environ else "none"),
         "repeats": len(times), "prewarm_ms": prewarm_ms, "prewarm_extra_steps": extra,
         "ms_per_step_median": dt / args.steps * 1e3, "ms_per_step_min": min(times) / args.steps * 1e3,
@@ -656,11 +891,19 @@ def main():
     del movies, users
 
     if not args.no_strong and wl == "ml1m":
+        wd.stage("strong_10Mx1M record", wd.default + 120)
         try:
             out["strong_10Mx1M"] = strong_10Mx1M(R, args.strong_steps, args.strong_scale)
-        except Exception as e:               # the headline must still be reported
-            out["strong_10Mx1M"] = {"error": repr(e)[:400]}
+        except Exception as e:               # the headline must still be reported -- with the failure in it, not instead of it
+            out["strong_10Mx1M"] = {"error": repr(e)[:400], "n_gpus": world}
+            if world > 1:                    # (the other ranks may be inside a collective of the record: no further collective here)
+                if rank == 0:
+                    out["wall_s"] = time.perf_counter() - t_process
+                    print(json.dumps(out), flush=True)
+                sys.stdout.flush()
+                os._exit(5 if rank == 0 else 0)
     if rank == 0:
+        wd.stage("cpu baseline", 700)
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies)

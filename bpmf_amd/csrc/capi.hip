@@ -34,7 +34,7 @@ Rccl *rccl()
 #define BPMF_SYM(f) r.f = reinterpret_cast<decltype(r.f)>(dlsym(r.handle, "nccl" #f))
             BPMF_SYM(GetUniqueId); BPMF_SYM(CommInitRank); BPMF_SYM(CommDestroy); BPMF_SYM(AllReduce);
             BPMF_SYM(Broadcast); BPMF_SYM(GroupStart); BPMF_SYM(GroupEnd); BPMF_SYM(GetErrorString); BPMF_SYM(CommSplit);
-            BPMF_SYM(Send); BPMF_SYM(Recv); BPMF_SYM(AllGather); BPMF_SYM(Reduce); BPMF_SYM(CommCount);
+            BPMF_SYM(Send); BPMF_SYM(Recv); BPMF_SYM(AllGather); BPMF_SYM(Reduce); BPMF_SYM(CommCount); BPMF_SYM(CommAbort);
 #undef BPMF_SYM
             if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.Broadcast || !r.GroupStart || !r.GroupEnd)
                 r.handle = nullptr;
@@ -77,6 +77,61 @@ struct TraceAtExit { ~TraceAtExit() { if (g_trace_on) trace_dump(); } } g_trace_
 
 namespace {
 
+// ---- bounded host-side waits (multi-GPU) --------------------------------------------------------
+double comm_timeout_s()
+{
+    static const double v = std::max(1, env_int("BPMF_HIP_COMM_TIMEOUT_MS", 60000)) * 1e-3;
+    return v;
+}
+
+// the peers never completed a collective: abort both communicators (their kernels leave the streams), mark the context
+int comm_abort(bpmf_hip_ctx *c, const std::string &what)
+{
+    std::lock_guard<std::mutex> lk(c->abort_mutex);
+    if (!c->comm_dead.exchange(true)) {
+        Rccl *R = rccl();
+        fprintf(stderr, "[bpmf_hip] rank %d of %d: %s did not complete within %.1f s: a peer rank stalled or died; aborting the communicator(s)\n",
+                c->rank, c->nranks, what.c_str(), comm_timeout_s());
+        if (R && R->CommAbort) {
+            if (c->comm2) (void)R->CommAbort(c->comm2);
+            if (c->comm) (void)R->CommAbort(c->comm);
+            c->comm2 = nullptr;                                       // (aborted = destroyed; `comm` stays non-NULL as "this context is sharded")
+        }
+    }
+    return fail(BPMF_HIP_ENODEV, "collective timed out (" + what + "): a peer rank stalled or died; the communicator was aborted");
+}
+
+// hipStreamSynchronize for a stream that may carry a collective: a poll with a deadline instead of a wait without one
+int bounded_stream_sync(bpmf_hip_ctx *c, hipStream_t st, const char *what)
+{
+    if (!c->comm) { HIP_TRY(hipStreamSynchronize(st)); return 0; }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) return fail(BPMF_HIP_ENODEV, std::string(what) + ": " + hipGetErrorString(q));
+        (void)hipGetLastError();
+        if (spins < 2000) { __builtin_ia32_pause(); continue; }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > comm_timeout_s()) return comm_abort(c, what);
+        std::this_thread::sleep_for(std::chrono::microseconds(spins < 20000 ? 20 : 200));
+    }
+}
+
+int bounded_event_sync(bpmf_hip_ctx *c, hipEvent_t ev, const char *what)
+{
+    if (!c->comm) { HIP_TRY(hipEventSynchronize(ev)); return 0; }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) return fail(BPMF_HIP_ENODEV, std::string(what) + ": " + hipGetErrorString(q));
+        (void)hipGetLastError();
+        if (spins < 2000) { __builtin_ia32_pause(); continue; }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > comm_timeout_s()) return comm_abort(c, what);
+        std::this_thread::sleep_for(std::chrono::microseconds(spins < 20000 ? 20 : 200));
+    }
+}
+
 // The kernels write their few result words straight into pinned host memory; the last block
 // of the last kernel then publishes a sequence number and the host thread spins on it.  This replaces
 // hipMemcpyAsync(D2H) + hipStreamSynchronize (a copy-engine hop and a sleeping wait per
@@ -94,7 +149,7 @@ int wait_host(bpmf_hip_ctx *c)
             if (s > spin_limit_s()) break;       // long kernel (big matrix) or an error: fall back to a blocking wait
         }
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    { const int rc = bounded_stream_sync(c, c->stream, "sampler + exchange + all-reduce of a half-iteration"); if (rc) return rc; }
     if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != c->seq) return fail(BPMF_HIP_ENODEV, "device did not publish its results");
     return 0;
 }
@@ -440,7 +495,7 @@ extern "C" int bpmf_hip_ctx_destroy(bpmf_hip_ctx *c)
     if (!c) return BPMF_HIP_OK;
     if (g_trace_on) trace_dump();
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)bounded_stream_sync(c, c->stream, __func__);
     if (c->d_stamps) {                                              // the last launch's stamps of the two probe items
         unsigned long long h[512];
         if (hipMemcpy(h, c->d_stamps, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
@@ -459,8 +514,10 @@ extern "C" int bpmf_hip_ctx_destroy(bpmf_hip_ctx *c)
     if (c->d_ticket) (void)hipFree(c->d_ticket);
     if (c->d_zero) (void)hipFree(c->d_zero);
     if (c->d_red) (void)hipFree(c->d_red);
-    if (c->comm2 && rccl()) (void)rccl()->CommDestroy(c->comm2);
-    if (c->comm && rccl()) (void)rccl()->CommDestroy(c->comm);
+    if (!c->comm_dead.load()) {                                      // (aborted communicators are gone already)
+        if (c->comm2 && rccl()) (void)rccl()->CommDestroy(c->comm2);
+        if (c->comm && rccl()) (void)rccl()->CommDestroy(c->comm);
+    }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return BPMF_HIP_OK;
@@ -478,15 +535,15 @@ extern "C" int bpmf_hip_ctx_sync(bpmf_hip_ctx *c)
     for (bpmf_hip_side *s : sides) flush_deferred(s->deferred_eval);
     // (a query first: after the collections above the streams are usually idle already, and a blocking
     // synchronize of an idle stream still costs ~10 us each -- 30 us per fence of a 2 ms block of bench.py)
-    auto sync_stream = [](hipStream_t st) -> hipError_t {
+    auto sync_stream = [c](hipStream_t st) -> int {
         const hipError_t q = hipStreamQuery(st);
-        if (q == hipSuccess) return hipSuccess;
-        if (q != hipErrorNotReady) return q;
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) return fail(BPMF_HIP_ENODEV, std::string("ctx_sync: ") + hipGetErrorString(q));
         (void)hipGetLastError();                                      // ("not ready" is no error: do not leave it for a later hipGetLastError())
-        return hipStreamSynchronize(st);
+        return bounded_stream_sync(c, st, "ctx_sync");
     };
-    HIP_TRY(sync_stream(c->stream));
-    for (bpmf_hip_side *s : sides) HIP_TRY(sync_stream(s->saux));
+    { const int r = sync_stream(c->stream); if (r) return r; }
+    for (bpmf_hip_side *s : sides) { const int r = sync_stream(s->saux); if (r) return r; }
     trace("ctx_sync: done", nullptr, 0);
     return rc;
 }
@@ -573,14 +630,14 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
             if (sd->deferred_eval && sd->deferred_eval->side == s) { sd->deferred_eval->deferred = false; sd->deferred_eval->cancelled = true; sd->deferred_eval = nullptr; }
     }
     flush_deferred(s->deferred_eval);                               // (it would go to this side's stream)
-    (void)hipStreamSynchronize(s->ctx->stream);
+    (void)bounded_stream_sync(s->ctx, s->ctx->stream, __func__);
     if (s->saux) {
-        (void)hipStreamSynchronize(s->saux); (void)hipStreamDestroy(s->saux);
+        (void)bounded_stream_sync(s->ctx, s->saux, __func__); (void)hipStreamDestroy(s->saux);
         std::lock_guard<std::mutex> lk(s->ctx->launch_mutex);
         auto &v = s->ctx->sides;
         v.erase(std::remove(v.begin(), v.end(), s), v.end());
     }
-    if (s->sx) { (void)hipStreamSynchronize(s->sx); (void)hipStreamDestroy(s->sx); }
+    if (s->sx) { (void)bounded_stream_sync(s->ctx, s->sx, __func__); (void)hipStreamDestroy(s->sx); }
     for (hipEvent_t e : s->sub_ev) if (e) (void)hipEventDestroy(e);
     if (s->sx_done) (void)hipEventDestroy(s->sx_done);
     if (s->ev_stat_a) (void)hipEventDestroy(s->ev_stat_a);
@@ -633,7 +690,7 @@ extern "C" int bpmf_hip_side_set_prop_posterior(bpmf_hip_side *s, const double *
     (void)mu;
     HIP_TRY(hipSetDevice(s->ctx->device));
     { const int rc = settle_async(s); if (rc) return rc; }
-    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    { const int rs_ = bounded_stream_sync(s->ctx, s->ctx->stream, __func__); if (rs_) return rs_; }
     if (s->d_prop) { (void)hipFree(s->d_prop); s->d_prop = nullptr; }
     if (!Lambda) return BPMF_HIP_OK;
     const int K = s->ctx->K, Kt = s->ctx->Kt;
@@ -695,8 +752,8 @@ extern "C" int bpmf_hip_side_bind_items(bpmf_hip_side *s, double *items_dev)
     if (s->ctx->dtype != BPMF_HIP_F64) return fail(BPMF_HIP_EINVAL, "bind_items: fp64 contexts only");
     HIP_TRY(hipSetDevice(s->ctx->device));
     (void)settle_async(s);
-    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
-    if (s->saux) HIP_TRY(hipStreamSynchronize(s->saux));
+    { const int rs_ = bounded_stream_sync(s->ctx, s->ctx->stream, __func__); if (rs_) return rs_; }
+    if (s->saux) { const int rs_ = bounded_stream_sync(s->ctx, s->saux, __func__); if (rs_) return rs_; }
     { const int rc = drop_second_copy(s); if (rc) return rc; }
     if (s->own_items && s->d_items) (void)hipFree(s->d_items);
     s->d_items = items_dev; s->own_items = false;
@@ -707,7 +764,7 @@ extern "C" int bpmf_hip_side_get_items(bpmf_hip_side *s, double *h)
 {
     if (!s || !h) return fail(BPMF_HIP_EINVAL, "get_items: NULL");
     HIP_TRY(hipSetDevice(s->ctx->device));
-    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    { const int rs_ = bounded_stream_sync(s->ctx, s->ctx->stream, __func__); if (rs_) return rs_; }
     const size_t K = (size_t)s->ctx->K, Kt = (size_t)s->ctx->Kt, n = (size_t)s->ncols;     // (device leading dimension K, the caller's rows Kt)
     const size_t words = K * n;
     if (s->ctx->dtype == BPMF_HIP_F32) {                            // fp32 factors: widen on the host
@@ -848,6 +905,16 @@ int sample_and_exchange(bpmf_hip_side *self, const bpmf_hip_side *other, int ite
 {
     bpmf_hip_ctx *c = self->ctx;
     const bool dist = c->comm != nullptr && !self->bounds.empty();
+    if (dist) {
+        // test hook: BPMF_HIP_TEST_STALL_RANK="rank:milliseconds[:iteration]" -- that rank goes to sleep before it enqueues this
+        // half-iteration (a rank that is descheduled, swapped out or stuck in I/O): its peers' collectives find nobody
+        static const char *stall = getenv("BPMF_HIP_TEST_STALL_RANK");
+        if (stall && *stall) {
+            int r = -1, ms = 0, at = 1;
+            if (sscanf(stall, "%d:%d:%d", &r, &ms, &at) >= 2 && r == c->rank && iter == at && ms > 0)
+                std::this_thread::sleep_for(std::chrono::milliseconds(ms));
+        }
+    }
     const bool parts = dist && self->nsub > 1 && self->sx && self->conn_send_ptr.empty() && (int)self->sub_item_off.size() == self->nsub + 1;
     if (self->reduce_on) {
         if constexpr (K == 128) return fail(BPMF_HIP_EINVAL, "the BPMF_REDUCE formulation exists for num_latent <= 64 in fp64");
@@ -991,10 +1058,11 @@ extern "C" int bpmf_hip_sample_side_launch(bpmf_hip_side *self, const bpmf_hip_s
     if (other->ncols != self->nrows) return fail(BPMF_HIP_EINVAL, "sample_side: other side has the wrong number of columns");
     if (iter < 0) return fail(BPMF_HIP_EINVAL, "sample_side: iter < 0");
     if (self->pending) return fail(BPMF_HIP_EINVAL, "sample_side_launch: previous launch not finished");
+    if (c->comm_dead.load()) return fail(BPMF_HIP_ENODEV, "sample_side: the communicator of this context was aborted (a collective timed out)");
     const int K = c->K;
     HIP_TRY(hipSetDevice(c->device));
     { const int rs = settle_async(self); if (rs) return rs; }
-    if (self->saux) HIP_TRY(hipStreamSynchronize(self->saux));
+    if (self->saux) { const int rs_ = bounded_stream_sync(self->ctx, self->saux, __func__); if (rs_) return rs_; }
     fill_blob_ctx(c, mu, LambdaF, c->h_in, K == 64 && c->dtype == BPMF_HIP_F64 && self->lr_n > 0);
     bpmf_launch::stage(c->h_in_dev, c->d_in, (int)c->in_words, c->stream);
     if (lf32_words(c)) bpmf_launch::lf32_tiles(c->d_in, reinterpret_cast<float *>(c->d_in + c->in_words), K, c->stream);
@@ -1090,7 +1158,7 @@ extern "C" int bpmf_hip_side_aggr_finalize(bpmf_hip_side *s, int nsamples, doubl
     HIP_TRY(hipSetDevice(c->device));
     const size_t K = (size_t)c->Kt, nloc = (size_t)(s->to - s->from);
     bpmf_launch::aggr_finalize(c->Kt, nsamples, (int64_t)nloc, s->d_aggr_mu, s->d_aggr_lambda, c->stream);
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    { const int rs_ = bounded_stream_sync(c, c->stream, __func__); if (rs_) return rs_; }
     HIP_TRY(hipMemcpy(mu_host, s->d_aggr_mu, K * nloc * sizeof(double), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(lambda_host, s->d_aggr_lambda, K * K * nloc * sizeof(double), hipMemcpyDeviceToHost));
     (void)hipFree(s->d_aggr_mu); (void)hipFree(s->d_aggr_lambda);
@@ -1104,7 +1172,7 @@ extern "C" int bpmf_hip_side_last_kernel_ms(bpmf_hip_side *s, float *sample_ms, 
     { const int rc = settle_async(s); if (rc) return rc; }      // stateful path: the worker has stored the times
     if (!s->timing_valid) {          // stateless path: the events of the last launch on this context
         bpmf_hip_ctx *c = s->ctx;
-        HIP_TRY(hipEventSynchronize(c->ev[2]));
+        { const int re_ = bounded_event_sync(c, c->ev[2], "last_kernel_ms"); if (re_) return re_; }
         if (hipEventElapsedTime(&s->last_sample_ms, c->ev[0], c->ev[1]) != hipSuccess ||
             hipEventElapsedTime(&s->last_reduce_ms, c->ev[1], c->ev[2]) != hipSuccess) {
             (void)hipGetLastError();                                  // nothing was launched (or timed) yet
@@ -1284,14 +1352,19 @@ void collect(bpmf_hip_side *s, const bpmf_hip_side::Job &job)
         // (an event, not the stream: our own next gate may be queued on it.)  The statistics may not
         // be enqueued yet: in the fused form they ride in the next sampler launch of the context
         const auto tw = std::chrono::steady_clock::now();
+        const double limit = c->comm ? comm_timeout_s() : 60.0;      // (sharded: the pass ends in an all-reduce that needs every peer)
         for (;;) {
             if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == job.seq) break;
             hipEvent_t sev = s->stats_ev[job.evset].load(std::memory_order_acquire);
-            if (sev) { (void)hipEventSynchronize(sev); break; }
-            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count() > 60.0) break;
+            if (sev) { if (bounded_event_sync(c, sev, "statistics + all-reduce of a half-iteration")) { rc = BPMF_HIP_ENODEV; msg = g_err; } break; }
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count() > limit) break;
             std::this_thread::sleep_for(std::chrono::microseconds(20));
         }
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != job.seq) { rc = BPMF_HIP_ENODEV; msg = "device did not publish its results"; }
+        if (!rc && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != job.seq) {
+            if (c->comm) { (void)comm_abort(c, "statistics + all-reduce of a half-iteration"); msg = g_err; }
+            else msg = "device did not publish its results";
+            rc = BPMF_HIP_ENODEV;
+        }
     }
     if (!rc) rc = check_timeout(s->a_h_out, K, &msg);     // a bounded in-kernel wait gave up: the sums are not to be used
     if (!rc) {
@@ -1454,6 +1527,7 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
                                      "(bpmf_hip_ctx_comm_init) and the side its ranges (bpmf_hip_side_set_ranges), "
                                      "or use bpmf_hip_sample_side and all-reduce the sums yourself");
     const int K = c->K;
+    if (c->comm_dead.load()) return fail(BPMF_HIP_ENODEV, "sys_sample: the communicator of this context was aborted (a collective timed out)");
     HIP_TRY(hipSetDevice(c->device));
     int rc;
     if ((rc = ensure_state(self)) || (rc = ensure_state(other))) return rc;
@@ -1865,7 +1939,7 @@ extern "C" int bpmf_hip_sys_set_reduce(bpmf_hip_side *a, bpmf_hip_side *b, int o
     HIP_TRY(hipSetDevice(c->device));
     int rc;
     if ((rc = settle_async(a)) || (rc = settle_async(b))) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    { const int rs_ = bounded_stream_sync(c, c->stream, __func__); if (rs_) return rs_; }
     if (!on) { a->reduce_on = b->reduce_on = false; return BPMF_HIP_OK; }
     if (!a->conn_send_ptr.empty() || !b->conn_send_ptr.empty())
         return fail(BPMF_HIP_EINVAL, "sys_set_reduce: not together with the connectivity-aware exchange");
@@ -1882,8 +1956,8 @@ extern "C" int bpmf_hip_side_set_overlap(bpmf_hip_side *s, int nparts)
     int rc;
     if ((rc = settle_async(s))) return rc;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (s->saux) HIP_TRY(hipStreamSynchronize(s->saux));
+    { const int rs_ = bounded_stream_sync(c, c->stream, __func__); if (rs_) return rs_; }
+    if (s->saux) { const int rs_ = bounded_stream_sync(s->ctx, s->saux, __func__); if (rs_) return rs_; }
     Rccl *R = rccl();
     if (nparts > 1 && (!R->AllGather || !R->Send || !R->Recv)) nparts = 1;          // (old RCCL: no parts)
     const int64_t nloc = s->to - s->from;
@@ -1907,7 +1981,8 @@ extern "C" int bpmf_hip_side_set_overlap(bpmf_hip_side *s, int nparts)
         HIP_TRY(hipMalloc((void **)&d, all.size() * sizeof(int64_t)));
         HIP_TRY(hipMemcpy(d + (size_t)c->rank * (nparts + 1), mine.data(), mine.size() * sizeof(int64_t), hipMemcpyHostToDevice));
         ncclResult_t nr = R->AllGather(d + (size_t)c->rank * (nparts + 1), d, (size_t)nparts + 1, ncclInt64, c->comm, c->stream);
-        hipError_t he = hipStreamSynchronize(c->stream);
+        hipError_t he = hipSuccess;
+        if (nr == ncclSuccess && bounded_stream_sync(c, c->stream, "side_set_overlap: all-gather of the parts") != 0) { (void)hipFree(d); return BPMF_HIP_ENODEV; }
         if (nr == ncclSuccess && he == hipSuccess) he = hipMemcpy(all.data(), d, all.size() * sizeof(int64_t), hipMemcpyDeviceToHost);
         (void)hipFree(d);
         if (nr != ncclSuccess) return fail(BPMF_HIP_ENODEV, "side_set_overlap: ncclAllGather failed");
@@ -1958,7 +2033,7 @@ extern "C" int bpmf_hip_side_set_conn(bpmf_hip_side *s, const int64_t *send_ptr,
     int rc;
     if ((rc = settle_async(s))) return rc;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    { const int rs_ = bounded_stream_sync(c, c->stream, __func__); if (rs_) return rs_; }
     for (void *p : {(void *)s->d_conn_send, (void *)s->d_conn_recv, (void *)s->d_conn_sbuf, (void *)s->d_conn_rbuf})
         if (p) HIP_TRY(hipFree(p));
     s->d_conn_send = s->d_conn_recv = nullptr; s->d_conn_sbuf = s->d_conn_rbuf = nullptr;
@@ -2000,7 +2075,7 @@ extern "C" int bpmf_hip_side_exchange(bpmf_hip_side *s)
     c->last_sampler_done = nullptr;
     rc = BPMF_DISPATCH_K(c->K, (bpmf_launch::exchange<KK, FF>(s, c->stream, -1)));
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    { const int rs_ = bounded_stream_sync(c, c->stream, __func__); if (rs_) return rs_; }
     return BPMF_HIP_OK;
 }
 
@@ -2079,7 +2154,7 @@ extern "C" int bpmf_hip_test_destroy(bpmf_hip_test *t)
     (void)hipSetDevice(c->device);
     if (t->owner) {                                                   // a twin: its owner's evaluation in flight reads its arrays
         flush_deferred(t->owner);
-        (void)hipStreamSynchronize(live_pstream(t->owner));
+        (void)bounded_stream_sync(t->owner->side->ctx, live_pstream(t->owner), __func__);
         if (t->owner->d_twin_perm) { (void)hipFree(t->owner->d_twin_perm); t->owner->d_twin_perm = nullptr; }
         t->owner->twin = nullptr; t->owner = nullptr;
     }
@@ -2089,8 +2164,8 @@ extern "C" int bpmf_hip_test_destroy(bpmf_hip_test *t)
         std::lock_guard<std::mutex> lk(c->launch_mutex);
         for (bpmf_hip_side *sd : c->sides) if (sd->deferred_eval == t) sd->deferred_eval = nullptr;
     }
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipStreamSynchronize(live_pstream(t));
+    (void)bounded_stream_sync(c, c->stream, __func__);
+    (void)bounded_stream_sync(t->side->ctx, live_pstream(t), __func__);
     {   // no side may wait for this evaluation any more
         std::lock_guard<std::mutex> lk(c->launch_mutex);
         for (bpmf_hip_side *sd : c->sides)
@@ -2270,7 +2345,7 @@ extern "C" int bpmf_hip_predict_finish(bpmf_hip_test *t, double *se, double *se_
             if ((spins & 0xFFFu) == 0xFFFu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > spin_limit_s()) break;
         }
         if (!seen) {
-            HIP_TRY(hipStreamSynchronize(live_pstream(t)));
+            { const int rs_ = bounded_stream_sync(t->side->ctx, live_pstream(t), __func__); if (rs_) return rs_; }
             if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != t->seq) return fail(BPMF_HIP_ENODEV, "device did not publish its results");
         }
     }
@@ -2285,7 +2360,7 @@ extern "C" int bpmf_hip_predict_finish(bpmf_hip_test *t, double *se, double *se_
             HIP_TRY(hipMemcpyAsync(d, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
             NCCL_TRY(rccl()->AllReduce(d, d, 1, ncclInt64, ncclSum, c->comm, c->stream));
             HIP_TRY(hipMemcpyAsync(&v, d, sizeof v, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
+            { const int rs_ = bounded_stream_sync(c, c->stream, __func__); if (rs_) return rs_; }
             t->global_nnz = v;
         }
         *count = t->global_nnz;
@@ -2306,9 +2381,9 @@ extern "C" int bpmf_hip_test_get(bpmf_hip_test *t, double *pavg, double *pm2)
 {
     if (!t) return fail(BPMF_HIP_EINVAL, "test_get: NULL");
     HIP_TRY(hipSetDevice(t->side->ctx->device));
-    HIP_TRY(hipStreamSynchronize(t->side->ctx->stream));
+    { const int rs_ = bounded_stream_sync(t->side->ctx, t->side->ctx->stream, __func__); if (rs_) return rs_; }
     flush_deferred(t);
-    HIP_TRY(hipStreamSynchronize(live_pstream(t)));
+    { const int rs_ = bounded_stream_sync(t->side->ctx, live_pstream(t), __func__); if (rs_) return rs_; }
     if (pavg) HIP_TRY(hipMemcpy(pavg, t->d_pavg, (size_t)t->nnz * sizeof(double), hipMemcpyDeviceToHost));
     if (pm2) HIP_TRY(hipMemcpy(pm2, t->d_pm2, (size_t)t->nnz * sizeof(double), hipMemcpyDeviceToHost));
     return BPMF_HIP_OK;

@@ -98,6 +98,7 @@ struct Rccl {
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclReduce) Reduce = nullptr;             // optional (BPMF_REDUCE formulation: the parts of a side's Gram onto the owners)
     decltype(&ncclCommCount) CommCount = nullptr;       // optional (bpmf_hip_ctx_comm_nranks)
+    decltype(&ncclCommAbort) CommAbort = nullptr;       // optional (a collective that never completes: comm_abort in capi.hip)
 };
 
 Rccl *rccl();      // capi.hip
@@ -159,6 +160,13 @@ struct bpmf_hip_ctx {
     // statistics runs on the side's own stream, beside the other side's sampler and exchange, which
     // two collectives on ONE communicator could not do.  NULL: everything on the main stream.
     ncclComm_t comm2 = nullptr;
+    // A collective whose peer never shows up would hold this rank for ever: every host-side wait on a stream that may carry
+    // one is bounded (BPMF_HIP_COMM_TIMEOUT_MS, default 60 s; bounded_stream_sync / bounded_event_sync in capi.hip); when it
+    // runs out both communicators are aborted (ncclCommAbort), the context is dead for collectives and every later call that
+    // needs them fails with BPMF_HIP_ENODEV -- the reference's MPI_ERRORS_ARE_FATAL / SUCCESS_OR_DIE (c++/mpi_common.h:16,
+    // c++/bpmf_gaspi.h:26-64) as an error code instead of a hang.
+    std::atomic<bool> comm_dead{false};
+    std::mutex abort_mutex;
     int nranks = 1, rank = 0;
     double *d_red = nullptr;
     unsigned seq = 0;                    // value the next publishing kernel writes behind its results

@@ -45,6 +45,21 @@ def main():
             rm.append(movies.rmse)
         res = dict(U=users.items(), V=movies.items(), rmse=rm, rmse_avg=rm, norm_u=[0.0], norm_m=[0.0], final_rmse_avg=movies.rmse_avg,
                    conn_used=(False, False), dom_m=movies.dom, dom_u=users.dom)
+    elif case == "stale_age":
+        # bounded staleness, observed directly: after every iteration this rank's replicas of both factor matrices
+        Sys.nsims, Sys.burnin, Sys.alpha = nsims, burnin, 2.0
+        movies, users = build_sharded(eng, comm, M, Mt, T, nu, nm, mean_rating=None, conn=False)
+        k = int(os.environ["BPMF_TEST_STALE_K"])
+        eng.side_set_staleness(movies.side, k); eng.side_set_staleness(users.side, k)
+        snaps_u, snaps_v, rm = [], [], []
+        for _ in range(nsims):
+            movies.sample(users); users.sample(movies)
+            movies.predict(users, True)
+            rm.append(movies.rmse)
+            snaps_u.append(users.items()); snaps_v.append(movies.items())
+        extra = dict(snaps_u=np.stack(snaps_u), snaps_v=np.stack(snaps_v))
+        res = dict(U=users.items(), V=movies.items(), rmse=rm, rmse_avg=rm, norm_u=[0.0], norm_m=[0.0], final_rmse_avg=movies.rmse_avg,
+                   conn_used=(False, False), dom_m=movies.dom, dom_u=users.dom)
     else:
         res = gibbs_sharded(eng, comm, M, Mt, T, nu, nm, nsims=nsims, burnin=burnin, conn=(case == "conn"))
     np.savez(out + ".rank%d.npz" % comm.rank, U=res["U"], V=res["V"], rmse=res["rmse"], rmse_avg=res["rmse_avg"],

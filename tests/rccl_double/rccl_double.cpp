@@ -26,6 +26,20 @@
 // ncclSystemError with a message on stderr.
 //
 // Ranks of one communicator must issue their operations in the same program order (NCCL's own rule).
+//
+// ASYNCHRONOUS MODE (BPMF_RCCL_DOUBLE_ASYNC=1; round 4).  The mode above cannot see what the real library would
+// punish: with it every operation is over when the call returns, so a caller that reads a result early, reuses a
+// buffer, or relies on two communicators / streams progressing in a particular relative order is never caught.  In
+// asynchronous mode a call (or ncclGroupEnd) only ENQUEUES, like NCCL:
+//   * a one-lane kernel (k_gate) goes onto the operation's stream: it tells the host "the stream has reached the
+//     operation" (everything enqueued before it is complete) and then holds the stream until the host says "done" --
+//     what an NCCL kernel does to its stream while it waits for its peers;
+//   * a helper thread per communicator takes the enqueued groups in order, waits for the stream(s) to arrive, sleeps a
+//     random, rank-dependent time (BPMF_RCCL_DOUBLE_ASYNC_DELAY_US, default up to 300 us: the two communicators and the
+//     exchange stream of a rank interleave differently from its peers' and from run to run), moves the data with copies
+//     on a stream of its own, and releases the kernel.
+// The caller returns at once with ncclSuccess; a failure makes the communicator's error sticky (every later call fails)
+// and releases the streams.  ncclCommAbort fails everything in flight on every rank of the communicator.
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -36,11 +50,15 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
+#include <random>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -79,6 +97,14 @@ double timeout_s()
     return v;
 }
 
+bool async_mode()
+{
+    static const bool v = [] { const char *e = getenv("BPMF_RCCL_DOUBLE_ASYNC"); return e && *e && atoi(e) != 0; }();
+    return v;
+}
+
+struct Group;
+
 struct Comm {
     std::string name;
     Header *h = nullptr;
@@ -86,9 +112,22 @@ struct Comm {
     int nranks = 0, rank = 0;
     int local_sense = 0;
     uint64_t ops = 0;                        // operations completed (diagnostics)
+    // asynchronous mode: the helper thread of this communicator, its queue of enqueued groups, its copy stream, and the
+    // (reached, done) flag pairs the gate kernels and the helper talk through (pinned host memory)
+    int device = 0;
+    std::thread helper;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Group *> q;
+    bool busy = false, stop = false;
+    hipStream_t hs = nullptr;
+    unsigned *flags = nullptr, *flags_dev = nullptr;
+    size_t next_flag = 0;
     char *slot(int src, int dst) const { return reinterpret_cast<char *>(h) + sizeof(Header) + ((size_t)src * nranks + dst) * CHUNK; }
     char *red_slot(int r) const { return reinterpret_cast<char *>(h) + sizeof(Header) + (size_t)nranks * nranks * CHUNK + (size_t)r * CHUNK; }
 };
+
+constexpr size_t NFLAG = 8192;              // flag pairs in flight per communicator (a ring)
 
 struct Op {
     enum Kind { SEND, RECV, ALLREDUCE, REDUCE, COPY } kind;
@@ -101,8 +140,16 @@ struct Op {
     hipStream_t stream;
 };
 
+struct Group {
+    std::vector<Op> ops;
+    std::vector<size_t> flag;                // one pair per distinct stream of the group
+};
+
 thread_local int g_depth = 0;
 thread_local std::vector<Op> g_ops;
+// set on a communicator's helper thread: copies go to its own stream (the operation's stream is held by the gate kernel)
+thread_local hipStream_t t_copy_stream = nullptr;
+thread_local bool t_async = false;
 
 int complain(Comm *c, const char *what)
 {
@@ -162,6 +209,22 @@ size_t type_bytes(ncclDataType_t t)
         }                                                                                      \
     } while (0)
 
+ncclResult_t copy_d2h(void *dst, const void *src, size_t n)
+{
+    if (!t_async) { HIP_OK(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost)); return ncclSuccess; }
+    HIP_OK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, t_copy_stream));
+    HIP_OK(hipStreamSynchronize(t_copy_stream));
+    return ncclSuccess;
+}
+ncclResult_t copy_to_dev(void *dst, const void *src, size_t n, hipMemcpyKind kind, hipStream_t op_stream)
+{
+    hipStream_t st = t_async ? t_copy_stream : op_stream;
+    HIP_OK(hipMemcpyAsync(dst, src, n, kind, st));
+    HIP_OK(hipStreamSynchronize(st));
+    return ncclSuccess;
+}
+#define NCCL_OK(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) return r_; } while (0)
+
 // all point-to-point operations of one group, progressed together (a rank that posts its sends first
 // and a peer that does the same must not wait for each other: chunks move whenever a slot allows it)
 ncclResult_t run_p2p(std::vector<Op> &ops)
@@ -189,7 +252,7 @@ ncclResult_t run_p2p(std::vector<Op> &ops)
                 Mailbox &b = c->h->box[c->rank][p];
                 if (b.posted.load(std::memory_order_acquire) == b.consumed.load(std::memory_order_acquire)) {      // slot free
                     const size_t n = std::min(CHUNK, x.op->bytes - x.done);
-                    if (n) HIP_OK(hipMemcpy(c->slot(c->rank, p), static_cast<const char *>(x.op->src) + x.done, n, hipMemcpyDeviceToHost));
+                    if (n) NCCL_OK(copy_d2h(c->slot(c->rank, p), static_cast<const char *>(x.op->src) + x.done, n));
                     b.total_bytes.store(x.op->bytes, std::memory_order_relaxed);
                     b.chunk_bytes.store(n, std::memory_order_relaxed);
                     b.posted.fetch_add(1, std::memory_order_release);
@@ -209,10 +272,7 @@ ncclResult_t run_p2p(std::vector<Op> &ops)
                         complain(c, msg);
                         return ncclInvalidArgument;
                     }
-                    if (n) {
-                        HIP_OK(hipMemcpyAsync(static_cast<char *>(x.op->dst) + x.done, c->slot(p, c->rank), n, hipMemcpyHostToDevice, x.op->stream));
-                        HIP_OK(hipStreamSynchronize(x.op->stream));
-                    }
+                    if (n) NCCL_OK(copy_to_dev(static_cast<char *>(x.op->dst) + x.done, c->slot(p, c->rank), n, hipMemcpyHostToDevice, x.op->stream));
                     b.consumed.fetch_add(1, std::memory_order_release);
                     x.done += n; moved = true;
                     if (x.done == x.op->bytes) { ++rhead[(size_t)p]; --pending; }
@@ -250,7 +310,7 @@ ncclResult_t run_reduce(const Op &o)
     std::vector<char> acc(CHUNK);
     for (size_t off = 0; off < o.bytes || off == 0; off += RCHUNK) {
         const size_t n = std::min(RCHUNK, o.bytes - off);
-        if (n) HIP_OK(hipMemcpy(c->red_slot(c->rank), static_cast<const char *>(o.src) + off, n, hipMemcpyDeviceToHost));
+        if (n) NCCL_OK(copy_d2h(c->red_slot(c->rank), static_cast<const char *>(o.src) + off, n));
         *reinterpret_cast<volatile uint64_t *>(c->red_slot(c->rank) + CHUNK - 8) = (uint64_t)o.bytes;      // (size check)
         ncclResult_t r = barrier(c);
         if (r != ncclSuccess) return r;
@@ -270,8 +330,7 @@ ncclResult_t run_reduce(const Op &o)
                 default: add_into(reinterpret_cast<uint32_t *>(acc.data()), reinterpret_cast<const uint32_t *>(c->red_slot(q)), cnt); break;
                 }
             }
-            HIP_OK(hipMemcpyAsync(static_cast<char *>(o.dst) + off, acc.data(), n, hipMemcpyHostToDevice, o.stream));
-            HIP_OK(hipStreamSynchronize(o.stream));
+            NCCL_OK(copy_to_dev(static_cast<char *>(o.dst) + off, acc.data(), n, hipMemcpyHostToDevice, o.stream));
         }
         r = barrier(c);                                             // (the slots are rewritten by the next piece / operation)
         if (r != ncclSuccess) return r;
@@ -283,17 +342,15 @@ ncclResult_t run_reduce(const Op &o)
 ncclResult_t run_group(std::vector<Op> &ops)
 {
     // everything enqueued before the operations must be visible to the copies below
+    // (asynchronous mode: the gate kernels have reported that their streams arrived; the streams themselves are held)
     std::vector<hipStream_t> seen;
     for (const Op &o : ops) {
         bool dup = false;
         for (hipStream_t s : seen) dup = dup || s == o.stream;
-        if (!dup) { seen.push_back(o.stream); HIP_OK(hipStreamSynchronize(o.stream)); }
+        if (!dup && !t_async) { seen.push_back(o.stream); HIP_OK(hipStreamSynchronize(o.stream)); }
     }
     for (Op &o : ops)
-        if (o.kind == Op::COPY && o.bytes && o.src != o.dst) {
-            HIP_OK(hipMemcpyAsync(o.dst, o.src, o.bytes, hipMemcpyDeviceToDevice, o.stream));
-            HIP_OK(hipStreamSynchronize(o.stream));
-        }
+        if (o.kind == Op::COPY && o.bytes && o.src != o.dst) NCCL_OK(copy_to_dev(o.dst, o.src, o.bytes, hipMemcpyDeviceToDevice, o.stream));
     ncclResult_t r = run_p2p(ops);
     if (r != ncclSuccess) return r;
     for (Op &o : ops)
@@ -305,13 +362,124 @@ ncclResult_t run_group(std::vector<Op> &ops)
     return ncclSuccess;
 }
 
+// ---- asynchronous mode ---------------------------------------------------------------------------------
+// reached = 1: everything ahead of the operation on this stream is complete; then the stream is held until done != 0
+// (bounded: a helper that died must not leave a wave spinning for ever)
+__global__ void k_gate(unsigned *reached, unsigned *done, unsigned long long max_ticks)
+{
+    __hip_atomic_store(reached, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long t0 = wall_clock64();                    // 100 MHz
+    while (__hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) {
+        __builtin_amdgcn_s_sleep(32);
+        if (wall_clock64() - t0 > max_ticks) break;
+    }
+}
+
+void helper_main(Comm *c)
+{
+    (void)hipSetDevice(c->device);
+    t_async = true; t_copy_stream = c->hs;
+    static const int max_delay_us = [] { const char *e = getenv("BPMF_RCCL_DOUBLE_ASYNC_DELAY_US"); return (e && *e) ? atoi(e) : 300; }();
+    std::mt19937 rng((unsigned)(c->rank * 7919 + std::hash<std::string>()(c->name) + (unsigned)getpid()));
+    for (;;) {
+        Group *g = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(c->m);
+            c->cv.wait(lk, [c] { return c->stop || !c->q.empty(); });
+            if (c->q.empty()) return;
+            g = c->q.front(); c->q.pop_front(); c->busy = true;
+        }
+        ncclResult_t r = ncclSuccess;
+        for (size_t f : g->flag) {                                   // the streams of the group arrive at the operation
+            Deadline d;
+            while (__atomic_load_n(&c->flags[2 * f], __ATOMIC_ACQUIRE) == 0u)
+                if (d.expired(c)) { complain(c, "asynchronous mode: a stream never reached its operation (held by another operation that cannot complete?)"); r = ncclSystemError; break; }
+            if (r != ncclSuccess) break;
+        }
+        if (r == ncclSuccess && max_delay_us > 0) usleep((useconds_t)(rng() % (unsigned)max_delay_us));
+        if (r == ncclSuccess && c->h->error.load()) r = ncclSystemError;
+        if (r == ncclSuccess) r = run_group(g->ops);
+        if (r != ncclSuccess) c->h->error.store(1);
+        for (size_t f : g->flag) __atomic_store_n(&c->flags[2 * f + 1], 1u, __ATOMIC_RELEASE);     // release the streams (also after a failure)
+        delete g;
+        { std::lock_guard<std::mutex> lk(c->m); c->busy = false; }
+        c->cv.notify_all();
+    }
+}
+
+ncclResult_t enqueue_async(std::vector<Op> &ops)
+{
+    Comm *c = ops[0].comm;
+    for (const Op &o : ops)
+        if (o.comm != c) { complain(c, "asynchronous mode: one communicator per group"); return ncclInvalidUsage; }
+    if (c->h->error.load()) return ncclSystemError;                   // sticky: something already failed (or the communicator was aborted)
+    Group *g = new Group();
+    g->ops = ops;
+    std::vector<hipStream_t> seen;
+    const unsigned long long max_ticks = (unsigned long long)((timeout_s() + 5.0) * 1e8);
+    for (const Op &o : ops) {
+        bool dup = false;
+        for (hipStream_t s : seen) dup = dup || s == o.stream;
+        if (dup) continue;
+        seen.push_back(o.stream);
+        const size_t f = c->next_flag++ % NFLAG;
+        __atomic_store_n(&c->flags[2 * f], 0u, __ATOMIC_RELAXED);
+        __atomic_store_n(&c->flags[2 * f + 1], 0u, __ATOMIC_RELEASE);
+        g->flag.push_back(f);
+        hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, o.stream, c->flags_dev + 2 * f, c->flags_dev + 2 * f + 1, max_ticks);
+        if (hipGetLastError() != hipSuccess) { delete g; complain(c, "asynchronous mode: the gate kernel could not be launched"); return ncclUnhandledCudaError; }
+    }
+    { std::lock_guard<std::mutex> lk(c->m); c->q.push_back(g); }
+    c->cv.notify_all();
+    return ncclSuccess;
+}
+
+// everything enqueued on this communicator is over (asynchronous mode)
+void drain(Comm *c)
+{
+    if (!c->helper.joinable()) return;
+    std::unique_lock<std::mutex> lk(c->m);
+    c->cv.wait(lk, [c] { return c->q.empty() && !c->busy; });
+}
+
+ncclResult_t start_helper(Comm *c)
+{
+    if (!async_mode()) return ncclSuccess;
+    HIP_OK(hipGetDevice(&c->device));
+    HIP_OK(hipStreamCreateWithFlags(&c->hs, hipStreamNonBlocking));
+    HIP_OK(hipHostMalloc((void **)&c->flags, 2 * NFLAG * sizeof(unsigned), hipHostMallocMapped));
+    HIP_OK(hipHostGetDevicePointer((void **)&c->flags_dev, c->flags, 0));
+    memset(c->flags, 0, 2 * NFLAG * sizeof(unsigned));
+    c->helper = std::thread(helper_main, c);
+    return ncclSuccess;
+}
+
+void stop_helper(Comm *c)
+{
+    if (!c->helper.joinable()) return;
+    drain(c);
+    { std::lock_guard<std::mutex> lk(c->m); c->stop = true; }
+    c->cv.notify_all();
+    c->helper.join();
+    if (c->hs) { (void)hipStreamSynchronize(c->hs); (void)hipStreamDestroy(c->hs); c->hs = nullptr; }
+    if (c->flags) { (void)hipHostFree(c->flags); c->flags = nullptr; }
+}
+
+ncclResult_t dispatch(std::vector<Op> &ops)
+{
+    if (ops.empty()) return ncclSuccess;
+    if (async_mode() && ops[0].comm->helper.joinable()) return enqueue_async(ops);
+    if (ops[0].comm->h->error.load()) return ncclSystemError;
+    return run_group(ops);
+}
+
 ncclResult_t submit(const Op &o)
 {
     g_ops.push_back(o);
     if (g_depth > 0) return ncclSuccess;
     std::vector<Op> ops;
     ops.swap(g_ops);
-    return run_group(ops);
+    return dispatch(ops);
 }
 
 ncclResult_t attach(const std::string &name, int nranks, int rank, Comm **out)
@@ -381,8 +549,9 @@ __attribute__((visibility("default"))) ncclResult_t ncclCommInitRank(ncclComm_t 
         return ncclInvalidArgument;
     }
     Comm *c = nullptr;
-    const ncclResult_t r = attach(id.internal, nranks, rank, &c);
+    ncclResult_t r = attach(id.internal, nranks, rank, &c);
     if (r != ncclSuccess) return r;
+    if ((r = start_helper(c)) != ncclSuccess) return r;
     *comm = reinterpret_cast<ncclComm_t>(c);
     return ncclSuccess;
 }
@@ -393,6 +562,7 @@ __attribute__((visibility("default"))) ncclResult_t ncclCommSplit(ncclComm_t com
     Comm *c = reinterpret_cast<Comm *>(comm);
     if (!c || !newcomm) return ncclInvalidArgument;
     if (color != 0 || key != c->rank) { complain(c, "ncclCommSplit: the test double only duplicates a communicator (colour 0, key = rank)"); return ncclInvalidUsage; }
+    drain(c);                                                       // (the barriers below are this thread's: the helper must be idle)
     ncclResult_t r = barrier(c);
     if (r != ncclSuccess) return r;
     const int gen = c->h->nsplit.load();
@@ -402,6 +572,7 @@ __attribute__((visibility("default"))) ncclResult_t ncclCommSplit(ncclComm_t com
     Comm *n = nullptr;
     r = attach(c->name + "_s" + std::to_string(gen), c->nranks, c->rank, &n);
     if (r != ncclSuccess) return r;
+    if ((r = start_helper(n)) != ncclSuccess) return r;
     *newcomm = reinterpret_cast<ncclComm_t>(n);
     return barrier(c);
 }
@@ -410,10 +581,29 @@ __attribute__((visibility("default"))) ncclResult_t ncclCommDestroy(ncclComm_t c
 {
     Comm *c = reinterpret_cast<Comm *>(comm);
     if (!c) return ncclSuccess;
+    stop_helper(c);
     const bool last = c->h->detached.fetch_add(1) + 1 == c->nranks;
     munmap(c->h, c->bytes);
     if (last) shm_unlink(c->name.c_str());
     delete c;
+    return ncclSuccess;
+}
+
+// ncclCommAbort: everything in flight on the communicator fails, on every rank (the sticky error word lives in the shared
+// segment: a peer waiting for this rank gives up at once instead of after its time-out), the held streams are released.
+__attribute__((visibility("default"))) ncclResult_t ncclCommAbort(ncclComm_t comm)
+{
+    Comm *c = reinterpret_cast<Comm *>(comm);
+    if (!c) return ncclSuccess;
+    c->h->error.store(1);
+    return ncclCommDestroy(comm);
+}
+
+__attribute__((visibility("default"))) ncclResult_t ncclCommGetAsyncError(ncclComm_t comm, ncclResult_t *asyncError)
+{
+    Comm *c = reinterpret_cast<Comm *>(comm);
+    if (!c || !asyncError) return ncclInvalidArgument;
+    *asyncError = c->h->error.load() ? ncclSystemError : ncclSuccess;
     return ncclSuccess;
 }
 
@@ -451,7 +641,7 @@ __attribute__((visibility("default"))) ncclResult_t ncclGroupEnd()
     if (--g_depth > 0) return ncclSuccess;
     std::vector<Op> ops;
     ops.swap(g_ops);
-    return run_group(ops);
+    return dispatch(ops);
 }
 
 __attribute__((visibility("default"))) ncclResult_t ncclSend(const void *sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream)
