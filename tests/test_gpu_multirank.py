@@ -34,6 +34,11 @@ def double_mode(request, monkeypatch):
     what the synchronous double serialises away).  Same assertions in both modes."""
     if request.param == "async":
         monkeypatch.setenv("BPMF_RCCL_DOUBLE_ASYNC", "1")
+        # The double's helper threads move the data with HIP copies on streams of their own, and HIP maps the streams of a
+        # process onto 4 hardware queues by default: a helper's copy can land in the queue of a stream that a LATER gate
+        # kernel holds, which only that helper can release -- a deadlock of the double's making (RCCL's kernels move their
+        # data themselves).  One hardware queue per stream for these runs.
+        monkeypatch.setenv("GPU_MAX_HW_QUEUES", "24")
     else:
         monkeypatch.delenv("BPMF_RCCL_DOUBLE_ASYNC", raising=False)
     return request.param
@@ -50,14 +55,14 @@ def run_ranks(tmp_path, nranks, case, dataset, K, nsims, burnin, env_extra=None)
     procs = []
     for rank in range(nranks):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(nranks), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   BPMF_HIP_RCCL_LIBRARY=DOUBLE, BPMF_RCCL_DOUBLE_TIMEOUT_S="120")
+                   BPMF_HIP_RCCL_LIBRARY=DOUBLE, BPMF_RCCL_DOUBLE_TIMEOUT_S="40")
         env.update(env_extra or {})
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_mr_worker.py"), case, dataset, str(K), str(nsims),
                                        str(burnin), out], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     errs = []
     for p in procs:
         try:
-            so, se = p.communicate(timeout=900)
+            so, se = p.communicate(timeout=420)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
