@@ -55,9 +55,9 @@ FP32_PEAK_TFLOPS = 157.3
 LDS_PER_CU = 160 * 1024
 
 WORKLOADS = {
-    #            K    dtype  LDS bytes / workgroup, workgroups resident per CU (launch bounds, LDS) of the K = 32 sampler
+    #            K    dtype  (two unused fields: the LDS figures come from the library, bpmf_hip_side_kernel_resources)
     # (the kernel names of the roofline object come from the library: bpmf_hip_side_kernel_name)
-    "ml1m":      (32, "f64", (32 * 34 + 4 * 32 + 2) * 8, 12),
+    "ml1m":      (32, "f64", None, None),
     "ml1m_k64":  (64, "f64", None, None),
     "chembl":    (64, "f64", None, None),
     "ml1m_k128": (128, "f32", None, None),
@@ -512,6 +512,15 @@ def strong_10Mx1M(R, steps, scale=1.0, check=True):
             mine["spot_check"] = {"columns_per_side": 16, "max_err_users_side": errs["users_side"], "max_err_items_side": errs["items_side"],
                                   "max_err": worst, "tolerance": 1e-9, "ok": bool(worst < 1e-9),
                                   "against": "host solve + bpmf_randn_stream (no oracle)", "seconds": time.perf_counter() - t_chk}
+    if world == 1 and "algorithmic_bytes_per_iteration_this_rank" in mine:
+        # HBM-side bytes per launch from the committed PMC pass of this record (profiles/r*_pmc_strong_10Mx1M.txt), if it was
+        # taken with these kernel sources; algorithmic bytes per launch = half an iteration's
+        p_traffic, _, pmc_file, pmc_sha = profiled("strong_10Mx1M")
+        cur = pmc_file is not None and pmc_sha == kernel_source_sha()
+        per_launch = mine["algorithmic_bytes_per_iteration_this_rank"] / 2.0
+        mine.update({"traffic": p_traffic if cur else None, "algorithmic_bytes_per_launch": per_launch,
+                     "hbm_traffic_over_algorithmic": (p_traffic / per_launch) if (cur and p_traffic) else None,
+                     "profiled": {"source": pmc_file, "kernel_source_sha": pmc_sha, "current": bool(cur), "traffic": p_traffic}})
     ranks = R.gather(mine)
     out.update({k: v for k, v in ranks[0].items() if k != "rank"})          # rank 0's figures at top level (as before)
     out["model"] = strong_model(big.NU, big.NI, K, world, ranks, dt / steps * 1e3)
@@ -522,6 +531,39 @@ def strong_10Mx1M(R, steps, scale=1.0, check=True):
             out["spot_check"] = dict(ranks[0]["spot_check"], max_err=max(errs), ok=bool(max(errs) < 1e-9))
     eng.close()
     return out
+
+
+def bpmf_exe_record(M, T, nusers, nmovies, K, nsims=25, burnin=5):
+    """The C++ host the north star names: the `bpmf` executable (bpmf_amd/csrc/bpmf_main.cpp -> C ABI -> the same kernels) on
+    the matrices of this run, written as .sdm: `bpmf -i 25 -b 5 -d K`, its own `Average items/sec` and `Final Avg RMSE`
+    (c++/bpmf.cpp:246-252) parsed from stdout.  The first iterations carry start-up (clock ramp, first launches): the
+    steady-state figure is the mean of the per-iteration items/sec of the second half of the run."""
+    import re
+    from bpmf_amd import io as bio
+    exe = os.path.join(ROOT, "bpmf_amd", "bpmf")
+    d = tempfile.mkdtemp(prefix="bpmf_exe_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        bio.write_sparse(os.path.join(d, "train.sdm"), nusers, nmovies, M)
+        bio.write_sparse(os.path.join(d, "test.sdm"), nusers, nmovies, T)
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, "-n", "train.sdm", "-p", "test.sdm", "-i", str(nsims), "-b", str(burnin), "-d", str(K)], cwd=d,
+                           capture_output=True, text=True, timeout=300)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": "bpmf exited with %d: %s" % (r.returncode, r.stderr[-300:])}
+        per_iter = [float(x) for x in re.findall(r"items/sec:\s*([0-9.eE+]+)", r.stdout)]
+        avg = float(re.search(r"Average items/sec: (\S+)", r.stdout).group(1))
+        final = float(re.search(r"Final Avg RMSE: (\S+)", r.stdout).group(1))
+        steady = per_iter[len(per_iter) // 2:]
+        return {"command": "bpmf -n train.sdm -p test.sdm -i %d -b %d -d %d" % (nsims, burnin, K), "average_items_per_s": avg,
+                "steady_items_per_s": float(np.mean(steady)) if steady else None, "final_avg_rmse": final, "iterations": len(per_iter),
+                "wall_s": wall, "unit": "samples/s (the reference's items/sec: users + movies per iteration time)",
+                "host": "C++ (bpmf_amd/csrc/bpmf_main.cpp) over the C ABI of include/bpmf_hip.h"}
+    except Exception as e:
+        return {"error": repr(e)[:300]}
+    finally:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def strong_model(NU, NI, K, world, ranks, ms_per_step):
@@ -617,6 +659,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=0, help="timed blocks of --steps steps (0 = auto: 5..25 within ~8 s)")
     ap.add_argument("--prewarm-ms", type=float, default=50.0, help="untimed steps until this much time has passed (0: the W warm-up steps only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bpmf-exe", action="store_true", help="skip the bpmf_exe sub-record (the `bpmf` executable on the same matrices)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong_10Mx1M sub-record")
     ap.add_argument("--strong-steps", type=int, default=8, help="timed steps of the strong_10Mx1M record (>= 8: the library times every 8th launch of a side)")
     ap.add_argument("--strong-scale", type=float, default=float(os.environ.get("BPMF_BENCH_STRONG_SCALE", "1.0")))
@@ -838,9 +881,23 @@ def run(args, wl, R, wd):
         roofline["effective_frac"] = eff / flop_peak
         roofline["effective_note"] = ("algorithmic flops of the reference's per-column factorisation / launch time: an algorithmic "
                                       "speed-up figure, not a fraction of the MFMA peak; `achieved` / `frac` count executed flops")
-    if lds_wg:
-        roofline["lds"] = {"bytes_per_workgroup": lds_wg, "workgroups_per_cu": wg_per_cu, "occupancy": lds_wg * wg_per_cu / LDS_PER_CU,
-                           "bank_conflict_rate": p_conflict if pmc_current else None}
+    # LDS occupancy of the kernels that hold the factorisation (north star: "LDS occupancy on the Cholesky"): static LDS per
+    # workgroup and workgroups resident per CU as the LIBRARY reports them for the kernels this side launches
+    # (bpmf_hip_side_kernel_resources: the runtime's occupancy query), for every workload; the bank-conflict rate from the
+    # sha-matched PMC pass (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE over the sampler kernels of the run)
+    try:
+        lds = {}
+        for sd in (movies, users):
+            ks = eng.kernel_resources(sd.side)
+            for k in ks:
+                k["lds_bytes_per_cu"] = k["lds_bytes_per_workgroup"] * k["workgroups_per_cu"]
+                k["lds_occupancy"] = k["lds_bytes_per_cu"] / LDS_PER_CU
+                k["waves_per_simd"] = k["workgroups_per_cu"] * k["threads_per_workgroup"] / 64.0 / 4.0
+            lds[sd.name] = ks
+        roofline["lds"] = {"per_side": lds, "lds_per_cu": LDS_PER_CU, "bank_conflict_rate": p_conflict if pmc_current else None,
+                           "bank_conflict_rate_of_committed_profile": p_conflict}
+    except Exception as e:
+        roofline["lds"] = {"error": repr(e)[:200]}
     bpmf_env = {k: v for k, v in sorted(os.environ.items()) if k.startswith("BPMF_") and k != "BPMF_BENCH_SELF_LAUNCHED"}
     out = {
         "metric": METRIC,
@@ -902,6 +959,11 @@ def run(args, wl, R, wd):
                     print(json.dumps(out), flush=True)
                 sys.stdout.flush()
                 os._exit(5 if rank == 0 else 0)
+    if rank == 0 and world == 1 and wl == "ml1m" and not args.no_bpmf_exe:
+        wd.stage("bpmf executable", 330)
+        out["bpmf_exe"] = bpmf_exe_record(M, T, nusers, nmovies, K, nsims=max(25, min(args.steps, 400)))
+        if out["bpmf_exe"].get("steady_items_per_s"):
+            out["bpmf_exe"]["over_python_host"] = out["bpmf_exe"]["steady_items_per_s"] / out["value"]
     if rank == 0:
         wd.stage("cpu baseline", 700)
         if not args.no_cpu_baseline and world == 1:

@@ -69,6 +69,7 @@ _SIGNATURES = {
     "bpmf_randn_stream": (None, [C.c_uint32, C.c_int, C.c_void_p]),
     "bpmf_hip_randn_stream": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
     "bpmf_hip_side_kernel_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "bpmf_hip_side_kernel_resources": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
     "bpmf_hip_side_schedule_info": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "bpmf_hip_side_schedule_items": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "bpmf_hip_side_kernel_ms_sum": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -1766,6 +1766,35 @@ extern "C" int bpmf_hip_side_kernel_name(const bpmf_hip_side *s, char *buf, int 
     return BPMF_HIP_OK;
 }
 
+// LDS / register budget and residency of the kernel(s) one sampler launch of the side consists of, asked of the dispatch logic
+// itself (launch.h: Probe): per kernel 4 words -- LDS bytes per workgroup, threads per workgroup, workgroups resident per CU
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor), VGPRs -- and its name as the launch site spells it, ';'-separated.
+// Returns the number of kernels (<= max_kernels), or a negative error code.  Nothing is launched.
+extern "C" int bpmf_hip_side_kernel_resources(bpmf_hip_side *s, int64_t *out, int max_kernels, char *names, int names_len)
+{
+    if (!s || !out || max_kernels <= 0) return fail(BPMF_HIP_EINVAL, "side_kernel_resources: bad argument");
+    bpmf_hip_ctx *c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    if (s->reduce_on) return 0;
+    bpmf_launch::Probe pr;
+    bpmf_launch::probe() = &pr;
+    const bool sa = s->stat_a_ready;
+    const int rc = BPMF_DISPATCH_K(c->K, (bpmf_launch::sampler_into<KK, FF>(s, s->d_items, s, 0, 1.0, c->d_in, c->stream, nullptr, nullptr)));
+    bpmf_launch::probe() = nullptr;
+    s->stat_a_ready = sa;
+    if (rc) return rc;
+    std::string all;
+    const int n = std::min(pr.n, max_kernels);
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < 4; ++j) out[4 * i + j] = pr.v[i][j];
+        std::string nm = pr.name[i];
+        for (const char *strip : {"bpmf::", "(", ")"}) { size_t p; while ((p = nm.find(strip)) != std::string::npos) nm.erase(p, strlen(strip)); }
+        all += (i ? ";" : "") + nm;
+    }
+    if (names && names_len > 0) snprintf(names, (size_t)names_len, "%s", all.c_str());
+    return n;
+}
+
 // The static schedule of a side in numbers (build_schedule), for reports: out[0..15] =
 //   0 sampler form (mode)   1 work items   2 chunks of heavy columns (partial slots)   3 heavy columns cut into chunks
 //   4 light columns in the low-rank / product forms   5 work items of the others   6..8 product-form columns with <= 2 | 3..6 | 7..12 ratings

@@ -8,12 +8,36 @@
 #define BPMF_LAUNCH(kernel, grid, block, st, e0, e1, ...)                                                         \
     do {                                                                                                          \
         const unsigned fl_ = bpmf_launch::take_flags();                                                           \
+        if (bpmf_launch::probe()) { bpmf_launch::probe()->record(reinterpret_cast<const void *>(kernel), #kernel, block); break; }   \
         hipEvent_t e0_ = (e0), e1_ = (e1);                                                                        \
         if (e0_ || e1_ || fl_) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, e0_, e1_, fl_, __VA_ARGS__);    \
         else hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                                         \
     } while (0)
 
 namespace bpmf_launch {
+
+// "What would this side's sampler launch?" (bpmf_hip_side_kernel_resources): with a probe installed on the calling thread,
+// BPMF_LAUNCH records the kernel's LDS / register budget and residency instead of launching it -- the dispatch logic of
+// sampler_into answers for itself, no second copy of it to keep in step.
+struct Probe {
+    static constexpr int MAXK = 8;
+    int n = 0;
+    int64_t v[MAXK][4];          // LDS bytes per workgroup (static) | threads per workgroup | workgroups resident per CU | VGPRs (arch + acc)
+    char name[MAXK][128];
+    void record(const void *kernel, const char *text, dim3 block)
+    {
+        if (n >= MAXK) return;
+        hipFuncAttributes a;
+        int nb = 0;
+        const int threads = (int)(block.x * block.y * block.z);
+        if (hipFuncGetAttributes(&a, kernel) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, 0) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+        v[n][0] = (int64_t)a.sharedSizeBytes; v[n][1] = threads; v[n][2] = nb; v[n][3] = a.numRegs;
+        snprintf(name[n], sizeof name[n], "%s", text);
+        ++n;
+    }
+};
+inline Probe *&probe() { static thread_local Probe *p = nullptr; return p; }
 
 // hipExtAnyOrderLaunch for the NEXT sampler launch of this thread, consumed by the first kernel of its sequence: that
 // launch may start while the packet ahead of it in the queue -- the statistics pass of the other side -- is still

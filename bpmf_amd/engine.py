@@ -219,6 +219,25 @@ class HipEngine:
         _lib.check(self.lib.bpmf_hip_side_kernel_name(side.handle, buf, 512))
         return buf.value.decode()
 
+    def kernel_resources(self, side):
+        """[{kernel, lds_bytes_per_workgroup, threads_per_workgroup, workgroups_per_cu, vgprs}] of the kernels one sampler
+        launch of the side consists of (asked of the library's dispatch logic; nothing is launched)."""
+        out = np.zeros(32, np.int64)
+        names = C.create_string_buffer(1024)
+        n = self.lib.bpmf_hip_side_kernel_resources(side.handle, _ptr(out), 8, names, 1024)
+        if n < 0:
+            _lib.check(n)
+        spelt = names.value.decode().split(";") if n else []
+        listed = [x.strip() for x in self.kernel_name(side).split(" + ")]
+        res = []
+        for i in range(n):
+            nm = spelt[i] if i < len(spelt) else "?"
+            if nm in ("kernel", "?") and len(listed) == n:            # (launched through a generic lambda: the name list says which)
+                nm = listed[i]
+            res.append({"kernel": nm, "lds_bytes_per_workgroup": int(out[4 * i]), "threads_per_workgroup": int(out[4 * i + 1]),
+                        "workgroups_per_cu": int(out[4 * i + 2]), "vgprs": int(out[4 * i + 3])})
+        return res
+
     def schedule_info(self, side):
         out = np.zeros(16, np.int64)
         _lib.check(self.lib.bpmf_hip_side_schedule_info(side.handle, _ptr(out), 16))

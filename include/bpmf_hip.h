@@ -307,6 +307,11 @@ BPMF_API int bpmf_hip_randn_stream(bpmf_hip_ctx *ctx, uint32_t counter, int n, d
  * the kernel(s) a sampler launch of this side consists of, by name, as a profile shows them; and the side's static
  * schedule in numbers (16 words, see capi.hip: form, work items, chunks, columns per product-form class ...). */
 BPMF_API int bpmf_hip_side_kernel_name(const bpmf_hip_side *side, char *buf, int n);
+/* LDS / register budget and residency of the kernel(s) of one sampler launch of the side (what `LDS occupancy on the Cholesky`
+ * of the north star is computed from): per kernel 4 words in `out` -- static LDS bytes per workgroup, threads per workgroup,
+ * workgroups resident per CU as the runtime's occupancy query reports it, VGPRs -- in launch order; `names`: the kernels as the
+ * launch sites spell them, ';'-separated.  Returns the number of kernels (<= max_kernels) or a negative error.  Launches nothing. */
+BPMF_API int bpmf_hip_side_kernel_resources(bpmf_hip_side *side, int64_t *out, int max_kernels, char *names, int names_len);
 BPMF_API int bpmf_hip_side_schedule_info(const bpmf_hip_side *side, int64_t *out16, int n);
 /* the side's work items in launch order (what replaces the `#pragma omp parallel for schedule(guided)` over the columns,
  * c++/sample.cpp:353-356): local column, number of ratings, and the ordinal of the item's heavy column (-1: the item is

@@ -473,7 +473,9 @@ def test_bad_arguments_are_rejected(hip_engine_factory):
     with pytest.raises(bpmf_amd.BpmfHipError):
         eng.side_create(2, 4, np.array([0, 1, 2], np.int64), np.array([0, 9], np.int32), np.ones(2), 1.0)   # row 9 >= nrows
     with pytest.raises(bpmf_amd.BpmfHipError):
-        bpmf_amd.HipEngine(24)                                                                              # unsupported K
+        bpmf_amd.HipEngine(129)                                                                             # unsupported K (1 .. 128 run)
+    with pytest.raises(bpmf_amd.BpmfHipError):
+        bpmf_amd.HipEngine(0)
 
 
 def test_sharded_path_over_rccl_single_rank(tmp_path):

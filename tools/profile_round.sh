@@ -8,7 +8,13 @@ O=gpurun_out/profiles; mkdir -p $O; rm -f $O/${R}_pmc_$W.txt
 # the kernel sources these counters belong to (bench.py reports figures of a profile of OTHER sources as stale)
 echo "# kernel-source-sha: $(python -c 'import bench; print(bench.kernel_source_sha())')" > $O/${R}_pmc_$W.txt
 echo "# rocprofv3 --pmc <one group per pass> --kernel-trace -- python bench.py --workload $W --steps 10 --warmup 2 --repeats 1 --prewarm-ms 0 --no-cpu-baseline --no-strong   (per-launch averages of the sampler kernels)" >> $O/${R}_pmc_$W.txt
-CMD="python bench.py --workload $W --no-cpu-baseline --no-strong"
+CMD="python bench.py --workload $W --no-cpu-baseline --no-strong --no-bpmf-exe"
+PCMD="python bench.py --workload $W --steps 10 --warmup 2 --repeats 1 --prewarm-ms 0 --no-cpu-baseline --no-strong --no-bpmf-exe"
+PAT="%k_sample%"
+if [ "$W" = "strong_10Mx1M" ]; then      # the strong-scaling record of the default workload (k_sample4<32> over the device-generated 10M x 1M matrix)
+  CMD="python bench.py --steps 5 --warmup 2 --repeats 1 --prewarm-ms 0 --no-cpu-baseline --no-bpmf-exe --strong-steps 8"
+  PCMD="$CMD"; PAT="%k_sample4%"
+fi
 rm -rf /tmp/prof_kt; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o kt -- $CMD > $O/${R}_bench_under_rocprof_$W.json 2> /tmp/prof_kt.err
 find /tmp/prof_kt -name "*kernel_stats.csv" -exec cp {} $O/${R}_kernel_stats_$W.csv \;
 python - <<PY
@@ -33,11 +39,14 @@ print(open('$O/${R}_kernel_trace_summary_$W.txt').read())
 PY
 if [ "$PMC" = "1" ]; then
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM"; do
-  rm -rf /tmp/prof_pmc; rocprofv3 --pmc $c --kernel-trace -d /tmp/prof_pmc -o p -- python bench.py --workload $W --steps 10 --warmup 2 --repeats 1 --prewarm-ms 0 --no-cpu-baseline --no-strong > /dev/null 2> /tmp/prof_pmc.err
+  rm -rf /tmp/prof_pmc; rocprofv3 --pmc $c --kernel-trace -d /tmp/prof_pmc -o p -- $PCMD > /dev/null 2> /tmp/prof_pmc.err
   DB=$(find /tmp/prof_pmc -name "*.db" | head -1)
-  python tools/pmc_dump.py "$DB" pmc >> $O/${R}_pmc_$W.txt
+  python tools/pmc_dump.py "$DB" pmc "$PAT" >> $O/${R}_pmc_$W.txt
 done
 cat $O/${R}_pmc_$W.txt
 fi
-python bench.py --workload $W --steps 20 --warmup 5 --no-strong --no-cpu-baseline > $O/${R}_bench20_$W.json 2>/dev/null
+# the 20-step line AFTER the counter passes, with their file in place: `profiled.current` is true, `traffic` is this source's
+if [ "$PMC" = "1" ]; then cp $O/${R}_pmc_$W.txt profiles/; fi
+if [ "$W" = "strong_10Mx1M" ]; then python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-bpmf-exe > $O/${R}_bench20_$W.json 2>/dev/null
+else python bench.py --workload $W --steps 20 --warmup 5 --no-strong --no-cpu-baseline --no-bpmf-exe > $O/${R}_bench20_$W.json 2>/dev/null; fi
 tail -1 $O/${R}_bench_under_rocprof_$W.json | cut -c1-400
