@@ -52,6 +52,7 @@ _SIGNATURES = {
     "bpmf_hip_sys_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double]),
     "bpmf_hip_sys_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
+    "bpmf_hip_sys_norm": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "bpmf_hip_failed_column": (C.c_int64, [C.c_void_p]),
     "bpmf_hip_side_aggr_add": (C.c_int, [C.c_void_p]),
     "bpmf_hip_side_aggr_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

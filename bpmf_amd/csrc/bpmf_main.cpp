@@ -318,11 +318,14 @@ void rank_main(Job &J, int rank, std::ostream &os)
         // never waits for the host's printing.  The per-iteration rate is the time between two lines.
         double mark = tick(), norm_m = 0.0, norm_u = 0.0;
         for (int i = 0; i < nsims; ++i) {
-            if (i > 0) check(bpmf_hip_sys_state(movies, nullptr, &norm_m, nullptr, nullptr, nullptr, nullptr));   // of iteration i-1
             check(bpmf_hip_sys_sample(movies, users, alpha));   // movies.sample(users)
-            if (i > 0) check(bpmf_hip_sys_state(users, nullptr, &norm_u, nullptr, nullptr, nullptr, nullptr));    // of iteration i-1
             check(bpmf_hip_sys_sample(users, movies, alpha));   // users.sample(movies)
             if (i > 0) {
+                // norms of iteration i-1 (bpmf_hip_sys_norm waits for THAT half-iteration's sums only: asking bpmf_hip_sys_state
+                // here drained each side's pipeline once per iteration -- 83 M against the 100 M samples/s of the same loop
+                // without it, bench.py's bpmf_exe record of round 4)
+                check(bpmf_hip_sys_norm(movies, i - 1, &norm_m));
+                check(bpmf_hip_sys_norm(users, i - 1, &norm_u));
                 // the evaluation of iteration i-1 ran beside the two samplers just queued
                 finish_both(&se, &se_avg, &num_predict);
                 rmse = std::sqrt(se / (double)num_predict);

@@ -1380,6 +1380,8 @@ void collect(bpmf_hip_side *s, const bpmf_hip_side::Job &job)
             double nn = 0.0;                                          // sum |x|^2 = trace(sum x x^T)  (:381)
             for (int i = 0; i < Kt; ++i) nn += prod[(size_t)i * K + i];
             s->norm = nn;
+            { std::lock_guard<std::mutex> lk(s->wm); s->norm_hist[job.iter & 7] = nn; s->collected_iter = job.iter; }
+            s->wcv.notify_all();
             if (Kt == K) bpmf_cov_from_sums(K, s->ncols, sum, prod, s->cov.data());   // :383-384
             else {                                                    // padded num_latent: the leading Kt x Kt block of the sums
                 static thread_local std::vector<double> pc;
@@ -1720,6 +1722,26 @@ extern "C" int bpmf_hip_sys_state(const bpmf_hip_side *cs, int *iter, double *no
     if (mu) { if (have) memcpy(mu, s->hp_mu.data(), sizeof(double) * K); else memset(mu, 0, sizeof(double) * K); }
     if (LambdaF) { if (have) memcpy(LambdaF, s->hp_LambdaF.data(), sizeof(double) * K * K); else memset(LambdaF, 0, sizeof(double) * K * K); }
     if (LambdaU) { if (have) memcpy(LambdaU, s->hp_LambdaU.data(), sizeof(double) * K * K); else memset(LambdaU, 0, sizeof(double) * K * K); }
+    return BPMF_HIP_OK;
+}
+
+// norm (c++/sample.cpp:381) of half-iteration `iter` of the side (one of its last 8), waiting only until THAT half-iteration has
+// been collected -- later ones may be in flight: the pipelined loop of the `bpmf` executable prints the line of iteration i - 1
+// after it has enqueued iteration i, and must not drain the side for it (bpmf_hip_sys_state does).
+extern "C" int bpmf_hip_sys_norm(bpmf_hip_side *s, int iter, double *norm)
+{
+    if (!s || !norm || iter < 0) return fail(BPMF_HIP_EINVAL, "sys_norm: bad argument");
+    if (iter > s->iter) return fail(BPMF_HIP_EINVAL, "sys_norm: that half-iteration has not been enqueued");
+    if (s->ctx->pending_stats == s && s->iter == iter) {             // its statistics still wait for a launch to ride in: start them
+        HIP_TRY(hipSetDevice(s->ctx->device));
+        const int rc = flush_pending_stats(s->ctx);
+        if (rc) return rc;
+    }
+    std::unique_lock<std::mutex> lk(s->wm);
+    s->wcv.wait(lk, [s, iter] { return s->collected_iter >= iter || s->async_rc != 0 || s->in_flight == 0; });
+    if (s->async_rc) { const int rc = s->async_rc; g_err = s->async_msg; return rc; }      // (left in place: the next sys_sample / sys_state reports it too)
+    if (s->collected_iter < iter || iter <= s->collected_iter - 8) return fail(BPMF_HIP_EINVAL, "sys_norm: that half-iteration is not among the last 8 collected");
+    *norm = s->norm_hist[iter & 7];
     return BPMF_HIP_OK;
 }
 

@@ -332,16 +332,21 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
         __syncthreads();
         stamp(a, w, 4 + 4 * s);
         if (s + 1 < NT) {
-            // C: panel  R_sJ = W_s^T A_sJ  by the owner of tile (s, J): operands from LDS, result back to LDS
+            // C: panel  R_sJ = W_s^T A_sJ  by the owner of tile (s, J): operands from LDS, result back to LDS.
+            // Contraction index of MFMA q, lane group kq: k = 4 kq + q (not 4 q + kq).  The B operands -- the bulk of the
+            // LDS reads of the factorisation -- then come from rows 4 apart, whose offsets 4 (width + 4) = 16 mod 64 words
+            // put the four 16-lane groups on disjoint banks; with consecutive rows (offset width + 4 = 4 mod 64) the groups
+            // overlapped in 12 of 16 banks (r03 PMC: 20.6 % of the LDS cycles were bank conflicts).  Any order of k is the
+            // same sum up to rounding; the order is fixed, so the result is as reproducible as before.
             T opA[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) opA[q] = Rs[li * LDs + 4 * q + kq];           // A[i = li][k = 4 q + kq] of W_s^T
+            for (int q = 0; q < 4; ++q) opA[q] = Rs[li * LDs + 4 * kq + q];           // A[i = li][k = 4 kq + q] of W_s^T
 #pragma unroll
             for (int J = s + 1; J < NT; ++J)
                 if ((G::tri(s, J) % NW) == W) {
                     T opB[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) opB[q] = Rs[(4 * q + kq) * LDs + 16 * (J - s) + li];
+                    for (int q = 0; q < 4; ++q) opB[q] = Rs[(4 * kq + q) * LDs + 16 * (J - s) + li];
                     acc_t t4 = acc_t{0, 0, 0, 0};
 #pragma unroll
                     for (int q = 0; q < 4; ++q) t4 = X::mfma(opA[q], opB[q], t4);
@@ -366,13 +371,13 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
                 if (!any) continue;                                  // compile-time
                 T opI[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) opI[q] = -Rs[(4 * q + kq) * LDs + 16 * (I - s) + li];
+                for (int q = 0; q < 4; ++q) opI[q] = -Rs[(4 * kq + q) * LDs + 16 * (I - s) + li];     // (k = 4 kq + q: see the panel)
 #pragma unroll
                 for (int J = I; J < NT; ++J)
                     if ((G::tri(I, J) % NW) == W) {
                         T opJ[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) opJ[q] = Rs[(4 * q + kq) * LDs + 16 * (J - s) + li];
+                        for (int q = 0; q < 4; ++q) opJ[q] = Rs[(4 * kq + q) * LDs + 16 * (J - s) + li];
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
                             acc[G::tri(I, J) / NW] = X::mfma(opI[q], opJ[q], acc[G::tri(I, J) / NW]);

@@ -287,6 +287,10 @@ struct bpmf_hip_side {
     // state of the reference's Sys (c++/bpmf.h:139,221-226) for bpmf_hip_sys_sample
     int iter = -1;
     double norm = 0.0;
+    // norm of the last few collected half-iterations (bpmf_hip_sys_norm: the line of iteration i - 1 is printed after iteration i
+    // has been enqueued; asking bpmf_hip_sys_state for it would drain the side's pipeline first).  Guarded by `wm`.
+    int collected_iter = -1;
+    double norm_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<double> cov, hp_mu, hp_LambdaU, hp_LambdaF;      // current
     std::vector<double> nx_mu, nx_LambdaU, nx_LambdaF;           // pre-drawn for iteration nx_iter
     int nx_iter = -2;

@@ -238,6 +238,10 @@ BPMF_API int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, doub
  * any output pointer may be NULL */
 BPMF_API int bpmf_hip_sys_state(const bpmf_hip_side *side, int *iter, double *norm, double *cov, double *mu,
                                 double *LambdaF, double *LambdaU);
+/* norm (c++/sample.cpp:381: sum of the squared samples) of half-iteration `iter` of the side -- one of its last 8 -- waiting only
+ * until that half-iteration's sums have landed; later half-iterations may be in flight (bpmf_hip_sys_state would wait for them).
+ * What Sys::print of iteration i - 1 needs (c++/sample.cpp:101-107) when iteration i is already enqueued. */
+BPMF_API int bpmf_hip_sys_norm(bpmf_hip_side *side, int iter, double *norm);
 /* Posterior aggregation for the -o outputs.  _aggr_add replaces `aggrMu.col(i) += r; aggrLambda.col(i) += r r^T` of
  * Sys::sample(Sys&) (c++/sample.cpp:364-368): call it after a post-burn-in bpmf_hip_sys_sample; the K + K*K doubles
  * per LOCAL column live on the device.  _aggr_finalize replaces Sys::finalize_mu_lambda (c++/bpmf.cpp:281-295):
