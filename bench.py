@@ -551,7 +551,7 @@ def bpmf_exe_record(M, T, nusers, nmovies, K, nsims=25, burnin=5):
         wall = time.perf_counter() - t0
         if r.returncode != 0:
             return {"error": "bpmf exited with %d: %s" % (r.returncode, r.stderr[-300:])}
-        per_iter = [float(x) for x in re.findall(r"items/sec:\s*([0-9.eE+]+)", r.stdout)]
+        per_iter = [float(m.group(1)) for l in r.stdout.splitlines() if " iteration " in l for m in [re.search(r"\titems/sec:\s*([0-9.eE+]+)", l)] if m]
         avg = float(re.search(r"Average items/sec: (\S+)", r.stdout).group(1))
         final = float(re.search(r"Final Avg RMSE: (\S+)", r.stdout).group(1))
         steady = per_iter[len(per_iter) // 2:]
