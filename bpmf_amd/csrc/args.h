@@ -101,6 +101,18 @@ struct FusedArgs {
     unsigned long long *st_tmo;        // sticky time-out word of the side the statistics belong to
 };
 
+// pair launch (k_sample1p, kernels.h): the completion count of the first side's columns the second side waits for
+struct PairArgs {
+    // One 128-byte line per word (PAIR_STRIDE unsigned apart): [0, 16) the arrival counters of the first side's columns by
+    // col & 15 (zero between launches), [16] the number of complete shards (zero between launches), [17, 17 + PAIR_NFLAG) copies
+    // of the generation word the second side polls -- thousands of waiting waves on ONE word (and on the line the arrivals
+    // count into) made the first side's tail crawl: pair launch 194 us against 95 us for the two launches.
+    unsigned *words;
+    unsigned gen;               // this launch's generation (monotonic per first side): the flag copies are set to it when all columns are written
+    int nloc;                   // columns the first side writes in this launch
+};
+enum { PAIR_STRIDE = 32, PAIR_NFLAG = 64, PAIR_WORDS = (17 + PAIR_NFLAG) * PAIR_STRIDE };
+
 // users.predict(movies) fused into movies.predict(users) (k_predict): the same prediction goes into the other side's copy
 // of the test entries as well -- entry q of this test matrix is entry perm[q] of the twin (its transpose).  perm = NULL: none.
 struct TwinArgs {

@@ -47,6 +47,7 @@ Rccl *rccl()
 static int settle_async(struct bpmf_hip_side *s);      // waits until the worker is done with `s`; returns its deferred error
 static void flush_deferred(struct bpmf_hip_test *t, bool on_main = false);   // enqueues an evaluation whose launch was put off
 namespace { void predraw_stop(struct bpmf_hip_side *s); }   // joins the side's pre-draw helper threads
+namespace { void discard_prelaunches_touching(struct bpmf_hip_side *s); }   // pair launch: half-iterations enqueued ahead of their sys_sample call that involve `s`
 namespace { int flush_pending_stats(struct bpmf_hip_ctx *c, bool on_main = false); }   // statistics without a launch to ride in: a kernel of their own
 
 struct bpmf_hip_side;
@@ -486,6 +487,11 @@ static int ctx_create_impl(int device, int Ktrue, int dtype, void *stream, bpmf_
 extern "C" int bpmf_hip_ctx_set_no_covariance(bpmf_hip_ctx *c, int on)
 {
     if (!c) return fail(BPMF_HIP_EINVAL, "set_no_covariance: NULL");
+    {
+        std::vector<bpmf_hip_side *> sides;
+        { std::lock_guard<std::mutex> lk(c->launch_mutex); sides = c->sides; }
+        for (bpmf_hip_side *sd : sides) discard_prelaunches_touching(sd);
+    }
     c->diag_only = on ? 1u : 0u;
     return BPMF_HIP_OK;
 }
@@ -613,6 +619,7 @@ extern "C" int bpmf_hip_side_create_dev(bpmf_hip_ctx *ctx, int64_t ncols, int64_
 extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
 {
     if (!s) return BPMF_HIP_OK;
+    discard_prelaunches_touching(s);
     (void)settle_async(s);
     if (s->worker.joinable()) {
         { std::lock_guard<std::mutex> lk(s->wm); s->wstop = true; }
@@ -661,6 +668,7 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
     if (s->a_ticket) (void)hipFree(s->a_ticket);
     if (s->a_dflag) (void)hipFree(s->a_dflag);
     if (s->a_d_red) (void)hipFree(s->a_d_red);
+    if (s->d_pair) (void)hipFree(s->d_pair);
     delete s;
     return BPMF_HIP_OK;
 }
@@ -689,6 +697,7 @@ extern "C" int bpmf_hip_side_set_prop_posterior(bpmf_hip_side *s, const double *
     if (!s) return fail(BPMF_HIP_EINVAL, "set_prop_posterior: NULL");
     (void)mu;
     HIP_TRY(hipSetDevice(s->ctx->device));
+    discard_prelaunches_touching(s);
     { const int rc = settle_async(s); if (rc) return rc; }
     { const int rs_ = bounded_stream_sync(s->ctx, s->ctx->stream, __func__); if (rs_) return rs_; }
     if (s->d_prop) { (void)hipFree(s->d_prop); s->d_prop = nullptr; }
@@ -730,6 +739,7 @@ static int drop_second_copy(bpmf_hip_side *s)
 {
     s->items_exposed = true;
     if (!s->d_items_alt) return 0;
+    discard_prelaunches_touching(s);
     flush_evals_touching(s);                                        // (one may have captured the copy about to be freed)
     (void)settle_async(s);
     HIP_TRY(hipSetDevice(s->ctx->device));
@@ -783,6 +793,7 @@ extern "C" int bpmf_hip_side_set_items(bpmf_hip_side *s, const double *h)
 {
     if (!s || !h) return fail(BPMF_HIP_EINVAL, "set_items: NULL");
     HIP_TRY(hipSetDevice(s->ctx->device));
+    discard_prelaunches_touching(s);                                // (a half-iteration of the partner drawn from the factors being replaced)
     { const int rc = settle_async(s); if (rc) return rc; }
     flush_evals_touching(s);
     HIP_TRY(hipDeviceSynchronize());                                // (an evaluation beside the samplers may still read the factors)
@@ -1061,6 +1072,7 @@ extern "C" int bpmf_hip_sample_side_launch(bpmf_hip_side *self, const bpmf_hip_s
     if (c->comm_dead.load()) return fail(BPMF_HIP_ENODEV, "sample_side: the communicator of this context was aborted (a collective timed out)");
     const int K = c->K;
     HIP_TRY(hipSetDevice(c->device));
+    discard_prelaunches_touching(self);                              // (a half-iteration of the partner drawn from the columns this launch replaces)
     { const int rs = settle_async(self); if (rs) return rs; }
     if (self->saux) { const int rs_ = bounded_stream_sync(self->ctx, self->saux, __func__); if (rs_) return rs_; }
     fill_blob_ctx(c, mu, LambdaF, c->h_in, K == 64 && c->dtype == BPMF_HIP_F64 && self->lr_n > 0);
@@ -1401,12 +1413,20 @@ void collect(bpmf_hip_side *s, const bpmf_hip_side::Job &job)
         const bool own_stats = s->stats_ev[job.evset].load(std::memory_order_acquire) == ev[2];   // else: inside another launch
         if (job.timed && hipEventSynchronize(own_stats ? ev[2] : ev[1]) == hipSuccess && hipEventElapsedTime(&a, ev[0], ev[1]) == hipSuccess) {
             if (own_stats) (void)hipEventElapsedTime(&b, ev[1], ev[2]);
+            if (job.paired && job.partner) {                      // a pair launch: the time of the launch split evenly between its two sides
+                a *= 0.5f;
+                job.partner->pair_credit_ms.store((double)a, std::memory_order_release);
+            }
             s->last_sample_ms = a; s->last_reduce_ms = b; s->timing_valid = true;
             s->tot_sample_ms += a; s->tot_reduce_ms += b; s->n_launches++;
             float g = 0.f;                                         // end of the other side's sampler -> start of this one
             if (job.prev_stop && hipEventElapsedTime(&g, job.prev_stop, ev[0]) == hipSuccess) { s->tot_gap_ms += g; s->n_gap++; }
             else (void)hipGetLastError();
         }
+    }
+    if (job.paired && !job.timed) {                                 // second side of a pair launch: its half, if the launch was timed
+        const double x = s->pair_credit_ms.exchange(0.0, std::memory_order_acq_rel);
+        if (x > 0.0) { s->last_sample_ms = (float)x; s->last_reduce_ms = 0.f; s->timing_valid = true; s->tot_sample_ms += x; s->n_launches++; }
     }
     if (rc && !s->async_rc) { s->async_rc = rc; s->async_msg = msg; }
     trace("collect: done", s, job.iter);
@@ -1518,6 +1538,63 @@ int wait_async(bpmf_hip_side *s, int depth)
 
 static int settle_async(bpmf_hip_side *s) { return wait_async(s, 0); }
 
+namespace {
+
+// the copy of the factors the side's next sampler writes: wait (on `st`) for the evaluation that may still read it
+int claim_second_copy(bpmf_hip_side *s, hipStream_t st)
+{
+    bpmf_hip_side::Reader &rd = s->readers[s->cur_buf ^ 1];
+    if (rd.t) {
+        if (rd.t->deferred && rd.seq == rd.t->seq + 1) flush_deferred(rd.t);
+        if (rd.t->done_seq < rd.seq) HIP_TRY(hipStreamWaitEvent(st, rd.t->ev_done[rd.seq & 1u], 0));
+    }
+    rd.t = nullptr;
+    return 0;
+}
+
+// a half-iteration that was enqueued inside the partner's pair launch and will not be used: wait for that launch, forget it
+void discard_prelaunch(bpmf_hip_side *s)
+{
+    if (s->pre.iter < 0) return;
+    if (s->pre.ev_stop) (void)hipEventSynchronize(s->pre.ev_stop);
+    s->pre = bpmf_hip_side::Prelaunch{};
+    trace("pair: prelaunched half-iteration discarded", s, s->iter + 1);
+}
+
+// every prelaunched half-iteration of the context that involves `s` (as the side it belongs to or as the partner it was computed from)
+void discard_prelaunches_touching(bpmf_hip_side *s)
+{
+    std::vector<bpmf_hip_side *> sides;
+    { std::lock_guard<std::mutex> lk(s->ctx->launch_mutex); sides = s->ctx->sides; }
+    for (bpmf_hip_side *sd : sides)
+        if (sd->pre.iter >= 0 && (sd == s || sd->pre.partner == s)) discard_prelaunch(sd);
+}
+
+// bpmf_hip_sys_sample of a side whose half-iteration already sits in its partner's pair launch: the bookkeeping of Sys::sample
+int accept_prelaunch(bpmf_hip_side *self, bpmf_hip_side *other)
+{
+    bpmf_hip_ctx *c = self->ctx;
+    const bpmf_hip_side::Prelaunch pr = self->pre;
+    self->pre = bpmf_hip_side::Prelaunch{};
+    self->iter = pr.iter;                                            // :344
+    flush_deferred(self->deferred_eval);                              // (beside the launch that is already running)
+    std::swap(self->d_items, self->d_items_alt);                     // everything enqueued from here on sees the new factors
+    self->cur_buf ^= 1;
+    c->last_sampler_done = (env_int("BPMF_HIP_EVAL_MARKER", 0) == 0) ? pr.ev_stop : nullptr;
+    self->stats_ev[pr.evset].store(nullptr, std::memory_order_release);
+    c->pending_stats = self; c->pending_seq = pr.seq; c->pending_evset = pr.evset;      // ride in the next launch
+    c->pending_inorder = false; c->pending_riders = false;
+    self->timing_valid = false;
+    self->last_stop = pr.ev_stop;
+    bpmf_hip_side::Job job{pr.iter, pr.seq, pr.evset, false, nullptr};
+    job.paired = true; job.partner = other;
+    post_collect(self, job);
+    trace("sys_sample: accepted the half-iteration of the partner's pair launch", self, pr.iter);
+    return BPMF_HIP_OK;
+}
+
+}  // namespace
+
 extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, double alpha)
 {
     if (!self || !other) return fail(BPMF_HIP_EINVAL, "sys_sample: NULL argument");
@@ -1537,6 +1614,11 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     // one half-iteration of this side may still be uncollected: its worker opens our gate
     if ((rc = wait_async(self, 1))) return rc;
     trace("sys_sample: may enqueue", self, self->iter + 1);
+    if (self->pre.iter >= 0) {
+        if (self->pre.iter == self->iter + 1 && self->pre.partner == other && self->pre.alpha == alpha) return accept_prelaunch(self, other);
+        discard_prelaunch(self);
+    }
+    if (other->pre.iter >= 0) discard_prelaunch(other);              // (the partner's prelaunched sample was drawn from the factors this call replaces)
 
     const int iter = self->iter + 1;                                  // :344
     bool chained;
@@ -1624,6 +1706,67 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     const bool ride = s1 != s0 && self->nwork > 0 && env_int("BPMF_HIP_EXT_EVENTS", 1) != 0;   // events on the sampler's own packet
     if (timed && !ride) HIP_TRY(hipEventRecord(ev[0], s0));
     if (inorder_flush) { if ((rc = flush_pending_stats_inorder(c))) return rc; }
+    // ---- pair launch: this half-iteration and the partner's next one in ONE grid (k_sample1p, kernels.h) ----
+    {
+        // BPMF_HIP_PAIR=1 (opt-in; read per call: the tests switch it inside one process).  Built in round 4 as costed in round 3,
+        // parity-green, and MEASURED: the pair launch takes what the two launches take (95.7 against 95.0 us on the ML-1M shape:
+        // the overlap of one side's tail with the other's ramp does not materialise, the waiting workgroups hold the slots the
+        // tail's last items would be dispatched into), and the evaluation that used to run in the boundary between the two
+        // launches lands a whole launch later, which the host loop waits for: 0.127 against 0.097 ms per iteration.
+        const int pair_on = env_int("BPMF_HIP_PAIR", 0);
+        bool pair = pair_on && fused && ride && K <= 32 && self != other && self->mode == 1 && other->mode == 1 && !c->ablate && !c->d_stamps &&
+                    env_int("BPMF_HIP_SLAB32", 0) == 0 && other->a_d_in && other->nwork > 0 && !other->reduce_on && other->iter >= 0 && other->pre.iter < 0 &&
+                    self->nsub <= 1 && other->nsub <= 1 && self->item_n < 0 && second_copy_usable(self) && second_copy_usable(other) &&
+                    (P == nullptr || (carry && P == other));
+        if (pair) {                                                   // the partner's gate for its next iteration will open without its sys_sample call
+            std::lock_guard<std::mutex> lk(other->wm);
+            pair = (other->in_flight > 0 || other->gate_iter == other->iter + 1) && other->async_rc == 0;
+        }
+        if (pair && !self->d_pair) {
+            if (hipMalloc((void **)&self->d_pair, bpmf::PAIR_WORDS * sizeof(unsigned)) != hipSuccess ||
+                hipMemsetAsync(self->d_pair, 0, bpmf::PAIR_WORDS * sizeof(unsigned), s0) != hipSuccess) { (void)hipGetLastError(); self->d_pair = nullptr; pair = false; }
+        }
+        if (pair) {
+            const int iterB = other->iter + 1;
+            const unsigned seqB = ++other->a_seq;
+            const int evsetB = (int)(seqB & 1u);
+            if ((rc = claim_second_copy(self, s0)) || (rc = claim_second_copy(other, s0))) return rc;
+            bpmf::FusedArgs fb{};
+            fb.gate_host = other->a_gate_dev; fb.gate_want = (unsigned)(iterB + 1); fb.src_host = other->a_h_in_dev;
+            fb.dst = other->a_d_in; fb.n = (int)c->in_words; fb.dflag = other->a_dflag; fb.dval = seqB;
+            // this side's own statistics ride in the second half (they wait for its columns like the partner's items do)
+            fb.nstat = self->nstat_waves; fb.st_items = self->d_items_alt; fb.st_c0 = self->from; fb.st_c1 = self->to;
+            fb.st_partials = self->d_stat_partials;
+            fb.st_fail = (const unsigned long long *)(self->a_d_in + (size_t)K * K + K);
+            fb.st_out = self->a_h_out_dev; fb.st_ticket = self->a_ticket;
+            fb.st_flag = reinterpret_cast<unsigned *>(self->a_h_out_dev + c->out_words - 1); fb.st_seq = seq;
+            fb.st_tmo = tmo_word(self->a_h_out_dev, K);
+            bpmf::PairArgs pa{};
+            pa.words = self->d_pair; pa.gen = ++self->pair_launches; pa.nloc = (int)(self->to - self->from);
+            rc = BPMF_DISPATCH_K(K, (bpmf_launch::sampler_pair<KK, FF>(self, self->d_items_alt, iter, self->a_d_in, fz, other, other->d_items_alt, iterB, other->a_d_in, fb,
+                                                                      seq, seqB, alpha, pa, s0, timed ? ev[0] : nullptr, ev[1])));
+            bpmf_launch::next_flags() = 0;
+            if (rc) return rc;
+            std::swap(self->d_items, self->d_items_alt);             // (the partner's copies swap when ITS sys_sample call accepts the half-iteration)
+            self->cur_buf ^= 1;
+            c->last_sampler_done = (env_int("BPMF_HIP_EVAL_MARKER", 0) == 0) ? ev[1] : nullptr;
+            // (P's statistics ride in the FIRST half; no event for its collector to block on: this launch only ends after P's own
+            // next gate has opened, which is that collector's job -- it polls the result word instead)
+            c->pending_stats = nullptr; c->pending_riders = false; c->pending_inorder = false;
+            self->stats_ev[evset].store(ev[1], std::memory_order_release);      // its statistics are inside this launch
+            other->pre.iter = iterB; other->pre.seq = seqB; other->pre.evset = evsetB; other->pre.alpha = alpha; other->pre.partner = self;
+            other->pre.ev_stop = ev[1];
+            self->pair_seen = other->pair_seen = true;
+            HIP_TRY(hipGetLastError());
+            self->timing_valid = false;
+            self->last_stop = ev[1];
+            bpmf_hip_side::Job job{iter, seq, evset, timed, nullptr};
+            job.paired = true; job.partner = other;
+            post_collect(self, job);
+            trace("sys_sample: pair launch enqueued", self, iter);
+            return BPMF_HIP_OK;
+        }
+    }
     self->cur_fused = fz;
     self->cur_riders = riders;
     self->cur_gate_flag = fused ? self->a_dflag : nullptr; self->cur_gate_want = seq;
@@ -1781,7 +1924,11 @@ extern "C" int bpmf_hip_side_kernel_name(const bpmf_hip_side *s, char *buf, int 
         else if (s->mode == 6) name = "k_sample1q<" + k + ">";
         else if (s->mode == 7) name = "k_sample1x<" + k + ">";
         else if (s->mode == 8) name = "k_sample1q<" + k + ",split> + k_finish_groups<" + k + ">";
-        else if (s->mode == 1) name = ((K == 32 || K == 16) && env_int("BPMF_HIP_SLAB32", 0) ? "k_sample1s<" : "k_sample1<") + k + ">";
+        else if (s->mode == 1) {
+            name = ((K == 32 || K == 16) && env_int("BPMF_HIP_SLAB32", 0) ? "k_sample1s<" : "k_sample1<") + k + ">";
+            // stateful single-GPU path: both half-iterations of an iteration in one grid (bpmf_hip_sys_sample: pair launch)
+            if (s->pair_seen) name = "k_sample1p<" + k + ">";
+        }
         else name = "k_sample<" + k + ">";
     }
     snprintf(buf, (size_t)n, "%s", name.c_str());
@@ -1801,7 +1948,13 @@ extern "C" int bpmf_hip_side_kernel_resources(bpmf_hip_side *s, int64_t *out, in
     bpmf_launch::Probe pr;
     bpmf_launch::probe() = &pr;
     const bool sa = s->stat_a_ready;
-    const int rc = BPMF_DISPATCH_K(c->K, (bpmf_launch::sampler_into<KK, FF>(s, s->d_items, s, 0, 1.0, c->d_in, c->stream, nullptr, nullptr)));
+    int rc;
+    if (s->pair_seen) {                                               // its half-iterations run inside pair launches
+        const bpmf::FusedArgs f0{};
+        const bpmf::PairArgs p0{};
+        rc = BPMF_DISPATCH_K(c->K, (bpmf_launch::sampler_pair<KK, FF>(s, s->d_items, 0, c->d_in, f0, s, s->d_items, 0, c->d_in, f0, 0u, 0u, 1.0, p0, c->stream, nullptr, nullptr)));
+    } else
+    rc = BPMF_DISPATCH_K(c->K, (bpmf_launch::sampler_into<KK, FF>(s, s->d_items, s, 0, 1.0, c->d_in, c->stream, nullptr, nullptr)));
     bpmf_launch::probe() = nullptr;
     s->stat_a_ready = sa;
     if (rc) return rc;
@@ -2166,7 +2319,13 @@ extern "C" int bpmf_hip_test_create(bpmf_hip_side *side, const int64_t *tcolptr,
         delete t;
         return fail(BPMF_HIP_ENOMEM, "test_create: device allocation failed");
     }
-    t->nblocks = std::max<int64_t>(1, (nnz + 255) / 256);       // one lane per test rating
+    // one lane per test rating, four-wave workgroups; BPMF_HIP_PREDICT_WG=64: single-wave workgroups (up to 4 M ratings, fp64
+    // contexts), which find wave slots beside a sampler launch that refills every slot with single-wave workgroups
+    // (MEASURED, ML-1M shape: 64-thread workgroups make the evaluation compete with the sampler's items for every slot -- the
+    // movies' launch 44.5 -> 53.6 us, the iteration 0.097 -> 0.107 ms; four-wave workgroups wait for the boundary between two
+    // launches, where the chip drains anyway.  256 stays the default.)
+    t->wg = (nnz <= ((int64_t)4 << 20) && side->ctx->dtype == BPMF_HIP_F64 && env_int("BPMF_HIP_PREDICT_WG", 256) == 64) ? 64 : 256;
+    t->nblocks = std::max<int64_t>(1, (nnz + t->wg - 1) / t->wg);
     const int64_t nw = t->nblocks;
     int rc;
     if ((rc = dev_upload(&t->d_tcol, tcol.data(), (size_t)nnz)) || (rc = dev_upload(&t->d_trow, trowidx, (size_t)nnz)) ||

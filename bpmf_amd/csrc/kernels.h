@@ -830,7 +830,9 @@ __device__ __forceinline__ void assemble16(const d4 (&acc)[Geo<K>::NTRI], const 
     }
 }
 
-template <int K, typename Assemble>
+// WT: the sample is stored write-through (relaxed device-scope atomic store): another workgroup of the SAME launch reads it
+// (k_sample1p: the partner side's items wait in-kernel for this side's columns)
+template <int K, bool WT = false, typename Assemble>
 __device__ __forceinline__ void finish_single(const SampleArgs &a, int col_local, double *lds, int lane_in, bool have_z,
                                               Assemble &&assemble)
 {
@@ -986,7 +988,8 @@ __device__ __forceinline__ void finish_single(const SampleArgs &a, int col_local
     }
     const double xi = bi * my_dinv;
 
-    if (lane < K) a.items[(size_t)idx * K + lane] = xi;           // items().col(idx) = rr (:324)
+    if constexpr (WT) { if (lane < K) __hip_atomic_store(&a.items[(size_t)idx * K + lane], xi, BPMF_RLX_AGENT); }
+    else if (lane < K) a.items[(size_t)idx * K + lane] = xi;       // items().col(idx) = rr (:324)
     // a non-positive (or NaN) pivot makes its 1/sqrt NaN or inf, which reaches every later entry
     // and the sample itself: Eigen LLT's info() != Success -> THROWERROR("Cholesky failed") (:308)
     const bool bad = !(fabs(xi) <= 1.79769313486231570815e+308);
@@ -1021,6 +1024,114 @@ __device__ __forceinline__ void colstats_body(int w, const double *__restrict__ 
 __device__ __forceinline__ void gate_stage_body(int block, int nblocks, const unsigned *gate_host, unsigned want, const double *src_host,
                                                 double *__restrict__ dst, int n, unsigned *dflag, unsigned dval,
                                                 unsigned long long *tmo, unsigned long long wait_ticks);
+
+// ---- pair launch (k_sample1p): both half-iterations of a Gibbs iteration in ONE grid ---------------------------
+// The second side's items sit behind the first side's in the same grid.  They request their index blocks and draw their
+// normals while the first side's last items still run, then wait (wait_partner) until every column of the first side has
+// been written: the tail of one launch and the ramp of the next overlap, and one of the two kernel boundaries per iteration
+// is gone.  Why this is safe: (a) the workgroups of a grid are handed out in order (per XCD: workgroup i -> XCD i mod 8), so
+// when a workgroup of the second side spins, every workgroup of the first side is resident or finished -- no deadlock (two
+// kernels on two queues do NOT have that property); (b) no cache can hold a stale line of the columns waited for: they are
+// stored write-through (finish_single<.., WT>) into the copy of the factor matrix that was last READ two launches ago (the
+// samplers write the copy that is not current), and every launch starts with invalidated caches.  Completion count: one
+// hot word takes ~88 RMW / us and a launch retires ~130 items / us, so the columns count into 16 shards (col & 15), each on
+// a line of its own; the last arriver of the last shard writes the launch's generation into 64 copies of the flag the
+// waiters poll (one copy per workgroup id mod 64).
+enum { BPMF_TMO_PARTNER = 4 };
+
+__device__ __forceinline__ void pair_signal(const PairArgs &p, int col, int lane)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the column's write-through stores have landed
+    if (lane == 0) {
+        const int sh = col & 15;
+        const unsigned expect = (unsigned)((p.nloc - sh + 15) >> 4);  // columns with col % 16 == sh
+        const unsigned nshard = (unsigned)(p.nloc < 16 ? p.nloc : 16); // shards that have columns at all
+        const unsigned t = __hip_atomic_fetch_add(&p.words[sh * PAIR_STRIDE], 1u, BPMF_RLX_AGENT);
+        if (t + 1u == expect) {
+            __hip_atomic_store(&p.words[sh * PAIR_STRIDE], 0u, BPMF_RLX_AGENT);      // re-arm for the next pair launch
+            const unsigned d = __hip_atomic_fetch_add(&p.words[16 * PAIR_STRIDE], 1u, BPMF_RLX_AGENT);
+            if (d + 1u == nshard) {                                   // every column of the first side is written
+                __hip_atomic_store(&p.words[16 * PAIR_STRIDE], 0u, BPMF_RLX_AGENT);
+                for (int j = 0; j < PAIR_NFLAG; ++j) __hip_atomic_store(&p.words[(17 + j) * PAIR_STRIDE], p.gen, BPMF_RLX_AGENT);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void wait_partner(const PairArgs &p, unsigned long long *tmo, unsigned long long wait_ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    const unsigned *flag = &p.words[(17 + (blockIdx.x & (PAIR_NFLAG - 1))) * PAIR_STRIDE];    // (one of 64 copies: the pollers spread over 64 lines)
+    // (signed distance: the generation is monotonic and may wrap)
+    while ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - p.gen) < 0) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wait_ticks && wall_clock64() - t0 > wait_ticks) {
+            if (threadIdx.x == 0) flag_timeout(tmo, BPMF_TMO_PARTNER);
+            break;
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+
+// one work item of a pair launch, K <= 32 (the item body of k_sample1: index blocks, normals, Gram on the 4x4x4 MFMA shape, chunk
+// hand-over, factorisation).  ROLE 1 / 2: first / second side (1 signals its columns, 2 waits for the first side's before its
+// first gather).
+template <int K, int ROLE>
+__device__ __forceinline__ void sample1_item44(const SampleArgs &a, int w, double *lds, int lane, const PairArgs &p)
+{
+    const int col = a.wi_col[w];
+    const int64_t p0 = a.wi_p0[w];
+    const int len = a.wi_len[w];
+    const int mc = a.wi_mc[w];
+    const int glen = (a.ablate & 2u) ? 0 : len;
+    const IdxBlock ib0 = load_idx_block(a.rowidx + p0, a.vals + p0, 0, lane, glen, a.zero_row);
+    const IdxBlock ib1 = load_idx_block(a.rowidx + p0, a.vals + p0, 64, lane, glen, a.zero_row);
+    if (mc < 0 && !(a.ablate & 1u))
+        draw_normals<K>(sample_counter(a.col_from + col, a.ktrue, a.iter_plus_1), a.ktrue, lds + Geo1<K>::AWORDS + K, lane, K);
+    if constexpr (ROLE == 2) wait_partner(p, a.tmo, a.wait_ticks);    // the rows gathered below are the first side's fresh columns
+    using G4 = Geo44<K>;
+    constexpr int NB = G4::NB, NG = G4::NG, PART = G4::PART;
+    double acc[NB], rr[NG];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) acc[t] = 0.0;
+#pragma unroll
+    for (int t = 0; t < NG; ++t) rr[t] = 0.0;
+    gram_chunk44<K>(a.rowidx + p0, a.vals + p0, glen, a.other_items, a.zero_row, a.mean_rating, a.alpha, ib0, ib1, acc, rr, lane,
+                    (a.ablate & 4u) ? 63 : -1);
+    if (mc >= 0) {
+        const int nch = a.mc_nchunks[mc];
+        double *pbase = a.partials + (size_t)a.mc_slot0[mc] * PART;
+        double *pp = pbase + (size_t)a.wi_chunk[w] * PART;
+#pragma unroll
+        for (int t = 0; t < NB; ++t) __hip_atomic_store(&pp[t * 64 + lane], acc[t], BPMF_RLX_AGENT);
+#pragma unroll
+        for (int t = 0; t < NG; ++t) __hip_atomic_store(&pp[(NB + t) * 64 + lane], rr[t], BPMF_RLX_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(&a.mc_count[mc], 1u, BPMF_RLX_AGENT);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if ((int)t != nch - 1) return;
+        if (lane == 0) __hip_atomic_store(&a.mc_count[mc], 0u, BPMF_RLX_AGENT);
+#pragma unroll
+        for (int t2 = 0; t2 < NB; ++t2) acc[t2] = 0.0;
+#pragma unroll
+        for (int t2 = 0; t2 < NG; ++t2) rr[t2] = 0.0;
+        for (int ch = 0; ch < nch; ++ch) {
+            const double *pc = pbase + (size_t)ch * PART;
+            double tmp[NB + NG];
+#pragma unroll
+            for (int t2 = 0; t2 < NB + NG; ++t2) tmp[t2] = __hip_atomic_load(&pc[t2 * 64 + lane], BPMF_RLX_AGENT);
+#pragma unroll
+            for (int t2 = 0; t2 < NB; ++t2) acc[t2] += tmp[t2];
+#pragma unroll
+            for (int t2 = 0; t2 < NG; ++t2) rr[t2] += tmp[NB + t2];
+        }
+    }
+    wait_params(a);
+    finish_single<K, true>(a, col, lds, lane, mc < 0,
+                           [&](double *sA, double *sb, int LD, int ln) { assemble44<K>(acc, rr, sA, sb, LD, ln); });
+    if constexpr (ROLE == 1) pair_signal(p, col, lane);
+}
 
 template <int K>
 __global__ __launch_bounds__(64, Geo1<K>::WPS) void k_sample1(SampleArgs a, FusedArgs f)
@@ -1157,6 +1268,44 @@ __global__ __launch_bounds__(64, Geo1<K>::WPS) void k_sample1(SampleArgs a, Fuse
         finish_single<K>(a, col, lds, lane, mc < 0,
                          [&](double *sA, double *sb, int LD, int ln) { assemble16<K>(acc, r, sA, sb, LD, ln); });
     }
+}
+
+// Pair launch: grid = [gate A][statistics riders of the side sampled before A][items of A] [gate B][statistics riders of A][items of B].
+// fa / fb: what each half carries besides its items (as k_sample1's FusedArgs); the riders of the second half read A's fresh
+// columns and wait for them like B's items do.
+template <int K>
+__global__ __launch_bounds__(64, Geo1<K>::WPS) void k_sample1p(SampleArgs a, FusedArgs fa, SampleArgs b, FusedArgs fb, PairArgs p)
+{
+    static_assert(K <= 32, "the pair launch exists for the one-item-per-wave form, K <= 32");
+    __shared__ __attribute__((aligned(16))) double lds[Geo1<K>::LDS_WORDS];
+    const int lane = threadIdx.x;
+    int bid = blockIdx.x;
+    const int n1 = (fa.gate_host ? 1 : 0) + fa.nstat + a.nwork;
+    if (bid < n1) {
+        if (fa.gate_host) {
+            if (bid == 0) { gate_stage_body(0, 1, fa.gate_host, fa.gate_want, fa.src_host, fa.dst, fa.n, fa.dflag, fa.dval, a.tmo, a.wait_ticks); return; }
+            --bid;
+        }
+        if (bid < fa.nstat) {
+            colstats_body<K>(bid, fa.st_items, fa.st_c0, fa.st_c1, fa.nstat, fa.st_partials, fa.st_fail, fa.st_out, fa.st_ticket, fa.st_flag, fa.st_seq,
+                             fa.st_tmo, a.wait_ticks);
+            return;
+        }
+        sample1_item44<K, 1>(a, bid - fa.nstat, lds, lane, p);
+        return;
+    }
+    bid -= n1;
+    if (fb.gate_host) {
+        if (bid == 0) { gate_stage_body(0, 1, fb.gate_host, fb.gate_want, fb.src_host, fb.dst, fb.n, fb.dflag, fb.dval, b.tmo, b.wait_ticks); return; }
+        --bid;
+    }
+    if (bid < fb.nstat) {
+        wait_partner(p, fb.st_tmo, b.wait_ticks);                     // A's columns are what these riders sum
+        colstats_body<K>(bid, fb.st_items, fb.st_c0, fb.st_c1, fb.nstat, fb.st_partials, fb.st_fail, fb.st_out, fb.st_ticket, fb.st_flag, fb.st_seq,
+                         fb.st_tmo, b.wait_ticks);
+        return;
+    }
+    sample1_item44<K, 2>(b, bid - fb.nstat, lds, lane, p);
 }
 
 // ---------------------------------------------------------------------------
@@ -1359,7 +1508,8 @@ __device__ __forceinline__ void colstats_body(int w, const double *__restrict__ 
     if (f == 0 && lane == 0) {
         // failed column: as the u64 word of the blob, and as a double (0 = none, id + 1 otherwise)
         // that survives a SUM all-reduce of the blob over the ranks
-        const unsigned long long fw = *fail_in;
+        // (device-scope load: in a pair launch the word may have been lowered by an item of this very launch on another XCD)
+        const unsigned long long fw = __hip_atomic_load(fail_in, BPMF_RLX_AGENT);
         __hip_atomic_store(&out[K * K + K], (fw == ~0ull) ? 0.0 : (double)(fw + 1ull), BPMF_RLX_SYSTEM);
         __hip_atomic_store(&reinterpret_cast<unsigned long long *>(out)[K * K + K + 1], fw, BPMF_RLX_SYSTEM);
     }
@@ -1513,18 +1663,22 @@ __global__ __launch_bounds__(256) void k_colstats_wg(const double *__restrict__ 
     publish_when_last(ticket + 1, (unsigned)nfin, flag, seq, ticket);
 }
 
-template <int K>
-__global__ __launch_bounds__(256) void k_predict(const int32_t *__restrict__ tcol, const int32_t *__restrict__ trow,
+// NT: threads per workgroup.  256 by default; 64 (single-wave workgroups) for small test sets: beside a sampler launch that
+// keeps refilling every wave slot with single-wave workgroups a four-wave workgroup only gets in when the launch drains --
+// with ONE launch per iteration (k_sample1p) the evaluation then landed a whole launch late and the host loop waited for it.
+template <int K, int NT = 256>
+__global__ __launch_bounds__(NT) void k_predict(const int32_t *__restrict__ tcol, const int32_t *__restrict__ trow,
                                                  const double *__restrict__ tval, int64_t nnz,
                                                  const double *__restrict__ items, const double *__restrict__ other,
                                                  int64_t col_from, double mean, int n, double *__restrict__ pavg,
                                                  double *__restrict__ pm2, double *partial, double *__restrict__ out,
                                                  unsigned *ticket, unsigned *flag, unsigned seq, TwinArgs tw)
 {
-    __shared__ double red[4][4];
-    __shared__ double fin[4][256];
+    __shared__ double red[4][NT / 64];
+    __shared__ double fin[4][NT];
     __shared__ unsigned last;
-    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    auto wsum = [](const double (&r)[NT / 64]) { if constexpr (NT == 256) return (r[0] + r[1]) + (r[2] + r[3]); else return r[0]; };
+    const int64_t q = (int64_t)blockIdx.x * NT + threadIdx.x;
     double se = 0.0, se_avg = 0.0, se_t = 0.0, se_avg_t = 0.0;
     if (q < nnz) {
         const double2 *m = reinterpret_cast<const double2 *>(items + (size_t)(col_from + tcol[q]) * K);
@@ -1570,11 +1724,11 @@ __global__ __launch_bounds__(256) void k_predict(const int32_t *__restrict__ tco
     if ((threadIdx.x & 63) == 0) { red[0][wv] = se; red[1][wv] = se_avg; red[2][wv] = se_t; red[3][wv] = se_avg_t; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_store(&partial[2 * blockIdx.x], (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), BPMF_RLX_AGENT);
-        __hip_atomic_store(&partial[2 * blockIdx.x + 1], (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]), BPMF_RLX_AGENT);
+        __hip_atomic_store(&partial[2 * blockIdx.x], wsum(red[0]), BPMF_RLX_AGENT);
+        __hip_atomic_store(&partial[2 * blockIdx.x + 1], wsum(red[1]), BPMF_RLX_AGENT);
         if (tw.perm) {
-            __hip_atomic_store(&tw.partial[2 * blockIdx.x], (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]), BPMF_RLX_AGENT);
-            __hip_atomic_store(&tw.partial[2 * blockIdx.x + 1], (red[3][0] + red[3][1]) + (red[3][2] + red[3][3]), BPMF_RLX_AGENT);
+            __hip_atomic_store(&tw.partial[2 * blockIdx.x], wsum(red[2]), BPMF_RLX_AGENT);
+            __hip_atomic_store(&tw.partial[2 * blockIdx.x + 1], wsum(red[3]), BPMF_RLX_AGENT);
         }
         // the last block to arrive adds the block partials up (fixed-shape tree: the result does
         // not depend on which block that is) and publishes the two sums
@@ -1587,7 +1741,7 @@ __global__ __launch_bounds__(256) void k_predict(const int32_t *__restrict__ tco
     {
         const int64_t nblocks = gridDim.x;
         double a = 0.0, b = 0.0, at = 0.0, bt = 0.0;
-        for (int64_t w = threadIdx.x; w < nblocks; w += 256) {
+        for (int64_t w = threadIdx.x; w < nblocks; w += NT) {
             a += __hip_atomic_load(&partial[2 * w], BPMF_RLX_AGENT);
             b += __hip_atomic_load(&partial[2 * w + 1], BPMF_RLX_AGENT);
             if (tw.perm) {
@@ -1597,7 +1751,7 @@ __global__ __launch_bounds__(256) void k_predict(const int32_t *__restrict__ tco
         }
         fin[0][threadIdx.x] = a; fin[1][threadIdx.x] = b; fin[2][threadIdx.x] = at; fin[3][threadIdx.x] = bt;
         __syncthreads();
-        for (int st = 128; st >= 1; st >>= 1) {
+        for (int st = NT / 2; st >= 1; st >>= 1) {
             if ((int)threadIdx.x < st) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) fin[c][threadIdx.x] += fin[c][threadIdx.x + st];

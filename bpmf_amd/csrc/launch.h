@@ -49,6 +49,13 @@ inline unsigned take_flags() { unsigned &f = next_flags(); const unsigned v = f;
 template <int K, bool F32>
 int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *other, int iter, double alpha, double *d_in, hipStream_t st,
                  hipEvent_t ev_start, hipEvent_t ev_stop);
+// Pair launch (K <= 32, one item per wave, fused stateful path): the half-iteration of `A` and the following one of `B` in ONE
+// grid (k_sample1p).  outA / outB: the factor copies they write; B gathers from outA.  fa / fb: gate + statistics riders of the
+// two halves.  Returns BPMF_HIP_EINVAL for K > 32.
+template <int K, bool F32>
+int sampler_pair(bpmf_hip_side *A, double *outA, int iterA, double *d_inA, const bpmf::FusedArgs &fa,
+                 bpmf_hip_side *B, double *outB, int iterB, double *d_inB, const bpmf::FusedArgs &fb,
+                 unsigned gate_wantA, unsigned gate_wantB, double alpha, const bpmf::PairArgs &p, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop);
 // multi-GPU: every rank's fresh columns travel to the others, in place in the replicated factor matrix.
 // sub < 0: the whole range of every rank; sub >= 0: sub-range `sub` of every rank (bpmf_hip_side_set_overlap:
 // the exchange of one part of a side's columns runs on a stream of its own beside the sampling of the next part)

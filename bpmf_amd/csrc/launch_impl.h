@@ -223,6 +223,39 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
 }
 
 template <int K, bool F32>
+int sampler_pair(bpmf_hip_side *A, double *outA, int iterA, double *d_inA, const bpmf::FusedArgs &fa,
+                 bpmf_hip_side *B, double *outB, int iterB, double *d_inB, const bpmf::FusedArgs &fb,
+                 unsigned gate_wantA, unsigned gate_wantB, double alpha, const bpmf::PairArgs &p, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop)
+{
+    using namespace bpmf;
+    if constexpr (K > 32 || F32) return fail(BPMF_HIP_EINVAL, "pair launch: K <= 32 in fp64 only");
+    else {
+    bpmf_hip_ctx *c = A->ctx;
+    auto fill = [&](SampleArgs &a, bpmf_hip_side *self, double *out_items, const double *other_items, int iter, double *d_in, unsigned gate_want) {
+        a = SampleArgs{};
+        a.rowidx = self->d_rowidx; a.vals = self->d_vals;
+        a.wi_col = self->d_wi_col; a.wi_p0 = self->d_wi_p0; a.wi_len = self->d_wi_len; a.wi_mc = self->d_wi_mc; a.wi_chunk = self->d_wi_chunk;
+        a.mc_slot0 = self->d_mc_slot0; a.mc_nchunks = self->d_mc_nch; a.mc_count = self->d_mc_count;
+        a.partials = self->d_partials; a.nwork = self->nwork;
+        a.other_items = other_items; a.items = out_items; a.col_from = self->from;
+        a.LambdaF = d_in; a.Lmu = d_in + (size_t)K * K;
+        a.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
+        a.mu = d_in + (size_t)K * K + K + 2; a.prop_lambda = self->d_prop; a.diag_only = c->diag_only;
+        a.mean_rating = self->mean_rating; a.alpha = alpha; a.iter_plus_1 = (uint32_t)(iter + 1); a.ktrue = c->Kt;
+        a.gate_flag = self->a_dflag; a.gate_want = gate_want;
+        a.tmo = tmo_word(self->a_h_out_dev, K); a.wait_ticks = wait_ticks();
+        a.zero_row = c->d_zero;
+    };
+    SampleArgs a, b;
+    fill(a, A, outA, B->d_items, iterA, d_inA, gate_wantA);            // A gathers from B's CURRENT copy
+    fill(b, B, outB, outA, iterB, d_inB, gate_wantB);                 // B gathers from the copy A writes in this launch
+    const unsigned grid = (unsigned)((fa.gate_host ? 1 : 0) + fa.nstat + a.nwork + (fb.gate_host ? 1 : 0) + fb.nstat + b.nwork);
+    BPMF_LAUNCH(k_sample1p<K>, dim3(grid), dim3(64), st, ev_start, ev_stop, a, fa, b, fb, p);
+    return 0;
+    }
+}
+
+template <int K, bool F32>
 int exchange(bpmf_hip_side *self, hipStream_t st, int sub)
 {
     bpmf_hip_ctx *c = self->ctx;
@@ -434,11 +467,19 @@ void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items
         tw.partial = u->d_partial; tw.out = u->h_res_dev; tw.flag = reinterpret_cast<unsigned *>(u->h_res_dev + 2); tw.seq = ++u->seq;
         u->pstream = ps; u->launched = true;
     }
-    hipLaunchKernelGGL(bpmf::k_predict<K>, dim3((unsigned)t->nblocks), dim3(256), 0, ps,
+    const unsigned pseq = dist ? 0u : ++t->seq;
+    if (t->wg == 64)                                                  // single-wave workgroups (small test sets: see k_predict)
+        hipLaunchKernelGGL((bpmf::k_predict<K, 64>), dim3((unsigned)t->nblocks), dim3(64), 0, ps,
+                           (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz,
+                           (const double *)self_items, (const double *)other_items, self->from, self->mean_rating, n,
+                           t->d_pavg, t->d_pm2, t->d_partial, dist ? red : t->h_res_dev, t->d_ticket,
+                           dist ? t->d_ticket + 8 : flag, pseq, tw);
+    else
+    hipLaunchKernelGGL((bpmf::k_predict<K, 256>), dim3((unsigned)t->nblocks), dim3(256), 0, ps,
                        (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz,
                        (const double *)self_items, (const double *)other_items, self->from, self->mean_rating, n,
                        t->d_pavg, t->d_pm2, t->d_partial, dist ? red : t->h_res_dev, t->d_ticket,
-                       dist ? t->d_ticket + 8 : flag, dist ? 0u : ++t->seq, tw);
+                       dist ? t->d_ticket + 8 : flag, pseq, tw);
     if (dist) {
         if (rccl()->AllReduce(red, red, 2, ncclDouble, ncclSum, c->comm, c->stream) != ncclSuccess) return;
         publish(red, t->h_res_dev, 2, flag, ++t->seq, -1, c->stream);
@@ -455,4 +496,6 @@ void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items
     template int bpmf_launch::exchange<KK, FF>(bpmf_hip_side *, hipStream_t, int);                                                        \
     template int bpmf_launch::stats<KK, FF>(bpmf_hip_side *, hipStream_t, const double *, double *, unsigned *, unsigned, unsigned *, hipEvent_t); \
     template int bpmf_launch::stats_a<KK, FF>(bpmf_hip_side *, hipStream_t, const double *, double *, unsigned *);                       \
-    template void bpmf_launch::predict<KK, FF>(bpmf_hip_test *, const bpmf_hip_side *, const void *, const void *, int, hipStream_t, bool);
+    template void bpmf_launch::predict<KK, FF>(bpmf_hip_test *, const bpmf_hip_side *, const void *, const void *, int, hipStream_t, bool);   \
+    template int bpmf_launch::sampler_pair<KK, FF>(bpmf_hip_side *, double *, int, double *, const bpmf::FusedArgs &, bpmf_hip_side *, double *, int, double *, \
+                                                   const bpmf::FusedArgs &, unsigned, unsigned, double, const bpmf::PairArgs &, hipStream_t, hipEvent_t, hipEvent_t);

@@ -76,9 +76,10 @@ inline unsigned long long wait_ticks()
     static const unsigned long long v = (unsigned long long)std::max(1, env_int("BPMF_HIP_WAIT_TIMEOUT_MS", 20000)) * 100000ull;
     return v;
 }
-static const char *const kTimeoutWhat[4] = {"", "the gate of the hyper-parameters never opened (host worker stalled?)",
+static const char *const kTimeoutWhat[5] = {"", "the gate of the hyper-parameters never opened (host worker stalled?)",
                                      "the staged parameters never arrived (gate workgroup not scheduled?)",
-                                     "the column statistics never completed (waves not scheduled?)"};
+                                     "the column statistics never completed (waves not scheduled?)",
+                                     "pair launch: the first side's columns never completed (workgroups of a grid not dispatched in order?)"};
 
 // RCCL entry points, resolved at run time: single-GPU users never load the library, and inside a
 // torch process the already-loaded librccl.so.1 is reused (one communicator runtime per process).
@@ -270,7 +271,21 @@ struct bpmf_hip_side {
     hipStream_t saux = nullptr;          // this side's statistics stream (high priority: its few blocks must not queue behind the other side's sampler)
     // host worker of this side: collects its sums when they land, forms cov, draws its next
     // hyper-parameters and releases the gate of its next sampler, all while the GPU samples the other side
-    struct Job { int iter; unsigned seq; int evset; bool timed; hipEvent_t prev_stop; };
+    struct Job { int iter; unsigned seq; int evset; bool timed; hipEvent_t prev_stop; bool paired = false; struct bpmf_hip_side *partner = nullptr; };
+    // Pair launch (k_sample1p): this side's NEXT half-iteration was enqueued inside its partner's launch -- the bookkeeping of
+    // Sys::sample (iter++, the copies swap, the collector's job) waits for the caller's bpmf_hip_sys_sample of this side
+    // (accept_prelaunch in capi.hip); anything that invalidates it (other alpha, other partner, factors replaced) discards it.
+    struct Prelaunch {
+        int iter = -1;                   // the half-iteration that is in flight (-1: none)
+        unsigned seq = 0; int evset = 0;
+        double alpha = 0.0;
+        struct bpmf_hip_side *partner = nullptr;
+        hipEvent_t ev_stop = nullptr;    // completes with the pair launch (the partner's event)
+    } pre;
+    unsigned *d_pair = nullptr;          // 16 shard counters + the word the partner's items poll (PairArgs); as first side of a pair
+    bool pair_seen = false;              // a half-iteration of this side ran inside a pair launch (reports name k_sample1p)
+    unsigned pair_launches = 0;          // pair launches with this side first (the poll word stands at 16 * pair_launches)
+    std::atomic<double> pair_credit_ms{0.0};   // this side's half of a timed pair launch, measured by the partner's collector
     hipEvent_t last_stop = nullptr;      // stop event of this side's newest sampler (diagnostic: boundary to the next launch)
     double tot_gap_ms = 0.0; int64_t n_gap = 0;
     std::thread worker;
@@ -319,6 +334,7 @@ struct bpmf_hip_test {
     int32_t *d_tcol = nullptr, *d_trow = nullptr;
     double *d_tval = nullptr, *d_pavg = nullptr, *d_pm2 = nullptr, *d_partial = nullptr;
     int64_t nblocks = 0;
+    int wg = 256;                        // threads per workgroup of k_predict (64: single-wave workgroups, small test sets)
     int64_t global_nnz = -1;             // multi-GPU: test ratings over all ranks (all-reduced once)
     double *h_res = nullptr, *h_res_dev = nullptr;       // pinned: se | se_avg | flag
     unsigned *d_ticket = nullptr;                        // arrival counter of k_predict's blocks
@@ -346,7 +362,7 @@ inline int check_timeout(double *h_blob, int K, std::string *msg)
     const unsigned long long v = __atomic_load_n(w, __ATOMIC_ACQUIRE);
     if (!v) return 0;
     __atomic_store_n(w, 0ull, __ATOMIC_RELEASE);
-    *msg = std::string("device wait timed out: ") + kTimeoutWhat[v < 4 ? v : 0];
+    *msg = std::string("device wait timed out: ") + kTimeoutWhat[v < 5 ? v : 0];
     return BPMF_HIP_ENODEV;
 }
 

@@ -453,6 +453,58 @@ def test_posterior_moments_of_one_column(hip_engine_factory):
     eng.side_destroy(me); eng.side_destroy(ot)
 
 
+@pytest.mark.parametrize("K", [8, 16, 32])
+def test_pair_launch_is_the_same_chain(oracle, hip_engine_factory, monkeypatch, K):
+    """Both half-iterations of a Gibbs iteration in ONE grid (k_sample1p, BPMF_HIP_PAIR=1; VERDICT r3 item 3 / DESIGN 8.6: the
+    second side's items wait in-kernel for the first side's columns; the caller's sys_sample of the second side only does the
+    bookkeeping) against the two launches: same hyper-parameters, samples, norms and RMSE sums bit for bit -- in the plain
+    loop, and in the odd call orders that must DISCARD a half-iteration enqueued ahead of its call: state read straight after
+    a sample, a side sampled twice in a row, a stateless launch that replaces the factors the prelaunched half was drawn
+    from, factors set from the host, a raw-pointer request.  And the plain loop against the oracle."""
+    from bpmf_amd.sys import Sys
+    M, Mt, T, Tt, nu, nm = util.ml100k()
+    eng = hip_engine_factory(K)
+
+    def run(pair, odd):
+        monkeypatch.setenv("BPMF_HIP_PAIR", pair)
+        Sys.nsims, Sys.burnin, Sys.alpha = 9, 2, 2.0
+        movies = Sys("movs", eng, M, nm, nu, T=T)
+        users = Sys("users", eng, Mt, nu, nm)
+        out = []
+        for i in range(9):
+            movies.sample(users)
+            if odd and i == 2:
+                out.append(eng.sys_state(movies.side)[1])
+            if odd and i == 4:
+                movies.sample(users)
+            users.sample(movies)
+            if odd and i == 5:
+                eng.sample_side(users.side, movies.side, 99, 2.0, np.zeros(K), np.eye(K))
+            if odd and i == 6:
+                eng.set_items(users.side, 0.5 * eng.get_items(users.side))
+            if odd and i == 7:
+                assert eng.items_dev_ptr(movies.side)
+            movies.predict(users)
+            out += [movies.rmse, movies.rmse_avg]
+        name = eng.kernel_name(users.side)
+        st_m, st_u = eng.sys_state(movies.side), eng.sys_state(users.side)
+        out += [st_m[1], st_u[1]]
+        U, V = users.items().copy(), movies.items().copy()
+        eng.side_destroy(movies.side); eng.side_destroy(users.side)
+        return np.asarray(out), U, V, name
+
+    for odd in (False, True):
+        a, b = run("0", odd), run("1", odd)
+        assert "k_sample1<" in a[3] and "k_sample1p<" in b[3], (a[3], b[3])
+        for x, y in zip(a[:3], b[:3]):
+            assert np.array_equal(x, y), "odd call order" if odd else "plain loop"
+    monkeypatch.setenv("BPMF_HIP_PAIR", "1")
+    import bpmf_amd
+    res = bpmf_amd.gibbs(eng, M, Mt, T, nu, nm, nsims=12, burnin=4)
+    ref = oracle.gibbs(K, M, Mt, T, Tt, nsims=12, burnin=4)
+    assert np.allclose(res["rmse"], ref["rmse"], atol=1e-6) and rel_err(res["U"], ref["U"]) < 1e-6 and rel_err(res["V"], ref["V"]) < 1e-6
+
+
 def test_cholesky_failure_is_reported(hip_engine_factory):
     """THROWERROR("Cholesky failed") (c++/sample.cpp:308) -> BPMF_HIP_ECHOL + column id."""
     import bpmf_amd
