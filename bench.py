@@ -203,7 +203,8 @@ class Watchdog:
         import threading
         self.rank, self.extra = rank, (extra if extra is not None else {})
         self.default = float(os.environ.get("BPMF_BENCH_WATCHDOG_S", "120"))
-        self.name, self.deadline, self.t0 = "start-up", time.time() + self.default, time.time()
+        # (start-up: the first `import torch` on a fresh box pages the image in -- minutes, not a hang)
+        self.name, self.deadline, self.t0 = "start-up", time.time() + max(self.default, 900.0), time.time()
         self.lock = threading.Lock()
         self.done = False
         threading.Thread(target=self._run, daemon=True).start()
@@ -717,7 +718,7 @@ def run(args, wl, R, wd):
         raise SystemExit("bench.py needs a HIP device (bpmf_amd has no CPU fallback)")
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: rank %d wants device %d, %d visible" % (rank, local_rank, torch.cuda.device_count()))
-    wd.stage("process group")
+    wd.stage("process group", max(wd.default, 300.0))
     R.init()
     comm = None
     force_dist = R.force_dist
@@ -730,7 +731,7 @@ def run(args, wl, R, wd):
             R.finish()
             raise SystemExit(2)
         wd.extra["exchange_config"] = exchange_config
-    wd.stage("matrices + engine + communicator")
+    wd.stage("matrices + engine + communicator", max(wd.default, 300.0))
 
     mult = world if (world > 1 or force_dist) else 1
     if wl == "chembl":
