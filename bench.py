@@ -296,6 +296,8 @@ def preflight_ladder(R, wd):
             s = socket.socket(); s.bind(("127.0.0.1", 0)); box[0] = s.getsockname()[1]; s.close()
         dist.broadcast_object_list(box, src=0)
         env = dict(os.environ, MASTER_PORT=str(box[0]), BPMF_BENCH_PREFLIGHT_CHILD="1", BPMF_BENCH_PREFLIGHT_RUNG=rung["name"])
+        for k in [k for k in env if k.startswith("TORCHELASTIC_")]:       # (under torchrun: the trial's rank 0 hosts its own store, the agent's
+            env.pop(k)                                                    #  store lives on the launcher's port -- every rank would wait as a client)
         env.setdefault("BPMF_HIP_COMM_TIMEOUT_MS", str(int(limit * 1000 * 0.4)))      # the library gives up (with a message) before the child is killed
         env.update(rung["env"]); env.update(rung["preflight"])
         t0 = time.time()

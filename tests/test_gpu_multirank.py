@@ -336,3 +336,24 @@ def test_bench_preflight_falls_down_the_ladder(double_mode):
     assert [l["config"] for l in x["ladder"]] == ["mesh+parts+2comms", "mesh+1comm"] and not x["ladder"][0]["ok"] and x["ladder"][1]["ok"]
     assert "killed" in x["ladder"][0]["why"] or "exit code" in x["ladder"][0]["why"]
     assert j["env"].get("BPMF_HIP_COMM_STREAMS") == "1"              # the run itself used the chosen configuration
+
+
+def test_bench_under_the_drivers_launcher(double_mode):
+    """The way the driver starts N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` (here N = 2 on the shared GPU with the double).  The preflight children must find
+    their own rendez-vous (not the elastic agent's store), and the line must say launcher: external, n_gpus 2, the exchange
+    configuration that was chosen, and carry the strong-scaling record with its model."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, BPMF_BENCH_SHARED_GPU="1", BPMF_HIP_RCCL_LIBRARY=DOUBLE, BPMF_BENCH_STRONG_SCALE="0.01", BPMF_RCCL_DOUBLE_TIMEOUT_S="40")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--repeats", "1", "--prewarm-ms", "0", "--strong-steps", "8"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    j = _bench_line(r.stdout)
+    assert r.returncode == 0 and j is not None and j["value"] and not j.get("error"), (r.stdout[-800:], r.stderr[-3000:])
+    assert j["n_gpus"] == 2 and j["rccl_nranks"] == 2 and j["launcher"] == "external"
+    assert j["exchange_config"]["chosen"] == "mesh+parts+2comms" and j["exchange_config"]["ladder"][0]["ok"]
+    st = j["strong_10Mx1M"]
+    assert st["n_gpus"] == 2 and st["spot_check"]["ok"] and set(st["model"]["per_n"]) == {"1", "2", "4", "8"}
