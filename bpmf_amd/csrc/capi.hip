@@ -194,6 +194,8 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     }
     if ((big || K == 64) && (s->mode == 6 || s->mode == 7 || s->mode == 8)) s->mode = big ? 5 : 4;
     const bool wg = s->mode == 2;
+    // (mode 5 in fp64 -- K = 128 fp64: chunks twice as long as the fp32 form's, ML-1M shape 768 against 384 ratings: 0.609 / 0.722 against
+    //  0.630 / 0.746 ms per launch; a chunk's partial is 75 KB there)
     int chunk = wg ? (1 << 30) : env_int("BPMF_HIP_CHUNK", 0);
     if (chunk <= 0) {
         const int64_t simds = (int64_t)s->ctx->num_cu * 4;
@@ -201,7 +203,7 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
         // mode 0: >= 8 work items per SIMD so the tail of the launch stays short.  Lower bound
         // 16 K: a chunk's partial tiles are ~1.3 K^2 doubles written and read back, against 8 K
         // bytes gathered per rating, so shorter chunks make the partials a first-order traffic term.
-        int64_t c = (s->mode == 0) ? s->nnz / (simds * 8) : (s->mode == 4 ? (s->nnz * 9) / (simds * 16) : (s->mode == 5 ? (s->nnz * 3) / (simds * 7) : (s->mode == 7 ? (s->nnz * 9) / (simds * 8) : s->nnz / simds)));   // (mode 7: a wave walks several items anyway; every chunk is a hand-over through memory: ML-1M shape 1 024 against 640: 48 / 53 us against 55 / 53)
+        int64_t c = (s->mode == 0) ? s->nnz / (simds * 8) : (s->mode == 4 ? (s->nnz * 9) / (simds * 16) : (s->mode == 5 ? (s->nnz * (f32 ? 3 : 6)) / (simds * 7) : (s->mode == 7 ? (s->nnz * 9) / (simds * 8) : s->nnz / simds)));   // (mode 7: a wave walks several items anyway; every chunk is a hand-over through memory: ML-1M shape 1 024 against 640: 48 / 53 us against 55 / 53)
         c = (c + 63) / 64 * 64;
         // slab form: ONE wave walks an item, and a rating costs 36 (K = 128) / 10 (K = 64) tile MFMAs per 4
         // ratings: a launch lasts (average load of a wave slot) + (longest item), so items must stay short (ML-1M shape,
