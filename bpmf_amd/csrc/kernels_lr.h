@@ -282,10 +282,15 @@ template <int K, int NCAP>
 __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
 {
     static_assert(K == 64, "one lane per latent index");
-    constexpr int LD = K + 1, NW = 8, NB = 4;                         // NB columns per wave and pass: their final products x = R0^-1 v run as ONE MFMA GEMM
+    constexpr int NW = 8, NB = 4;                                     // NB columns per wave and pass: their final products x = R0^-1 v run as ONE MFMA GEMM
+    // Row strides chosen for the operand reads of that GEMM (the bulk of this kernel's LDS traffic; r03 PMC: 25 % of its LDS
+    // cycles were bank conflicts).  A operand: lanes (b, x) -> 16 consecutive rows of S0, lanes k -> 4 consecutive columns: with
+    // LD = K + 1 the 64 addresses fell on 19 of the 32 eight-byte bank pairs (up to 4 lanes each); LD = 4 mod 32 puts exactly
+    // two lanes on every pair.  B operand: lanes x -> the four columns' v vectors, K doubles apart = the same banks: K + 8.
+    constexpr int LD = K + 4, SV = K + 8;
     __shared__ double S0[K * LD];                                     // S0[i * LD + j] = (R0^-1)[i][j]
     __shared__ double sr[NW][2][K];                                   // r2 of the accepted polar attempts of a pair of columns (draw_normals_pair)
-    __shared__ double sv[NW][NB][K];                                  // per column of a pass: its normals z, then v, then x
+    __shared__ double sv[NW][NB][SV];                                 // per column of a pass: its normals z, then v, then x
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int q = tid; q < K * K; q += 64 * NW) {                       // a.S0t[j * K + i] = (R0^-1)[i][j]
         const int j = q / K, i = q % K;
