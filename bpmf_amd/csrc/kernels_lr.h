@@ -283,11 +283,10 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
 {
     static_assert(K == 64, "one lane per latent index");
     constexpr int NW = 8, NB = 4;                                     // NB columns per wave and pass: their final products x = R0^-1 v run as ONE MFMA GEMM
-    // Row strides chosen for the operand reads of that GEMM (the bulk of this kernel's LDS traffic; r03 PMC: 25 % of its LDS
-    // cycles were bank conflicts).  A operand: lanes (b, x) -> 16 consecutive rows of S0, lanes k -> 4 consecutive columns: with
-    // LD = K + 1 the 64 addresses fell on 19 of the 32 eight-byte bank pairs (up to 4 lanes each); LD = 4 mod 32 puts exactly
-    // two lanes on every pair.  B operand: lanes x -> the four columns' v vectors, K doubles apart = the same banks: K + 8.
-    constexpr int LD = K + 4, SV = K + 8;
+    // (round 4, measured: LD = K + 4 / v slots K + 8 -- which a bank model of the GEMM's operand reads says are conflict-free where
+    // K + 1 / K put up to 4 lanes on a bank pair -- made the compounds side of the ChEMBL shape SLOWER, 770 against 733 us,
+    // interleaved A/B of the two builds: the 25 % of r03_pmc_chembl.txt are not these reads; K + 1 / K stay)
+    constexpr int LD = K + 1, SV = K;
     __shared__ double S0[K * LD];                                     // S0[i * LD + j] = (R0^-1)[i][j]
     __shared__ double sr[NW][2][K];                                   // r2 of the accepted polar attempts of a pair of columns (draw_normals_pair)
     __shared__ double sv[NW][NB][SV];                                 // per column of a pass: its normals z, then v, then x
