@@ -172,6 +172,7 @@ struct LrArgs {
     double mean_rating, alpha, sqrt_alpha;
     uint32_t iter_plus_1;
     int ktrue;                 // (see SampleArgs)
+    int pf_c[4];               // k_sample_pf_all: the product-form classes of the item list, class c = [pf_c[c], pf_c[c+1])
 };
 
 // BPMF_REDUCE formulation (kernels_reduce.h): the pass that computes the other side's precomputed Gram parts

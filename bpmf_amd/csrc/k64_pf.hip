@@ -19,6 +19,11 @@ void k64_pf(int cls, int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, con
     }
 }
 
+void k64_pf_all(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::LrArgs &a)
+{
+    go(bpmf::k_sample_pf_all<64>, grid, 512, st, e0, e1, a);
+}
+
 void k64_pf_prepare(int grid, hipStream_t st, hipEvent_t e0, const double *S0t, const double *other_items, int64_t nrows, double *Q)
 {
     BPMF_LAUNCH(bpmf::k_pf_prepare<64>, dim3(grid), dim3(512), st, e0, (hipEvent_t) nullptr, S0t, other_items, nrows, Q);

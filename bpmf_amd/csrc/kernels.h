@@ -164,8 +164,7 @@ __device__ __forceinline__ void draw_normals(uint32_t counter, int n, double *ou
         const unsigned long long m = __ballot(acc);
         const int rank = produced + __popcll(m & ((1ull << lane) - 1ull));
         if (acc && rank < n) {
-            const double mult = sqrt(-2 * log(r2) / r2);
-            out_lds[rank] = y * mult;
+            out_lds[rank] = y * polar_mult(r2);                        // sqrt(-2 log(r2) / r2), philox.h
         }
         produced += __popcll(m);
         base += 64u;
@@ -195,8 +194,7 @@ __device__ __forceinline__ void draw_normals_deferred(uint32_t counter, int n, d
     }
     for (int i = lane; i < n; i += 64) {
         const double r2 = r2_lds[i];
-        const double mult = sqrt(-2 * log(r2) / r2);
-        out_lds[i] = out_lds[i] * mult;
+        out_lds[i] = out_lds[i] * polar_mult(r2);
     }
 }
 
@@ -246,9 +244,8 @@ __device__ __forceinline__ void draw_normals_pair(uint32_t counterA, uint32_t co
     }
     for (int i = lane; i < n; i += 64) {
         const double ra = r2A[i], rb = r2B[i];
-        const double multA = sqrt(-2 * log(ra) / ra), multB = sqrt(-2 * log(rb) / rb);
-        outA[i] = outA[i] * multA;
-        outB[i] = outB[i] * multB;
+        outA[i] = outA[i] * polar_mult(ra);
+        outB[i] = outB[i] * polar_mult(rb);
     }
 }
 

@@ -278,6 +278,90 @@ __global__ __launch_bounds__(512, 4) void k_pf_prepare(const double *__restrict_
     }
 }
 
+// One pass of a wave: the items [w0, wend) (at most NB = 4 columns of at most NCAP ratings each) -- normals, the product-form
+// solves, x = R0^-1 v of the four as one MFMA GEMM, stores.  S0 = (R0^-1) in LDS (K x (K + 1)), sr / sv this wave's slots.
+template <int K, int NCAP>
+__device__ __forceinline__ void pf_pass(const LrArgs &a, int w0, int wend, const double *S0, double (*sr)[K], double (*sv)[K], double y0, int lane)
+{
+    constexpr int NB = 4, LD = K + 1;
+    // z ~ N(0, I) of the pass's columns, two columns at a time (the later Philox rounds of a pair are shared), straight
+    // into their slots of sv
+#pragma unroll 1
+    for (int cb = 0; cb < NB; cb += 2) {
+        const int w = w0 + cb;
+        if (w >= wend) break;                                         // wave-uniform
+        const uint32_t cA = sample_counter(a.col_from + a.col[w], a.ktrue, a.iter_plus_1);
+        if (w + 1 < wend) {
+            const uint32_t cB = sample_counter(a.col_from + a.col[w + 1], a.ktrue, a.iter_plus_1);
+            draw_normals_pair<K>(cA, cB, a.ktrue, sv[cb], sv[cb + 1], sr[0], sr[1], lane, K);
+        } else {
+            draw_normals_deferred<K>(cA, a.ktrue, sv[cb], sr[0], lane, K);
+        }
+    }
+#pragma unroll 1
+    for (int cb = 0; cb < NB; ++cb) {
+        const int w = w0 + cb;
+        if (w >= wend) { sv[cb][lane] = 0.0; continue; }              // wave-uniform
+        const int64_t p0 = a.p0[w];
+        const int len = a.len[w];
+
+        PfFactor f[NCAP];
+        double c = y0;                                                // R0^-T b = y0 + sum_m kappa_m R0^-T x_m
+#pragma unroll
+        for (int m = 0; m < NCAP; ++m) {
+            if (m < len) {                                            // wave-uniform
+                const int row = a.rowidx[p0 + m];
+                const double wv = (a.vals[p0 + m] - a.mean_rating) * a.alpha;                   // c++/sample.cpp:256
+                double q = a.Q[(size_t)row * K + lane];               // q = R0^-T u_row (k_pf_prepare)
+                c = fma(wv, q, c);                                    // R0^-T b = y0 + sum_m wv_m R0^-T u_m
+                q *= a.sqrt_alpha;                                    // R0^-T x_m, x_m = sqrt(alpha) u_m
+#pragma unroll
+                for (int k = 0; k < m; ++k) q = pf_solve_t(f[k], q, lane);  // p_m = C_{m-1}^-T ... C_1^-T q
+                f[m] = pf_make(q, lane);
+            }
+        }
+        double t = c;
+#pragma unroll
+        for (int m = 0; m < NCAP; ++m)
+            if (m < len) t = pf_solve_t(f[m], t, lane);
+        double v = t + sv[cb][lane];                                  // :322 (same wave wrote the normals)
+#pragma unroll
+        for (int m = NCAP - 1; m >= 0; --m)
+            if (m < len) v = pf_solve(f[m], v, lane);
+        sv[cb][lane] = v;
+    }
+    // x = R0^-1 v for the NB columns at once: X (K x NB) = S0 (K x K) V (K x NB) on the 4x4x4 shape -- block b of an
+    // instruction is row block 4 It + b of S0, the B operand (the four v's, k = lane / 16 picks the latent index
+    // 4 kk + k, x = lane % 4 the column) is the same for every b: 64 MFMAs of 16 cycles for four columns against
+    // 4 x 64 x (LDS read + two v_readlane + FMA) on the VALU.  D[b][i][j]: lane (i, b, j), register It = x[16 It + 4 b + i] of column j.
+    double X[4] = {0.0, 0.0, 0.0, 0.0};
+    int ln = lane;                                                    // (opaque: the operand addresses are not to be hoisted out of the column loop)
+    asm volatile("" : "+v"(ln));
+    const int kq2 = ln >> 4, bq2 = (ln >> 2) & 3, xq2 = ln & 3;        // operand view of v_mfma_f64_4x4x4_4b_f64: lane (k, b, x)
+#pragma unroll
+    for (int kk = 0; kk < K / 4; ++kk) {
+        const double vb = sv[xq2][4 * kk + kq2];                     // B[k][j] = v_j[4 kk + k]
+#pragma unroll
+        for (int It = 0; It < 4; ++It) {
+            const double sa = S0[(16 * It + 4 * bq2 + xq2) * LD + 4 * kk + kq2];   // A[b][i][k] = S0[16 It + 4 b + i][4 kk + k]
+            X[It] = mfma44(sa, vb, X[It]);
+        }
+    }
+    // back to one lane per latent index (through the same LDS tile), coalesced stores
+#pragma unroll
+    for (int It = 0; It < 4; ++It) sv[xq2][16 * It + 4 * bq2 + kq2] = X[It];
+#pragma unroll 1
+    for (int cb = 0; cb < NB; ++cb) {
+        const int w = w0 + cb;
+        if (w >= wend) break;                                         // wave-uniform
+        const int col = a.col[w];
+        const double xs = sv[cb][lane];
+        a.items[(size_t)(a.col_from + col) * K + lane] = xs;
+        const bool bad = !(fabs(xs) <= 1.79769313486231570815e+308);
+        if (__any(bad)) { if (lane == 0) atomicMin(a.fail, (unsigned long long)(a.col_from + col)); }
+    }
+}
+
 template <int K, int NCAP>
 __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
 {
@@ -286,10 +370,10 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
     // (round 4, measured: LD = K + 4 / v slots K + 8 -- which a bank model of the GEMM's operand reads says are conflict-free where
     // K + 1 / K put up to 4 lanes on a bank pair -- made the compounds side of the ChEMBL shape SLOWER, 770 against 733 us,
     // interleaved A/B of the two builds: the 25 % of r03_pmc_chembl.txt are not these reads; K + 1 / K stay)
-    constexpr int LD = K + 1, SV = K;
+    constexpr int LD = K + 1;
     __shared__ double S0[K * LD];                                     // S0[i * LD + j] = (R0^-1)[i][j]
     __shared__ double sr[NW][2][K];                                   // r2 of the accepted polar attempts of a pair of columns (draw_normals_pair)
-    __shared__ double sv[NW][NB][SV];                                 // per column of a pass: its normals z, then v, then x
+    __shared__ double sv[NW][NB][K];                                  // per column of a pass: its normals z, then v, then x
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int q = tid; q < K * K; q += 64 * NW) {                       // a.S0t[j * K + i] = (R0^-1)[i][j]
         const int j = q / K, i = q % K;
@@ -297,85 +381,48 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
     }
     const double y0 = a.y0[lane];
     __syncthreads();
-    const int kq = lane >> 4, bq = (lane >> 2) & 3, xq = lane & 3;      // operand view of v_mfma_f64_4x4x4_4b_f64: lane (k, b, x)
+    for (int w0 = ((int)blockIdx.x * NW + wave) * NB; w0 < a.nitems; w0 += (int)gridDim.x * NW * NB)
+        pf_pass<K, NCAP>(a, w0, a.nitems, S0, sr[wave], sv[wave], y0, lane);
+}
 
-    for (int w0 = ((int)blockIdx.x * NW + wave) * NB; w0 < a.nitems; w0 += (int)gridDim.x * NW * NB) {
-        // z ~ N(0, I) of the pass's columns, two columns at a time (the later Philox rounds of a pair are shared), straight
-        // into their slots of sv
-#pragma unroll 1
-        for (int cb = 0; cb < NB; cb += 2) {
-            const int w = w0 + cb;
-            if (w >= a.nitems) break;                                 // wave-uniform
-            const uint32_t cA = sample_counter(a.col_from + a.col[w], a.ktrue, a.iter_plus_1);
-            if (w + 1 < a.nitems) {
-                const uint32_t cB = sample_counter(a.col_from + a.col[w + 1], a.ktrue, a.iter_plus_1);
-                draw_normals_pair<K>(cA, cB, a.ktrue, sv[wave][cb], sv[wave][cb + 1], sr[wave][0], sr[wave][1], lane, K);
-            } else {
-                draw_normals_deferred<K>(cA, a.ktrue, sv[wave][cb], sr[wave][0], lane, K);
-            }
-        }
-#pragma unroll 1
-        for (int cb = 0; cb < NB; ++cb) {
-            const int w = w0 + cb;
-            if (w >= a.nitems) { sv[wave][cb][lane] = 0.0; continue; }    // wave-uniform
-            const int64_t p0 = a.p0[w];
-            const int len = a.len[w];
-
-            PfFactor f[NCAP];
-            double c = y0;                                            // R0^-T b = y0 + sum_m kappa_m R0^-T x_m
-#pragma unroll
-            for (int m = 0; m < NCAP; ++m) {
-                if (m < len) {                                        // wave-uniform
-                    const int row = a.rowidx[p0 + m];
-                    const double wv = (a.vals[p0 + m] - a.mean_rating) * a.alpha;                   // c++/sample.cpp:256
-                    double q = a.Q[(size_t)row * K + lane];           // q = R0^-T u_row (k_pf_prepare)
-                    c = fma(wv, q, c);                                // R0^-T b = y0 + sum_m wv_m R0^-T u_m
-                    q *= a.sqrt_alpha;                                // R0^-T x_m, x_m = sqrt(alpha) u_m
-#pragma unroll
-                    for (int k = 0; k < m; ++k) q = pf_solve_t(f[k], q, lane);  // p_m = C_{m-1}^-T ... C_1^-T q
-                    f[m] = pf_make(q, lane);
-                }
-            }
-            double t = c;
-#pragma unroll
-            for (int m = 0; m < NCAP; ++m)
-                if (m < len) t = pf_solve_t(f[m], t, lane);
-            double v = t + sv[wave][cb][lane];                        // :322 (same wave wrote the normals)
-#pragma unroll
-            for (int m = NCAP - 1; m >= 0; --m)
-                if (m < len) v = pf_solve(f[m], v, lane);
-            sv[wave][cb][lane] = v;
-        }
-        // x = R0^-1 v for the NB columns at once: X (K x NB) = S0 (K x K) V (K x NB) on the 4x4x4 shape -- block b of an
-        // instruction is row block 4 It + b of S0, the B operand (the four v's, k = lane / 16 picks the latent index
-        // 4 kk + k, x = lane % 4 the column) is the same for every b: 64 MFMAs of 16 cycles for four columns against
-        // 4 x 64 x (LDS read + two v_readlane + FMA) on the VALU.  D[b][i][j]: lane (i, b, j), register It = x[16 It + 4 b + i] of column j.
-        double X[4] = {0.0, 0.0, 0.0, 0.0};
-        int ln = lane;                                                // (opaque: the operand addresses are not to be hoisted out of the column loop)
-        asm volatile("" : "+v"(ln));
-        const int kq2 = ln >> 4, bq2 = (ln >> 2) & 3, xq2 = ln & 3;
-#pragma unroll
-        for (int kk = 0; kk < K / 4; ++kk) {
-            const double vb = sv[wave][xq2][4 * kk + kq2];           // B[k][j] = v_j[4 kk + k]
-#pragma unroll
-            for (int It = 0; It < 4; ++It) {
-                const double sa = S0[(16 * It + 4 * bq2 + xq2) * LD + 4 * kk + kq2];   // A[b][i][k] = S0[16 It + 4 b + i][4 kk + k]
-                X[It] = mfma44(sa, vb, X[It]);
-            }
-        }
-        (void)kq; (void)bq; (void)xq;
-        // back to one lane per latent index (through the same LDS tile), coalesced stores
-#pragma unroll
-        for (int It = 0; It < 4; ++It) sv[wave][xq2][16 * It + 4 * bq2 + kq2] = X[It];
-#pragma unroll 1
-        for (int cb = 0; cb < NB; ++cb) {
-            const int w = w0 + cb;
-            if (w >= a.nitems) break;                                 // wave-uniform
-            const int col = a.col[w];
-            const double xs = sv[wave][cb][lane];
-            a.items[(size_t)(a.col_from + col) * K + lane] = xs;
-            const bool bad = !(fabs(xs) <= 1.79769313486231570815e+308);
-            if (__any(bad)) { if (lane == 0) atomicMin(a.fail, (unsigned long long)(a.col_from + col)); }
+// The three classes of product-form columns (<= 2 | 3..6 | 7..12 ratings: pf_c[0..3], the item list is sorted by the
+// number of ratings) in ONE launch.  As three launches each class ended on its own tail -- with 512 resident workgroups
+// of eight waves a launch is a whole number of rounds of 16 384 columns: the 20 876 columns with 7..12 ratings of the
+// ChEMBL-shaped side took two rounds for 1.27 rounds of work.  Here the passes (four columns of one class) of all three
+// form one list, the most expensive first (classes in descending order, inside a class from its end: the item list is
+// ascending in the number of ratings), and wave w of the N resident ones takes the passes w, w + N, w + 2 N, ...: every
+// round of N passes is of (nearly) one cost, so the waves' totals differ by less than the cost of one pass of the most
+// expensive kind and the launch ends on passes of the cheapest.  (A ticket counter handing out the passes one at a time
+// was built first and measured 2.4 x SLOWER -- 1 603 against 677 us for the compounds side of the ChEMBL shape: 120 000
+// read-modify-writes of one hot word at ~88 per microsecond are 1.4 ms.)  The three bodies are the three instantiations
+// of pf_pass; all of them fit the 128 registers the LDS-bound occupancy (2 workgroups per CU) leaves a wave.
+template <int K>
+__global__ __launch_bounds__(512, 4) void k_sample_pf_all(LrArgs a)
+{
+    static_assert(K == 64, "one lane per latent index");
+    constexpr int NW = 8, NB = 4, LD = K + 1;
+    __shared__ double S0[K * LD];
+    __shared__ double sr[NW][2][K];
+    __shared__ double sv[NW][NB][K];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int q = tid; q < K * K; q += 64 * NW) {
+        const int j = q / K, i = q % K;
+        S0[i * LD + j] = a.S0t[q];
+    }
+    const double y0 = a.y0[lane];
+    __syncthreads();
+    const int np2 = (a.pf_c[3] - a.pf_c[2] + NB - 1) / NB, np1 = (a.pf_c[2] - a.pf_c[1] + NB - 1) / NB, np0 = (a.pf_c[1] - a.pf_c[0] + NB - 1) / NB;
+    const int npass = np2 + np1 + np0;
+    for (int p = (int)blockIdx.x * NW + wave; p < npass; p += (int)gridDim.x * NW) {
+        if (p < np2) {
+            const int q = np2 - 1 - p;
+            pf_pass<K, 12>(a, a.pf_c[2] + q * NB, a.pf_c[3], S0, sr[wave], sv[wave], y0, lane);
+        } else if (p < np2 + np1) {
+            const int q = np1 - 1 - (p - np2);
+            pf_pass<K, 6>(a, a.pf_c[1] + q * NB, a.pf_c[2], S0, sr[wave], sv[wave], y0, lane);
+        } else {
+            const int q = np0 - 1 - (p - np2 - np1);
+            pf_pass<K, 2>(a, a.pf_c[0] + q * NB, a.pf_c[1], S0, sr[wave], sv[wave], y0, lane);
         }
     }
 }

@@ -131,8 +131,21 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
                 k64_pf_prepare(grid, st, started ? nullptr : ev_start, l.S0t, other->d_items, self->nrows, self->d_pf_q);
                 started = true;
             }
-            int last_pf = -1;
-            for (int pc = 0; pc < 3; ++pc) if (self->pf_class[pc + 1] > self->pf_class[pc]) last_pf = pc;
+            int last_pf = -1, npf = 0;
+            for (int pc = 0; pc < 3; ++pc) if (self->pf_class[pc + 1] > self->pf_class[pc]) { last_pf = pc; ++npf; }
+            const int pf_merge = env_int("BPMF_HIP_PF_MERGE", 1);     // (read per launch: the tests flip it)
+            if (npf > 1 && pf_merge && !self->d_stat_list) {
+                // the three classes in one launch of persistent workgroups, passes dealt round-robin, most expensive first (k_sample_pf_all)
+                LrArgs lc = l;
+                for (int q = 0; q < 4; ++q) lc.pf_c[q] = self->pf_class[q];
+                lc.nitems = self->pf_class[3];
+                const bool is_last = last == 0;
+                int npass = 0;
+                for (int pc = 0; pc < 3; ++pc) npass += (self->pf_class[pc + 1] - self->pf_class[pc] + 3) / 4;
+                const int grid = std::max(1, std::min((npass + 7) / 8, c->num_cu * 2));       // two workgroups per CU are resident (58 KB of LDS each)
+                k64_pf_all(grid, st, started ? nullptr : ev_start, is_last ? ev_stop : nullptr, lc);
+                started = true;
+            } else
             for (int pc = 0; pc < 3; ++pc) {
                 const int n0 = self->pf_class[pc], n1 = self->pf_class[pc + 1];
                 if (n1 <= n0) continue;

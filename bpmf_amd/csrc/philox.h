@@ -65,6 +65,82 @@ BPMF_HD double canonical53(uint32_t w_first, uint32_t w_second)
     return r >= 1.0 ? 0.99999999999999988897769753748434595763683319091796875 : r;
 }
 
+// The factor of the polar method, sqrt(-2 log(r2) / r2) for 0 < r2 <= 1 (libstdc++ normal_distribution::operator(),
+// bits/random.tcc: `__mult = std::sqrt(-2 * std::log(__r2) / __r2)`).
+//
+// The device's math library evaluates the three library calls of that expression in ~125 VALU instructions (a
+// double-double logarithm, a correctly rounded division, a correctly rounded square root).  A column's normals do not
+// need any of the three to be correctly rounded -- they need to be the reference's normals to a few ulp (the device
+// already differs from an x86 run by the rounding of its own log) -- and 125 instructions are 5 % of a K = 32 column
+// and a sixth of a product-form column.  Here, in ~45:
+//   * log after fdlibm's e_log.c (r2 = 2^k (1 + f), sqrt(2)/2 < 1 + f < sqrt(2); s = f / (2 + f);
+//     log(1 + f) = f - hfsq + s (hfsq + R(s^2)), hfsq = f^2 / 2, R the degree-14 minimax polynomial: error < 1 ulp);
+//     the quotient s only enters the small correction term, so a reciprocal with two Newton steps is enough;
+//   * sqrt(L / r2) = L / sqrt(L r2) with one reciprocal square root (hardware seed + one third-order step), L = -2 log r2.
+// Measured against glibc's long-double evaluation: <= 2 ulp (tools/probes/polar_mult_check.cpp, tests/test_polar_mult.py);
+// the device stream test keeps its bound of 8 ulp on the normals.  r2 = 1 gives 0 like the reference (log 1 = 0).
+#if !defined(__HIP_DEVICE_COMPILE__)
+inline double polar_chop_(double v)                                    // keeps 23 bits of the mantissa: what a hardware seed is good for
+{
+    uint64_t u;
+    __builtin_memcpy(&u, &v, 8);
+    u &= ~((1ull << 29) - 1ull);
+    __builtin_memcpy(&v, &u, 8);
+    return v;
+}
+#endif
+BPMF_HD double polar_rcp_seed(double d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(d);
+#else
+    return polar_chop_(1.0 / d);                                       // host stand-in of the hardware seed (tests only)
+#endif
+}
+BPMF_HD double polar_rsq_seed(double d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsq(d);
+#else
+    return polar_chop_(1.0 / __builtin_sqrt(d));
+#endif
+}
+BPMF_HD double polar_mult(double r2)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double m = __builtin_amdgcn_frexp_mant(r2);                         // r2 = m 2^k, m in [0.5, 1)
+    int k = __builtin_amdgcn_frexp_exp(r2);
+#else
+    int k;
+    double m = __builtin_frexp(r2, &k);
+#endif
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;                                               // m in [sqrt(2)/2, sqrt(2))
+    k = low ? k - 1 : k;
+    const double f = m - 1.0, d = m + 1.0;
+    double r = polar_rcp_seed(d);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    const double s = f * r;
+    const double z = s * s, w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    const double corr = __builtin_fma(s, hfsq + (t2 + t1), dk * ln2_lo);
+    const double L = -2.0 * __builtin_fma(dk, ln2_hi, -((hfsq - corr) - f));   // -2 log(r2) >= 0
+    double p = L * r2;
+    p = p > 1e-300 ? p : 1e-300;                                       // r2 = 1: L = 0, the product below stays 0
+    const double y0 = polar_rsq_seed(p);
+    const double e = __builtin_fma(-p, y0 * y0, 1.0);
+    const double y = __builtin_fma(y0, e * __builtin_fma(0.375, e, 0.5), y0);   // 1 / sqrt(L r2)
+    return L * y;
+}
+
 // Host-side URNG with the MicroURNG interface expected by <random>.
 struct MicroPhilox {
     typedef uint32_t result_type;

@@ -115,6 +115,56 @@ def test_low_rank_columns(oracle, hip_engine_factory, monkeypatch):
     assert rel_err(hip[0], reg[0]) < RTOL
 
 
+def test_product_form_classes_in_one_launch(oracle, hip_engine_factory, monkeypatch):
+    """k_sample_pf_all: the three classes of product-form columns (<= 2 | 3..6 | 7..12 ratings) as ONE launch whose waves
+    take passes of four columns round-robin from one list, most expensive first.  Several launches on the same side, class
+    sizes that are not multiples of four (ragged last pass of every class), against the oracle and bit for bit against the
+    three separate launches (BPMF_HIP_PF_MERGE=0)."""
+    K = 64
+    rng = np.random.default_rng(641)
+    nrows = 120
+    counts = np.concatenate([np.full(301, 0), np.full(203, 1), np.full(97, 2), rng.integers(3, 7, 1001), rng.integers(7, 13, 333),
+                             np.full(9, 30)])
+    rng.shuffle(counts)
+    ncols = len(counts)
+    colptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    rowidx = np.concatenate([np.sort(rng.choice(nrows, size=c, replace=False)) for c in counts]).astype(np.int32)
+    vals = rng.normal(5.0, 1.1, size=len(rowidx))
+    M = (colptr, rowidx, vals)
+    mean = util.mean_rating(M)
+    eng = hip_engine_factory(K)
+    A = rng.standard_normal((K, 3 * K)); cov = A @ A.T / (3 * K)
+
+    def run(merge):
+        monkeypatch.setenv("BPMF_HIP_PF_MERGE", merge)
+        me = eng.side_create(ncols, nrows, *M, mean)
+        ot = eng.side_create(nrows, ncols, np.zeros(nrows + 1, np.int64), np.zeros(0, np.int32), np.zeros(0), 0.0)
+        name = eng.kernel_name(me)
+        out = []
+        r = np.random.default_rng(7)
+        for it in range(4):
+            U = (0.3 + 0.05 * it) * r.standard_normal((nrows, K))
+            mu, LU, LF = oracle.hyper_sample(K, ncols, cov * (1.0 + it), it)
+            eng.set_items(ot, U)
+            s, p, n = eng.sample_side(me, ot, it, 2.0, mu, LF)
+            out.append((eng.get_items(me).copy(), s, p, n, U, mu, LF))
+        eng.side_destroy(me); eng.side_destroy(ot)
+        return out, name
+
+    merged, name = run("1")
+    if name:
+        assert "k_sample_pf_all<64>" in name
+    for it, (items, s, p, n, U, mu, LF) in enumerate(merged):
+        ref = np.zeros((ncols, K))
+        s_ref, p_ref, n_ref = oracle.sample_side(K, M, mean, 2.0, U, ref, it, mu, LF)
+        check_half_iteration((items, s, p, n), (ref, s_ref, p_ref, n_ref))
+    separate, name0 = run("0")
+    if name0:
+        assert "k_sample_pf<64,2>" in name0
+    for a, b in zip(merged, separate):
+        assert np.array_equal(a[0], b[0])
+
+
 @pytest.mark.parametrize("K", [16, 32, 64])
 def test_ml100k_half_iterations(oracle, hip_engine_factory, K, sampler_mode):
     M, Mt, T, Tt, nu, nm = util.ml100k()
