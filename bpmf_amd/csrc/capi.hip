@@ -1917,7 +1917,7 @@ extern "C" int bpmf_hip_side_kernel_name(const bpmf_hip_side *s, char *buf, int 
             static const char *nb[3] = {"2", "6", "12"};
             int npf = 0;
             for (int pc = 0; pc < 3; ++pc) npf += s->pf_class[pc + 1] > s->pf_class[pc];
-            if (npf > 1 && !s->d_stat_list && env_int("BPMF_HIP_PF_MERGE", 1) != 0) name = "k_sample_pf_all<64>";     // (launch_impl.h)
+            if (npf > 1 && !s->d_stat_list && env_int("BPMF_HIP_PF_MERGE", 0) != 0) name = "k_sample_pf_all<64>";     // (launch_impl.h)
             else
             for (int pc = 0; pc < 3; ++pc)
                 if (s->pf_class[pc + 1] > s->pf_class[pc]) name += std::string(name.empty() ? "" : " + ") + "k_sample_pf<64," + nb[pc] + ">";

@@ -189,13 +189,13 @@ __global__ __launch_bounds__(64, 3) void k_sample_lr(LrArgs a)
 //     C  v = w :  v_k = (w_k - p_k sqrt(s_{k+1} / s_k) F_k) sqrt(s_k / s_{k+1}),   F_k = sum_{j>k} g_j w_j,  g = p / sqrt(s s')
 // R0^-1 (host side, like R0 itself) sits in LDS once per workgroup, padded to K + 1 so that rows and
 // columns are both conflict-free; eight waves walk the light columns of the side.  A column costs
-// n + 1 matrix-vector products with R0^-1 (256 instructions each) and n (n - 1) / 2 + 3 n scans
-// (~35 each) instead of ~25-43 instructions x 64 steps per sweep plus two triangular solves.
+// ONE matrix-vector product with R0^-1 (its share of an MFMA GEMM over four columns; the n products R0^-T u_row come
+// from k_pf_prepare) and n (n - 1) / 2 + 3 n scans instead of ~25-43 instructions x 64 steps per sweep plus two
+// triangular solves.  Round 4: the scans serve two or four columns at a time (pf_group, pf_group_stream below).
 // ---------------------------------------------------------------------------
-// Wave-wide inclusive prefix sum on the DPP network (no LDS crossbar round trips): four shifts inside the rows of 16
-// lanes (zeros shifted in), then lane 15 of row 0 / 2 into rows 1 / 3 (row_bcast:15) and lane 31 into rows 2, 3
-// (row_bcast:31).  A 64-lane __shfl_up ladder is six dependent ds_bpermute pairs (~100+ cycles each): these scans are
-// the critical chain of a product-form column (n (n - 1) / 2 + 3 n of them).
+// x + (the value a DPP move fetches): the step of the scans below (no LDS crossbar round trips; a 64-lane __shfl_up
+// ladder is six dependent ds_bpermute pairs of ~100+ cycles each, and the scans are the critical chain of a
+// product-form column: n (n - 1) / 2 + 3 n of them)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add(double v)
 {
@@ -204,52 +204,6 @@ __device__ __forceinline__ double dpp_add(double v)
     const int hi = __builtin_amdgcn_update_dpp(0, (int)(w >> 32), CTRL, ROW_MASK, 0xF, true);
     return v + __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
-__device__ __forceinline__ double wave_incl_prefix(double v, int lane)
-{
-    (void)lane;
-    v = dpp_add<0x111, 0xF>(v);                                       // row_shr:1
-    v = dpp_add<0x112, 0xF>(v);                                       // row_shr:2
-    v = dpp_add<0x114, 0xF>(v);                                       // row_shr:4
-    v = dpp_add<0x118, 0xF>(v);                                       // row_shr:8
-    v = dpp_add<0x142, 0xA>(v);                                       // row_bcast:15 -> rows 1, 3
-    v = dpp_add<0x143, 0xC>(v);                                       // row_bcast:31 -> rows 2, 3
-    return v;
-}
-__device__ __forceinline__ double wave_incl_suffix(double v, int lane)
-{
-    const double p = wave_incl_prefix(v, lane);                       // sum_{k <= lane}
-    const double total = readlane_d(p, 63);
-    return total - p + v;                                             // sum_{k >= lane}
-}
-
-struct PfFactor { double p, is, rs, irs; };                        // p_j, 1 / s_j, sqrt(s_j / s_{j+1}), sqrt(s_{j+1} / s_j)
-
-__device__ __forceinline__ PfFactor pf_make(double p, int lane)
-{
-    PfFactor f;
-    const double p2 = p * p;
-    const double s = 1.0 + (wave_incl_prefix(p2, lane) - p2);          // s_j = 1 + sum_{i<j} p_i^2
-    const double sn = s + p2;
-    const double rsq_s = rsqrt_nr(s), rsq_sn = rsqrt_nr(sn);
-    f.p = p;
-    f.is = rsq_s * rsq_s;
-    f.rs = (s * rsq_s) * rsq_sn;
-    f.irs = rsq_s * (sn * rsq_sn);
-    return f;
-}
-__device__ __forceinline__ double pf_solve_t(const PfFactor &f, double c, int lane)     // C^T t = c
-{
-    const double pc = f.p * c;
-    const double B = wave_incl_prefix(pc, lane) - pc;
-    return (c - f.p * B * f.is) * f.rs;
-}
-__device__ __forceinline__ double pf_solve(const PfFactor &f, double w, int lane)       // C v = w
-{
-    const double gw = (f.p * f.rs * f.is) * w;
-    const double F = wave_incl_suffix(gw, lane) - gw;
-    return (w - (f.p * f.irs) * F) * f.rs;
-}
-
 // q_row = R0^-T u_row depends on the ROW (a column of the other side), not on the column that reads it: it is
 // computed ONCE per half-iteration for every row (Q = U_other R0^-1, nrows x K) instead of once per rating --
 // on the ChEMBL-shaped compounds side that turns n + 1 = 2.7 matrix-vector products per column into one (plus n
@@ -278,6 +232,247 @@ __global__ __launch_bounds__(512, 4) void k_pf_prepare(const double *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------
+// The product-form solves of SEVERAL columns at once (round 4).  A scan over the 64 latent indices of one column costs
+// the wave six DPP steps of three instructions whichever way the data lies, so the layout that pays is the one in
+// which a step serves more than one column: NCOL columns share the wave, column c on the LPC = 64 / NCOL lanes
+// c LPC .. c LPC + LPC - 1, lane (c, l) holding the E = NCOL consecutive entries l E .. l E + E - 1 of each of its
+// column's vectors.  A scan is then E - 1 additions inside the lane, a scan of the lane totals over one DPP row
+// (NCOL = 4: row_shr / row_shl 1, 2, 4, 8; NCOL = 2: + one row_bcast:15) and E additions -- ~20 instructions for all
+// NCOL columns instead of 18 per column -- while everything element-wise costs what it did (E instructions per lane
+// = one per column).  Columns with fewer ratings than their neighbours in the group are padded with zero vectors:
+// p = 0 makes C = I, exactly (s = 1, rs = 1, a = 0).
+// Per factor a lane keeps p, a = p / s and rs = sqrt(s / s') for its E entries -- with v = w rs - p F in the solve
+// with C (sqrt(s'/s) sqrt(s/s') = 1) the fourth value of PfFactor is not needed -- and s'_j = s_{j+1}, so E + 1
+// reciprocal square roots per lane serve the 2 E of (s, s').  Registers bound NCOL: 2 factors x 4 entries (<= 2 ratings)
+// and 6 factors x 2 entries (<= 6) fit the 128 of this kernel's occupancy, 12 factors do not (k_sample_pf<.., 12>
+// keeps one column per wave).
+// ---------------------------------------------------------------------------
+template <int E> struct PfT { double p[E], a[E], rs[E]; };
+
+template <int NCOL>
+__device__ __forceinline__ double group_incl_prefix(double v)       // inclusive prefix over the LPC lanes of every column
+{
+    v = dpp_add<0x111, 0xF>(v);                                       // row_shr:1
+    v = dpp_add<0x112, 0xF>(v);                                       // row_shr:2
+    v = dpp_add<0x114, 0xF>(v);                                       // row_shr:4
+    v = dpp_add<0x118, 0xF>(v);                                       // row_shr:8
+    if constexpr (NCOL == 2) v = dpp_add<0x142, 0xA>(v);              // row_bcast:15 -> rows 1, 3 (a column = two rows)
+    return v;
+}
+template <int NCOL>
+__device__ __forceinline__ double group_incl_suffix(double v, int last_lane_bytes)
+{
+    if constexpr (NCOL == 4) {
+        v = dpp_add<0x101, 0xF>(v);                                   // row_shl:1
+        v = dpp_add<0x102, 0xF>(v);                                   // row_shl:2
+        v = dpp_add<0x104, 0xF>(v);                                   // row_shl:4
+        v = dpp_add<0x108, 0xF>(v);                                   // row_shl:8
+        return v;
+    } else {
+        const double p = group_incl_prefix<NCOL>(v);
+        return gbcast(p, last_lane_bytes, 0) - p + v;                 // total of the column (its last lane's prefix) - prefix + own
+    }
+}
+// B_e = base + sum of the entries of the column BEFORE entry e of this lane
+template <int NCOL, int E>
+__device__ __forceinline__ void group_excl_prefix(const double (&x)[E], double (&B)[E], double base)
+{
+    double run[E];
+    run[0] = x[0];
+#pragma unroll
+    for (int e = 1; e < E; ++e) run[e] = run[e - 1] + x[e];
+    const double O = (group_incl_prefix<NCOL>(run[E - 1]) - run[E - 1]) + base;
+    B[0] = O;
+#pragma unroll
+    for (int e = 1; e < E; ++e) B[e] = O + run[e - 1];
+}
+// F_e = sum of the entries of the column AFTER entry e of this lane
+template <int NCOL, int E>
+__device__ __forceinline__ void group_excl_suffix(const double (&x)[E], double (&F)[E], int last_lane_bytes)
+{
+    double run[E];
+    run[E - 1] = x[E - 1];
+#pragma unroll
+    for (int e = E - 2; e >= 0; --e) run[e] = run[e + 1] + x[e];
+    const double O = group_incl_suffix<NCOL>(run[0], last_lane_bytes) - run[0];
+    F[E - 1] = O;
+#pragma unroll
+    for (int e = E - 2; e >= 0; --e) F[e] = O + run[e + 1];
+}
+template <int NCOL, int E>
+__device__ __forceinline__ PfT<E> pft_make(const double (&q)[E])
+{
+    PfT<E> f;
+    double p2[E], S[E], R[E + 1];
+#pragma unroll
+    for (int e = 0; e < E; ++e) p2[e] = q[e] * q[e];
+    group_excl_prefix<NCOL, E>(p2, S, 1.0);                           // s_j = 1 + sum_{i<j} p_i^2
+#pragma unroll
+    for (int e = 0; e < E; ++e) R[e] = rsqrt_nr(S[e]);
+    R[E] = rsqrt_nr(S[E - 1] + p2[E - 1]);                            // (s' of the lane's last entry; the others' s' is the next entry's s)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        f.p[e] = q[e];
+        f.a[e] = q[e] * (R[e] * R[e]);                                // p / s
+        f.rs[e] = (S[e] * R[e]) * R[e + 1];                           // sqrt(s / s')
+    }
+    return f;
+}
+template <int NCOL, int E>
+__device__ __forceinline__ void pft_solve_t(const PfT<E> &f, double (&c)[E])       // C^T t = c, in place
+{
+    double pc[E], B[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) pc[e] = f.p[e] * c[e];
+    group_excl_prefix<NCOL, E>(pc, B, 0.0);
+#pragma unroll
+    for (int e = 0; e < E; ++e) c[e] = fma(-f.a[e], B[e], c[e]) * f.rs[e];
+}
+template <int NCOL, int E>
+__device__ __forceinline__ void pft_solve(const PfT<E> &f, double (&w)[E], int last_lane_bytes)   // C v = w, in place
+{
+    double gw[E], F[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) gw[e] = (f.a[e] * f.rs[e]) * w[e];
+    group_excl_suffix<NCOL, E>(gw, F, last_lane_bytes);
+#pragma unroll
+    for (int e = 0; e < E; ++e) w[e] = fma(-f.p[e], F[e], w[e] * f.rs[e]);
+}
+
+// the columns w0 + g .. w0 + g + NCOL - 1 of a pass: everything between their normals (in sv) and their v (back into sv)
+template <int K, int NCAP, int NCOL>
+__device__ __forceinline__ void pf_group(const LrArgs &a, int w0, int g, int wend, double (*sv)[K], int lane)
+{
+    constexpr int E = NCOL, LPC = 64 / NCOL;
+    static_assert(K == 64 && LPC * E == K, "a column's K entries over its LPC lanes");
+    const int c = lane / LPC, l = lane % LPC;
+    const int w = w0 + g + c;
+    const bool valid = w < wend;
+    const int len = valid ? a.len[w] : 0;
+    const int64_t p0 = valid ? a.p0[w] : 0;
+    int nmax = __builtin_amdgcn_readlane(len, 0);
+#pragma unroll
+    for (int cc = 1; cc < NCOL; ++cc) nmax = max(nmax, __builtin_amdgcn_readlane(len, cc * LPC));
+    const int last_lane_bytes = 4 * (c * LPC + LPC - 1);
+    typedef double dd2 __attribute__((ext_vector_type(2)));
+    double cv[E];
+    {
+        const dd2 *py = reinterpret_cast<const dd2 *>(a.y0 + l * E);
+#pragma unroll
+        for (int e = 0; e < E; e += 2) { const dd2 t = py[e / 2]; cv[e] = t.x; cv[e + 1] = t.y; }
+    }
+    PfT<E> f[NCAP];
+#pragma unroll
+    for (int m = 0; m < NCAP; ++m) {
+        if (m < nmax) {                                               // wave-uniform
+            const bool has = m < len;
+            const int row = has ? a.rowidx[p0 + m] : 0;
+            const double wv = has ? (a.vals[p0 + m] - a.mean_rating) * a.alpha : 0.0;       // c++/sample.cpp:256
+            const double sa = has ? a.sqrt_alpha : 0.0;               // (a column past its last rating: a zero vector, C = I)
+            const dd2 *pq = reinterpret_cast<const dd2 *>(a.Q + (size_t)row * K + l * E);   // q = R0^-T u_row (k_pf_prepare)
+            double q[E];
+#pragma unroll
+            for (int e = 0; e < E; e += 2) { const dd2 t = pq[e / 2]; q[e] = t.x; q[e + 1] = t.y; }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                cv[e] = fma(wv, q[e], cv[e]);                         // R0^-T b = y0 + sum_m wv_m R0^-T u_m
+                q[e] *= sa;                                           // R0^-T x_m, x_m = sqrt(alpha) u_m
+            }
+#pragma unroll
+            for (int k = 0; k < m; ++k) pft_solve_t<NCOL, E>(f[k], q);   // p_m = C_{m-1}^-T ... C_1^-T q
+            f[m] = pft_make<NCOL, E>(q);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < NCAP; ++m)
+        if (m < nmax) pft_solve_t<NCOL, E>(f[m], cv);
+    double *slot = &sv[g + c][l * E];
+    double v[E];
+#pragma unroll
+    for (int e = 0; e < E; e += 2) { const dd2 t = *reinterpret_cast<const dd2 *>(slot + e); v[e] = cv[e] + t.x; v[e + 1] = cv[e + 1] + t.y; }   // :322
+#pragma unroll
+    for (int m = NCAP - 1; m >= 0; --m)
+        if (m < nmax) pft_solve<NCOL, E>(f[m], v, last_lane_bytes);
+#pragma unroll
+    for (int e = 0; e < E; e += 2) {
+        dd2 t; t.x = valid ? v[e] : 0.0; t.y = valid ? v[e + 1] : 0.0;
+        *reinterpret_cast<dd2 *>(slot + e) = t;
+    }
+}
+
+// The same for columns with up to 12 ratings: twelve factors of three values do not fit the registers, twelve VECTORS do.
+// The rating vectors q_m stay in registers; factor k is made from q_k once every earlier factor has been applied to it,
+// applied at once to the later vectors and to the right-hand side (the same solves in the same order per vector as in
+// pf_group), dropped -- and made AGAIN from the kept p_k = q_k when the backward pass needs it: n extra pft_make
+// (one scan each) for scans that serve two columns instead of one.
+template <int K, int NCAP, int NCOL>
+__device__ __forceinline__ void pf_group_stream(const LrArgs &a, int w0, int g, int wend, double (*sv)[K], int lane)
+{
+    constexpr int E = NCOL, LPC = 64 / NCOL;
+    static_assert(K == 64 && LPC * E == K, "a column's K entries over its LPC lanes");
+    const int c = lane / LPC, l = lane % LPC;
+    const int w = w0 + g + c;
+    const bool valid = w < wend;
+    const int len = valid ? a.len[w] : 0;
+    const int64_t p0 = valid ? a.p0[w] : 0;
+    int nmax = __builtin_amdgcn_readlane(len, 0);
+#pragma unroll
+    for (int cc = 1; cc < NCOL; ++cc) nmax = max(nmax, __builtin_amdgcn_readlane(len, cc * LPC));
+    const int last_lane_bytes = 4 * (c * LPC + LPC - 1);
+    typedef double dd2 __attribute__((ext_vector_type(2)));
+    double cv[E];
+    {
+        const dd2 *py = reinterpret_cast<const dd2 *>(a.y0 + l * E);
+#pragma unroll
+        for (int e = 0; e < E; e += 2) { const dd2 t = py[e / 2]; cv[e] = t.x; cv[e + 1] = t.y; }
+    }
+    double q[NCAP][E];
+#pragma unroll
+    for (int m = 0; m < NCAP; ++m) {
+        if (m < nmax) {                                               // wave-uniform
+            const bool has = m < len;
+            const int row = has ? a.rowidx[p0 + m] : 0;
+            const double wv = has ? (a.vals[p0 + m] - a.mean_rating) * a.alpha : 0.0;       // c++/sample.cpp:256
+            const double sa = has ? a.sqrt_alpha : 0.0;
+            const dd2 *pq = reinterpret_cast<const dd2 *>(a.Q + (size_t)row * K + l * E);
+#pragma unroll
+            for (int e = 0; e < E; e += 2) { const dd2 t = pq[e / 2]; q[m][e] = t.x; q[m][e + 1] = t.y; }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                cv[e] = fma(wv, q[m][e], cv[e]);
+                q[m][e] *= sa;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NCAP; ++k) {
+        if (k < nmax) {
+            const PfT<E> f = pft_make<NCOL, E>(q[k]);                 // q_k has taken C_1^-T .. C_{k-1}^-T: it is p_k
+#pragma unroll
+            for (int m = k + 1; m < NCAP; ++m)
+                if (m < nmax) pft_solve_t<NCOL, E>(f, q[m]);
+            pft_solve_t<NCOL, E>(f, cv);
+        }
+    }
+    double *slot = &sv[g + c][l * E];
+    double v[E];
+#pragma unroll
+    for (int e = 0; e < E; e += 2) { const dd2 t = *reinterpret_cast<const dd2 *>(slot + e); v[e] = cv[e] + t.x; v[e + 1] = cv[e + 1] + t.y; }   // :322
+#pragma unroll
+    for (int k = NCAP - 1; k >= 0; --k) {
+        if (k < nmax) {
+            const PfT<E> f = pft_make<NCOL, E>(q[k]);
+            pft_solve<NCOL, E>(f, v, last_lane_bytes);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; e += 2) {
+        dd2 t; t.x = valid ? v[e] : 0.0; t.y = valid ? v[e + 1] : 0.0;
+        *reinterpret_cast<dd2 *>(slot + e) = t;
+    }
+}
+
 // One pass of a wave: the items [w0, wend) (at most NB = 4 columns of at most NCAP ratings each) -- normals, the product-form
 // solves, x = R0^-1 v of the four as one MFMA GEMM, stores.  S0 = (R0^-1) in LDS (K x (K + 1)), sr / sv this wave's slots.
 template <int K, int NCAP>
@@ -298,37 +493,15 @@ __device__ __forceinline__ void pf_pass(const LrArgs &a, int w0, int wend, const
             draw_normals_deferred<K>(cA, a.ktrue, sv[cb], sr[0], lane, K);
         }
     }
+    if constexpr (NCAP <= 6) {
+        // several columns per scan (pf_group): four with <= 2 ratings, two with <= 6
+        constexpr int NCOL = NCAP <= 2 ? 4 : 2;
 #pragma unroll 1
-    for (int cb = 0; cb < NB; ++cb) {
-        const int w = w0 + cb;
-        if (w >= wend) { sv[cb][lane] = 0.0; continue; }              // wave-uniform
-        const int64_t p0 = a.p0[w];
-        const int len = a.len[w];
-
-        PfFactor f[NCAP];
-        double c = y0;                                                // R0^-T b = y0 + sum_m kappa_m R0^-T x_m
-#pragma unroll
-        for (int m = 0; m < NCAP; ++m) {
-            if (m < len) {                                            // wave-uniform
-                const int row = a.rowidx[p0 + m];
-                const double wv = (a.vals[p0 + m] - a.mean_rating) * a.alpha;                   // c++/sample.cpp:256
-                double q = a.Q[(size_t)row * K + lane];               // q = R0^-T u_row (k_pf_prepare)
-                c = fma(wv, q, c);                                    // R0^-T b = y0 + sum_m wv_m R0^-T u_m
-                q *= a.sqrt_alpha;                                    // R0^-T x_m, x_m = sqrt(alpha) u_m
-#pragma unroll
-                for (int k = 0; k < m; ++k) q = pf_solve_t(f[k], q, lane);  // p_m = C_{m-1}^-T ... C_1^-T q
-                f[m] = pf_make(q, lane);
-            }
-        }
-        double t = c;
-#pragma unroll
-        for (int m = 0; m < NCAP; ++m)
-            if (m < len) t = pf_solve_t(f[m], t, lane);
-        double v = t + sv[cb][lane];                                  // :322 (same wave wrote the normals)
-#pragma unroll
-        for (int m = NCAP - 1; m >= 0; --m)
-            if (m < len) v = pf_solve(f[m], v, lane);
-        sv[cb][lane] = v;
+        for (int g = 0; g < NB; g += NCOL) pf_group<K, NCAP, NCOL>(a, w0, g, wend, sv, lane);
+    } else {
+        // two columns per scan, the factors made twice (pf_group_stream)
+#pragma unroll 1
+        for (int g = 0; g < NB; g += 2) pf_group_stream<K, NCAP, 2>(a, w0, g, wend, sv, lane);
     }
     // x = R0^-1 v for the NB columns at once: X (K x NB) = S0 (K x K) V (K x NB) on the 4x4x4 shape -- block b of an
     // instruction is row block 4 It + b of S0, the B operand (the four v's, k = lane / 16 picks the latent index

@@ -133,7 +133,7 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
             }
             int last_pf = -1, npf = 0;
             for (int pc = 0; pc < 3; ++pc) if (self->pf_class[pc + 1] > self->pf_class[pc]) { last_pf = pc; ++npf; }
-            const int pf_merge = env_int("BPMF_HIP_PF_MERGE", 1);     // (read per launch: the tests flip it)
+            const int pf_merge = env_int("BPMF_HIP_PF_MERGE", 0);     // (read per launch: the tests flip it)
             if (npf > 1 && pf_merge && !self->d_stat_list) {
                 // the three classes in one launch of persistent workgroups, passes dealt round-robin, most expensive first (k_sample_pf_all)
                 LrArgs lc = l;
