@@ -1803,12 +1803,16 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     const bool inorder = stats_inorder && !fused && !defer && !dist && s1 != s0 && self->nwork > 0 && !self->reduce_on && !self->d_stat_list &&
                          (self->nstat_wg > 0 || K == 128);
     // fp32 path (workgroup-per-item form, single GPU): the pass rides at the head of the next k_sample_wg2 launch of the
-    // context -- no stream of its own, no head start to buy with event hops (BPMF_HIP_F32_RIDERS=0: the two kernels on S1)
-    // MEASURED: no gain, off.  The two 30-us gaps go (rocprofv3 timeline: 9 / 14 us between the samplers), but the riders
-    // -- 576 two-wave workgroups that each hold the kernel's 40 KB of LDS -- lengthen the launches by ~23 us per iteration, and
-    // with the gaps gone the host chain (sums -> cov -> 230 us Normal-Wishart finish -> staging) becomes the critical path of
-    // one side: 0.806 / 0.864 against 0.810 / 0.833 ms in interleaved runs.
-    static const int f32_riders = env_int("BPMF_HIP_F32_RIDERS", 0);
+    // context -- no stream of its own, no head start to buy with event hops (BPMF_HIP_F32_RIDERS=0: the two kernels on S1).
+    // Round 3 measured no gain (the two 30-us gaps go -- rocprofv3 timeline: 9 / 14 us between the samplers -- but the riders,
+    // 576 two-wave workgroups that each hold the kernel's 40 KB of LDS, lengthen the launches by ~23 us per iteration, and with
+    // the gaps gone the host chain sums -> cov -> 230 us Normal-Wishart finish -> staging became the critical path of one
+    // side: 0.806 / 0.864 against 0.810 / 0.833 ms).  Round 4, after the samplers' LDS conflicts were cut: 0.716 / 0.722
+    // against 0.730 / 0.731 ms in interleaved runs (0.719 / 0.712 against 0.735 / 0.729 in another session): ON by default.
+    // The fp64 form of K = 128 was given the same riders (colstats_f32_rider over doubles) and measured SLOWER, 1.46 / 1.44
+    // against 1.386 / 1.380 ms: 288 four-wave workgroups holding 80 KB of LDS each lengthen the two launches by 45 + 70 us,
+    // more than the two ~27-us gaps they remove; it keeps its stand-alone pass.
+    static const int f32_riders = env_int("BPMF_HIP_F32_RIDERS", 1);
     const bool riders_next = f32_riders && !fused && !defer && !inorder && !dist && s1 != s0 && c->dtype == BPMF_HIP_F32 && self->mode == 5 &&
                              other->mode == 5 && self->nwork > 0 && other->nwork > 0 && self->nsub <= 1;
     if (fused || defer || inorder || riders_next) {

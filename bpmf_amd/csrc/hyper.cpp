@@ -23,6 +23,20 @@ struct Mat {   // column-major K x K view
     double &operator()(int i, int j) const { return p[(size_t)j * K + i]; }
 };
 
+// dst(c, r) = src(r, c) for the rows r >= r0(c) / all rows of a column-major K x K matrix, in 8 x 8 tiles: a plain double
+// loop writes (or reads) with a stride of K doubles -- one cache line per element, 8 cycles per element at K = 128 where
+// the tiles take ~1: the three transposes of the draw were a sixth of its time (tools/probes/hyper_bench.cpp)
+void transpose_tiles(int K, const double *src, double *dst)
+{
+    constexpr int T = 8;
+    for (int c0 = 0; c0 < K; c0 += T)
+        for (int r0 = 0; r0 < K; r0 += T) {
+            const int cn = c0 + T < K ? c0 + T : K, rn = r0 + T < K ? r0 + T : K;
+            for (int c = c0; c < cn; ++c)
+                for (int r = r0; r < rn; ++r) dst[(size_t)r * K + c] = src[(size_t)c * K + r];
+        }
+}
+
 double randn(bpmf::MicroPhilox &rng) { return std::normal_distribution<>()(rng); }   // c++/mvnormal.cpp:41-43
 
 // Advances the stream exactly as `n` calls of randn() would, without the log/sqrt of the
@@ -169,11 +183,10 @@ bool inverse_factor_spd(int K, const double *X_in, double *L_out)
         if (!finish_column(c)) return false;
         for (int j = 0; j < c; ++j) update_column(j, c);
     }
-    std::memset(L_out, 0, sizeof(double) * K * K);
-    static thread_local std::vector<double> x;
-    x.assign(K, 0.0);
+    static thread_local std::vector<double> rc;          // R column by column (contiguous), transposed into L_out at the end
+    rc.assign((size_t)K * K, 0.0);
     for (int c = 0; c < K; ++c) {                         // column c of R = Ux^-1: Ux x = e_c, x_r = 0 for r > c
-        for (int r = 0; r < c; ++r) x[r] = 0.0;
+        double *x = rc.data() + (size_t)c * K;
         x[c] = 1.0;
         int j = c;
         for (; j >= 3; j -= 4) {                          // four steps of the back substitution at a time (same order per entry)
@@ -196,8 +209,8 @@ bool inverse_factor_spd(int K, const double *X_in, double *L_out)
             const double xj = (x[j] /= uj[j]);
             for (int r = 0; r < j; ++r) x[r] -= uj[r] * xj;
         }
-        for (int r = 0; r <= c; ++r) L_out[(size_t)r * K + c] = x[r];   // L(c, r) = R(r, c)
     }
+    transpose_tiles(K, rc.data(), L_out);                 // L(c, r) = R(r, c)
     return true;
 }
 
@@ -310,8 +323,7 @@ extern "C" int bpmf_hyper_finish(int K, int64_t N, const double *cov, const doub
     for (int i = 0; i < K; ++i) mu[i] = z[i] / sk + mu_c[i];
     {   // LambdaF = LambdaU^T LambdaU (c++/bpmf.h:101): F(i,j) = sum_{k <= min(i,j)} U(k,i) U(k,j), again as
         // column updates F(k.., j) += W(k.., k) * U(k,j) with W = U^T (row k of U made contiguous), k ascending
-        for (int c = 0; c < K; ++c)
-            for (int r = 0; r < K; ++r) W[(size_t)r * K + c] = U(r, c);      // W(c, r) = U(r, c): column r of W = row r of U
+        transpose_tiles(K, LambdaU, W.data());               // W(c, r) = U(r, c): column r of W = row r of U
         // Only the lower triangle (i >= j) is accumulated: F(i,j) and F(j,i) are sums of the same products in the
         // same order (k ascending), i.e. bit-identical -- the upper triangle is a copy.  Half the multiply-adds of this
         // product.  (Round 3 also tried helper threads for the three stages of the draw whose result columns are
@@ -337,8 +349,15 @@ extern "C" int bpmf_hyper_finish(int K, int64_t N, const double *cov, const doub
                 for (int i = j; i < K; ++i) fj[i] += wk[i] * f;
             }
         }
-        for (int j = 0; j < K; ++j)
-            for (int i = j + 1; i < K; ++i) F(j, i) = F(i, j);
+        {   // the upper triangle: a copy of the lower one, tile by tile
+            constexpr int T = 8;
+            for (int j0 = 0; j0 < K; j0 += T)
+                for (int i0 = j0; i0 < K; i0 += T) {
+                    const int jn = j0 + T < K ? j0 + T : K, in = i0 + T < K ? i0 + T : K;
+                    for (int j = j0; j < jn; ++j)
+                        for (int i = (i0 > j + 1 ? i0 : j + 1); i < in; ++i) F(j, i) = F(i, j);
+                }
+        }
     }
     return BPMF_HIP_OK;
 }
