@@ -505,7 +505,7 @@ def test_posterior_moments_of_one_column(hip_engine_factory):
 
 @pytest.mark.parametrize("K", [8, 16, 32])
 def test_pair_launch_is_the_same_chain(oracle, hip_engine_factory, monkeypatch, K):
-    """Both half-iterations of a Gibbs iteration in ONE grid (k_sample1p, BPMF_HIP_PAIR=1; VERDICT r3 item 3 / DESIGN 8.6: the
+    """Both half-iterations of a Gibbs iteration in ONE grid (k_sample1p, BPMF_HIP_PAIR=1; VERDICT r3 item 3 / docs/FINDINGS.md 8.6: the
     second side's items wait in-kernel for the first side's columns; the caller's sys_sample of the second side only does the
     bookkeeping) against the two launches: same hyper-parameters, samples, norms and RMSE sums bit for bit -- in the plain
     loop, and in the odd call orders that must DISCARD a half-iteration enqueued ahead of its call: state read straight after
