@@ -85,6 +85,7 @@ struct SampleArgs {
     unsigned long long wait_ticks;
     unsigned long long *stamps; // profiling only (BPMF_HIP_STAMPS=1): s_memtime at phase boundaries of two probe items, or NULL
     uint32_t ablate;            // profiling only (BPMF_HIP_ABLATE): 1 = skip the factorisation, 2 = skip the Gram, 4 = gather from 64 hot rows only
+    uint32_t wt_store;          // k_sample_wg2 with tail riders: samples are stored write-through (read by workgroups of the SAME launch)
     // k_sample1q (kernels_q1.h): groups of four columns whose factorisation one wave runs in lockstep
     const int32_t *q_col_slot;  // per LOCAL column: 4 * group + slot
     const int32_t *q_grp_cols;  // per group: its four local columns (-1: empty slot of the last group)
@@ -124,14 +125,19 @@ struct TwinArgs {
     unsigned *flag; unsigned seq;
 };
 
-// fp32 path (K = 128): the column statistics of the PREVIOUS launch's side as the first workgroups of a k_sample_wg2 launch
-// (colstats_f32_rider, kernels_f32.h) -- what FusedArgs' st_* fields are to k_sample1.  nblocks = 0: none.
+// K = 128: column statistics as rider workgroups of a k_sample_wg2 launch (colstats_f32_rider, kernels_f32.h) -- what
+// FusedArgs' st_* fields are to k_sample1.  nblocks = 0: none.  Two forms:
+//   tail = 0 (fp32 path): the statistics of the PREVIOUS launch's side as the FIRST workgroups of the grid;
+//   tail = 1: the statistics of THIS launch's side as the LAST workgroups of the grid -- dispatched behind every item,
+//             they wait until `done` has counted the launch's `nitems` work items (whose samples were stored write-through).
 struct StatRiders {
-    int nblocks;                       // rider workgroups at the head of the grid
-    const float *items; int64_t c0, c1; int nsl;
+    int nblocks;                       // rider workgroups
+    int tail;                          // 0: head riders (another side's columns), 1: tail riders (this launch's columns)
+    const void *items; int64_t c0, c1; int nsl;      // the side's factors in its own type (float | double)
     double *partials; const unsigned long long *fail_in; double *out;
     unsigned *ticket; unsigned *flag; unsigned seq;
     unsigned long long *tmo; unsigned long long wait_ticks;
+    unsigned *done; int nitems;        // tail riders: completion count of the launch's work items (zero between launches); done[16]: set to `seq` by the last item
 };
 
 // one workgroup per column (kernels_f32.h): the fp32 large-K path, and K = 64 in fp64 behind BPMF_HIP_MODE=2

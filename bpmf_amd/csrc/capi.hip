@@ -1233,8 +1233,8 @@ int ensure_state(bpmf_hip_side *s)
     memset(s->a_h_out, 0, c->out_words * sizeof(double));
     memset(s->a_gate, 0, 64);
     HIP_TRY(hipMalloc((void **)&s->a_d_in, (c->in_words + lf32_words(c)) * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&s->a_ticket, 64));
-    HIP_TRY(hipMemset(s->a_ticket, 0, 64));
+    HIP_TRY(hipMalloc((void **)&s->a_ticket, 256));                 // [0], [1] statistics tickets; [8] tail riders' item count; [24] their go word
+    HIP_TRY(hipMemset(s->a_ticket, 0, 256));
     HIP_TRY(hipMalloc((void **)&s->a_dflag, 64));
     HIP_TRY(hipMemset(s->a_dflag, 0, 64));
     HIP_TRY(hipMalloc((void **)&s->a_d_red, (c->out_words + 8) * sizeof(double)));
@@ -1667,12 +1667,37 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
         const int nw = env_int("BPMF_HIP_WG_WAVES", 2) == 4 ? 4 : 2;
         const int njobs = P->nstat_waves * (K / 16) * (K / 16 + 1) / 2;
         riders.nblocks = (njobs + nw - 1) / nw;
-        riders.items = reinterpret_cast<const float *>(P->d_items); riders.c0 = P->from; riders.c1 = P->to; riders.nsl = P->nstat_waves;
+        riders.items = P->d_items; riders.c0 = P->from; riders.c1 = P->to; riders.nsl = P->nstat_waves;
         riders.partials = P->d_stat_partials;
         riders.fail_in = (const unsigned long long *)(P->a_d_in + (size_t)K * K + K);
         riders.out = P->a_h_out_dev; riders.ticket = P->a_ticket;
         riders.flag = reinterpret_cast<unsigned *>(P->a_h_out_dev + c->out_words - 1); riders.seq = c->pending_seq;
         riders.tmo = tmo_word(P->a_h_out_dev, K); riders.wait_ticks = wait_ticks();
+    }
+    // K = 128, single GPU: this side's own statistics as the LAST workgroups of its sampler launch (StatRiders::tail): no
+    // stream of their own, no cross-queue hops between the sampler, its statistics pass and the partner's sampler.
+    // Built in round 4 ("statistics at the tail of the launch"), parity-green, and MEASURED SLOWER, off:
+    // fp64 1.54-1.63 against 1.41-1.42 ms per iteration, fp32 0.86-0.88 against 0.73.  In-kernel clocks: the riders are
+    // resident 35-65 us before the last item ends and need 20-35 us after it, as planned -- but the last item ends
+    // 50-90 us LATER than the whole launch used to take (680 / 800 us from the first workgroup's start against launches of
+    // 626 / 729 us) although the mean life of an item is unchanged (63.2 against 62.5 us): items are dispatched later.
+    // Polling a word of their own instead of the item counter, no acquire fence (1 152 `buffer_inv sc1`), fewer rider
+    // workgroups: no difference.  Not understood; BPMF_HIP_TAIL_STATS=1 keeps it reachable.
+    static const int tail_stats = env_int("BPMF_HIP_TAIL_STATS", 0);
+    const bool tail = tail_stats && !fused && !dist && s1 != s0 && K == 128 && self->mode == 5 && self->nwork > 0 && self->nsub <= 1 &&
+                      !self->reduce_on && !self->d_stat_list && !c->ablate && !(carry && ride_f32) && second_copy_usable(self);
+    if (tail) {
+        const int nw = c->dtype == BPMF_HIP_F32 ? (env_int("BPMF_HIP_WG_WAVES", 2) == 4 ? 4 : 2) : (env_int("BPMF_HIP_WG_WAVES_F64", 4) == 2 ? 2 : 4);
+        const int nsl_t = self->nstat_waves;
+        const int njobs = nsl_t * (K / 16) * (K / 16 + 1) / 2;
+        riders = bpmf::StatRiders{};
+        riders.tail = 1; riders.nblocks = (njobs + nw - 1) / nw;
+        riders.c0 = self->from; riders.c1 = self->to; riders.nsl = nsl_t;     // (items / nitems: filled where the launch knows them)
+        riders.partials = self->d_stat_partials;
+        riders.fail_in = (const unsigned long long *)(self->a_d_in + (size_t)K * K + K);
+        riders.out = self->a_h_out_dev; riders.ticket = self->a_ticket; riders.done = self->a_ticket + 8;
+        riders.flag = reinterpret_cast<unsigned *>(self->a_h_out_dev + c->out_words - 1); riders.seq = seq;
+        riders.tmo = tmo_word(self->a_h_out_dev, K); riders.wait_ticks = wait_ticks();
     }
     if (fused) {
         fz.gate_host = self->a_gate_dev; fz.gate_want = (unsigned)(iter + 1); fz.src_host = self->a_h_in_dev;
@@ -1813,9 +1838,11 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     // against 1.386 / 1.380 ms: 288 four-wave workgroups holding 80 KB of LDS each lengthen the two launches by 45 + 70 us,
     // more than the two ~27-us gaps they remove; it keeps its stand-alone pass.
     static const int f32_riders = env_int("BPMF_HIP_F32_RIDERS", 1);
-    const bool riders_next = f32_riders && !fused && !defer && !inorder && !dist && s1 != s0 && c->dtype == BPMF_HIP_F32 && self->mode == 5 &&
+    const bool riders_next = f32_riders && !tail && !fused && !defer && !inorder && !dist && s1 != s0 && c->dtype == BPMF_HIP_F32 && self->mode == 5 &&
                              other->mode == 5 && self->nwork > 0 && other->nwork > 0 && self->nsub <= 1;
-    if (fused || defer || inorder || riders_next) {
+    if (tail) {
+        self->stats_ev[evset].store(ev[1], std::memory_order_release);      // its statistics are inside its own launch
+    } else if (fused || defer || inorder || riders_next) {
         c->pending_stats = self; c->pending_seq = seq; c->pending_evset = evset;     // ride in / go ahead of the next launch
         c->pending_inorder = inorder;
         c->pending_riders = riders_next;

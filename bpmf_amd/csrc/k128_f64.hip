@@ -5,13 +5,13 @@
 
 namespace bpmf_launch {
 
-void k128_wg2_f64(int grid, int nwaves, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a)
+void k128_wg2_f64(int grid, int nwaves, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a, const bpmf::StatRiders &r)
 {
-    const bpmf::StatRiders none{};
+    grid += r.nblocks;                                              // (riders: ahead of the items, or -- tail -- behind them)
     if (nwaves == 2) {
-        BPMF_LAUNCH((bpmf::k_sample_wg2<128, 2, double>), dim3(grid), dim3(128), st, e0, e1, a, none);
+        BPMF_LAUNCH((bpmf::k_sample_wg2<128, 2, double>), dim3(grid), dim3(128), st, e0, e1, a, r);
     } else {
-        BPMF_LAUNCH((bpmf::k_sample_wg2<128, 4, double>), dim3(grid), dim3(256), st, e0, e1, a, none);
+        BPMF_LAUNCH((bpmf::k_sample_wg2<128, 4, double>), dim3(grid), dim3(256), st, e0, e1, a, r);
     }
 }
 

@@ -7,7 +7,7 @@ namespace bpmf_launch {
 
 void k128_wg2(int grid, int nwaves, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a, const bpmf::StatRiders &r)
 {
-    grid += r.nblocks;                                              // (riders first: they are dispatched ahead of the items)
+    grid += r.nblocks;                                              // (riders: ahead of the items, or -- tail -- behind them)
     if (a.stamps) {                                                 // profiling: what the runtime says about residency
         static bool said = false;
         if (!said) {

@@ -1326,7 +1326,7 @@ __global__ __launch_bounds__(64, Geo1<K>::WPS) void k_sample1p(SampleArgs a, Fus
 // pinned memory, the sequence number last.
 #define BPMF_RLX_SYSTEM __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM
 __device__ __forceinline__ void publish_when_last(unsigned *ticket, unsigned nblocks, unsigned *flag_host, unsigned seq,
-                                                  unsigned *rearm = nullptr)
+                                                  unsigned *rearm = nullptr, unsigned *rearm2 = nullptr)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's result stores have landed
     __syncthreads();
@@ -1335,6 +1335,7 @@ __device__ __forceinline__ void publish_when_last(unsigned *ticket, unsigned nbl
         if (t == nblocks - 1) {
             __hip_atomic_store(ticket, 0u, BPMF_RLX_AGENT);          // re-arm
             if (rearm) __hip_atomic_store(rearm, 0u, BPMF_RLX_AGENT);
+            if (rearm2) __hip_atomic_store(rearm2, 0u, BPMF_RLX_AGENT);
             __hip_atomic_store(flag_host, seq, BPMF_RLX_SYSTEM);
         }
     }

@@ -456,12 +456,30 @@ __global__ __launch_bounds__(256) void k_colstats_f32_final(const double *__rest
 // k_colstats_f32_final, bit for bit.  Why: as kernels of their own on the side's stream the pass needed a head start over
 // the partner's sampler, bought with two cross-queue event hops of ~15 us each per half-iteration (DESIGN.md section 4,
 // "what the K = 128 iteration is made of"); as riders the partner's launch follows its predecessor on ONE queue.
-template <int K, int NW>
+template <int K, int NW, typename T = float>
 __device__ __forceinline__ void colstats_f32_rider(const StatRiders &r, int rb, int tid)
 {
     constexpr int NT = K / 16, NTRI = NT * (NT + 1) / 2, PARTW = NTRI * 256 + K, NOUT = K * K + K, NTH = 64 * NW;
     __shared__ unsigned stk;
     const int wave = tid >> 6, lane = tid & 63, kq = lane >> 4, li = lane & 15;
+    if (r.tail) {
+        // tail riders: the columns are this launch's own.  Workgroups are dispatched in grid order, so every work item is
+        // resident or finished when a rider starts (no deadlock); their samples were stored write-through ahead of their
+        // count and are read with device-scope loads below.
+        if (tid == 0) {
+            const unsigned long long t0 = wall_clock64();
+            // (polled: a word of its own that the LAST item sets to this launch's sequence number -- hundreds of riders polling
+            //  the counter itself kept its cache line so busy that the items' increments queued behind the polls: launches
+            //  90-110 us longer)
+            while (__hip_atomic_load(r.done + 16, BPMF_RLX_AGENT) != r.seq) {
+                __builtin_amdgcn_s_sleep(32);
+                if (r.wait_ticks && wall_clock64() - t0 > r.wait_ticks) { flag_timeout(r.tmo, BPMF_TMO_STATS); break; }
+            }
+        }
+        __syncthreads();
+        // (no acquire fence here: a `buffer_inv sc1` per rider wave -- 1 152 cache invalidates behind one another -- made the
+        //  launches ~100 us longer; the columns are read with device-scope loads instead, which cannot hit a stale line)
+    }
     const int job = rb * NW + wave;
     if (job < r.nsl * NTRI) {                                         // wave-uniform
         const int tri = job % NTRI, sl = job / NTRI;
@@ -473,15 +491,15 @@ __device__ __forceinline__ void colstats_f32_rider(const StatRiders &r, int rb, 
         const int64_t b = r.c0 + sl * per, e = (b + per < r.c1) ? b + per : r.c1;
         d4 acc = d4{0.0, 0.0, 0.0, 0.0};
         double rs = 0.0;
-        const float *xi = r.items + 16 * I + li, *xj = r.items + 16 * J + li;
-        float fa[4], fb[4], na[4], nb[4];
-        auto fetch = [&](int64_t c, float (&a4)[4], float (&b4)[4]) {
+        const T *xi = reinterpret_cast<const T *>(r.items) + 16 * I + li, *xj = reinterpret_cast<const T *>(r.items) + 16 * J + li;
+        T fa[4], fb[4], na[4], nb[4];
+        auto fetch = [&](int64_t c, T (&a4)[4], T (&b4)[4]) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t cc = c + 4 * u + kq;
                 const size_t at = (size_t)((cc < e) ? cc : b) * K;
-                a4[u] = xi[at];
-                b4[u] = xj[at];
+                if (r.tail) { a4[u] = __hip_atomic_load(&xi[at], BPMF_RLX_AGENT); b4[u] = __hip_atomic_load(&xj[at], BPMF_RLX_AGENT); }
+                else { a4[u] = xi[at]; b4[u] = xj[at]; }
             }
         };
         if (b < e) fetch(b, fa, fb);
@@ -547,7 +565,7 @@ __device__ __forceinline__ void colstats_f32_rider(const StatRiders &r, int rb, 
         __hip_atomic_store(&r.out[NOUT], (fw == ~0ull) ? 0.0 : (double)(fw + 1ull), BPMF_RLX_SYSTEM);
         __hip_atomic_store(&reinterpret_cast<unsigned long long *>(r.out)[NOUT + 1], fw, BPMF_RLX_SYSTEM);
     }
-    publish_when_last(r.ticket + 1, (unsigned)nfin, r.flag, r.seq, r.ticket);
+    publish_when_last(r.ticket + 1, (unsigned)nfin, r.flag, r.seq, r.ticket, r.tail ? r.done : nullptr);
 }
 
 // ---------------------------------------------------------------------------

@@ -87,7 +87,7 @@ void k128_slab(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpm
 // (r: column statistics of another side as rider workgroups at the head of the grid, or r.nblocks == 0)
 void k128_wg2(int grid, int nwaves, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a, const bpmf::StatRiders &r);
 // K = 128 fp64 (num_latent 65 .. 128 in the reference's arithmetic): the same form with fp64 factors (k128_f64.hip)
-void k128_wg2_f64(int grid, int nwaves, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a);
+void k128_wg2_f64(int grid, int nwaves, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a, const bpmf::StatRiders &r);
 
 // BPMF_REDUCE formulation (kernels_reduce.h, kreduce.hip): fp64, K = 8 .. 64
 int reduce_part_words(int K);                  // doubles per column of a side's `prec` array (0: K not supported)

@@ -74,20 +74,22 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
     a.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
     a.mu = d_in + (size_t)K * K + K + 2; a.prop_lambda = self->d_prop; a.diag_only = c->diag_only;
     a.mean_rating = self->mean_rating; a.alpha = alpha; a.iter_plus_1 = (uint32_t)(iter + 1); a.ktrue = c->Kt;
-    a.ablate = c->ablate; a.stamps = c->d_stamps;
+    a.ablate = c->ablate; a.stamps = c->d_stamps; a.wt_store = 0u;
     a.gate_flag = self->cur_gate_flag; a.gate_want = self->cur_gate_want;
     a.tmo = self->cur_gate_flag ? tmo_word(self->a_h_out_dev, K) : nullptr; a.wait_ticks = wait_ticks();
     a.zero_row = c->d_zero;
     a.lf32 = (lf32_words(c) && !self->d_prop) ? reinterpret_cast<const float *>(d_in + c->in_words) : nullptr;
     a.q_col_slot = self->d_q_col_slot; a.q_grp_cols = self->d_q_grp_cols; a.q_count = self->d_q_count; a.q_scratch = self->d_q_scratch;
+    bpmf::StatRiders rr = self->cur_riders;                          // (K = 128 only)
+    if (rr.tail) { rr.items = out_items; rr.nitems = nwork; a.wt_store = 1u; }   // this launch's own columns: the copy it writes
     if constexpr (F32) {                                             // fp32 factors (items / other_items are float arrays)
         if (nwork > 0) {
             if (self->mode == 4) k128_slab(nwork, st, ev_start, ev_stop, a);
-            else k128_wg2(nwork, env_int("BPMF_HIP_WG_WAVES", 2) == 4 ? 4 : 2, st, ev_start, ev_stop, a, self->cur_riders);
+            else k128_wg2(nwork, env_int("BPMF_HIP_WG_WAVES", 2) == 4 ? 4 : 2, st, ev_start, ev_stop, a, rr);
         }
         return 0;
     } else if constexpr (K == 128) {                                 // fp64 factors, workgroup of four waves per item (kernels_wg2.h, T = double)
-        if (nwork > 0) k128_wg2_f64(nwork, env_int("BPMF_HIP_WG_WAVES_F64", 4) == 2 ? 2 : 4, st, ev_start, ev_stop, a);
+        if (nwork > 0) k128_wg2_f64(nwork, env_int("BPMF_HIP_WG_WAVES_F64", 4) == 2 ? 2 : 4, st, ev_start, ev_stop, a, rr);
         return 0;
     } else {
     if constexpr (K <= 32) {
