@@ -1683,7 +1683,7 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     // 626 / 729 us) although the mean life of an item is unchanged (63.2 against 62.5 us): items are dispatched later.
     // Polling a word of their own instead of the item counter, no acquire fence (1 152 `buffer_inv sc1`), fewer rider
     // workgroups: no difference.  Not understood; BPMF_HIP_TAIL_STATS=1 keeps it reachable.
-    static const int tail_stats = env_int("BPMF_HIP_TAIL_STATS", 0);
+    const int tail_stats = env_int("BPMF_HIP_TAIL_STATS", 0);     // (read per call: the tests flip it)
     const bool tail = tail_stats && !fused && !dist && s1 != s0 && K == 128 && self->mode == 5 && self->nwork > 0 && self->nsub <= 1 &&
                       !self->reduce_on && !self->d_stat_list && !c->ablate && !(carry && ride_f32) && second_copy_usable(self);
     if (tail) {
@@ -1837,7 +1837,7 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     // The fp64 form of K = 128 was given the same riders (colstats_f32_rider over doubles) and measured SLOWER, 1.46 / 1.44
     // against 1.386 / 1.380 ms: 288 four-wave workgroups holding 80 KB of LDS each lengthen the two launches by 45 + 70 us,
     // more than the two ~27-us gaps they remove; it keeps its stand-alone pass.
-    static const int f32_riders = env_int("BPMF_HIP_F32_RIDERS", 1);
+    const int f32_riders = env_int("BPMF_HIP_F32_RIDERS", 1);      // (read per call: the tests flip it)
     const bool riders_next = f32_riders && !tail && !fused && !defer && !inorder && !dist && s1 != s0 && c->dtype == BPMF_HIP_F32 && self->mode == 5 &&
                              other->mode == 5 && self->nwork > 0 && other->nwork > 0 && self->nsub <= 1;
     if (tail) {
