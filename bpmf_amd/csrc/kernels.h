@@ -148,6 +148,12 @@ __device__ __forceinline__ void stamp(const SampleArgs &a, int w, int slot)
     if (probe >= 0 && slot < 64) a.stamps[probe * 64 + slot] = wall_clock64();
 }
 
+// number of set bits of `m` below this lane (v_mbcnt_lo / v_mbcnt_hi: two instructions)
+__device__ __forceinline__ int rank_below(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
 // pad_to > n: out_lds[n .. pad_to) = 0 (the extra dimensions of a padded num_latent draw nothing: x stays 0 there)
 template <int NMAX>
 __device__ __forceinline__ void draw_normals(uint32_t counter, int n, double *out_lds, int lane, int pad_to = 0)
@@ -162,7 +168,7 @@ __device__ __forceinline__ void draw_normals(uint32_t counter, int n, double *ou
         const double r2 = polar_r2(x, y);
         const bool acc = !(r2 > 1.0 || r2 == 0.0);
         const unsigned long long m = __ballot(acc);
-        const int rank = produced + __popcll(m & ((1ull << lane) - 1ull));
+        const int rank = produced + rank_below(m);
         if (acc && rank < n) {
             out_lds[rank] = y * polar_mult(r2);                        // sqrt(-2 log(r2) / r2), philox.h
         }
@@ -187,7 +193,7 @@ __device__ __forceinline__ void draw_normals_deferred(uint32_t counter, int n, d
         const double r2 = polar_r2(x, y);
         const bool acc = !(r2 > 1.0 || r2 == 0.0);
         const unsigned long long m = __ballot(acc);
-        const int rank = produced + __popcll(m & ((1ull << lane) - 1ull));
+        const int rank = produced + rank_below(m);
         if (acc && rank < n) { out_lds[rank] = y; r2_lds[rank] = r2; }
         produced += __popcll(m);
         base += 64u;
@@ -220,12 +226,12 @@ __device__ __forceinline__ void draw_normals_pair(uint32_t counterA, uint32_t co
         double y, r2;
         bool acc = attempt(counterA, (uint32_t)lane, y, r2);
         unsigned long long m = __ballot(acc);
-        int rank = __popcll(m & ((1ull << lane) - 1ull));
+        int rank = rank_below(m);
         if (acc && rank < n) { outA[rank] = y; r2A[rank] = r2; }
         prodA = __popcll(m);
         acc = attempt(counterB, (uint32_t)lane, y, r2);
         m = __ballot(acc);
-        rank = __popcll(m & ((1ull << lane) - 1ull));
+        rank = rank_below(m);
         if (acc && rank < n) { outB[rank] = y; r2B[rank] = r2; }
         prodB = __popcll(m);
     }
@@ -237,7 +243,7 @@ __device__ __forceinline__ void draw_normals_pair(uint32_t counterA, uint32_t co
         const bool acc = attempt(hi ? counterB : counterA, base + (uint32_t)l32, y, r2);
         const unsigned long long m = __ballot(acc);
         const unsigned mA = (unsigned)m, mB = (unsigned)(m >> 32);
-        const int rank = (hi ? prodB : prodA) + __popc((hi ? mB : mA) & ((1u << l32) - 1u));
+        const int rank = hi ? prodB + (int)__builtin_amdgcn_mbcnt_hi(mB, 0u) : prodA + (int)__builtin_amdgcn_mbcnt_lo(mA, 0u);   // accepted attempts of the same column below this lane
         if (acc && rank < n) { (hi ? outB : outA)[rank] = y; (hi ? r2B : r2A)[rank] = r2; }
         prodA += __popc(mA); prodB += __popc(mB);                     // (a column that is complete just drops its extra attempts)
         base += 32u;

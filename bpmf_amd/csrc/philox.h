@@ -39,8 +39,8 @@ BPMF_HD Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3
 #pragma unroll
 #endif
     for (int r = 0; r < 10; ++r) {
-        // one 32 x 32 -> 64 product per multiplier (v_mad_u64_u32 on the device: both halves from ONE quarter-rate
-        // instruction instead of v_mul_hi_u32 + v_mul_lo_u32)
+        // one 32 x 32 -> 64 product per multiplier (v_mad_u64_u32 on the device: both halves from ONE instruction instead of
+        // v_mul_hi_u32 + v_mul_lo_u32; all three issue at the rate of a v_fma_f64 on gfx950: tools/probes/valu_rate_probe.hip)
         const uint64_t p0 = (uint64_t)M0 * (uint64_t)c0, p1 = (uint64_t)M1 * (uint64_t)c2;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
@@ -62,7 +62,11 @@ BPMF_HD double canonical53(uint32_t w_first, uint32_t w_second)
     // the product is exact, so one rounding happens in the add, as in libstdc++
     const double s = (double)w_first + (double)w_second * 4294967296.0;
     const double r = s * 5.421010862427522170037264004349708557128906250e-20;   // 2^-64, exact
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmin(r, 0.99999999999999988897769753748434595763683319091796875);   // (r <= 1, never NaN: one v_min_f64 for a compare + two selects)
+#else
     return r >= 1.0 ? 0.99999999999999988897769753748434595763683319091796875 : r;
+#endif
 }
 
 // The factor of the polar method, sqrt(-2 log(r2) / r2) for 0 < r2 <= 1 (libstdc++ normal_distribution::operator(),
