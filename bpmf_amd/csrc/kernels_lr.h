@@ -187,8 +187,8 @@ __global__ __launch_bounds__(64, 3) void k_sample_lr(LrArgs a)
 // and a solve with C or C^T collapses to ONE prefix (suffix) sum across the wave:
 //     C^T t = c :  t_j = (c_j - p_j B_j / s_j) sqrt(s_j / s_{j+1}),        B_j = sum_{k<j} p_k c_k
 //     C  v = w :  v_k = (w_k - p_k sqrt(s_{k+1} / s_k) F_k) sqrt(s_k / s_{k+1}),   F_k = sum_{j>k} g_j w_j,  g = p / sqrt(s s')
-// R0^-1 (host side, like R0 itself) sits in LDS once per workgroup, padded to K + 1 so that rows and
-// columns are both conflict-free; eight waves walk the light columns of the side.  A column costs
+// R0^-1 (host side, like R0 itself) sits in LDS once per workgroup, in the order the final GEMM's A operand reads it
+// (pf_fill_s0 below); eight waves walk the light columns of the side.  A column costs
 // ONE matrix-vector product with R0^-1 (its share of an MFMA GEMM over four columns; the n products R0^-T u_row come
 // from k_pf_prepare) and n (n - 1) / 2 + 3 n scans instead of ~25-43 instructions x 64 steps per sweep plus two
 // triangular solves.  Round 4: the scans serve two or four columns at a time (pf_group, pf_group_stream below).
@@ -249,6 +249,24 @@ __global__ __launch_bounds__(512, 4) void k_pf_prepare(const double *__restrict_
 // keeps one column per wave).
 // ---------------------------------------------------------------------------
 template <int E> struct PfT { double p[E], a[E], rs[E]; };
+
+// LDS layout of the product-form kernels (round 4).  R0^-1 sits in the ORDER the GEMM's A operand reads it: lane (k, b, x) of
+// row tile It holds (R0^-1)[16 It + 4 b + x][4 kk + k], kk = 0 .. 15, as 16 consecutive doubles (+ 2 of padding: lane stride
+// 18 doubles = 36 banks, 16 lanes of a 16-byte read cover the 64 banks once) -- 32 ds_read_b128 per pass instead of 64
+// ds_read_b64 whose row stride of K + 1 put up to four lanes on a bank.  The four columns of a pass are K + 8 doubles apart:
+// the B operand's read of entry 4 kk + k of columns 0 .. 3 then hits four different bank groups (at stride K: one).
+constexpr int PF_SLD = 18;                                          // doubles per (row tile, lane) of R0^-1 in LDS
+template <int K> constexpr int pf_s0_words() { return (K / 16) * 64 * PF_SLD; }
+template <int K> constexpr int pf_svld() { return K + 8; }
+template <int K>
+__device__ __forceinline__ void pf_fill_s0(double *S0, const double *__restrict__ S0t, int tid, int nthreads)
+{
+    for (int q = tid; q < K * K; q += nthreads) {                      // S0t[j * K + i] = (R0^-1)[i][j]
+        const int j = q / K, i = q % K;
+        const int It = i >> 4, b = (i >> 2) & 3, x = i & 3, kk = j >> 2, k = j & 3;
+        S0[(It * 64 + k * 16 + b * 4 + x) * PF_SLD + kk] = S0t[q];
+    }
+}
 
 template <int NCOL>
 __device__ __forceinline__ double group_incl_prefix(double v)       // inclusive prefix over the LPC lanes of every column
@@ -342,7 +360,7 @@ __device__ __forceinline__ void pft_solve(const PfT<E> &f, double (&w)[E], int l
 
 // the columns w0 + g .. w0 + g + NCOL - 1 of a pass: everything between their normals (in sv) and their v (back into sv)
 template <int K, int NCAP, int NCOL>
-__device__ __forceinline__ void pf_group(const LrArgs &a, int w0, int g, int wend, double (*sv)[K], int lane)
+__device__ __forceinline__ void pf_group(const LrArgs &a, int w0, int g, int wend, double (*sv)[pf_svld<K>()], int lane)
 {
     constexpr int E = NCOL, LPC = 64 / NCOL;
     static_assert(K == 64 && LPC * E == K, "a column's K entries over its LPC lanes");
@@ -407,7 +425,7 @@ __device__ __forceinline__ void pf_group(const LrArgs &a, int w0, int g, int wen
 // pf_group), dropped -- and made AGAIN from the kept p_k = q_k when the backward pass needs it: n extra pft_make
 // (one scan each) for scans that serve two columns instead of one.
 template <int K, int NCAP, int NCOL>
-__device__ __forceinline__ void pf_group_stream(const LrArgs &a, int w0, int g, int wend, double (*sv)[K], int lane)
+__device__ __forceinline__ void pf_group_stream(const LrArgs &a, int w0, int g, int wend, double (*sv)[pf_svld<K>()], int lane)
 {
     constexpr int E = NCOL, LPC = 64 / NCOL;
     static_assert(K == 64 && LPC * E == K, "a column's K entries over its LPC lanes");
@@ -476,9 +494,9 @@ __device__ __forceinline__ void pf_group_stream(const LrArgs &a, int w0, int g, 
 // One pass of a wave: the items [w0, wend) (at most NB = 4 columns of at most NCAP ratings each) -- normals, the product-form
 // solves, x = R0^-1 v of the four as one MFMA GEMM, stores.  S0 = (R0^-1) in LDS (K x (K + 1)), sr / sv this wave's slots.
 template <int K, int NCAP>
-__device__ __forceinline__ void pf_pass(const LrArgs &a, int w0, int wend, const double *S0, double (*sr)[K], double (*sv)[K], double y0, int lane)
+__device__ __forceinline__ void pf_pass(const LrArgs &a, int w0, int wend, const double *S0, double (*sr)[K], double (*sv)[pf_svld<K>()], double y0, int lane)
 {
-    constexpr int NB = 4, LD = K + 1;
+    constexpr int NB = 4;
     // z ~ N(0, I) of the pass's columns, two columns at a time (the later Philox rounds of a pair are shared), straight
     // into their slots of sv
 #pragma unroll 1
@@ -511,15 +529,19 @@ __device__ __forceinline__ void pf_pass(const LrArgs &a, int w0, int wend, const
     int ln = lane;                                                    // (opaque: the operand addresses are not to be hoisted out of the column loop)
     asm volatile("" : "+v"(ln));
     const int kq2 = ln >> 4, bq2 = (ln >> 2) & 3, xq2 = ln & 3;        // operand view of v_mfma_f64_4x4x4_4b_f64: lane (k, b, x)
+    typedef double dd2 __attribute__((ext_vector_type(2)));
+    const dd2 *sop = reinterpret_cast<const dd2 *>(S0 + ln * PF_SLD);   // this lane's operands of row tile 0 (tile It: + 64 PF_SLD doubles)
 #pragma unroll
-    for (int kk = 0; kk < K / 4; ++kk) {
-        const double vb = sv[xq2][4 * kk + kq2];                     // B[k][j] = v_j[4 kk + k]
+    for (int kk = 0; kk < K / 4; kk += 2) {
+        const double vb0 = sv[xq2][4 * kk + kq2], vb1 = sv[xq2][4 * kk + 4 + kq2];   // B[k][j] = v_j[4 kk + k]
 #pragma unroll
         for (int It = 0; It < 4; ++It) {
-            const double sa = S0[(16 * It + 4 * bq2 + xq2) * LD + 4 * kk + kq2];   // A[b][i][k] = S0[16 It + 4 b + i][4 kk + k]
-            X[It] = mfma44(sa, vb, X[It]);
+            const dd2 sa = sop[(It * 64 * PF_SLD + kk) / 2];          // A[b][i][k] = (R0^-1)[16 It + 4 b + i][4 kk + k], kk and kk + 1
+            X[It] = mfma44(sa.x, vb0, X[It]);
+            X[It] = mfma44(sa.y, vb1, X[It]);
         }
     }
+    (void)bq2;
     // back to one lane per latent index (through the same LDS tile), coalesced stores
 #pragma unroll
     for (int It = 0; It < 4; ++It) sv[xq2][16 * It + 4 * bq2 + kq2] = X[It];
@@ -543,15 +565,11 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
     // (round 4, measured: LD = K + 4 / v slots K + 8 -- which a bank model of the GEMM's operand reads says are conflict-free where
     // K + 1 / K put up to 4 lanes on a bank pair -- made the compounds side of the ChEMBL shape SLOWER, 770 against 733 us,
     // interleaved A/B of the two builds: the 25 % of r03_pmc_chembl.txt are not these reads; K + 1 / K stay)
-    constexpr int LD = K + 1;
-    __shared__ double S0[K * LD];                                     // S0[i * LD + j] = (R0^-1)[i][j]
+    __shared__ __attribute__((aligned(16))) double S0[pf_s0_words<K>()];   // R0^-1 in operand order (pf_fill_s0)
     __shared__ double sr[NW][2][K];                                   // r2 of the accepted polar attempts of a pair of columns (draw_normals_pair)
-    __shared__ double sv[NW][NB][K];                                  // per column of a pass: its normals z, then v, then x
+    __shared__ __attribute__((aligned(16))) double sv[NW][NB][pf_svld<K>()];   // per column of a pass: its normals z, then v, then x
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int q = tid; q < K * K; q += 64 * NW) {                       // a.S0t[j * K + i] = (R0^-1)[i][j]
-        const int j = q / K, i = q % K;
-        S0[i * LD + j] = a.S0t[q];
-    }
+    pf_fill_s0<K>(S0, a.S0t, tid, 64 * NW);
     const double y0 = a.y0[lane];
     __syncthreads();
     for (int w0 = ((int)blockIdx.x * NW + wave) * NB; w0 < a.nitems; w0 += (int)gridDim.x * NW * NB)
@@ -573,15 +591,12 @@ template <int K>
 __global__ __launch_bounds__(512, 4) void k_sample_pf_all(LrArgs a)
 {
     static_assert(K == 64, "one lane per latent index");
-    constexpr int NW = 8, NB = 4, LD = K + 1;
-    __shared__ double S0[K * LD];
+    constexpr int NW = 8, NB = 4;
+    __shared__ __attribute__((aligned(16))) double S0[pf_s0_words<K>()];
     __shared__ double sr[NW][2][K];
-    __shared__ double sv[NW][NB][K];
+    __shared__ __attribute__((aligned(16))) double sv[NW][NB][pf_svld<K>()];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int q = tid; q < K * K; q += 64 * NW) {
-        const int j = q / K, i = q % K;
-        S0[i * LD + j] = a.S0t[q];
-    }
+    pf_fill_s0<K>(S0, a.S0t, tid, 64 * NW);
     const double y0 = a.y0[lane];
     __syncthreads();
     const int np2 = (a.pf_c[3] - a.pf_c[2] + NB - 1) / NB, np1 = (a.pf_c[2] - a.pf_c[1] + NB - 1) / NB, np0 = (a.pf_c[1] - a.pf_c[0] + NB - 1) / NB;
