@@ -572,8 +572,11 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
     pf_fill_s0<K>(S0, a.S0t, tid, 64 * NW);
     const double y0 = a.y0[lane];
     __syncthreads();
-    for (int w0 = ((int)blockIdx.x * NW + wave) * NB; w0 < a.nitems; w0 += (int)gridDim.x * NW * NB)
-        pf_pass<K, NCAP>(a, w0, a.nitems, S0, sr[wave], sv[wave], y0, lane);
+    // passes of four columns, the LAST of the list first: the items are ascending in their number of ratings, so the most
+    // expensive passes start the launch and its last round is made of the cheapest
+    const int npass = (a.nitems + NB - 1) / NB;
+    for (int p = (int)blockIdx.x * NW + wave; p < npass; p += (int)gridDim.x * NW)
+        pf_pass<K, NCAP>(a, (npass - 1 - p) * NB, a.nitems, S0, sr[wave], sv[wave], y0, lane);
 }
 
 // The three classes of product-form columns (<= 2 | 3..6 | 7..12 ratings: pf_c[0..3], the item list is sorted by the

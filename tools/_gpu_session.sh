@@ -1,2 +1,3 @@
-cd $GRAFT_REPO_ROOT
-BPMF_HIP_STAMPS=1 timeout 300 python bench.py --workload chembl --no-cpu-baseline --no-strong --no-bpmf-exe --steps 10 --warmup 3 --repeats 1 --prewarm-ms 0 2>&1 | grep 'bpmf_hip' | cut -c1-400
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "low_rank or product_form" 2>&1 | tail -3
+bash tools/ab_lib.sh chembl 200 bpmf_amd/csrc/variants/prerev.so bpmf_amd/libbpmf_hip.so 2>&1 | tee gpurun_out/r4_ab_rev.log
