@@ -78,7 +78,7 @@ def algorithmic_flops(nnz, ncols, K):
 
 def executed_flops(info, nnz, ncols, K):
     """Flops one sampler launch of a side EXECUTES, given its schedule (bpmf_hip_side_schedule_info).  Columns in the
-    regular forms: the algorithmic count.  Columns in the product form (k_sample_pf, K = 64, <= 12 ratings) are never
+    regular forms: the algorithmic count.  Columns in the product form (k_sample_pf, K = 64, <= 16 ratings) are never
     factorised -- that is the point of the form -- so they are charged what the kernel does per column with n ratings:
     one dense K x K matrix-vector product on the MFMA (2 K^2), n(n-1)/2 + 2n solves with a rank-one factor (~11 K flops
     each: one product, a 6-step wave scan, the combine), n rank-one factors (~30 K: scan, two rsqrt + Newton, ratios),

@@ -302,14 +302,14 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     s->nwork = (int)nw; s->nmulti = (int)mc_slot0.size(); s->nslots = slots;
     int rc;
     if (K == 64 && !f32 && (s->mode == 0 || s->mode == 1 || s->mode == 4) && s->nsub <= 1) {
-        // Low-rank form for the columns with at most BPMF_HIP_LOWRANK_MAX ratings (default 6; 0: off):
+        // Low-rank form for the columns with at most BPMF_HIP_LOWRANK_MAX ratings (default 16; 0: off):
         // worth a second launch when they are at least half of the side (ChEMBL-shaped compounds)
-        const int nlr = std::min(env_int("BPMF_HIP_LOWRANK_MAX", 12), 32);
+        const int nlr = std::min(env_int("BPMF_HIP_LOWRANK_MAX", 16), 32);
         // sweep width of a light column: 1 | 2 | 3 (3, 5, 6, 9 ratings) | 4 (4, 7, 8, 10, 11, 12); none: with width 1
         auto width = [](int n) { return n <= 1 ? 1 : n == 2 ? 2 : (n == 3 || n == 5 || n == 6 || n == 9) ? 3 : 4; };
         std::vector<int32_t> lc, ll, hc, hl, hm, hk; std::vector<int64_t> lp, hp;
         // up to 6 ratings: product form (k_sample_pf), sorted by their number so that the waves of a workgroup stay in step
-        const int pfmax = std::min(nlr, std::min(env_int("BPMF_HIP_PF", 12), 12));            // (0: product form off)
+        const int pfmax = std::min(nlr, std::min(env_int("BPMF_HIP_PF", 16), 16));            // (0: product form off; 16: what k_sample_pf<64, 16> holds)
         for (int n = 0; n <= pfmax && pfmax > 0; ++n) {
             for (const Item &it : items)
                 if (it.mc < 0 && it.len == n) { lc.push_back(it.col); ll.push_back(it.len); lp.push_back(it.p0); }
@@ -1945,7 +1945,7 @@ extern "C" int bpmf_hip_side_kernel_name(const bpmf_hip_side *s, char *buf, int 
             return s->mode == 1 ? "k_sample1<64>" : "k_sample<64>";
         };
         if (s->lr_n > 0 && s->mode != 2 && !s->d_prop && !c->diag_only) {
-            static const char *nb[3] = {"2", "6", "12"};
+            static const char *nb[3] = {"2", "6", "16"};
             int npf = 0;
             for (int pc = 0; pc < 3; ++pc) npf += s->pf_class[pc + 1] > s->pf_class[pc];
             if (npf > 1 && !s->d_stat_list && env_int("BPMF_HIP_PF_MERGE", 0) != 0) name = "k_sample_pf_all<64>";     // (launch_impl.h)
@@ -2009,7 +2009,7 @@ extern "C" int bpmf_hip_side_kernel_resources(bpmf_hip_side *s, int64_t *out, in
 
 // The static schedule of a side in numbers (build_schedule), for reports: out[0..15] =
 //   0 sampler form (mode)   1 work items   2 chunks of heavy columns (partial slots)   3 heavy columns cut into chunks
-//   4 light columns in the low-rank / product forms   5 work items of the others   6..8 product-form columns with <= 2 | 3..6 | 7..12 ratings
+//   4 light columns in the low-rank / product forms   5 work items of the others   6..8 product-form columns with <= 2 | 3..6 | 7..16 ratings
 //   9 columns in k_sample_lr   10 parts (bpmf_hip_side_set_overlap)   11 local columns   12 local ratings
 //   13, 14 sum over the product-form columns of their number of ratings n, of n^2   15 reserved (0)
 extern "C" int bpmf_hip_side_schedule_info(const bpmf_hip_side *s, int64_t *out, int n)

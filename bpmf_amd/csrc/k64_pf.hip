@@ -1,4 +1,4 @@
-// k64_pf.hip -- K = 64, product form for columns with <= 12 ratings (see launch.h)
+// k64_pf.hip -- K = 64, product form for columns with <= 16 ratings (see launch.h)
 #include "launch.h"
 #include "kernels_lr.h"
 
@@ -15,7 +15,7 @@ void k64_pf(int cls, int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, con
     switch (cls) {
     case 0: go(bpmf::k_sample_pf<64, 2>, grid, 512, st, e0, e1, a); break;
     case 1: go(bpmf::k_sample_pf<64, 6>, grid, 512, st, e0, e1, a); break;
-    default: go(bpmf::k_sample_pf<64, 12>, grid, 512, st, e0, e1, a); break;
+    default: go(bpmf::k_sample_pf<64, 16>, grid, 512, st, e0, e1, a); break;
     }
 }
 

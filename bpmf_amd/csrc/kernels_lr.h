@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64, 3) void k_sample_lr(LrArgs a)
 
 
 // ---------------------------------------------------------------------------
-// k_sample_pf<K, NCAP>: the same update in PRODUCT FORM, for columns with at most NCAP <= 12 ratings.
+// k_sample_pf<K, NCAP>: the same update in PRODUCT FORM, for columns with at most NCAP <= 16 ratings.
 //
 // With x_1 = sqrt(alpha) u_1 and p_1 = R0^-T x_1:  Lambda* = R0^T (I + p_1 p_1^T) R0, and the Cholesky
 // factor of a rank-one update of the identity is known in closed form: I + p p^T = C^T C with
@@ -419,7 +419,9 @@ __device__ __forceinline__ void pf_group(const LrArgs &a, int w0, int g, int wen
     }
 }
 
-// The same for columns with up to 12 ratings: twelve factors of three values do not fit the registers, twelve VECTORS do.
+// The same for columns with up to 16 ratings: that many factors of three values do not fit the registers, the VECTORS do
+// (round 4: a cap of 16 instead of 12 moved 2 957 of the 5 370 heavier columns of the ChEMBL-shaped compounds side out of the
+// slab launch, 539 -> 529 us for the side; at 20 the kernel spills 124 registers and the side takes 579 us).
 // The rating vectors q_m stay in registers; factor k is made from q_k once every earlier factor has been applied to it,
 // applied at once to the later vectors and to the right-hand side (the same solves in the same order per vector as in
 // pf_group), dropped -- and made AGAIN from the kept p_k = q_k when the backward pass needs it: n extra pft_make
@@ -579,9 +581,9 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
         pf_pass<K, NCAP>(a, (npass - 1 - p) * NB, a.nitems, S0, sr[wave], sv[wave], y0, lane);
 }
 
-// The three classes of product-form columns (<= 2 | 3..6 | 7..12 ratings: pf_c[0..3], the item list is sorted by the
+// The three classes of product-form columns (<= 2 | 3..6 | 7..16 ratings: pf_c[0..3], the item list is sorted by the
 // number of ratings) in ONE launch.  As three launches each class ended on its own tail -- with 512 resident workgroups
-// of eight waves a launch is a whole number of rounds of 16 384 columns: the 20 876 columns with 7..12 ratings of the
+// of eight waves a launch is a whole number of rounds of 16 384 columns: the 20 876 columns with 7..12 ratings (the third class then) of the
 // ChEMBL-shaped side took two rounds for 1.27 rounds of work.  Here the passes (four columns of one class) of all three
 // form one list, the most expensive first (classes in descending order, inside a class from its end: the item list is
 // ascending in the number of ratings), and wave w of the N resident ones takes the passes w, w + N, w + 2 N, ...: every
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf_all(LrArgs a)
     for (int p = (int)blockIdx.x * NW + wave; p < npass; p += (int)gridDim.x * NW) {
         if (p < np2) {
             const int q = np2 - 1 - p;
-            pf_pass<K, 12>(a, a.pf_c[2] + q * NB, a.pf_c[3], S0, sr[wave], sv[wave], y0, lane);
+            pf_pass<K, 16>(a, a.pf_c[2] + q * NB, a.pf_c[3], S0, sr[wave], sv[wave], y0, lane);
         } else if (p < np2 + np1) {
             const int q = np1 - 1 - (p - np2);
             pf_pass<K, 6>(a, a.pf_c[1] + q * NB, a.pf_c[2], S0, sr[wave], sv[wave], y0, lane);

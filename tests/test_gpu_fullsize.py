@@ -79,12 +79,12 @@ def test_ml1m_k64_every_column_matches_the_oracle(oracle, hip_engine_factory):
 
 
 def test_chembl_k64_every_column_matches_the_oracle(oracle, hip_engine_factory):
-    """Default schedule: the compounds side splits into k_sample_pf<64,NB> (<= 12 activities) and the
+    """Default schedule: the compounds side splits into k_sample_pf<64,NB> (<= 16 activities) and the
     regular form; the targets side is all regular (heavy columns chunked)."""
     from bpmf_amd import synth
     data = synth.ratings(483500, 5775, 1_023_952, seed=42, real_valued=True)
     nnzc = np.diff(data[1][0])
-    assert (nnzc <= 12).mean() > 0.5 and (nnzc == 0).any() and (nnzc > 12).any()
+    assert (nnzc <= 16).mean() > 0.5 and (nnzc == 0).any() and (nnzc > 16).any()
     w = _both_sides(oracle, hip_engine_factory(64), 64, data, 1e-9, 1e-8, seed=13)
     print("ChEMBL-shaped K=64 worst column error / max|U|:", w)
 

@@ -116,14 +116,14 @@ def test_low_rank_columns(oracle, hip_engine_factory, monkeypatch):
 
 
 def test_product_form_classes_in_one_launch(oracle, hip_engine_factory, monkeypatch):
-    """k_sample_pf_all: the three classes of product-form columns (<= 2 | 3..6 | 7..12 ratings) as ONE launch whose waves
+    """k_sample_pf_all: the three classes of product-form columns (<= 2 | 3..6 | 7..16 ratings) as ONE launch whose waves
     take passes of four columns round-robin from one list, most expensive first.  Several launches on the same side, class
     sizes that are not multiples of four (ragged last pass of every class), against the oracle and bit for bit against the
     three separate launches (BPMF_HIP_PF_MERGE=0)."""
     K = 64
     rng = np.random.default_rng(641)
     nrows = 120
-    counts = np.concatenate([np.full(301, 0), np.full(203, 1), np.full(97, 2), rng.integers(3, 7, 1001), rng.integers(7, 13, 333),
+    counts = np.concatenate([np.full(301, 0), np.full(203, 1), np.full(97, 2), rng.integers(3, 7, 1001), rng.integers(7, 17, 333),
                              np.full(9, 30)])
     rng.shuffle(counts)
     ncols = len(counts)
