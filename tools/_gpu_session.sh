@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_latent.py tests/test_gpu_scale.py tests/test_cli.py -q -x 2>&1 | tail -4
+bash tools/ab_lib.sh ml1m_k64 200 bpmf_amd/csrc/variants/wps2.so bpmf_amd/libbpmf_hip.so 2>&1 | tee gpurun_out/r4_ab_wps3.log
+bash tools/ab_lib.sh chembl 200 bpmf_amd/csrc/variants/wps2.so bpmf_amd/libbpmf_hip.so 2>&1 | tee -a gpurun_out/r4_ab_wps3.log
