@@ -2487,7 +2487,7 @@ extern "C" int bpmf_hip_test_set_twin(bpmf_hip_test *t, bpmf_hip_test *twin)
     // (Otherwise -- shards of different column ranges -- the twin keeps a kernel of its own.)
     bpmf_hip_ctx *c = t->side->ctx;
     const bool whole = t->side->to - t->side->from == t->side->ncols && twin->side->to - twin->side->from == twin->side->ncols;
-    if (whole && c->dtype == BPMF_HIP_F64 && t->nnz == twin->nnz && t->nnz > 0 && t->nnz < ((int64_t)1 << 31)) {
+    if (whole && t->nnz == twin->nnz && t->nnz > 0 && t->nnz < ((int64_t)1 << 31)) {
         const int64_t n = t->nnz, ncm = t->side->ncols;
         std::vector<int64_t> ka((size_t)n), kb((size_t)n);
         std::vector<int32_t> ia((size_t)n), ib((size_t)n);

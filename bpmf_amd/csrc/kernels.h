@@ -1670,10 +1670,10 @@ __global__ __launch_bounds__(256) void k_colstats_wg(const double *__restrict__ 
 // NT: threads per workgroup.  256 by default; 64 (single-wave workgroups) for small test sets: beside a sampler launch that
 // keeps refilling every wave slot with single-wave workgroups a four-wave workgroup only gets in when the launch drains --
 // with ONE launch per iteration (k_sample1p) the evaluation then landed a whole launch late and the host loop waited for it.
-template <int K, int NT = 256>
+template <int K, int NT = 256, typename T = double>
 __global__ __launch_bounds__(NT) void k_predict(const int32_t *__restrict__ tcol, const int32_t *__restrict__ trow,
                                                  const double *__restrict__ tval, int64_t nnz,
-                                                 const double *__restrict__ items, const double *__restrict__ other,
+                                                 const T *__restrict__ items, const T *__restrict__ other,
                                                  int64_t col_from, double mean, int n, double *__restrict__ pavg,
                                                  double *__restrict__ pm2, double *partial, double *__restrict__ out,
                                                  unsigned *ticket, unsigned *flag, unsigned seq, TwinArgs tw)
@@ -1685,14 +1685,27 @@ __global__ __launch_bounds__(NT) void k_predict(const int32_t *__restrict__ tcol
     const int64_t q = (int64_t)blockIdx.x * NT + threadIdx.x;
     double se = 0.0, se_avg = 0.0, se_t = 0.0, se_avg_t = 0.0;
     if (q < nnz) {
-        const double2 *m = reinterpret_cast<const double2 *>(items + (size_t)(col_from + tcol[q]) * K);
-        const double2 *u = reinterpret_cast<const double2 *>(other + (size_t)trow[q] * K);
         double d0 = 0.0, d1 = 0.0;
+        if constexpr (sizeof(T) == 4) {                             // fp32 factors (K = 128 opt-in): fp64 accumulation, the order of k_predict_f32
+            const float4 *m = reinterpret_cast<const float4 *>(items + (size_t)(col_from + tcol[q]) * K);
+            const float4 *u = reinterpret_cast<const float4 *>(other + (size_t)trow[q] * K);
+#pragma unroll 8
+            for (int t = 0; t < K / 4; ++t) {
+                const float4 x = m[t], y = u[t];
+                d0 = fma((double)x.x, (double)y.x, d0);
+                d1 = fma((double)x.y, (double)y.y, d1);
+                d0 = fma((double)x.z, (double)y.z, d0);
+                d1 = fma((double)x.w, (double)y.w, d1);
+            }
+        } else {
+            const double2 *m = reinterpret_cast<const double2 *>(items + (size_t)(col_from + tcol[q]) * K);
+            const double2 *u = reinterpret_cast<const double2 *>(other + (size_t)trow[q] * K);
 #pragma unroll
-        for (int t = 0; t < K / 2; ++t) {
-            const double2 a = m[t], b = u[t];
-            d0 = fma(a.x, b.x, d0);
-            d1 = fma(a.y, b.y, d1);
+            for (int t = 0; t < K / 2; ++t) {
+                const double2 a = m[t], b = u[t];
+                d0 = fma(a.x, b.x, d0);
+                d1 = fma(a.y, b.y, d1);
+            }
         }
         const double pred = (d0 + d1) + mean;                       // :78
         const double v = tval[q];

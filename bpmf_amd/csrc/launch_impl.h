@@ -456,7 +456,7 @@ void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items
     if (beside) (void)hipStreamWaitEvent(ps, t->in_ev, 0);
     // users.predict(movies) (c++/bpmf.cpp:190): the twin's entries with the roles of the two factor matrices swapped, on
     // the same stream and AHEAD of this evaluation, so that the completion event below covers both
-    const bool fused_twin = t->twin && t->d_twin_perm && !dist && !F32;
+    const bool fused_twin = t->twin && t->d_twin_perm && !dist;
     if (t->twin && !fused_twin && (t->twin->nnz > 0 || dist)) {      // (sharded: its all-reduce is collective, entries or not)
         t->twin->in_ev = t->in_ev;
         predict<K, F32>(t->twin, t->twin->side, other_items, self_items, n, ps, false);
@@ -465,6 +465,20 @@ void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items
     // se | se_avg of this rank's test ratings: straight to the host, or -> all-reduce -> host
     double *red = c->d_red + c->out_words + (t->owner ? 2 : 0);      // 2 spare words behind the sampler's blob (the twin: the next 2)
     if constexpr (F32) {
+        if (fused_twin) {
+            // round 4: the twin inside the same kernel here too (k_predict<K, 256, float>) -- as two kernels the second one
+            // started when the partner's sampler had filled the chip and ended with it (347 us for 20 us of work), and the
+            // host loop, which collects both sums before it enqueues the next iteration, came 45 us late every iteration
+            bpmf::TwinArgs tw{};
+            bpmf_hip_test *u = t->twin;
+            tw.perm = t->d_twin_perm; tw.pavg = u->d_pavg; tw.pm2 = u->d_pm2; tw.mean = u->side->mean_rating;
+            tw.partial = u->d_partial; tw.out = u->h_res_dev; tw.flag = reinterpret_cast<unsigned *>(u->h_res_dev + 2); tw.seq = ++u->seq;
+            u->pstream = ps; u->launched = true;
+            hipLaunchKernelGGL((bpmf::k_predict<K, 256, float>), dim3((unsigned)t->nblocks), dim3(256), 0, ps,
+                               (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz,
+                               reinterpret_cast<const float *>(self_items), reinterpret_cast<const float *>(other_items), self->from,
+                               self->mean_rating, n, t->d_pavg, t->d_pm2, t->d_partial, t->h_res_dev, t->d_ticket, flag, ++t->seq, tw);
+        } else
         hipLaunchKernelGGL(bpmf::k_predict_f32<K>, dim3((unsigned)t->nblocks), dim3(256), 0, ps,
                            (const int32_t *)t->d_tcol, (const int32_t *)t->d_trow, (const double *)t->d_tval, t->nnz,
                            reinterpret_cast<const float *>(self_items), reinterpret_cast<const float *>(other_items), self->from,
