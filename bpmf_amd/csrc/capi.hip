@@ -1865,7 +1865,9 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
         // S1 passes just ahead of the statistics kernel: the pass (0.1 ms alone) starts a hop ahead of the sampler, keeps
         // its slots, and the side's host chain is done before the partner's sampler is.
         static const int head_start = env_int("BPMF_HIP_STATS_HEADSTART", 1);
-        if (head_start && sst != s0 && !dist && (self->nstat_wg > 0 || K == 128)) {   // (fp32 path: 1 152 single-wave tile workgroups, same reasoning: 0.84 -> 0.81 ms)
+        // (fp32 path: 1 152 single-wave tile workgroups, same reasoning: 0.84 -> 0.81 ms.  NOT the fp64 form of K = 128 -- round 4,
+        //  interleaved: 1.383 / 1.392 ms without the head start against 1.404 / 1.408 with it: its 22-us pass finds room anyway)
+        if (head_start && sst != s0 && !dist && (self->nstat_wg > 0 || (K == 128 && c->dtype == BPMF_HIP_F32))) {
             if (!self->ev_stat_go) HIP_TRY(hipEventCreateWithFlags(&self->ev_stat_go, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(self->ev_stat_go, sst));
             HIP_TRY(hipStreamWaitEvent(s0, self->ev_stat_go, 0));
