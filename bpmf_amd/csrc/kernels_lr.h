@@ -538,6 +538,9 @@ __device__ __forceinline__ void pf_pass(const LrArgs &a, int w0, int wend, const
         const double vb0 = sv[xq2][4 * kk + kq2], vb1 = sv[xq2][4 * kk + 4 + kq2];   // B[k][j] = v_j[4 kk + k]
 #pragma unroll
         for (int It = 0; It < 4; ++It) {
+            // R0^-1 is upper triangular: rows 16 It .. of its columns 4 kk .. 4 kk + 7 are exact zeros while kk + 1 < 4 It
+            // (adding 0 x v changes nothing for finite v): 40 of the 64 products are issued
+            if (kk + 1 < 4 * It) continue;
             const dd2 sa = sop[(It * 64 * PF_SLD + kk) / 2];          // A[b][i][k] = (R0^-1)[16 It + 4 b + i][4 kk + k], kk and kk + 1
             X[It] = mfma44(sa.x, vb0, X[It]);
             X[It] = mfma44(sa.y, vb1, X[It]);
