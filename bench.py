@@ -83,7 +83,7 @@ def executed_flops(info, nnz, ncols, K):
     one dense K x K matrix-vector product on the MFMA (2 K^2), n(n-1)/2 + 2n solves with a rank-one factor (~11 K flops
     each: one product, a 6-step wave scan, the combine), n rank-one factors (~30 K: scan, two rsqrt + Newton, ratios),
     3 K per rating for the right-hand side, ~30 K for the normal draw; plus k_pf_prepare: 2 K^2 per ROW of the side."""
-    npf = info["pf_le2"] + info["pf_3to6"] + info["pf_7to16"]
+    npf = info["pf_le3"] + info["pf_4to6"] + info["pf_7to16"]
     if npf == 0:
         return algorithmic_flops(nnz, ncols, K)
     n1, n2 = info["pf_ratings"], info["pf_ratings_sq"]

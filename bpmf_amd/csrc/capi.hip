@@ -313,12 +313,12 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
         for (int n = 0; n <= pfmax && pfmax > 0; ++n) {
             for (const Item &it : items)
                 if (it.mc < 0 && it.len == n) { lc.push_back(it.col); ll.push_back(it.len); lp.push_back(it.p0); }
-            if (n == 2) s->pf_class[1] = (int)lc.size();
+            if (n == 3) s->pf_class[1] = (int)lc.size();
             if (n == 6) s->pf_class[2] = (int)lc.size();
         }
         s->pf_ratings = s->pf_ratings2 = 0;
         for (int32_t l : ll) { s->pf_ratings += l; s->pf_ratings2 += (int64_t)l * l; }
-        if (pfmax < 2) s->pf_class[1] = (int)lc.size();
+        if (pfmax < 3) s->pf_class[1] = (int)lc.size();
         if (pfmax < 6) s->pf_class[2] = (int)lc.size();
         s->pf_class[3] = (int)lc.size();
         s->lr_class[0] = (int)lc.size();
@@ -1947,7 +1947,7 @@ extern "C" int bpmf_hip_side_kernel_name(const bpmf_hip_side *s, char *buf, int 
             return s->mode == 1 ? "k_sample1<64>" : "k_sample<64>";
         };
         if (s->lr_n > 0 && s->mode != 2 && !s->d_prop && !c->diag_only) {
-            static const char *nb[3] = {"2", "6", "16"};
+            static const char *nb[3] = {"3", "6", "16"};
             int npf = 0;
             for (int pc = 0; pc < 3; ++pc) npf += s->pf_class[pc + 1] > s->pf_class[pc];
             if (npf > 1 && !s->d_stat_list && env_int("BPMF_HIP_PF_MERGE", 0) != 0) name = "k_sample_pf_all<64>";     // (launch_impl.h)
@@ -2011,7 +2011,7 @@ extern "C" int bpmf_hip_side_kernel_resources(bpmf_hip_side *s, int64_t *out, in
 
 // The static schedule of a side in numbers (build_schedule), for reports: out[0..15] =
 //   0 sampler form (mode)   1 work items   2 chunks of heavy columns (partial slots)   3 heavy columns cut into chunks
-//   4 light columns in the low-rank / product forms   5 work items of the others   6..8 product-form columns with <= 2 | 3..6 | 7..16 ratings
+//   4 light columns in the low-rank / product forms   5 work items of the others   6..8 product-form columns with <= 3 | 4..6 | 7..16 ratings
 //   9 columns in k_sample_lr   10 parts (bpmf_hip_side_set_overlap)   11 local columns   12 local ratings
 //   13, 14 sum over the product-form columns of their number of ratings n, of n^2   15 reserved (0)
 extern "C" int bpmf_hip_side_schedule_info(const bpmf_hip_side *s, int64_t *out, int n)

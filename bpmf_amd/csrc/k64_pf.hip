@@ -13,7 +13,7 @@ static void go(Kern kernel, int grid, int block, hipStream_t st, hipEvent_t e0, 
 void k64_pf(int cls, int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::LrArgs &a)
 {
     switch (cls) {
-    case 0: go(bpmf::k_sample_pf<64, 2>, grid, 512, st, e0, e1, a); break;
+    case 0: go(bpmf::k_sample_pf<64, 3>, grid, 512, st, e0, e1, a); break;
     case 1: go(bpmf::k_sample_pf<64, 6>, grid, 512, st, e0, e1, a); break;
     default: go(bpmf::k_sample_pf<64, 16>, grid, 512, st, e0, e1, a); break;
     }

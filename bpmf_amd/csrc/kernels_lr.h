@@ -244,7 +244,7 @@ __global__ __launch_bounds__(512, 4) void k_pf_prepare(const double *__restrict_
 // p = 0 makes C = I, exactly (s = 1, rs = 1, a = 0).
 // Per factor a lane keeps p, a = p / s and rs = sqrt(s / s') for its E entries -- with v = w rs - p F in the solve
 // with C (sqrt(s'/s) sqrt(s/s') = 1) the fourth value of PfFactor is not needed -- and s'_j = s_{j+1}, so E + 1
-// reciprocal square roots per lane serve the 2 E of (s, s').  Registers bound NCOL: 2 factors x 4 entries (<= 2 ratings)
+// reciprocal square roots per lane serve the 2 E of (s, s').  Registers bound NCOL: 3 factors x 4 entries (<= 3 ratings: 124 registers; 4 factors spill)
 // and 6 factors x 2 entries (<= 6) fit the 128 of this kernel's occupancy, 12 factors do not (k_sample_pf<.., 12>
 // keeps one column per wave).
 // ---------------------------------------------------------------------------
@@ -514,8 +514,8 @@ __device__ __forceinline__ void pf_pass(const LrArgs &a, int w0, int wend, const
         }
     }
     if constexpr (NCAP <= 6) {
-        // several columns per scan (pf_group): four with <= 2 ratings, two with <= 6
-        constexpr int NCOL = NCAP <= 2 ? 4 : 2;
+        // several columns per scan (pf_group): four with <= 3 ratings, two with <= 6
+        constexpr int NCOL = NCAP <= 3 ? 4 : 2;
 #pragma unroll 1
         for (int g = 0; g < NB; g += NCOL) pf_group<K, NCAP, NCOL>(a, w0, g, wend, sv, lane);
     } else {
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
         pf_pass<K, NCAP>(a, (npass - 1 - p) * NB, a.nitems, S0, sr[wave], sv[wave], y0, lane);
 }
 
-// The three classes of product-form columns (<= 2 | 3..6 | 7..16 ratings: pf_c[0..3], the item list is sorted by the
+// The three classes of product-form columns (<= 3 | 4..6 | 7..16 ratings: pf_c[0..3], the item list is sorted by the
 // number of ratings) in ONE launch.  As three launches each class ended on its own tail -- with 512 resident workgroups
 // of eight waves a launch is a whole number of rounds of 16 384 columns: the 20 876 columns with 7..12 ratings (the third class then) of the
 // ChEMBL-shaped side took two rounds for 1.27 rounds of work.  Here the passes (four columns of one class) of all three
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf_all(LrArgs a)
             pf_pass<K, 6>(a, a.pf_c[1] + q * NB, a.pf_c[2], S0, sr[wave], sv[wave], y0, lane);
         } else {
             const int q = np0 - 1 - (p - np2 - np1);
-            pf_pass<K, 2>(a, a.pf_c[0] + q * NB, a.pf_c[1], S0, sr[wave], sv[wave], y0, lane);
+            pf_pass<K, 3>(a, a.pf_c[0] + q * NB, a.pf_c[1], S0, sr[wave], sv[wave], y0, lane);
         }
     }
 }

@@ -76,7 +76,7 @@ void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items
 void k64_persistent(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a);
 void k64_wg(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgsW<double> &a);
 void k64_lr(int width, int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::LrArgs &a);     // sweep width 1..4
-void k64_pf(int cls, int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::LrArgs &a);       // class 0..2: <= 2 | 6 | 16 ratings
+void k64_pf(int cls, int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::LrArgs &a);       // class 0..2: <= 3 | 6 | 16 ratings
 void k64_pf_all(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::LrArgs &a);                // all three classes in one launch (k_sample_pf_all)
 void k64_pf_prepare(int grid, hipStream_t st, hipEvent_t e0, const double *S0t, const double *other_items, int64_t nrows, double *Q);
 

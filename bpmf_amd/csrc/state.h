@@ -205,7 +205,7 @@ struct bpmf_hip_side {
     int lr_class[5] = {0, 0, 0, 0, 0};     // light items sorted by sweep width: class c (1..4 ratings per sweep) is [lr_class[c-1], lr_class[c])
     int64_t pf_ratings2 = 0;
     int64_t pf_ratings = 0;                // ratings of the product-form columns (bpmf_hip_side_schedule_info)
-    int pf_class[4] = {0, 0, 0, 0};        // ahead of them: product-form items (k_sample_pf): <= 2 ratings, 3..6, 7..16 -- class c is [pf_class[c], pf_class[c+1])
+    int pf_class[4] = {0, 0, 0, 0};        // ahead of them: product-form items (k_sample_pf): <= 3 ratings, 4..6, 7..16 -- class c is [pf_class[c], pf_class[c+1])
     double *d_pf_q = nullptr;              // product form: R0^-T u_row for every row of the other side (nrows x K), per half-iteration
     int32_t *d_lr_col = nullptr, *d_lr_len = nullptr; int64_t *d_lr_p0 = nullptr;
     int32_t *d_hv_col = nullptr, *d_hv_len = nullptr, *d_hv_mc = nullptr, *d_hv_chunk = nullptr; int64_t *d_hv_p0 = nullptr;

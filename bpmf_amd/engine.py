@@ -241,7 +241,7 @@ class HipEngine:
     def schedule_info(self, side):
         out = np.zeros(16, np.int64)
         _lib.check(self.lib.bpmf_hip_side_schedule_info(side.handle, _ptr(out), 16))
-        keys = ("mode", "work_items", "chunks", "chunked_columns", "light_columns", "other_items", "pf_le2", "pf_3to6", "pf_7to16",
+        keys = ("mode", "work_items", "chunks", "chunked_columns", "light_columns", "other_items", "pf_le3", "pf_4to6", "pf_7to16",
                 "lr_columns", "parts", "local_columns", "local_ratings", "pf_ratings", "pf_ratings_sq")
         return {k: int(v) for k, v in zip(keys, out)}
 

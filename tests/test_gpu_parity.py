@@ -116,7 +116,7 @@ def test_low_rank_columns(oracle, hip_engine_factory, monkeypatch):
 
 
 def test_product_form_classes_in_one_launch(oracle, hip_engine_factory, monkeypatch):
-    """k_sample_pf_all: the three classes of product-form columns (<= 2 | 3..6 | 7..16 ratings) as ONE launch whose waves
+    """k_sample_pf_all: the three classes of product-form columns (<= 3 | 4..6 | 7..16 ratings) as ONE launch whose waves
     take passes of four columns round-robin from one list, most expensive first.  Several launches on the same side, class
     sizes that are not multiples of four (ragged last pass of every class), against the oracle and bit for bit against the
     three separate launches (BPMF_HIP_PF_MERGE=0)."""
@@ -160,7 +160,7 @@ def test_product_form_classes_in_one_launch(oracle, hip_engine_factory, monkeypa
         check_half_iteration((items, s, p, n), (ref, s_ref, p_ref, n_ref))
     separate, name0 = run("0")
     if name0:
-        assert "k_sample_pf<64,2>" in name0
+        assert "k_sample_pf<64,3>" in name0
     for a, b in zip(merged, separate):
         assert np.array_equal(a[0], b[0])
 
