@@ -136,10 +136,44 @@ def profiled(workload):
     return traffic, conflict, os.path.basename(files[-1]), sha
 
 
-def cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies, budget_s=12.0):
-    """oracle/cpu_baseline.py in a process of its own (placement: one thread per physical core, spread)."""
+PARITY_TOL = {"f64": {"rmse": 1e-6, "items_rel": 1e-6, "norm_rel": 1e-7}, "f32": {"rmse": 1e-3, "items_rel": 2e-3, "norm_rel": 1e-3}}
+
+
+def parity_record(gpu, ref, dtype, nsims, burnin, chain_info):
+    """bench.py's `parity` object: the chain the timed pipeline produced against the oracle's chain on the same matrix
+    and seeds ("test RMSE vs reference", the metric's second half; north star: RMSE within 1e-3).  gpu / ref: dicts with
+    rmse, rmse_avg, norm_u, norm_m (per iteration), final_rmse_avg, num_predict, U, V."""
+    tol = PARITY_TOL[dtype]
+    g = {k: np.asarray(gpu[k], np.float64) for k in ("rmse", "rmse_avg", "norm_u", "norm_m")}
+    r = {k: np.asarray(ref[k], np.float64) for k in ("rmse", "rmse_avg", "norm_u", "norm_m")}
+    d_rmse = float(np.abs(g["rmse"] - r["rmse"]).max())
+    d_avg = float(np.abs(g["rmse_avg"] - r["rmse_avg"]).max())
+    d_final = abs(float(gpu["final_rmse_avg"]) - float(ref["final_rmse_avg"]))
+    d_norm = float(max(np.abs(g["norm_u"] / r["norm_u"] - 1).max(), np.abs(g["norm_m"] / r["norm_m"] - 1).max()))
+    d_u = float(np.abs(gpu["U"] - ref["U"]).max() / np.abs(ref["U"]).max())
+    d_v = float(np.abs(gpu["V"] - ref["V"]).max() / np.abs(ref["V"]).max())
+    ok = (d_rmse < tol["rmse"] and d_avg < tol["rmse"] and d_final < tol["rmse"] and d_norm < tol["norm_rel"]
+          and d_u < tol["items_rel"] and d_v < tol["items_rel"] and int(gpu["num_predict"]) == int(ref["num_predict"]))
+    out = {"iterations": nsims, "burnin": burnin,
+           "path": "bpmf_amd.gibbs(pipelined=True) on the bench's own engine: the software-pipelined stateful loop the timed region runs "
+                   "(default schedule, fused launches, riders, twin evaluation), from the reference's start (zero factors, iter = -1)",
+           "against": "oracle/bpmf_oracle.c chain (CPU restatement of c++/bpmf.cpp:180-253 + c++/sample.cpp), same matrix, identical seeds",
+           "rmse_gpu": float(g["rmse"][-1]), "rmse_cpu": float(r["rmse"][-1]),
+           "final_avg_rmse_gpu": float(gpu["final_rmse_avg"]), "final_avg_rmse_cpu": float(ref["final_rmse_avg"]),
+           "d_rmse_max": d_rmse, "d_rmse_avg_max": d_avg, "d_final_avg_rmse": d_final, "d_norm_rel": d_norm,
+           "d_items_rel": {"U": d_u, "V": d_v}, "tolerance": dict(tol, north_star_rmse=1e-3), "ok": bool(ok),
+           "oracle_pinned": os.path.exists(os.path.join(ROOT, "oracle", "_ref", "PINNED"))}
+    out.update(chain_info or {})
+    return out
+
+
+def cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies, budget_s=12.0, parity=None):
+    """oracle/cpu_baseline.py in a process of its own (placement: one thread per physical core, spread).
+    parity = (nsims, burnin): the child also runs the oracle's chain of that length and this function returns its
+    traces + factors under the key "parity_ref" (popped by the caller)."""
     fd, path = tempfile.mkstemp(suffix=".npz", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     os.close(fd)
+    ppath = path[:-4] + "_parity.npz"
     try:
         arrs = {}
         for name, m in (("M", M), ("Mt", Mt), ("T", T), ("Tt", Tt)):
@@ -153,17 +187,26 @@ def cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies, budget_s=12.0):
             usable = len(os.sched_getaffinity(0))
         except AttributeError:
             usable = os.cpu_count() or 1
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--matrix", path, "--K", str(K),
-                            "--budget", str(budget_s), "--usable", str(usable)], env=env, capture_output=True, text=True, timeout=600)
+        cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--matrix", path, "--K", str(K),
+               "--budget", str(budget_s), "--usable", str(usable)]
+        if parity:
+            cmd += ["--parity-nsims", str(parity[0]), "--parity-burnin", str(parity[1]), "--parity-out", ppath]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not line:
             raise RuntimeError("cpu_baseline.py rc=%d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:]))
-        return json.loads(line[-1])
+        rec = json.loads(line[-1])
+        if parity and os.path.exists(ppath):
+            z = np.load(ppath)
+            rec["parity_ref"] = {"rmse": z["rmse"], "rmse_avg": z["rmse_avg"], "norm_u": z["norm_u"], "norm_m": z["norm_m"],
+                                 "final_rmse_avg": float(z["final"][0]), "num_predict": int(z["final"][1]), "U": z["U"], "V": z["V"]}
+        return rec
     finally:
-        try:
-            os.unlink(path)
-        except OSError:
-            pass
+        for f in (path, ppath):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
 
 
 def timed_blocks(step_block, fence, steps, dist_max, min_blocks=5, max_blocks=25, budget_s=8.0):
@@ -662,6 +705,7 @@ def main():
     ap.add_argument("--repeats", type=int, default=0, help="timed blocks of --steps steps (0 = auto: 5..25 within ~8 s)")
     ap.add_argument("--prewarm-ms", type=float, default=50.0, help="untimed steps until this much time has passed (0: the W warm-up steps only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the `parity` object (the -i N -b B chain through the timed pipeline against the oracle's chain)")
     ap.add_argument("--no-bpmf-exe", action="store_true", help="skip the bpmf_exe sub-record (the `bpmf` executable on the same matrices)")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong_10Mx1M sub-record")
     ap.add_argument("--strong-steps", type=int, default=8, help="timed steps of the strong_10Mx1M record (>= 8: the library times every 8th launch of a side)")
@@ -944,6 +988,29 @@ def run(args, wl, R, wd):
         out["per_rank"] = R.gather({"rank": rank, "device": local_rank, "columns": {"movs": dom_m[1] - dom_m[0], "users": dom_u[1] - dom_u[0]},
                                     "launch_ms_per_side": per_side, "hbm_frac": hbm_gbs / HBM_PEAK_GBS,
                                     "exchange_and_rest_ms": dt / args.steps * 1e3 - sum(per_side.values())})
+    # "test RMSE vs reference": the default run of the reference (-i 20 -b 5, c++/bpmf.cpp:30-31; -i 6 -b 2 on the K >= 64 workloads,
+    # whose CPU chain costs seconds per iteration) through the SAME pipelined stateful path that was just timed, from the
+    # reference's start; compared below with the oracle's chain, which the cpu_baseline child computes on the same matrix
+    gpu_chain, parity_cfg, parity_skip = None, ((20, 5) if K <= 32 else (6, 2)), None
+    if world != 1:
+        parity_skip = "N > 1: the chain parity of the sharded path is tests/test_gpu_multirank.py's; this object is the N = 1 record's"
+    elif args.no_parity or args.no_cpu_baseline:
+        parity_skip = "skipped (--no-parity / --no-cpu-baseline: no oracle chain to compare with)"
+    elif args.ablate is not None:
+        parity_skip = "skipped (--ablate: the samples are wrong by construction)"
+    else:
+        wd.stage("parity chain", wd.default + 60)
+        try:
+            t_par = time.perf_counter()
+            movies.refresh(); users.refresh()
+            res = bpmf_amd.gibbs(eng, M, Mt, T, nusers, nmovies, nsims=parity_cfg[0], burnin=parity_cfg[1], Tt=Tt if both_predicts else None,
+                                 pipelined=True)
+            gpu_chain = {k: res[k] for k in ("rmse", "rmse_avg", "norm_u", "norm_m", "final_rmse_avg", "num_predict", "U", "V")}
+            gpu_chain["info"] = {"gpu_chain_s": time.perf_counter() - t_par,
+                                 "kernel_per_side": {"movs": eng.kernel_name(res["movies"].side), "users": eng.kernel_name(res["users"].side)}}
+            del res
+        except Exception as e:
+            parity_skip = "the chain through the timed pipeline failed: %r" % (e,)
     try:
         eng.close()                      # sides, collector threads, streams, (RCCL communicator)
     except Exception:
@@ -971,10 +1038,18 @@ def run(args, wl, R, wd):
         wd.stage("cpu baseline", 700)
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies)
+                out["cpu_baseline"] = cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies, parity=parity_cfg if gpu_chain else None)
             except Exception as e:  # the GPU number must still be reported
                 out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}
+                parity_skip = parity_skip or "the CPU leg failed: %r" % (e,)
+        ref_chain = out.get("cpu_baseline", {}).pop("parity_ref", None) if isinstance(out.get("cpu_baseline"), dict) else None
+        if gpu_chain is not None and ref_chain is not None:
+            info = dict(gpu_chain.pop("info"), cpu_chain=out["cpu_baseline"].get("parity_chain"))
+            out["parity"] = parity_record(gpu_chain, ref_chain, dtype, parity_cfg[0], parity_cfg[1], info)
+        else:
+            out["parity"] = {"value": None, "reason": parity_skip or "the CPU leg returned no chain",
+                             "oracle_pinned": os.path.exists(os.path.join(ROOT, "oracle", "_ref", "PINNED"))}
         out["wall_s"] = time.perf_counter() - t_process
         print(json.dumps(out), flush=True)
     R.finish()

@@ -42,7 +42,7 @@ _SIGNATURES = {
     "bpmf_hip_side_set_prop_posterior": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "bpmf_hip_side_destroy": (C.c_int, [C.c_void_p]),
     "bpmf_hip_side_items_dev": (C.c_void_p, [C.c_void_p]),
-    "bpmf_hip_side_bind_items": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bpmf_hip_side_bind_items": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
     "bpmf_hip_side_get_items": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bpmf_hip_side_set_items": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bpmf_hip_sample_side": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p,

@@ -96,7 +96,8 @@ int comm_abort(bpmf_hip_ctx *c, const std::string &what)
         if (R && R->CommAbort) {
             if (c->comm2) (void)R->CommAbort(c->comm2);
             if (c->comm) (void)R->CommAbort(c->comm);
-            c->comm2 = nullptr;                                       // (aborted = destroyed; `comm` stays non-NULL as "this context is sharded")
+            // (aborted = destroyed.  Both handles stay in place as "this context is sharded / has a second communicator": they
+            // are read without a lock by the launch paths, and nothing uses them once comm_dead is set -- COMM_ALIVE_OR_FAIL)
         }
     }
     return fail(BPMF_HIP_ENODEV, "collective timed out (" + what + "): a peer rank stalled or died; the communicator was aborted");
@@ -113,7 +114,10 @@ int bounded_stream_sync(bpmf_hip_ctx *c, hipStream_t st, const char *what)
         if (q != hipErrorNotReady) return fail(BPMF_HIP_ENODEV, std::string(what) + ": " + hipGetErrorString(q));
         (void)hipGetLastError();
         if (spins < 2000) { __builtin_ia32_pause(); continue; }
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > comm_timeout_s()) return comm_abort(c, what);
+        // (once the communicators are dead a stream may hold collective kernels that will never end -- with an RCCL that has no
+        // ncclCommAbort for certain: no second full timeout for every later wait, ctx_destroy included)
+        const double limit = c->comm_dead.load(std::memory_order_acquire) ? std::min(2.0, comm_timeout_s()) : comm_timeout_s();
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) return comm_abort(c, what);
         std::this_thread::sleep_for(std::chrono::microseconds(spins < 20000 ? 20 : 200));
     }
 }
@@ -128,7 +132,10 @@ int bounded_event_sync(bpmf_hip_ctx *c, hipEvent_t ev, const char *what)
         if (q != hipErrorNotReady) return fail(BPMF_HIP_ENODEV, std::string(what) + ": " + hipGetErrorString(q));
         (void)hipGetLastError();
         if (spins < 2000) { __builtin_ia32_pause(); continue; }
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > comm_timeout_s()) return comm_abort(c, what);
+        // (once the communicators are dead a stream may hold collective kernels that will never end -- with an RCCL that has no
+        // ncclCommAbort for certain: no second full timeout for every later wait, ctx_destroy included)
+        const double limit = c->comm_dead.load(std::memory_order_acquire) ? std::min(2.0, comm_timeout_s()) : comm_timeout_s();
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) return comm_abort(c, what);
         std::this_thread::sleep_for(std::chrono::microseconds(spins < 20000 ? 20 : 200));
     }
 }
@@ -758,10 +765,18 @@ extern "C" double *bpmf_hip_side_items_dev(bpmf_hip_side *s)
     return s->d_items;
 }
 
-extern "C" int bpmf_hip_side_bind_items(bpmf_hip_side *s, double *items_dev)
+extern "C" int bpmf_hip_side_bind_items(bpmf_hip_side *s, double *items_dev, int ld, size_t bytes)
 {
     if (!s || !items_dev) return fail(BPMF_HIP_EINVAL, "bind_items: NULL");
     if (s->ctx->dtype != BPMF_HIP_F64) return fail(BPMF_HIP_EINVAL, "bind_items: fp64 contexts only");
+    // the kernels address the storage with the context's leading dimension (bpmf_hip_ctx_ld: 32 for num_latent 20), not with
+    // num_latent: a caller that sized its buffer num_latent x ncols would have every sampler launch write past it
+    if (ld != s->ctx->K)
+        return fail(BPMF_HIP_EINVAL, "bind_items: leading dimension " + std::to_string(ld) + " given, the context's device arrays have " +
+                    std::to_string(s->ctx->K) + " (bpmf_hip_ctx_ld; num_latent " + std::to_string(s->ctx->Kt) + ")");
+    if (bytes < sizeof(double) * (size_t)s->ctx->K * (size_t)s->ncols)
+        return fail(BPMF_HIP_EINVAL, "bind_items: " + std::to_string(bytes) + " bytes given, ld x ncols doubles = " +
+                    std::to_string(sizeof(double) * (size_t)s->ctx->K * (size_t)s->ncols) + " needed");
     HIP_TRY(hipSetDevice(s->ctx->device));
     (void)settle_async(s);
     { const int rs_ = bounded_stream_sync(s->ctx, s->ctx->stream, __func__); if (rs_) return rs_; }
@@ -860,6 +875,7 @@ int reduce_half_iteration(bpmf_hip_side *self, const bpmf_hip_side *other, int i
     const bool dist = c->comm != nullptr && !self->bounds.empty();
     if (dist) {                                                     // (one rank: the reduce is the identity, the path is the same)
         Rccl *R = rccl();
+        COMM_ALIVE_OR_FAIL(c, "BPMF_REDUCE half-iteration");
         if (!R->Reduce) return fail(BPMF_HIP_ENODEV, "BPMF_REDUCE formulation: this RCCL has no ncclReduce");
         NcclGroup group(R);
         NCCL_TRY(group.start());
@@ -2196,6 +2212,7 @@ extern "C" int bpmf_hip_side_set_overlap(bpmf_hip_side *s, int nparts)
     if (!s || nparts < 1 || nparts > 8) return fail(BPMF_HIP_EINVAL, "side_set_overlap: 1..8 parts");
     bpmf_hip_ctx *c = s->ctx;
     if (!c->comm || s->bounds.empty()) return fail(BPMF_HIP_EINVAL, "side_set_overlap: set the communicator and the ranges first");
+    COMM_ALIVE_OR_FAIL(c, "side_set_overlap");
     int rc;
     if ((rc = settle_async(s))) return rc;
     HIP_TRY(hipSetDevice(c->device));
@@ -2271,6 +2288,7 @@ extern "C" int bpmf_hip_side_set_conn(bpmf_hip_side *s, const int64_t *send_ptr,
     if (!s) return fail(BPMF_HIP_EINVAL, "side_set_conn: NULL");
     bpmf_hip_ctx *c = s->ctx;
     if (!c->comm || s->bounds.empty()) return fail(BPMF_HIP_EINVAL, "side_set_conn: set the communicator and the ranges first");
+    COMM_ALIVE_OR_FAIL(c, "side_set_conn");
     if (c->dtype != BPMF_HIP_F64) return fail(BPMF_HIP_EINVAL, "side_set_conn: the packed exchange is fp64 only (the fp32 context uses the all-gather form)");
     if (s->stale_k > 0 && (send_ptr || recv_ptr)) return fail(BPMF_HIP_EINVAL, "side_set_conn: not together with the bounded-staleness exchange");
     int rc;
@@ -2312,6 +2330,7 @@ extern "C" int bpmf_hip_side_exchange(bpmf_hip_side *s)
     if (!s) return fail(BPMF_HIP_EINVAL, "side_exchange: NULL");
     bpmf_hip_ctx *c = s->ctx;
     if (!c->comm || s->bounds.empty()) return fail(BPMF_HIP_EINVAL, "side_exchange: set the communicator and the ranges first");
+    COMM_ALIVE_OR_FAIL(c, "side_exchange");
     int rc;
     if ((rc = settle_async(s))) return rc;
     HIP_TRY(hipSetDevice(c->device));
@@ -2531,6 +2550,7 @@ extern "C" int bpmf_hip_predict_launch(bpmf_hip_test *t, const bpmf_hip_side *se
     bpmf_hip_side *other = const_cast<bpmf_hip_side *>(other_c);
     HIP_TRY(hipSetDevice(c->device));
     const bool dist = c->comm && !self->bounds.empty();
+    if (dist) COMM_ALIVE_OR_FAIL(c, "predict_launch");               // (its sums are all-reduced)
     if (t->twin && t->twin->nnz == 0 && !dist) t->twin->launched = true;     // (nothing to enqueue for it)
     if (t->nnz == 0 && !dist) {
         t->launched = true;
@@ -2605,6 +2625,7 @@ extern "C" int bpmf_hip_predict_finish(bpmf_hip_test *t, double *se, double *se_
     *count = t->nnz;
     if (dist) {
         if (t->global_nnz < 0) {                                   // once: number of test ratings over all ranks
+            COMM_ALIVE_OR_FAIL(c, "predict_finish");
             long long v = (long long)t->nnz, *d = reinterpret_cast<long long *>(c->d_red + c->out_words + 4);
             HIP_TRY(hipMemcpyAsync(d, &v, sizeof v, hipMemcpyHostToDevice, c->stream));
             NCCL_TRY(rccl()->AllReduce(d, d, 1, ncclInt64, ncclSum, c->comm, c->stream));

@@ -275,6 +275,7 @@ int exchange(bpmf_hip_side *self, hipStream_t st, int sub)
 {
     bpmf_hip_ctx *c = self->ctx;
     if (!(c->comm != nullptr && !self->bounds.empty())) return 0;
+    COMM_ALIVE_OR_FAIL(c, "exchange");
     // factors are fp64 (8 K bytes per column) or, in the fp32 context, fp32
     const bool f32 = c->dtype == BPMF_HIP_F32;
     const ncclDataType_t ty = f32 ? ncclFloat : ncclDouble;
@@ -356,6 +357,7 @@ int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_h
         typedef typename std::conditional<F32, float, double>::type T;
         const bool dist = c->comm != nullptr && !self->bounds.empty();
         const bool own = st != c->stream && c->comm2 && self->a_d_red;
+        if (dist) COMM_ALIVE_OR_FAIL(c, "statistics all-reduce");
         double *red = own ? self->a_d_red : c->d_red;
         hipLaunchKernelGGL((k_colstats_f32<K, T>), dim3(self->nstat_waves * (K / 16) * (K / 16 + 1) / 2), dim3(64), 0, st, reinterpret_cast<const T *>(self->d_items),
                            self->from, self->to, self->nstat_waves, self->d_stat_partials);
@@ -405,6 +407,7 @@ int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_h
         // local sums into a device blob, all-reduce them (cov is then formed once from the GLOBAL
         // sums: SURVEY Q19) together with the failed-column word, publish to the host
         Rccl *R = rccl();
+        COMM_ALIVE_OR_FAIL(c, "statistics all-reduce");
         // on the side's own stream: its own reduction blob and the second communicator
         const bool own = st != c->stream && c->comm2 && self->a_d_red;
         double *red = own ? self->a_d_red : c->d_red;

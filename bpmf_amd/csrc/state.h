@@ -104,6 +104,14 @@ struct Rccl {
 
 Rccl *rccl();      // capi.hip
 
+// Every path that would enqueue a collective asks first: after a timed-out collective the communicators were aborted
+// (capi.hip comm_abort) and their handles must not be used again -- the call fails with BPMF_HIP_ENODEV instead.
+#define COMM_ALIVE_OR_FAIL(ctx_, who_)                                                                         \
+    do {                                                                                                       \
+        if ((ctx_)->comm_dead.load(std::memory_order_acquire))                                                 \
+            return fail(BPMF_HIP_ENODEV, std::string(who_) + ": the communicator of this context was aborted (a collective timed out)"); \
+    } while (0)
+
 #define NCCL_TRY(expr)                                                                                 \
     do {                                                                                               \
         ncclResult_t r_ = (expr);                                                                      \

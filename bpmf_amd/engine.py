@@ -141,16 +141,26 @@ class HipEngine:
     def items_dev_ptr(self, side):
         return self.lib.bpmf_hip_side_items_dev(side.handle)
 
-    def bind_items(self, side, dev_ptr, keep=None):
-        _lib.check(self.lib.bpmf_hip_side_bind_items(side.handle, C.c_void_p(dev_ptr)))
+    def ld(self):
+        """Rows per column of the context's DEVICE arrays (bpmf_hip_ctx_ld): K for 8 / 16 / 32 / 64 / 128, else the next of those."""
+        return int(self.lib.bpmf_hip_ctx_ld(self.ctx))
+
+    def bind_items(self, side, dev_ptr, keep=None, ld=None, nbytes=None):
+        """`ld` / `nbytes`: what the caller allocated (default: the caller's K x ncols doubles); the library refuses storage
+        whose leading dimension is not the context's or that is too small (a padded num_latent needs ld() rows per column)."""
+        ld = self.K if ld is None else int(ld)
+        nbytes = 8 * ld * side.ncols if nbytes is None else int(nbytes)
+        _lib.check(self.lib.bpmf_hip_side_bind_items(side.handle, C.c_void_p(dev_ptr), ld, nbytes))
         side._items_keep = keep
 
     def items_tensor(self, side, device):
-        """Allocates the factor matrix as a torch tensor [ncols, K] on `device`, binds the side to
-        it (bpmf_hip_side_bind_items) and returns it, so RCCL collectives work on it in place."""
+        """Allocates the factor matrix as a torch tensor [ncols, ld()] on `device` (rows num_latent .. ld()-1 of every column
+        stay zero), binds the side to it (bpmf_hip_side_bind_items) and returns the WHOLE tensor, so that RCCL collectives move
+        full device rows in place; t[:, :K] are the factors."""
         import torch
-        t = torch.zeros((side.ncols, self.K), dtype=torch.float64, device=device)
-        self.bind_items(side, t.data_ptr(), keep=t)
+        ld = self.ld()
+        t = torch.zeros((side.ncols, ld), dtype=torch.float64, device=device)
+        self.bind_items(side, t.data_ptr(), keep=t, ld=ld, nbytes=t.numel() * 8)
         return t
 
     def set_prop_posterior(self, side, Lambda):
@@ -201,6 +211,12 @@ class HipEngine:
         cov = np.empty((K, K), order="F"); mu = np.empty(K); LF = np.empty((K, K), order="F"); LU = np.empty((K, K), order="F")
         _lib.check(self.lib.bpmf_hip_sys_state(side.handle, C.byref(it), C.byref(nrm), _ptr(cov), _ptr(mu), _ptr(LF), _ptr(LU)))
         return it.value, nrm.value, cov, mu, LF, LU
+
+    def sys_norm(self, side, it):
+        """Sys::norm of half-iteration `it` of the side (one of its last 8), without draining later half-iterations."""
+        nrm = C.c_double()
+        _lib.check(self.lib.bpmf_hip_sys_norm(side.handle, int(it), C.byref(nrm)))
+        return nrm.value
 
     def aggr_add(self, side):
         """aggrMu / aggrLambda += r, r r^T of the side's local columns (device)."""

@@ -177,11 +177,16 @@ class Sys:
             Sys.procid, phase, self.iter, self.rmse, self.rmse_avg, norm_u, norm_m, items_per_sec, ratings_per_sec / 1e6)
 
 
-def gibbs(engine, M, Mt, T, nusers, nmovies, nsims=20, burnin=5, alpha=2.0, out=None, keep_samples=False, Tt=None):
+def gibbs(engine, M, Mt, T, nusers, nmovies, nsims=20, burnin=5, alpha=2.0, out=None, keep_samples=False, Tt=None, pipelined=False):
     """The loop of main() (c++/bpmf.cpp:131-253) in NO_COMM mode.  M / T: CSC
     with one column per movie (rows = users); Mt its transpose.  Returns a dict
     with the per-iteration trace; `out` (a file object) receives the reference's
-    stdout lines."""
+    stdout lines.
+
+    pipelined=True: the same iterations the way the `bpmf` executable (bpmf_main.cpp) and bench.py's timed
+    region run them -- the line of iteration i - 1 (RMSE sums, norms) is collected after iteration i has been
+    enqueued, the evaluation of i - 1 runs beside the samplers of i (which write the other copy of the factors).
+    Same chain, same numbers; `secs` is then the time between two collected lines."""
     Sys.nsims, Sys.burnin, Sys.alpha = nsims, burnin, alpha
     movies = Sys("movs", engine, M, nmovies, nusers, T=T)
     users = Sys("users", engine, Mt, nusers, nmovies, T=Tt)
@@ -189,26 +194,51 @@ def gibbs(engine, M, Mt, T, nusers, nmovies, nsims=20, burnin=5, alpha=2.0, out=
         movies.set_twin(users)                       # users.predict(movies) rides with movies.predict(users)
     res = dict(rmse=[], rmse_avg=[], norm_u=[], norm_m=[], secs=[], samples=[])
     nnz = movies.local_nnz
-    avg_items = 0.0
-    for i in range(nsims):
-        start = time.perf_counter()
-        movies.sample(users)
-        users.sample(movies)
-        movies.predict(users)
-        if Tt is not None:
-            users.predict(movies)                    # c++/bpmf.cpp:190 (nothing reads its results; Tt = None leaves it out)
-        stop = time.perf_counter()
-        movies.refresh(); users.refresh()
-        ips = (users.num() + movies.num()) / (stop - start)
-        rps = nnz / (stop - start)
-        avg_items += ips
+
+    def line(it, secs, norm_u, norm_m):
+        ips = (users.num() + movies.num()) / secs
         if out is not None:
-            out.write(movies.format_line(ips, rps, math.sqrt(users.norm), math.sqrt(movies.norm)))
+            saved, movies.iter = movies.iter, it
+            out.write(movies.format_line(ips, nnz / secs, math.sqrt(norm_u), math.sqrt(norm_m)))
+            movies.iter = saved
         res["rmse"].append(movies.rmse); res["rmse_avg"].append(movies.rmse_avg)
-        res["norm_u"].append(math.sqrt(users.norm)); res["norm_m"].append(math.sqrt(movies.norm))
-        res["secs"].append(stop - start)
-        if keep_samples:
-            res["samples"].append((users.items(), movies.items()))
+        res["norm_u"].append(math.sqrt(norm_u)); res["norm_m"].append(math.sqrt(norm_m))
+        res["secs"].append(secs)
+
+    if pipelined and not keep_samples and hasattr(engine, "sys_norm"):
+        mark = time.perf_counter()
+        for i in range(nsims):
+            movies.sample(users)
+            users.sample(movies)
+            if i > 0:
+                norm_m = engine.sys_norm(movies.side, i - 1)
+                norm_u = engine.sys_norm(users.side, i - 1)
+                movies.predict_finish()
+                if Tt is not None:
+                    users.predict_finish()
+                now = time.perf_counter()
+                line(i - 1, now - mark, norm_u, norm_m)
+                mark = now
+            movies.predict_launch(users)
+        if nsims > 0:
+            movies.predict_finish()
+            if Tt is not None:
+                users.predict_finish()
+            movies.refresh(); users.refresh()
+            line(nsims - 1, time.perf_counter() - mark, users.norm, movies.norm)
+    else:
+        for i in range(nsims):
+            start = time.perf_counter()
+            movies.sample(users)
+            users.sample(movies)
+            movies.predict(users)
+            if Tt is not None:
+                users.predict(movies)                # c++/bpmf.cpp:190 (nothing reads its results; Tt = None leaves it out)
+            stop = time.perf_counter()
+            movies.refresh(); users.refresh()
+            line(i, stop - start, users.norm, movies.norm)
+            if keep_samples:
+                res["samples"].append((users.items(), movies.items()))
     movies.predict(users, True)                      # c++/bpmf.cpp:242 (the extra call of Q6)
     if Tt is not None:
         users.predict(movies)                        # (the twin was evaluated with it: collect its sums)

@@ -191,9 +191,12 @@ BPMF_API int bpmf_hip_side_destroy(bpmf_hip_side *side);
  * torch tensor / RCCL buffer can be exchanged in place; replaces the
  * backend's malloc in alloc_and_init, c++/nocomm.h:31).  Either call pins the
  * factors to ONE address: the side gives up its second copy (see
- * bpmf_hip_predict_launch) and its samplers write in place from then on. */
+ * bpmf_hip_predict_launch) and its samplers write in place from then on.
+ * The caller states what it allocated: `ld` (rows per column of its storage) must equal
+ * bpmf_hip_ctx_ld -- NOT num_latent when that is not one of 8 / 16 / 32 / 64 / 128 -- and `bytes`
+ * must cover ld x ncols doubles; otherwise BPMF_HIP_EINVAL and nothing is bound. */
 BPMF_API double *bpmf_hip_side_items_dev(bpmf_hip_side *side);
-BPMF_API int bpmf_hip_side_bind_items(bpmf_hip_side *side, double *items_dev);
+BPMF_API int bpmf_hip_side_bind_items(bpmf_hip_side *side, double *items_dev, int ld, size_t bytes);
 /* host <-> device copies of the whole K x ncols matrix (the -v / -o dumps,
  * c++/bpmf.cpp:206-207,234-239) */
 BPMF_API int bpmf_hip_side_get_items(bpmf_hip_side *side, double *items_host);

@@ -79,6 +79,10 @@ def main():
     ap.add_argument("--budget", type=float, default=12.0, help="seconds of CPU work for the final measurement")
     ap.add_argument("--usable", type=int, default=0, help="hardware threads the launching process may use (with OMP_PROC_BIND "
                     "the OpenMP runtime pins THIS process's initial thread to one core as soon as it loads, so sched_getaffinity here says 2)")
+    ap.add_argument("--parity-nsims", type=int, default=0, help="also run the CHECKER build's chain of this many iterations (bpmf -i) "
+                    "on the same matrix and write its traces + factors to --parity-out: what bench.py's `parity` object is compared with")
+    ap.add_argument("--parity-burnin", type=int, default=5)
+    ap.add_argument("--parity-out", default=None)
     args = ap.parse_args()
 
     from oracle import oracle as orc
@@ -98,6 +102,18 @@ def main():
 
     quota = cpu_quota()
     limit = min(usable, quota) if quota else usable
+
+    parity = None
+    if args.parity_nsims > 0 and args.parity_out:
+        # "test RMSE vs reference": the oracle proper (libbpmf_oracle.so, -O2 -ffp-contract=off: the build the parity tests
+        # check against, not the -O3 -march=native one that is timed below) runs main()'s loop (c++/bpmf.cpp:180-253) on the
+        # matrix the GPU ran, identical seeds; bench.py diffs the traces and the factors with those of its own chain
+        t0 = time.time()
+        r = orc.Oracle().gibbs(K, M, Mt, T, Tt, nsims=args.parity_nsims, burnin=args.parity_burnin, nthreads=limit)
+        np.savez(args.parity_out, rmse=r["rmse"], rmse_avg=r["rmse_avg"], norm_u=r["norm_u"], norm_m=r["norm_m"],
+                 final=np.array([r["final_rmse_avg"], float(r["num_predict"])]), U=r["U"], V=r["V"])
+        parity = {"iterations": args.parity_nsims, "burnin": args.parity_burnin, "threads": limit, "seconds": time.time() - t0,
+                  "build": "oracle/libbpmf_oracle.so (gcc -O2 -ffp-contract=off -fopenmp)"}
 
     def per_iter(nt, n):
         o.gibbs(K, M, Mt, T, Tt, nsims=1, burnin=0, nthreads=nt)               # first touch + warm-up
@@ -124,6 +140,7 @@ def main():
     t_phys = sweep_in.get(physical)
     nsamp = nusers + nmovies
     print(json.dumps({
+        "parity_chain": parity,
         "value": nsamp / t_best, "unit": "samples/s", "cores": best, "kind": "port",
         "all_usable_cores": {"cores": physical, "value": (nsamp / t_phys) if t_phys else None,
                              "ms_per_iter": t_phys * 1e3 if t_phys else None},

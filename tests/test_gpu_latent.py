@@ -151,3 +151,45 @@ def test_state_and_raw_layout_of_a_padded_context(oracle, hip_engine_factory):
     assert hip.hipMemcpy(raw.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(ptr), ctypes.c_size_t(raw.nbytes), 2) == 0   # hipMemcpyDeviceToHost
     assert np.array_equal(raw[:, :K], X) and not raw[:, K:].any()
     eng.side_destroy(movies.side); eng.side_destroy(users.side)
+
+
+def test_bind_items_refuses_storage_with_the_callers_leading_dimension():
+    """bpmf_hip_side_bind_items states what was allocated: num_latent 20 runs with 32 rows per column on the device, so a
+    [ncols, 20] buffer (what a caller thinking in num_latent would allocate) is refused instead of being written past; with
+    [ncols, ld] the samplers stay inside it (guard words behind the storage).  Raw hipMalloc through ctypes: the HIP runtime
+    the library itself is linked against (torch brings its own copy, which must be the first one a process loads)."""
+    import ctypes as C
+    import bpmf_amd
+    from bpmf_amd import _lib
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    eng = bpmf_amd.HipEngine(20)
+    dev = C.c_void_p()
+    try:
+        assert eng.ld() == 32
+        n, guard = 300, 64
+        side = eng.side_create(n, 50, np.zeros(n + 1, np.int64), np.zeros(0, np.int32), np.zeros(0), 0.0)
+        other = eng.side_create(50, n, np.zeros(51, np.int64), np.zeros(0, np.int32), np.zeros(0), 0.0)
+        host = np.zeros(n * 32 + guard); host[n * 32:] = 7.0
+        assert hip.hipMalloc(C.byref(dev), host.nbytes) == 0
+        assert hip.hipMemcpy(dev, host.ctypes.data_as(C.c_void_p), host.nbytes, 1) == 0
+        with pytest.raises(_lib.BpmfHipError) as e:
+            eng.bind_items(side, dev.value)                                              # ld = num_latent = 20
+        assert "leading dimension" in str(e.value)
+        with pytest.raises(_lib.BpmfHipError):
+            eng.bind_items(side, dev.value, ld=32, nbytes=n * 20 * 8)                    # right ld, too few bytes
+        eng.bind_items(side, dev.value, ld=32, nbytes=n * 32 * 8)
+        eng.sample_side(side, other, 0, 2.0, np.zeros(20), np.eye(20))
+        eng.sync()
+        assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), dev, host.nbytes, 2) == 0
+        assert (host[n * 32:] == 7.0).all()
+        X = host[:n * 32].reshape(n, 32)
+        assert (X[:, 20:] == 0).all() and (X[:, :20] != 0).any()
+        assert np.array_equal(eng.get_items(side), X[:, :20])
+        eng.side_destroy(side)
+    finally:
+        eng.close()
+        if dev.value:
+            hip.hipFree(dev)

@@ -614,12 +614,14 @@ def test_sharded_path_over_rccl_single_rank(tmp_path):
     assert ja["value"] > 0 and ja["n_gpus"] == 1
 
 
-@pytest.mark.parametrize("dataset,K", [("ml100k", 16), ("blocks", 32)])
+@pytest.mark.parametrize("dataset,K", [("ml100k", 16), ("blocks", 32), ("ml100k", 20)])
 def test_two_ranks_share_one_gpu(oracle, tmp_path, dataset, K):
     """Two processes, both driving the HIP kernels on cuda:0, joined by gloo (RCCL refuses two ranks on
     one device): the sharded path with REAL kernels on REAL shards -- nnz-balanced column ranges, CSC
     slices, shard-local launches (col_from / col_to), exchange of the fresh ranges, all-reduced sums
-    and RMSE -- must reproduce the single-process chain.  "blocks": the connectivity-aware exchange."""
+    and RMSE -- must reproduce the single-process chain.  "blocks": the connectivity-aware exchange.
+    K = 20: a num_latent that runs on the K = 32 kernels -- the tensor TorchComm binds and exchanges must
+    have the DEVICE's leading dimension (HipEngine.items_tensor: [ncols, 32]), ADVICE r4 (high)."""
     import os
     import socket
     import subprocess
