@@ -26,6 +26,8 @@ def main():
     assert os.environ.get("BPMF_HIP_RCCL_LIBRARY"), "the test sets BPMF_HIP_RCCL_LIBRARY"
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
+    if case == "big":
+        return big(dataset, K, nsims, burnin, out)
     data = {"ml100k": util.ml100k, "blocks": util.blocks,
             "heavy": lambda: util.synthetic(700, 500, 30000, seed=3, heavy=(7, 650))}[dataset]
     M, Mt, T, Tt, nu, nm = data()
@@ -69,6 +71,61 @@ def main():
     eng.close()
     dist.destroy_process_group()
     print("MR-OK rank %d" % comm.rank)
+
+
+def big(scale, K, nsims, burnin, out):
+    """One rank of the north star's strong-scaling set-up (BASELINE configs[3], bench.py::strong_10Mx1M) at a reduced size: the
+    device-generated users x items x 200-per-user matrix cut into 8 user chunks / 8 nnz-balanced item ranges, rank r of N
+    holding [8r/N, 8(r+1)/N), parts forced through BPMF_HIP_OVERLAP.  Rank 0 also writes the WHOLE matrix for the oracle."""
+    import torch
+    import torch.distributed as dist
+    import bpmf_amd
+    from bpmf_amd.dist import NativeComm
+    from bpmf_amd.synth_dev import BigMatrix
+    from bpmf_amd.sys import Sys
+    scale = float(scale)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    G = 8
+    dev = torch.device("cuda", 0)
+    bm_ = BigMatrix(dev, nusers=int(10_000_000 * scale), nitems=int(1_000_000 * scale), groups=G)
+    parts = list(range(rank * G // world, (rank + 1) * G // world))
+    bnd = bm_.item_bounds()
+    bm = [bnd[r * G // world] for r in range(world)] + [bm_.NI]
+    bu = [bm_.chunk_range(r * G // world)[0] for r in range(world)] + [bm_.NU]
+    ucp, uri, uva, u0, u1 = bm_.users_csc(parts)
+    mcp, mri, mva, i0, i1 = bm_.items_csc(parts)
+    tcsc = bm_.test_csc(i0, i1)
+    box = [None]
+    if rank == 0:                                                   # the whole matrix, by item (= M of gibbs()), and the whole test set
+        fcp, fri, fva, _, _ = bm_.items_csc(list(range(G)))
+        tcp, tri, tva = bm_.test_csc(0, bm_.NI)
+        Mv = fva.cpu().numpy()
+        np.savez(out + ".matrix.npz", m0=fcp, m1=fri.cpu().numpy(), m2=Mv, t0=tcp, t1=tri, t2=tva, shape=np.array([bm_.NU, bm_.NI]))
+        box[0] = float(np.sum(Mv)) / len(Mv)                        # Sys::init's mean_rating (c++/sample.cpp:183), the oracle's expression
+        del fri, fva
+    dist.broadcast_object_list(box, src=0)
+    mean = box[0]
+    eng = bpmf_amd.HipEngine(K, device=0)
+    comm = NativeComm(eng)
+    Sys.nsims, Sys.burnin, Sys.alpha = nsims, burnin, 2.0
+    movies = Sys("movs", eng, (mcp, mri, mva), bm_.NI, bm_.NU, T=tcsc, dom=(i0, i1), mean_rating=mean, comm=comm)
+    users = Sys("users", eng, (ucp, uri, uva), bm_.NU, bm_.NI, dom=(u0, u1), mean_rating=mean, comm=comm)
+    comm.register(movies, bm); comm.register(users, bu)
+    rm, rma, nu_, nm_ = [], [], [], []
+    for _ in range(nsims):
+        movies.sample(users); users.sample(movies)
+        movies.predict(users, True)
+        movies.refresh(); users.refresh()
+        rm.append(movies.rmse); rma.append(movies.rmse_avg); nu_.append(float(np.sqrt(users.norm))); nm_.append(float(np.sqrt(movies.norm)))
+    movies.predict(users, True)
+    info_m, info_u = eng.schedule_info(movies.side), eng.schedule_info(users.side)
+    np.savez(out + ".rank%d.npz" % rank, U=users.items(), V=movies.items(), rmse=rm, rmse_avg=rma, norm_u=nu_, norm_m=nm_,
+             final=movies.rmse_avg, conn_used=np.asarray((False, False)), dom_m=np.asarray(movies.dom), dom_u=np.asarray(users.dom),
+             nranks=eng.comm_nranks(), parts=np.asarray([info_m["parts"], info_u["parts"]]))
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+    print("MR-OK rank %d" % rank)
 
 
 if __name__ == "__main__":

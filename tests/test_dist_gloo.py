@@ -32,7 +32,8 @@ def run_job(tmp_path, dataset, K, nsims, burnin, world=2):
     return [np.load(out + ".rank%d.npz" % r) for r in range(world)]
 
 
-@pytest.mark.parametrize("dataset,K,nsims,burnin,world", [("tiny", 8, 4, 1, 2), ("ml100k", 8, 3, 1, 2), ("ml100k", 8, 2, 0, 3)])
+@pytest.mark.parametrize("dataset,K,nsims,burnin,world", [("tiny", 8, 4, 1, 2), ("ml100k", 8, 3, 1, 2), ("ml100k", 8, 2, 0, 3),
+                                                           ("ml100k", 8, 2, 0, 8)])        # BASELINE configs[3]'s rank count
 def test_sharded_equals_single_process(oracle, tmp_path, dataset, K, nsims, burnin, world):
     res = run_job(tmp_path, dataset, K, nsims, burnin, world)
     M, Mt, T, Tt, nu, nm = util.tiny() if dataset == "tiny" else util.ml100k()
