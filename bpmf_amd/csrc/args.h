@@ -85,12 +85,6 @@ struct SampleArgs {
     unsigned long long wait_ticks;
     unsigned long long *stamps; // profiling only (BPMF_HIP_STAMPS=1): s_memtime at phase boundaries of two probe items, or NULL
     uint32_t ablate;            // profiling only (BPMF_HIP_ABLATE): 1 = skip the factorisation, 2 = skip the Gram, 4 = gather from 64 hot rows only
-    uint32_t wt_store;          // k_sample_wg2 with tail riders: samples are stored write-through (read by workgroups of the SAME launch)
-    // k_sample1q (kernels_q1.h): groups of four columns whose factorisation one wave runs in lockstep
-    const int32_t *q_col_slot;  // per LOCAL column: 4 * group + slot
-    const int32_t *q_grp_cols;  // per group: its four local columns (-1: empty slot of the last group)
-    unsigned *q_count;          // arrival counters of the groups (zero between launches)
-    double *q_scratch;          // per group: GeoQ<K>::GWORDS doubles (blocks | rhs | normals of its four columns)
 };
 
 // What else one k_sample1 launch carries besides its work items (see k_sample1 in kernels.h): the gate +
@@ -101,18 +95,6 @@ struct FusedArgs {
     double *st_out; unsigned *st_ticket; unsigned *st_flag; unsigned st_seq;
     unsigned long long *st_tmo;        // sticky time-out word of the side the statistics belong to
 };
-
-// pair launch (k_sample1p, kernels.h): the completion count of the first side's columns the second side waits for
-struct PairArgs {
-    // One 128-byte line per word (PAIR_STRIDE unsigned apart): [0, 16) the arrival counters of the first side's columns by
-    // col & 15 (zero between launches), [16] the number of complete shards (zero between launches), [17, 17 + PAIR_NFLAG) copies
-    // of the generation word the second side polls -- thousands of waiting waves on ONE word (and on the line the arrivals
-    // count into) made the first side's tail crawl: pair launch 194 us against 95 us for the two launches.
-    unsigned *words;
-    unsigned gen;               // this launch's generation (monotonic per first side): the flag copies are set to it when all columns are written
-    int nloc;                   // columns the first side writes in this launch
-};
-enum { PAIR_STRIDE = 32, PAIR_NFLAG = 64, PAIR_WORDS = (17 + PAIR_NFLAG) * PAIR_STRIDE };
 
 // users.predict(movies) fused into movies.predict(users) (k_predict): the same prediction goes into the other side's copy
 // of the test entries as well -- entry q of this test matrix is entry perm[q] of the twin (its transpose).  perm = NULL: none.
@@ -125,43 +107,17 @@ struct TwinArgs {
     unsigned *flag; unsigned seq;
 };
 
-// K = 128: column statistics as rider workgroups of a k_sample_wg2 launch (colstats_f32_rider, kernels_f32.h) -- what
-// FusedArgs' st_* fields are to k_sample1.  nblocks = 0: none.  Two forms:
-//   tail = 0 (fp32 path): the statistics of the PREVIOUS launch's side as the FIRST workgroups of the grid;
-//   tail = 1: the statistics of THIS launch's side as the LAST workgroups of the grid -- dispatched behind every item,
-//             they wait until `done` has counted the launch's `nitems` work items (whose samples were stored write-through).
+// K = 128 fp32: column statistics as rider workgroups of a k_sample_wg2 launch (colstats_f32_rider, kernels_f32.h) -- what
+// FusedArgs' st_* fields are to k_sample1: the statistics of the PREVIOUS launch's side as the FIRST workgroups of the grid.
+// nblocks = 0: none.
 struct StatRiders {
     int nblocks;                       // rider workgroups
-    int tail;                          // 0: head riders (another side's columns), 1: tail riders (this launch's columns)
     const void *items; int64_t c0, c1; int nsl;      // the side's factors in its own type (float | double)
     double *partials; const unsigned long long *fail_in; double *out;
     unsigned *ticket; unsigned *flag; unsigned seq;
     unsigned long long *tmo; unsigned long long wait_ticks;
-    unsigned *done; int nitems;        // tail riders: completion count of the launch's work items (zero between launches); done[16]: set to `seq` by the last item
 };
 
-// one workgroup per column (kernels_f32.h): the fp32 large-K path, and K = 64 in fp64 behind BPMF_HIP_MODE=2
-template <typename T>
-struct SampleArgsW {
-    const int32_t *rowidx;
-    const double *vals;
-    const int32_t *wi_col;      // work item -> local column (cost-sorted; no chunking on this path)
-    const int64_t *wi_p0;
-    const int32_t *wi_len;
-    const T *other_items;       // K x nrows
-    T *items;                   // K x ncols
-    int64_t col_from;
-    const double *LambdaF;      // K x K col-major (device, fp64)
-    const double *Lmu;
-    const double *mu;
-    const double *prop_lambda;  // propagated posterior: K x K per local column, or NULL (see SampleArgs)
-    uint32_t diag_only;         // BPMF_NO_COVARIANCE (see SampleArgs)
-    unsigned long long *fail;
-    double mean_rating;
-    double alpha;
-    uint32_t iter_plus_1;
-    int ktrue;                  // (see SampleArgs)
-};
 
 // columns with a handful of ratings at K = 64 (kernels_lr.h)
 struct LrArgs {
@@ -178,7 +134,6 @@ struct LrArgs {
     double mean_rating, alpha, sqrt_alpha;
     uint32_t iter_plus_1;
     int ktrue;                 // (see SampleArgs)
-    int pf_c[4];               // k_sample_pf_all: the product-form classes of the item list, class c = [pf_c[c], pf_c[c+1])
 };
 
 // BPMF_REDUCE formulation (kernels_reduce.h): the pass that computes the other side's precomputed Gram parts

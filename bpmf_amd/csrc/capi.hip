@@ -47,7 +47,6 @@ Rccl *rccl()
 static int settle_async(struct bpmf_hip_side *s);      // waits until the worker is done with `s`; returns its deferred error
 static void flush_deferred(struct bpmf_hip_test *t, bool on_main = false);   // enqueues an evaluation whose launch was put off
 namespace { void predraw_stop(struct bpmf_hip_side *s); }   // joins the side's pre-draw helper threads
-namespace { void discard_prelaunches_touching(struct bpmf_hip_side *s); }   // pair launch: half-iterations enqueued ahead of their sys_sample call that involve `s`
 namespace { int flush_pending_stats(struct bpmf_hip_ctx *c, bool on_main = false); }   // statistics without a launch to ride in: a kernel of their own
 
 struct bpmf_hip_side;
@@ -168,49 +167,34 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
 {
     const int64_t nloc = s->to - s->from;
     const int K = s->ctx->K;
-    // Form of the sampler.  K <= 32, up to ~20 000 columns per side: every work item gets its own
-    // single-wave workgroup and the hardware dispatcher balances them (k_sample1: Gram on the 4x4x4
-    // MFMA shape, factorisation on the VALU; ML-1M: 53 us against 79 us of the persistent form).
-    // More columns: four work items per wave with the factorisation on the MFMA as well (k_sample4:
-    // a third of the VALU work per column, but a quarter of the workgroups, which only pays when
-    // there are enough of them -- 24 000 x 14 800: even; 60 400 x 37 060: 349 / 382 us against
-    // 401 / 510 us; 1M x 500K x 45M ratings: 2.35 / 3.13 ms against 3.5 / 5.3 ms, 3.8 / 5.7 ms persistent).
-    // K = 64: one item per workgroup as well (k_sample1<64>, 16x16x4 Gram, one wave per SIMD): 0.63 against
-    // 0.77 ms per iteration on the ML-1M shape, 4.4 / 6.0 ms at 60 400 x 37 060 x 10 M, 13.5 / 16.5 ms at
-    // 300 000 x 100 000 x 20 M, 2.15 / 2.45 ms ChEMBL-shaped -- the persistent form (k_sample) is BPMF_HIP_MODE=0.
+    // Form of the sampler (s->mode).
+    //   K <= 32, up to ~20 000 columns per side: 1 -- every work item gets its own single-wave workgroup and the hardware
+    //     dispatcher balances them (k_sample1: Gram on the 4x4x4 MFMA shape, factorisation on the VALU).
+    //   K <= 32, more columns: 3 -- four work items per wave with the factorisation on the MFMA as well (k_sample4: a third of
+    //     the VALU work per column, but a quarter of the workgroups, which only pays when there are enough of them --
+    //     24 000 x 14 800: even; 60 400 x 37 060: 349 / 382 us against 401 / 510 us; 1M x 500K x 45M ratings: 2.35 / 3.13 ms
+    //     against 3.5 / 5.3 ms).  BPMF_HIP_MODE=1 | 3 forces one of the two (the tests run small matrices through both).
+    //   K = 64: 4 -- the slab form (kernels_slab.h: one wave per item, factorisation on the 4x4x4 f64 MFMA), the product form
+    //     for columns with <= 16 ratings when those are at least half of the side (kernels_lr.h).
+    //   K = 128: 5 -- a workgroup per item (kernels_wg2.h), fp64 or fp32 factors.
+    // The forms that lost their place over rounds 1-4 (persistent waves, workgroup per column, Gram per wave + factorisation
+    // per group of four, four items in a row per wave, the pair launch, Householder sweeps for light columns, the K = 128
+    // slab form) left the library in round 5; what each measured is in docs/FINDINGS.md.
     const int mode_env = env_int("BPMF_HIP_MODE", -1);
     const bool f32 = s->ctx->dtype == BPMF_HIP_F32;
-    // K >= 64: the slab form (mode 4, kernels_slab.h: one wave per item, factorisation on the 4x4x4 f64 MFMA).
-    // The earlier forms stay selectable for A/B runs: K = 64: 0 persistent, 1 per item with the lane-per-row
-    // factorisation, 2 one workgroup per column; K = 128: 2 (workgroup per column, fp32 16x16 blocked factorisation).
-    s->mode = mode_env >= 0 ? mode_env : (K <= 32 ? (nloc >= 20000 ? 3 : 1) : 4);
-    // K = 128: the slab form measured slower than the workgroup form (one wave per SIMD cannot hide the gather
-    // latency of a 36-tile Gram, and its 120 KB of straight-line code thrash the instruction cache): opt-in
-    // the default: workgroup per item, second form (kernels_wg2.h, mode 5); 2 = the first workgroup form (no chunking)
-    // (K = 128 in fp64 -- num_latent 65 .. 128 in the reference's arithmetic: the same workgroup form with fp64 factors, mode 5 only)
     const bool big = K == 128;
-    if (big) s->mode = f32 ? ((mode_env == 4) ? 4 : (mode_env == 2 ? 2 : 5)) : 5;
-    else if (K == 64) { if (s->mode == 3) s->mode = 4; }
-    else {
-        if (s->mode == 2 || s->mode == 4) s->mode = 1;                             // (BPMF_HIP_MODE=2 / 4 exist for K >= 64 only)
-        // mode 6 (k_sample1q, kernels_q1.h): Gram per wave as in mode 1, factorisation four columns per wave as in mode 3.
-        // Its groups are built over the whole item list: a side cut into parts keeps mode 1.
-        if ((s->mode == 6 || s->mode == 8) && s->nsub > 1) s->mode = 1;   // (8: mode 6 in two launches, see kernels_q1.h)
-        // mode 7 (k_sample1x, kernels_x4.h): up to four items per wave one after the other (Gram as in mode 1 on natural
-        // blocks), their columns factorised in lockstep as in mode 3; item list and chunks as mode 1
-    }
-    if ((big || K == 64) && (s->mode == 6 || s->mode == 7 || s->mode == 8)) s->mode = big ? 5 : 4;
-    const bool wg = s->mode == 2;
+    if (big) s->mode = 5;
+    else if (K == 64) s->mode = 4;
+    else s->mode = (mode_env == 1 || mode_env == 3) ? mode_env : (nloc >= 20000 ? 3 : 1);
     // (mode 5 in fp64 -- K = 128 fp64: chunks twice as long as the fp32 form's, ML-1M shape 768 against 384 ratings: 0.609 / 0.722 against
     //  0.630 / 0.746 ms per launch; a chunk's partial is 75 KB there)
-    int chunk = wg ? (1 << 30) : env_int("BPMF_HIP_CHUNK", 0);
+    int chunk = env_int("BPMF_HIP_CHUNK", 0);
     if (chunk <= 0) {
         const int64_t simds = (int64_t)s->ctx->num_cu * 4;
-        // mode 1: ~one chunk of work per SIMD (ML-1M shape, round 3: 896 ratings 0.1011 ms per iteration, 640: 0.1025, 1 280: 0.1047);
-        // mode 0: >= 8 work items per SIMD so the tail of the launch stays short.  Lower bound
-        // 16 K: a chunk's partial tiles are ~1.3 K^2 doubles written and read back, against 8 K
+        // mode 1: ~one chunk of work per SIMD (ML-1M shape, round 3: 896 ratings 0.1011 ms per iteration, 640: 0.1025, 1 280: 0.1047).
+        // Lower bound 16 K: a chunk's partial tiles are ~1.3 K^2 doubles written and read back, against 8 K
         // bytes gathered per rating, so shorter chunks make the partials a first-order traffic term.
-        int64_t c = (s->mode == 0) ? s->nnz / (simds * 8) : (s->mode == 4 ? (s->nnz * 9) / (simds * 16) : (s->mode == 5 ? (s->nnz * (f32 ? 3 : 6)) / (simds * 7) : (s->mode == 7 ? (s->nnz * 9) / (simds * 8) : s->nnz / simds)));   // (mode 7: a wave walks several items anyway; every chunk is a hand-over through memory: ML-1M shape 1 024 against 640: 48 / 53 us against 55 / 53)
+        int64_t c = s->mode == 4 ? (s->nnz * 9) / (simds * 16) : (s->mode == 5 ? (s->nnz * (f32 ? 3 : 6)) / (simds * 7) : s->nnz / simds);
         c = (c + 63) / 64 * 64;
         // slab form: ONE wave walks an item, and a rating costs 36 (K = 128) / 10 (K = 64) tile MFMAs per 4
         // ratings: a launch lasts (average load of a wave slot) + (longest item), so items must stay short (ML-1M shape,
@@ -283,24 +267,6 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
             s->sub_item_off.push_back((int)i);
         }
     }
-    if (s->mode == 6 || s->mode == 8) {
-        // groups of four columns in the order in which the sorted item list first mentions them: columns of similar
-        // cost, dispatched -- and therefore complete -- at about the same time
-        std::vector<int32_t> col_slot((size_t)std::max<int64_t>(nloc, 1), -1), grp_cols;
-        int32_t n = 0;
-        for (const Item &it : items)
-            if (col_slot[(size_t)it.col] < 0) { col_slot[(size_t)it.col] = n++; grp_cols.push_back(it.col); }
-        while (grp_cols.size() % 4) grp_cols.push_back(-1);
-        if (grp_cols.empty()) grp_cols.assign(4, -1);
-        s->q_ngroups = (int)(grp_cols.size() / 4);
-        int rcq;
-        std::vector<unsigned> zeros((size_t)s->q_ngroups, 0u);
-        if ((rcq = dev_upload(&s->d_q_col_slot, col_slot.data(), col_slot.size())) || (rcq = dev_upload(&s->d_q_grp_cols, grp_cols.data(), grp_cols.size())) ||
-            (rcq = dev_upload(&s->d_q_count, zeros.data(), zeros.size())) ||
-            (rcq = dev_upload<double>(&s->d_q_scratch, nullptr, (size_t)s->q_ngroups * (size_t)((K / 4) * (K / 4 + 1) / 2 + 2 * (K / 4)) * 64)))
-            return rcq;
-        HIP_TRY(hipMemset(s->d_q_scratch, 0, (size_t)s->q_ngroups * (size_t)((K / 4) * (K / 4 + 1) / 2 + 2 * (K / 4)) * 64 * sizeof(double)));
-    }
     const size_t nw = items.size();
     std::vector<int32_t> wcol(nw), wlen(nw), wmc(nw), wchunk(nw);
     std::vector<int64_t> wp0(nw);
@@ -308,15 +274,13 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
 
     s->nwork = (int)nw; s->nmulti = (int)mc_slot0.size(); s->nslots = slots;
     int rc;
-    if (K == 64 && !f32 && (s->mode == 0 || s->mode == 1 || s->mode == 4) && s->nsub <= 1) {
-        // Low-rank form for the columns with at most BPMF_HIP_LOWRANK_MAX ratings (default 16; 0: off):
-        // worth a second launch when they are at least half of the side (ChEMBL-shaped compounds)
-        const int nlr = std::min(env_int("BPMF_HIP_LOWRANK_MAX", 16), 32);
-        // sweep width of a light column: 1 | 2 | 3 (3, 5, 6, 9 ratings) | 4 (4, 7, 8, 10, 11, 12); none: with width 1
-        auto width = [](int n) { return n <= 1 ? 1 : n == 2 ? 2 : (n == 3 || n == 5 || n == 6 || n == 9) ? 3 : 4; };
+    if (K == 64 && !f32 && s->nsub <= 1) {
+        // Product form (k_sample_pf) for the columns with at most BPMF_HIP_PF ratings (default and maximum 16: what
+        // k_sample_pf<64, 16> holds; 0: off), sorted by their number so that the waves of a workgroup stay in step:
+        // worth launches of their own when they are at least half of the side (ChEMBL-shaped compounds)
         std::vector<int32_t> lc, ll, hc, hl, hm, hk; std::vector<int64_t> lp, hp;
-        // up to 6 ratings: product form (k_sample_pf), sorted by their number so that the waves of a workgroup stay in step
-        const int pfmax = std::min(nlr, std::min(env_int("BPMF_HIP_PF", 16), 16));            // (0: product form off; 16: what k_sample_pf<64, 16> holds)
+        const int pfmax = std::max(0, std::min(env_int("BPMF_HIP_PF", 16), 16));
+        const int nlr = pfmax;
         for (int n = 0; n <= pfmax && pfmax > 0; ++n) {
             for (const Item &it : items)
                 if (it.mc < 0 && it.len == n) { lc.push_back(it.col); ll.push_back(it.len); lp.push_back(it.p0); }
@@ -328,29 +292,10 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
         if (pfmax < 3) s->pf_class[1] = (int)lc.size();
         if (pfmax < 6) s->pf_class[2] = (int)lc.size();
         s->pf_class[3] = (int)lc.size();
-        s->lr_class[0] = (int)lc.size();
-        for (int cls = 1; cls <= 4; ++cls) {
-            for (const Item &it : items)
-                if (it.mc < 0 && (pfmax <= 0 || it.len > pfmax) && it.len <= nlr && width(it.len) == cls) { lc.push_back(it.col); ll.push_back(it.len); lp.push_back(it.p0); }
-            s->lr_class[cls] = (int)lc.size();
-        }
         for (const Item &it : items)
             if (!(it.mc < 0 && it.len <= nlr)) { hc.push_back(it.col); hl.push_back(it.len); hm.push_back(it.mc); hk.push_back(it.chunk); hp.push_back(it.p0); }
         if (nlr > 0 && (int64_t)lc.size() * 2 >= nloc && !lc.empty()) {
             s->lr_n = (int)lc.size(); s->hv_nwork = (int)hc.size();
-            if (nloc > 100000 && env_int("BPMF_HIP_STATS_SPLIT", 0) != 0 && s->pf_class[1] > 0 && s->pf_class[1] < (int)lc.size()) {
-                // statistics in two groups (bpmf_hip_side::d_stat_list): A = heavy columns + product-form class 0.
-                // Measured SLOWER on the ChEMBL shape (1.25 against 1.18 ms): group A's pass beside k_sample_pf<64,6> costs that
-                // launch 0.11 ms, and group B's 256-thread workgroups still only get in as the partner's sampler drains.  Off.
-                std::vector<int32_t> list; list.reserve((size_t)nloc);
-                std::vector<char> seen((size_t)nloc, 0);
-                for (int32_t col : hc) if (!seen[(size_t)col]) { seen[(size_t)col] = 1; list.push_back(col); }
-                for (int q = 0; q < s->pf_class[1]; ++q) list.push_back(lc[(size_t)q]);
-                s->stat_nA = (int64_t)list.size();
-                for (size_t q = (size_t)s->pf_class[1]; q < lc.size(); ++q) list.push_back(lc[q]);
-                s->stat_n = (int64_t)list.size();
-                if (s->stat_n == nloc && (rc = dev_upload(&s->d_stat_list, list.data(), list.size()))) return rc;
-            }
             if (s->pf_class[3] > 0 && (rc = dev_upload<double>(&s->d_pf_q, nullptr, (size_t)s->nrows * K))) return rc;
             if ((rc = dev_upload(&s->d_lr_col, lc.data(), lc.size())) || (rc = dev_upload(&s->d_lr_len, ll.data(), ll.size())) ||
                 (rc = dev_upload(&s->d_lr_p0, lp.data(), lp.size())) || (rc = dev_upload(&s->d_hv_col, hc.data(), hc.size())) ||
@@ -390,11 +335,6 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     if (env_int("BPMF_HIP_NSTAT", 0) > 0) s->nstat_waves = (int)std::min<int64_t>(env_int("BPMF_HIP_NSTAT", 0), std::max<int64_t>(1, (nloc + 31) / 32));   // (experiments)
     // big sides: four-wave workgroups with a finisher that reads the partials contiguously (k_colstats_wg)
     s->nstat_wg = (nloc > 100000 && env_int("BPMF_HIP_STATS_WG", 1) != 0) ? (int)std::min<int64_t>((nloc + 127) / 128, (int64_t)s->ctx->num_cu * 2) : 0;
-    if (s->d_stat_list && s->nstat_wg > 0) {
-        s->stat_wgA = (int)std::max<int64_t>(1, std::min<int64_t>((s->stat_nA + 127) / 128, s->nstat_wg));
-        s->stat_wgB = (int)std::max<int64_t>(1, std::min<int64_t>((s->stat_n - s->stat_nA + 127) / 128, s->nstat_wg));
-        if (!s->ev_stat_a) HIP_TRY(hipEventCreate(&s->ev_stat_a));
-    }
     if ((rc = dev_upload<double>(&s->d_stat_partials, nullptr, (size_t)std::max(s->nstat_waves, 2 * s->nstat_wg) * pw))) return rc;
     return 0;
 }
@@ -405,11 +345,9 @@ void free_schedule(bpmf_hip_side *s)
     void **ptrs[] = {(void **)&s->d_wi_col, (void **)&s->d_wi_len, (void **)&s->d_wi_mc, (void **)&s->d_wi_chunk, (void **)&s->d_wi_p0,
                      (void **)&s->d_mc_slot0, (void **)&s->d_mc_nch, (void **)&s->d_mc_count, (void **)&s->d_partials, (void **)&s->d_stat_partials,
                      (void **)&s->d_lr_col, (void **)&s->d_lr_len, (void **)&s->d_lr_p0, (void **)&s->d_hv_col, (void **)&s->d_hv_len,
-                     (void **)&s->d_hv_mc, (void **)&s->d_hv_chunk, (void **)&s->d_hv_p0, (void **)&s->d_pf_q, (void **)&s->d_stat_list,
-                     (void **)&s->d_q_col_slot, (void **)&s->d_q_grp_cols, (void **)&s->d_q_count, (void **)&s->d_q_scratch};
+                     (void **)&s->d_hv_mc, (void **)&s->d_hv_chunk, (void **)&s->d_hv_p0, (void **)&s->d_pf_q};
     for (void **p : ptrs) if (*p) { (void)hipFree(*p); *p = nullptr; }
     s->lr_n = s->hv_nwork = 0;
-    s->stat_nA = s->stat_n = 0; s->stat_wgA = s->stat_wgB = 0; s->stat_a_ready = s->stat_a_done = false;
 }
 
 }  // namespace
@@ -496,11 +434,6 @@ static int ctx_create_impl(int device, int Ktrue, int dtype, void *stream, bpmf_
 extern "C" int bpmf_hip_ctx_set_no_covariance(bpmf_hip_ctx *c, int on)
 {
     if (!c) return fail(BPMF_HIP_EINVAL, "set_no_covariance: NULL");
-    {
-        std::vector<bpmf_hip_side *> sides;
-        { std::lock_guard<std::mutex> lk(c->launch_mutex); sides = c->sides; }
-        for (bpmf_hip_side *sd : sides) discard_prelaunches_touching(sd);
-    }
     c->diag_only = on ? 1u : 0u;
     return BPMF_HIP_OK;
 }
@@ -628,7 +561,6 @@ extern "C" int bpmf_hip_side_create_dev(bpmf_hip_ctx *ctx, int64_t ncols, int64_
 extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
 {
     if (!s) return BPMF_HIP_OK;
-    discard_prelaunches_touching(s);
     (void)settle_async(s);
     if (s->worker.joinable()) {
         { std::lock_guard<std::mutex> lk(s->wm); s->wstop = true; }
@@ -656,7 +588,6 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
     if (s->sx) { (void)bounded_stream_sync(s->ctx, s->sx, __func__); (void)hipStreamDestroy(s->sx); }
     for (hipEvent_t e : s->sub_ev) if (e) (void)hipEventDestroy(e);
     if (s->sx_done) (void)hipEventDestroy(s->sx_done);
-    if (s->ev_stat_a) (void)hipEventDestroy(s->ev_stat_a);
     if (s->ev_stat_go) (void)hipEventDestroy(s->ev_stat_go);
     if (s->own_csc) { if (s->d_rowidx) (void)hipFree(s->d_rowidx); if (s->d_vals) (void)hipFree(s->d_vals); }
     if (s->own_items && s->d_items) (void)hipFree(s->d_items);
@@ -667,8 +598,7 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
     void *ptrs[] = {s->d_wi_col, s->d_wi_len, s->d_wi_mc, s->d_wi_chunk, s->d_wi_p0, s->d_mc_slot0, s->d_mc_nch, s->d_mc_count, s->d_partials, s->d_stat_partials, s->a_d_in,
                     s->d_lr_col, s->d_lr_len, s->d_lr_p0, s->d_hv_col, s->d_hv_len, s->d_hv_mc, s->d_hv_chunk, s->d_hv_p0,
                     s->d_conn_send, s->d_conn_recv, s->d_conn_sbuf, s->d_conn_rbuf, s->d_pf_q,
-                    s->d_prec, s->d_t_colptr, s->d_t_rowidx, s->d_t_vals, s->d_t_order,
-                    s->d_q_col_slot, s->d_q_grp_cols, s->d_q_count, s->d_q_scratch};
+                    s->d_prec, s->d_t_colptr, s->d_t_rowidx, s->d_t_vals, s->d_t_order};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (s->a_h_in) (void)hipHostFree(s->a_h_in);
     if (s->a_h_out) (void)hipHostFree(s->a_h_out);
@@ -677,7 +607,6 @@ extern "C" int bpmf_hip_side_destroy(bpmf_hip_side *s)
     if (s->a_ticket) (void)hipFree(s->a_ticket);
     if (s->a_dflag) (void)hipFree(s->a_dflag);
     if (s->a_d_red) (void)hipFree(s->a_d_red);
-    if (s->d_pair) (void)hipFree(s->d_pair);
     delete s;
     return BPMF_HIP_OK;
 }
@@ -706,7 +635,6 @@ extern "C" int bpmf_hip_side_set_prop_posterior(bpmf_hip_side *s, const double *
     if (!s) return fail(BPMF_HIP_EINVAL, "set_prop_posterior: NULL");
     (void)mu;
     HIP_TRY(hipSetDevice(s->ctx->device));
-    discard_prelaunches_touching(s);
     { const int rc = settle_async(s); if (rc) return rc; }
     { const int rs_ = bounded_stream_sync(s->ctx, s->ctx->stream, __func__); if (rs_) return rs_; }
     if (s->d_prop) { (void)hipFree(s->d_prop); s->d_prop = nullptr; }
@@ -748,7 +676,6 @@ static int drop_second_copy(bpmf_hip_side *s)
 {
     s->items_exposed = true;
     if (!s->d_items_alt) return 0;
-    discard_prelaunches_touching(s);
     flush_evals_touching(s);                                        // (one may have captured the copy about to be freed)
     (void)settle_async(s);
     HIP_TRY(hipSetDevice(s->ctx->device));
@@ -810,7 +737,6 @@ extern "C" int bpmf_hip_side_set_items(bpmf_hip_side *s, const double *h)
 {
     if (!s || !h) return fail(BPMF_HIP_EINVAL, "set_items: NULL");
     HIP_TRY(hipSetDevice(s->ctx->device));
-    discard_prelaunches_touching(s);                                // (a half-iteration of the partner drawn from the factors being replaced)
     { const int rc = settle_async(s); if (rc) return rc; }
     flush_evals_touching(s);
     HIP_TRY(hipDeviceSynchronize());                                // (an evaluation beside the samplers may still read the factors)
@@ -1090,7 +1016,6 @@ extern "C" int bpmf_hip_sample_side_launch(bpmf_hip_side *self, const bpmf_hip_s
     if (c->comm_dead.load()) return fail(BPMF_HIP_ENODEV, "sample_side: the communicator of this context was aborted (a collective timed out)");
     const int K = c->K;
     HIP_TRY(hipSetDevice(c->device));
-    discard_prelaunches_touching(self);                              // (a half-iteration of the partner drawn from the columns this launch replaces)
     { const int rs = settle_async(self); if (rs) return rs; }
     if (self->saux) { const int rs_ = bounded_stream_sync(self->ctx, self->saux, __func__); if (rs_) return rs_; }
     fill_blob_ctx(c, mu, LambdaF, c->h_in, K == 64 && c->dtype == BPMF_HIP_F64 && self->lr_n > 0);
@@ -1100,7 +1025,6 @@ extern "C" int bpmf_hip_sample_side_launch(bpmf_hip_side *self, const bpmf_hip_s
     c->last_sampler_done = nullptr;
     int rc = BPMF_DISPATCH_K(K, sample_and_exchange<KK, FF>(self, other, iter, alpha, c->d_in, c->stream, nullptr, nullptr));
     if (rc) return rc;
-    self->stat_a_ready = false;                                     // (the split statistics pass belongs to the asynchronous path)
     HIP_TRY(hipEventRecord(c->ev[1], c->stream));
     unsigned *flag = reinterpret_cast<unsigned *>(c->h_out_dev + c->out_words - 1);
     rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK, FF>(self, c->stream, c->d_in, c->h_out_dev, flag, ++c->seq, c->d_ticket));
@@ -1431,20 +1355,12 @@ void collect(bpmf_hip_side *s, const bpmf_hip_side::Job &job)
         const bool own_stats = s->stats_ev[job.evset].load(std::memory_order_acquire) == ev[2];   // else: inside another launch
         if (job.timed && hipEventSynchronize(own_stats ? ev[2] : ev[1]) == hipSuccess && hipEventElapsedTime(&a, ev[0], ev[1]) == hipSuccess) {
             if (own_stats) (void)hipEventElapsedTime(&b, ev[1], ev[2]);
-            if (job.paired && job.partner) {                      // a pair launch: the time of the launch split evenly between its two sides
-                a *= 0.5f;
-                job.partner->pair_credit_ms.store((double)a, std::memory_order_release);
-            }
             s->last_sample_ms = a; s->last_reduce_ms = b; s->timing_valid = true;
             s->tot_sample_ms += a; s->tot_reduce_ms += b; s->n_launches++;
             float g = 0.f;                                         // end of the other side's sampler -> start of this one
             if (job.prev_stop && hipEventElapsedTime(&g, job.prev_stop, ev[0]) == hipSuccess) { s->tot_gap_ms += g; s->n_gap++; }
             else (void)hipGetLastError();
         }
-    }
-    if (job.paired && !job.timed) {                                 // second side of a pair launch: its half, if the launch was timed
-        const double x = s->pair_credit_ms.exchange(0.0, std::memory_order_acq_rel);
-        if (x > 0.0) { s->last_sample_ms = (float)x; s->last_reduce_ms = 0.f; s->timing_valid = true; s->tot_sample_ms += x; s->n_launches++; }
     }
     if (rc && !s->async_rc) { s->async_rc = rc; s->async_msg = msg; }
     trace("collect: done", s, job.iter);
@@ -1484,7 +1400,7 @@ int flush_pending_stats(bpmf_hip_ctx *c, bool on_main)
     bpmf_hip_side *P = c->pending_stats;
     if (!P) return 0;
     c->pending_stats = nullptr;
-    c->pending_inorder = false; c->pending_riders = false;
+    c->pending_riders = false;
     const int K = c->K;
     HIP_TRY(hipSetDevice(c->device));
     hipEvent_t *ev = P->evs[c->pending_evset];
@@ -1492,40 +1408,11 @@ int flush_pending_stats(bpmf_hip_ctx *c, bool on_main)
     if (!on_main) HIP_TRY(hipStreamWaitEvent(sst, ev[1], 0));        // (ev[1]: recorded with / behind P's sampler)
     else c->last_sampler_done = nullptr;                              // (the newest thing on S0 is no longer a sampler)
     unsigned *flag = reinterpret_cast<unsigned *>(P->a_h_out_dev + c->out_words - 1);
-    P->stat_a_ready = false;
     const int rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK, FF>(P, sst, P->a_d_in, P->a_h_out_dev, flag, c->pending_seq, P->a_ticket));
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ev[2], sst));
     P->stats_ev[c->pending_evset].store(ev[2], std::memory_order_release);
     trace("statistics flushed (no launch to ride in)", P, P->iter);
-    return 0;
-}
-
-// "In-order head start": the pending statistics pass goes onto the MAIN stream, directly ahead of the sampler launch the
-// caller is about to enqueue there, and that launch is flagged hipExtAnyOrderLaunch: its dispatch packet carries no
-// barrier bit, so the command processor hands out its workgroups as soon as the statistics kernel has been LAUNCHED,
-// not finished.  The pass gets what the cross-queue head start bought it -- its workgroups are dispatched first and keep
-// their slots beside a sampler that fills the chip -- without the two event hops that cost (S0 -> S1: the pass waits for
-// the sampler's end; S1 -> S0: the next sampler waits for the marker ahead of the pass; ~30 us per half-iteration in the
-// K = 128 timeline, profiles/r03_timeline_ml1m_k128.txt).  Ordering: the pass is a normal packet behind P's sampler on
-// the same queue; the any-order launch is consumed in queue order behind it, i.e. after P's sampler has completed too.
-int flush_pending_stats_inorder(bpmf_hip_ctx *c)
-{
-    bpmf_hip_side *P = c->pending_stats;
-    if (!P) return 0;
-    c->pending_stats = nullptr;
-    c->pending_inorder = false; c->pending_riders = false;
-    const int K = c->K;
-    hipEvent_t *ev = P->evs[c->pending_evset];
-    unsigned *flag = reinterpret_cast<unsigned *>(P->a_h_out_dev + c->out_words - 1);
-    P->stat_a_ready = false;
-    // (completion event on the pass's own dispatch packet: a marker packet behind it would carry a barrier bit and hold the
-    // any-order launch back until the pass has FINISHED)
-    const int rc = BPMF_DISPATCH_K(K, bpmf_launch::stats<KK, FF>(P, c->stream, P->a_d_in, P->a_h_out_dev, flag, c->pending_seq, P->a_ticket, ev[2]));
-    if (rc) return rc;
-    P->stats_ev[c->pending_evset].store(ev[2], std::memory_order_release);
-    bpmf_launch::next_flags() = hipExtAnyOrderLaunch;                // consumed by the first kernel of the sampler sequence that follows
-    trace("statistics in order ahead of the next sampler", P, P->iter);
     return 0;
 }
 
@@ -1570,47 +1457,6 @@ int claim_second_copy(bpmf_hip_side *s, hipStream_t st)
     return 0;
 }
 
-// a half-iteration that was enqueued inside the partner's pair launch and will not be used: wait for that launch, forget it
-void discard_prelaunch(bpmf_hip_side *s)
-{
-    if (s->pre.iter < 0) return;
-    if (s->pre.ev_stop) (void)hipEventSynchronize(s->pre.ev_stop);
-    s->pre = bpmf_hip_side::Prelaunch{};
-    trace("pair: prelaunched half-iteration discarded", s, s->iter + 1);
-}
-
-// every prelaunched half-iteration of the context that involves `s` (as the side it belongs to or as the partner it was computed from)
-void discard_prelaunches_touching(bpmf_hip_side *s)
-{
-    std::vector<bpmf_hip_side *> sides;
-    { std::lock_guard<std::mutex> lk(s->ctx->launch_mutex); sides = s->ctx->sides; }
-    for (bpmf_hip_side *sd : sides)
-        if (sd->pre.iter >= 0 && (sd == s || sd->pre.partner == s)) discard_prelaunch(sd);
-}
-
-// bpmf_hip_sys_sample of a side whose half-iteration already sits in its partner's pair launch: the bookkeeping of Sys::sample
-int accept_prelaunch(bpmf_hip_side *self, bpmf_hip_side *other)
-{
-    bpmf_hip_ctx *c = self->ctx;
-    const bpmf_hip_side::Prelaunch pr = self->pre;
-    self->pre = bpmf_hip_side::Prelaunch{};
-    self->iter = pr.iter;                                            // :344
-    flush_deferred(self->deferred_eval);                              // (beside the launch that is already running)
-    std::swap(self->d_items, self->d_items_alt);                     // everything enqueued from here on sees the new factors
-    self->cur_buf ^= 1;
-    c->last_sampler_done = (env_int("BPMF_HIP_EVAL_MARKER", 0) == 0) ? pr.ev_stop : nullptr;
-    self->stats_ev[pr.evset].store(nullptr, std::memory_order_release);
-    c->pending_stats = self; c->pending_seq = pr.seq; c->pending_evset = pr.evset;      // ride in the next launch
-    c->pending_inorder = false; c->pending_riders = false;
-    self->timing_valid = false;
-    self->last_stop = pr.ev_stop;
-    bpmf_hip_side::Job job{pr.iter, pr.seq, pr.evset, false, nullptr};
-    job.paired = true; job.partner = other;
-    post_collect(self, job);
-    trace("sys_sample: accepted the half-iteration of the partner's pair launch", self, pr.iter);
-    return BPMF_HIP_OK;
-}
-
 }  // namespace
 
 extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, double alpha)
@@ -1632,12 +1478,6 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     // one half-iteration of this side may still be uncollected: its worker opens our gate
     if ((rc = wait_async(self, 1))) return rc;
     trace("sys_sample: may enqueue", self, self->iter + 1);
-    if (self->pre.iter >= 0) {
-        if (self->pre.iter == self->iter + 1 && self->pre.partner == other && self->pre.alpha == alpha) return accept_prelaunch(self, other);
-        discard_prelaunch(self);
-    }
-    if (other->pre.iter >= 0) discard_prelaunch(other);              // (the partner's prelaunched sample was drawn from the factors this call replaces)
-
     const int iter = self->iter + 1;                                  // :344
     bool chained;
     { std::lock_guard<std::mutex> lk(self->wm); chained = self->in_flight > 0; }
@@ -1664,23 +1504,22 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     // (K = 64, slab form without low-rank columns: the same launch format, k_sample1s<64>; only the words the slab
     // form reads are staged -- the R0 / R0^-1 tail of the K = 64 blob belongs to the low-rank forms)
     const size_t stage_words = (K == 64 && self->lr_n == 0) ? (size_t)K * K + K + 2 + K : c->in_words;
-    const bool fusable_form = (K <= 32 && (self->mode == 1 || self->mode == 6 || self->mode == 7 || self->mode == 8)) || (K == 64 && self->mode == 4 && self->lr_n == 0 && self->nsub <= 1);
+    const bool fusable_form = (K <= 32 && self->mode == 1) || (K == 64 && self->lr_n == 0 && self->nsub <= 1);
     const bool fused = s1 != s0 && !dist && stage_words <= 8192 && fusable_form && self->nwork > 0 && !self->reduce_on &&
                        c->dtype == BPMF_HIP_F64 && env_int("BPMF_HIP_FUSED", 1) != 0;
     bpmf::FusedArgs fz{};
-    bool inorder_flush = c->pending_stats != nullptr && c->pending_inorder;   // the partner's pass goes ahead of this launch, on S0
-    bpmf_hip_side *P = inorder_flush ? nullptr : c->pending_stats;
+    bpmf_hip_side *P = c->pending_stats;
     // statistics waiting for a carrier: they ride here, unless this launch cannot take them, or would
     // overwrite in place the very columns they read (the same side twice in a row without a second copy)
     bool carry = fused && P != nullptr && !c->pending_riders;
     // fp32 path: P's pass as the first workgroups of this side's k_sample_wg2 launch (StatRiders)
-    const bool ride_f32 = P != nullptr && c->pending_riders && c->dtype == BPMF_HIP_F32 && self->mode == 5 && self->nwork > 0 && !dist && self->nsub <= 1;
+    const bool ride_f32 = P != nullptr && c->pending_riders && c->dtype == BPMF_HIP_F32 && self->nwork > 0 && !dist && self->nsub <= 1;
     if (ride_f32) carry = true;
     if (carry && P == self && !second_copy_usable(self)) carry = false;
     if (P && !carry) { if ((rc = flush_pending_stats(c))) return rc; }
     bpmf::StatRiders riders{};
     if (carry && ride_f32) {
-        const int nw = env_int("BPMF_HIP_WG_WAVES", 2) == 4 ? 4 : 2;
+        const int nw = 2;                                             // waves per workgroup of k_sample_wg2<128, 2, float>
         const int njobs = P->nstat_waves * (K / 16) * (K / 16 + 1) / 2;
         riders.nblocks = (njobs + nw - 1) / nw;
         riders.items = P->d_items; riders.c0 = P->from; riders.c1 = P->to; riders.nsl = P->nstat_waves;
@@ -1689,31 +1528,6 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
         riders.out = P->a_h_out_dev; riders.ticket = P->a_ticket;
         riders.flag = reinterpret_cast<unsigned *>(P->a_h_out_dev + c->out_words - 1); riders.seq = c->pending_seq;
         riders.tmo = tmo_word(P->a_h_out_dev, K); riders.wait_ticks = wait_ticks();
-    }
-    // K = 128, single GPU: this side's own statistics as the LAST workgroups of its sampler launch (StatRiders::tail): no
-    // stream of their own, no cross-queue hops between the sampler, its statistics pass and the partner's sampler.
-    // Built in round 4 ("statistics at the tail of the launch"), parity-green, and MEASURED SLOWER, off:
-    // fp64 1.54-1.63 against 1.41-1.42 ms per iteration, fp32 0.86-0.88 against 0.73.  In-kernel clocks: the riders are
-    // resident 35-65 us before the last item ends and need 20-35 us after it, as planned -- but the last item ends
-    // 50-90 us LATER than the whole launch used to take (680 / 800 us from the first workgroup's start against launches of
-    // 626 / 729 us) although the mean life of an item is unchanged (63.2 against 62.5 us): items are dispatched later.
-    // Polling a word of their own instead of the item counter, no acquire fence (1 152 `buffer_inv sc1`), fewer rider
-    // workgroups: no difference.  Not understood; BPMF_HIP_TAIL_STATS=1 keeps it reachable.
-    const int tail_stats = env_int("BPMF_HIP_TAIL_STATS", 0);     // (read per call: the tests flip it)
-    const bool tail = tail_stats && !fused && !dist && s1 != s0 && K == 128 && self->mode == 5 && self->nwork > 0 && self->nsub <= 1 &&
-                      !self->reduce_on && !self->d_stat_list && !c->ablate && !(carry && ride_f32) && second_copy_usable(self);
-    if (tail) {
-        const int nw = c->dtype == BPMF_HIP_F32 ? (env_int("BPMF_HIP_WG_WAVES", 2) == 4 ? 4 : 2) : (env_int("BPMF_HIP_WG_WAVES_F64", 4) == 2 ? 2 : 4);
-        const int nsl_t = self->nstat_waves;
-        const int njobs = nsl_t * (K / 16) * (K / 16 + 1) / 2;
-        riders = bpmf::StatRiders{};
-        riders.tail = 1; riders.nblocks = (njobs + nw - 1) / nw;
-        riders.c0 = self->from; riders.c1 = self->to; riders.nsl = nsl_t;     // (items / nitems: filled where the launch knows them)
-        riders.partials = self->d_stat_partials;
-        riders.fail_in = (const unsigned long long *)(self->a_d_in + (size_t)K * K + K);
-        riders.out = self->a_h_out_dev; riders.ticket = self->a_ticket; riders.done = self->a_ticket + 8;
-        riders.flag = reinterpret_cast<unsigned *>(self->a_h_out_dev + c->out_words - 1); riders.seq = seq;
-        riders.tmo = tmo_word(self->a_h_out_dev, K); riders.wait_ticks = wait_ticks();
     }
     if (fused) {
         fz.gate_host = self->a_gate_dev; fz.gate_want = (unsigned)(iter + 1); fz.src_host = self->a_h_in_dev;
@@ -1748,68 +1562,6 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     const bool timed = every > 0 && seq % (unsigned)(seq <= 64u ? every : 4 * every) == 0;
     const bool ride = s1 != s0 && self->nwork > 0 && env_int("BPMF_HIP_EXT_EVENTS", 1) != 0;   // events on the sampler's own packet
     if (timed && !ride) HIP_TRY(hipEventRecord(ev[0], s0));
-    if (inorder_flush) { if ((rc = flush_pending_stats_inorder(c))) return rc; }
-    // ---- pair launch: this half-iteration and the partner's next one in ONE grid (k_sample1p, kernels.h) ----
-    {
-        // BPMF_HIP_PAIR=1 (opt-in; read per call: the tests switch it inside one process).  Built in round 4 as costed in round 3,
-        // parity-green, and MEASURED: the pair launch takes what the two launches take (95.7 against 95.0 us on the ML-1M shape:
-        // the overlap of one side's tail with the other's ramp does not materialise, the waiting workgroups hold the slots the
-        // tail's last items would be dispatched into), and the evaluation that used to run in the boundary between the two
-        // launches lands a whole launch later, which the host loop waits for: 0.127 against 0.097 ms per iteration.
-        const int pair_on = env_int("BPMF_HIP_PAIR", 0);
-        bool pair = pair_on && fused && ride && K <= 32 && self != other && self->mode == 1 && other->mode == 1 && !c->ablate && !c->d_stamps &&
-                    env_int("BPMF_HIP_SLAB32", 0) == 0 && other->a_d_in && other->nwork > 0 && !other->reduce_on && other->iter >= 0 && other->pre.iter < 0 &&
-                    self->nsub <= 1 && other->nsub <= 1 && self->item_n < 0 && second_copy_usable(self) && second_copy_usable(other) &&
-                    (P == nullptr || (carry && P == other));
-        if (pair) {                                                   // the partner's gate for its next iteration will open without its sys_sample call
-            std::lock_guard<std::mutex> lk(other->wm);
-            pair = (other->in_flight > 0 || other->gate_iter == other->iter + 1) && other->async_rc == 0;
-        }
-        if (pair && !self->d_pair) {
-            if (hipMalloc((void **)&self->d_pair, bpmf::PAIR_WORDS * sizeof(unsigned)) != hipSuccess ||
-                hipMemsetAsync(self->d_pair, 0, bpmf::PAIR_WORDS * sizeof(unsigned), s0) != hipSuccess) { (void)hipGetLastError(); self->d_pair = nullptr; pair = false; }
-        }
-        if (pair) {
-            const int iterB = other->iter + 1;
-            const unsigned seqB = ++other->a_seq;
-            const int evsetB = (int)(seqB & 1u);
-            if ((rc = claim_second_copy(self, s0)) || (rc = claim_second_copy(other, s0))) return rc;
-            bpmf::FusedArgs fb{};
-            fb.gate_host = other->a_gate_dev; fb.gate_want = (unsigned)(iterB + 1); fb.src_host = other->a_h_in_dev;
-            fb.dst = other->a_d_in; fb.n = (int)c->in_words; fb.dflag = other->a_dflag; fb.dval = seqB;
-            // this side's own statistics ride in the second half (they wait for its columns like the partner's items do)
-            fb.nstat = self->nstat_waves; fb.st_items = self->d_items_alt; fb.st_c0 = self->from; fb.st_c1 = self->to;
-            fb.st_partials = self->d_stat_partials;
-            fb.st_fail = (const unsigned long long *)(self->a_d_in + (size_t)K * K + K);
-            fb.st_out = self->a_h_out_dev; fb.st_ticket = self->a_ticket;
-            fb.st_flag = reinterpret_cast<unsigned *>(self->a_h_out_dev + c->out_words - 1); fb.st_seq = seq;
-            fb.st_tmo = tmo_word(self->a_h_out_dev, K);
-            bpmf::PairArgs pa{};
-            pa.words = self->d_pair; pa.gen = ++self->pair_launches; pa.nloc = (int)(self->to - self->from);
-            rc = BPMF_DISPATCH_K(K, (bpmf_launch::sampler_pair<KK, FF>(self, self->d_items_alt, iter, self->a_d_in, fz, other, other->d_items_alt, iterB, other->a_d_in, fb,
-                                                                      seq, seqB, alpha, pa, s0, timed ? ev[0] : nullptr, ev[1])));
-            bpmf_launch::next_flags() = 0;
-            if (rc) return rc;
-            std::swap(self->d_items, self->d_items_alt);             // (the partner's copies swap when ITS sys_sample call accepts the half-iteration)
-            self->cur_buf ^= 1;
-            c->last_sampler_done = (env_int("BPMF_HIP_EVAL_MARKER", 0) == 0) ? ev[1] : nullptr;
-            // (P's statistics ride in the FIRST half; no event for its collector to block on: this launch only ends after P's own
-            // next gate has opened, which is that collector's job -- it polls the result word instead)
-            c->pending_stats = nullptr; c->pending_riders = false; c->pending_inorder = false;
-            self->stats_ev[evset].store(ev[1], std::memory_order_release);      // its statistics are inside this launch
-            other->pre.iter = iterB; other->pre.seq = seqB; other->pre.evset = evsetB; other->pre.alpha = alpha; other->pre.partner = self;
-            other->pre.ev_stop = ev[1];
-            self->pair_seen = other->pair_seen = true;
-            HIP_TRY(hipGetLastError());
-            self->timing_valid = false;
-            self->last_stop = ev[1];
-            bpmf_hip_side::Job job{iter, seq, evset, timed, nullptr};
-            job.paired = true; job.partner = other;
-            post_collect(self, job);
-            trace("sys_sample: pair launch enqueued", self, iter);
-            return BPMF_HIP_OK;
-        }
-    }
     self->cur_fused = fz;
     self->cur_riders = riders;
     self->cur_gate_flag = fused ? self->a_dflag : nullptr; self->cur_gate_want = seq;
@@ -1828,21 +1580,6 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
         c->pending_riders = false;
     }
     self->stats_ev[evset].store(nullptr, std::memory_order_release);
-    // An unfused side whose partner launches in the fused format (ChEMBL shape: the compounds side runs the low-rank
-    // forms, the targets side k_sample1s<64>) hands its statistics to the partner's launch as well: as a kernel of their
-    // own on S1 their 2 048 waves only got wave slots as the partner's sampler -- which fills the chip -- drained, i.e.
-    // the sums of the 483 k compounds arrived when the targets' sampler ended (0.34 ms after their own sampler), and the
-    // compounds' host chain (cov, Normal-Wishart draw, factor of LambdaF: 0.12 ms) started only then.
-    const bool partner_fusable = (K <= 32 && (other->mode == 1 || other->mode == 6 || other->mode == 7 || other->mode == 8)) || (K == 64 && other->mode == 4 && other->lr_n == 0 && other->nsub <= 1);
-    const bool defer = !fused && !dist && s1 != s0 && c->dtype == BPMF_HIP_F64 && partner_fusable && other->nwork > 0 && other->a_d_in &&
-                       self->nwork > 0 && env_int("BPMF_HIP_FUSED", 1) != 0 && env_int("BPMF_HIP_DEFER_STATS", 0) != 0;   // (measured slower: 1.72 against 1.26 ms -- the 2 048 rider waves stream 247 MB at the head of the partner's launch; kept as a switch)
-    // unfused side with a stand-alone pass that wants a head start (big side: k_colstats_wg; fp32 path): in order on S0,
-    // ahead of the next sampler launch, which is launched any-order (flush_pending_stats_inorder)
-    // MEASURED SLOWER, off: the queue still ran pass and sampler one after the other (rocprofv3 timeline: the any-order launch
-    // started ~5 us after the pass's last kernel ENDED) -- K = 128 0.857 against 0.818 ms, ChEMBL shape 1.35 against 1.07.
-    static const int stats_inorder = env_int("BPMF_HIP_STATS_INORDER", 0);
-    const bool inorder = stats_inorder && !fused && !defer && !dist && s1 != s0 && self->nwork > 0 && !self->reduce_on && !self->d_stat_list &&
-                         (self->nstat_wg > 0 || K == 128);
     // fp32 path (workgroup-per-item form, single GPU): the pass rides at the head of the next k_sample_wg2 launch of the
     // context -- no stream of its own, no head start to buy with event hops (BPMF_HIP_F32_RIDERS=0: the two kernels on S1).
     // Round 3 measured no gain (the two 30-us gaps go -- rocprofv3 timeline: 9 / 14 us between the samplers -- but the riders,
@@ -1854,26 +1591,15 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     // against 1.386 / 1.380 ms: 288 four-wave workgroups holding 80 KB of LDS each lengthen the two launches by 45 + 70 us,
     // more than the two ~27-us gaps they remove; it keeps its stand-alone pass.
     const int f32_riders = env_int("BPMF_HIP_F32_RIDERS", 1);      // (read per call: the tests flip it)
-    const bool riders_next = f32_riders && !tail && !fused && !defer && !inorder && !dist && s1 != s0 && c->dtype == BPMF_HIP_F32 && self->mode == 5 &&
-                             other->mode == 5 && self->nwork > 0 && other->nwork > 0 && self->nsub <= 1;
-    if (tail) {
-        self->stats_ev[evset].store(ev[1], std::memory_order_release);      // its statistics are inside its own launch
-    } else if (fused || defer || inorder || riders_next) {
-        c->pending_stats = self; c->pending_seq = seq; c->pending_evset = evset;     // ride in / go ahead of the next launch
-        c->pending_inorder = inorder;
+    const bool riders_next = f32_riders && !fused && !dist && s1 != s0 && c->dtype == BPMF_HIP_F32 && self->nwork > 0 && other->nwork > 0 && self->nsub <= 1;
+    if (fused || riders_next) {
+        c->pending_stats = self; c->pending_seq = seq; c->pending_evset = evset;     // ride in the next launch
         c->pending_riders = riders_next;
     } else {
         // (fp32 path: the statistics used to take 0.2 ms from the end of the sampler to the sums, on the critical path of
         // the side's host chain: their 256-thread workgroups had to find room beside the NEXT side's sampler, whose
         // 128-thread workgroups refill every slot that frees up.  Now single-wave workgroups without LDS: k_colstats_f32.)
-        static const int stats_s0 = env_int("BPMF_HIP_STATS_S0", 0);   // experiment: big sides' statistics on S0 directly behind their sampler
-        hipStream_t sst = (stats_s0 && !dist && s1 != s0 && self->nstat_waves >= 1024) ? s0 : s1;
-        if (self->stat_a_ready && sst != s0) {                        // group A of a split pass: behind the launch of its columns
-            HIP_TRY(hipStreamWaitEvent(sst, self->ev_stat_a, 0));
-            rc = BPMF_DISPATCH_K(K, bpmf_launch::stats_a<KK, FF>(self, sst, self->a_d_in, self->a_h_out_dev, self->a_ticket));
-            if (rc) return rc;
-        }
-        self->stat_a_ready = false;
+        hipStream_t sst = s1;
         if (sst != s0) HIP_TRY(hipStreamWaitEvent(sst, ev[1], 0));
         // Big side (k_colstats_wg): its 256-thread workgroups only find room beside the partner's sampler if they are
         // dispatched first -- both kernels become ready when this side's sampler ends, and the partner's launch, sitting
@@ -1951,41 +1677,16 @@ extern "C" int bpmf_hip_side_kernel_name(const bpmf_hip_side *s, char *buf, int 
     const bool fusable = !dist && !s->reduce_on && env_int("BPMF_HIP_FUSED", 1) != 0 && s->nwork > 0;
     std::string name;
     if (s->reduce_on) name = "k_sample_prec<" + k + "> + k_precompute<" + k + ">";
-    else if (c->dtype == BPMF_HIP_F32) {
-        const std::string w = env_int("BPMF_HIP_WG_WAVES", 2) == 4 ? "4" : "2";
-        name = s->mode == 4 ? "k_sample_slab<128>" : s->mode == 2 ? "k_sample_wg<128,float," + w + ">" : "k_sample_wg2<128," + w + ">";
-    } else if (K == 128) {
-        name = std::string("k_sample_wg2<128,") + (env_int("BPMF_HIP_WG_WAVES_F64", 4) == 2 ? "2" : "4") + ",double>";
-    } else if (K == 64) {
-        auto heavy = [&]() -> std::string {
-            if (s->mode == 2) return "k_sample_wg<64,double,1>";
-            if (s->mode == 4) return (fusable && s->lr_n == 0 && s->nsub <= 1) ? "k_sample1s<64>" : "k_sample_slab<64>";
-            return s->mode == 1 ? "k_sample1<64>" : "k_sample<64>";
-        };
-        if (s->lr_n > 0 && s->mode != 2 && !s->d_prop && !c->diag_only) {
+    else if (c->dtype == BPMF_HIP_F32) name = "k_sample_wg2<128,2>";
+    else if (K == 128) name = "k_sample_wg2<128,4,double>";
+    else if (K == 64) {
+        if (s->lr_n > 0 && !s->d_prop && !c->diag_only) {
             static const char *nb[3] = {"3", "6", "16"};
-            int npf = 0;
-            for (int pc = 0; pc < 3; ++pc) npf += s->pf_class[pc + 1] > s->pf_class[pc];
-            if (npf > 1 && !s->d_stat_list && env_int("BPMF_HIP_PF_MERGE", 0) != 0) name = "k_sample_pf_all<64>";     // (launch_impl.h)
-            else
             for (int pc = 0; pc < 3; ++pc)
                 if (s->pf_class[pc + 1] > s->pf_class[pc]) name += std::string(name.empty() ? "" : " + ") + "k_sample_pf<64," + nb[pc] + ">";
-            for (int cls = 1; cls <= 4; ++cls)
-                if (s->lr_class[cls] > s->lr_class[cls - 1]) name += std::string(name.empty() ? "" : " + ") + "k_sample_lr<64," + std::to_string(cls) + ">";
-            if (s->hv_nwork > 0) name += " + " + (s->mode == 4 ? std::string("k_sample_slab<64>") : heavy());
-        } else name = heavy();
-    } else {
-        if (s->mode == 3) name = "k_sample4<" + k + ">";
-        else if (s->mode == 6) name = "k_sample1q<" + k + ">";
-        else if (s->mode == 7) name = "k_sample1x<" + k + ">";
-        else if (s->mode == 8) name = "k_sample1q<" + k + ",split> + k_finish_groups<" + k + ">";
-        else if (s->mode == 1) {
-            name = ((K == 32 || K == 16) && env_int("BPMF_HIP_SLAB32", 0) ? "k_sample1s<" : "k_sample1<") + k + ">";
-            // stateful single-GPU path: both half-iterations of an iteration in one grid (bpmf_hip_sys_sample: pair launch)
-            if (s->pair_seen) name = "k_sample1p<" + k + ">";
-        }
-        else name = "k_sample<" + k + ">";
-    }
+            if (s->hv_nwork > 0) name += " + k_sample_slab<64>";
+        } else name = (fusable && s->lr_n == 0 && s->nsub <= 1) ? "k_sample1s<64>" : "k_sample_slab<64>";
+    } else name = (s->mode == 3 ? "k_sample4<" : "k_sample1<") + k + ">";
     snprintf(buf, (size_t)n, "%s", name.c_str());
     return BPMF_HIP_OK;
 }
@@ -2002,16 +1703,9 @@ extern "C" int bpmf_hip_side_kernel_resources(bpmf_hip_side *s, int64_t *out, in
     if (s->reduce_on) return 0;
     bpmf_launch::Probe pr;
     bpmf_launch::probe() = &pr;
-    const bool sa = s->stat_a_ready;
-    int rc;
-    if (s->pair_seen) {                                               // its half-iterations run inside pair launches
-        const bpmf::FusedArgs f0{};
-        const bpmf::PairArgs p0{};
-        rc = BPMF_DISPATCH_K(c->K, (bpmf_launch::sampler_pair<KK, FF>(s, s->d_items, 0, c->d_in, f0, s, s->d_items, 0, c->d_in, f0, 0u, 0u, 1.0, p0, c->stream, nullptr, nullptr)));
-    } else
-    rc = BPMF_DISPATCH_K(c->K, (bpmf_launch::sampler_into<KK, FF>(s, s->d_items, s, 0, 1.0, c->d_in, c->stream, nullptr, nullptr)));
+    // (every kernel of sampler_into goes through BPMF_LAUNCH, which records instead of launching while the probe is installed)
+    const int rc = BPMF_DISPATCH_K(c->K, (bpmf_launch::sampler_into<KK, FF>(s, s->d_items, s, 0, 1.0, c->d_in, c->stream, nullptr, nullptr)));
     bpmf_launch::probe() = nullptr;
-    s->stat_a_ready = sa;
     if (rc) return rc;
     std::string all;
     const int n = std::min(pr.n, max_kernels);
@@ -2037,7 +1731,7 @@ extern "C" int bpmf_hip_side_schedule_info(const bpmf_hip_side *s, int64_t *out,
     out[0] = s->mode; out[1] = s->nwork; out[2] = s->nslots; out[3] = s->nmulti;
     out[4] = s->lr_n; out[5] = s->lr_n > 0 ? s->hv_nwork : s->nwork;
     for (int pc = 0; pc < 3; ++pc) out[6 + pc] = s->lr_n > 0 ? s->pf_class[pc + 1] - s->pf_class[pc] : 0;    // (the classes are only in use when the side is split)
-    out[9] = s->lr_n > 0 ? s->lr_class[4] - s->lr_class[0] : 0;
+    out[9] = 0;                                                       // (round 2's reflector sweeps, k_sample_lr: gone)
     out[10] = s->nsub; out[11] = s->to - s->from; out[12] = s->nnz; out[13] = s->lr_n > 0 ? s->pf_ratings : 0; out[14] = s->lr_n > 0 ? s->pf_ratings2 : 0;
     return BPMF_HIP_OK;
 }

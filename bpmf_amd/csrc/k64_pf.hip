@@ -4,24 +4,13 @@
 
 namespace bpmf_launch {
 
-template <typename Kern, typename Args>
-static void go(Kern kernel, int grid, int block, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const Args &a)
-{
-    BPMF_LAUNCH(kernel, dim3(grid), dim3(block), st, e0, e1, a);
-}
-
 void k64_pf(int cls, int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::LrArgs &a)
 {
     switch (cls) {
-    case 0: go(bpmf::k_sample_pf<64, 3>, grid, 512, st, e0, e1, a); break;
-    case 1: go(bpmf::k_sample_pf<64, 6>, grid, 512, st, e0, e1, a); break;
-    default: go(bpmf::k_sample_pf<64, 16>, grid, 512, st, e0, e1, a); break;
+    case 0: BPMF_LAUNCH((bpmf::k_sample_pf<64, 3>), dim3(grid), dim3(512), st, e0, e1, a); break;
+    case 1: BPMF_LAUNCH((bpmf::k_sample_pf<64, 6>), dim3(grid), dim3(512), st, e0, e1, a); break;
+    default: BPMF_LAUNCH((bpmf::k_sample_pf<64, 16>), dim3(grid), dim3(512), st, e0, e1, a); break;
     }
-}
-
-void k64_pf_all(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::LrArgs &a)
-{
-    go(bpmf::k_sample_pf_all<64>, grid, 512, st, e0, e1, a);
 }
 
 void k64_pf_prepare(int grid, hipStream_t st, hipEvent_t e0, const double *S0t, const double *other_items, int64_t nrows, double *Q)

@@ -15,15 +15,14 @@
 //                    right-looking Cholesky two columns per step with the pivot block through
 //                    v_readlane and the scaled columns broadcast through LDS, fused forward
 //                    solve, Philox/polar normal draw, backward solve, coalesced 8*K-byte store.
-//   k_sample<K>      (K = 64) persistent single-wave workgroups walk the static item list; Gram on
-//                    v_mfma_f64_16x16x4_f64 tiles (gram_chunk), C = 64/K columns factorised side by
-//                    side (deposit_column, finish_slots).
+//   deposit_column / finish_slots: C = 64/K columns factorised side by side by one wave, Gram on
+//                    v_mfma_f64_16x16x4_f64 tiles (gram_chunk): the BPMF_REDUCE formulation (kernels_reduce.h).
 //   k_colstats<K>    sum x, sum x x^T of the fresh columns (again an MFMA Gram); the last waves to
 //                    arrive add the partials in a fixed order (run-to-run identical) and publish.
 //   k_predict<K>     test-set dot products, running mean / M2, squared errors; last block publishes.
 //   k_gate_stage     polls the host's gate word, then stages the parameter blob (asynchronous path).
-// (kernels_f32.h: k_sample_wg, one workgroup per column with a blocked factorisation on MFMA tiles:
-//  K = 128 in fp32, K = 64 in fp64 behind BPMF_HIP_MODE=2.)
+// (kernels_q4.h: k_sample4, four columns per wave for sides of >= 20 000 columns; kernels_slab.h: K = 64;
+//  kernels_lr.h: K = 64 product form for columns with <= 16 ratings; kernels_wg2.h: K = 128, fp64 and fp32.)
 //
 // Everything is fp64 like the reference (c++/bpmf.h:55-58).
 #pragma once
@@ -671,101 +670,7 @@ __device__ __forceinline__ void finish_slots(const SampleArgs &a, double *lds, i
     __syncthreads();                                               // the slots are free again
 }
 
-// ---------------------------------------------------------------------------
-// The sampler: persistent single-wave workgroups walk a static, cost-sorted list of work
-// items (column, chunk).  A chunk of a heavy column parks its partial tiles with write-through
-// stores and takes a ticket; the wave that draws the last ticket sums the partials in chunk
-// order (so the result does not depend on who was last).  A wave that holds a complete Gram
-// deposits the column in an LDS slot and factorises C = 64/K deposited columns together.
-// No wave ever waits for another.
-// ---------------------------------------------------------------------------
 #define BPMF_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-
-template <int K>
-__global__ __launch_bounds__(64, Geo<K>::WPS) void k_sample(SampleArgs a)
-{
-    constexpr int NT = Geo<K>::NT, NTRI = Geo<K>::NTRI, PART = Geo<K>::PART, C = Geo<K>::C;
-    __shared__ __attribute__((aligned(16))) double lds[Geo<K>::LDS_WORDS];
-    const int grid = gridDim.x;
-    int nfilled = 0;
-
-    // Static schedule: the items are sorted by decreasing cost; round r hands item r*grid + b
-    // (even r) or r*grid + grid-1-b (odd r) to workgroup b, so the workgroup that got the most
-    // expensive item of one round gets the cheapest of the next.  (A dynamic queue was measured
-    // slower here: a dequeue costs 1-3 us of exposed latency against ~5 us of work per column.)
-    for (int round = 0;; ++round) {
-        // a fresh, opaque copy of the lane id per work item keeps lane-derived addresses and
-        // masks from being hoisted out of this loop and held (spilled) across the whole kernel
-        int lane = threadIdx.x;
-        asm volatile("" : "+v"(lane));
-        const long long base = (long long)round * grid;
-        if (base >= a.nwork) break;
-        const long long wl = base + ((round & 1) ? (grid - 1 - (int)blockIdx.x) : (int)blockIdx.x);
-        if (wl >= a.nwork) { if (round & 1) continue; else break; }
-        const int w = (int)wl;
-
-        const int col = a.wi_col[w];
-        const int64_t p0 = a.wi_p0[w];
-        const int len = a.wi_len[w];
-        const int mc = a.wi_mc[w];
-
-        d4 acc[NTRI];
-        double r[NT];
-#pragma unroll
-        for (int t = 0; t < NTRI; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int t = 0; t < NT; ++t) r[t] = 0.0;
-
-        gram_chunk<K>(a.rowidx + p0, a.vals + p0, (a.ablate & 2u) ? 0 : len, a.other_items, a.zero_row, a.mean_rating, a.alpha, acc, r, lane, (a.ablate & 4u) ? 63 : -1);
-
-        if (a.ablate & 1u) {                                       // timing ablation: keep the Gram live, skip the rest
-            double v = r[0];
-#pragma unroll
-            for (int t = 0; t < NTRI; ++t) v += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
-            if (mc < 0 && lane < K) a.items[(size_t)(a.col_from + col) * K + lane] = v;
-            continue;
-        }
-        if (mc >= 0) {
-            const int nch = a.mc_nchunks[mc];
-            double *pbase = a.partials + (size_t)a.mc_slot0[mc] * PART;
-            double *p = pbase + (size_t)a.wi_chunk[w] * PART;
-            // write-through (sc1) stores: visible to every XCD once they have drained
-#pragma unroll
-            for (int t = 0; t < NTRI; ++t)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) __hip_atomic_store(&p[(t * 4 + reg) * 64 + lane], acc[t][reg], BPMF_RLX_AGENT);
-            if (lane < 16) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) __hip_atomic_store(&p[NTRI * 256 + t * 16 + lane], r[t], BPMF_RLX_AGENT);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            unsigned t = 0;
-            if (lane == 0) t = __hip_atomic_fetch_add(&a.mc_count[mc], 1u, BPMF_RLX_AGENT);
-            t = __builtin_amdgcn_readfirstlane(t);
-            if ((int)t != nch - 1) continue;                       // not the last chunk of this column
-            if (lane == 0) __hip_atomic_store(&a.mc_count[mc], 0u, BPMF_RLX_AGENT);     // re-arm for the next launch
-#pragma unroll
-            for (int t2 = 0; t2 < NTRI; ++t2) acc[t2] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int t2 = 0; t2 < NT; ++t2) r[t2] = 0.0;
-            for (int ch = 0; ch < nch; ++ch) {                     // fixed chunk order: deterministic
-                const double *pc = pbase + (size_t)ch * PART;
-#pragma unroll
-                for (int t2 = 0; t2 < NTRI; ++t2)
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) acc[t2][reg] += __hip_atomic_load(&pc[(t2 * 4 + reg) * 64 + lane], BPMF_RLX_AGENT);
-#pragma unroll
-                for (int t2 = 0; t2 < NT; ++t2) r[t2] += __hip_atomic_load(&pc[NTRI * 256 + t2 * 16 + (lane & 15)], BPMF_RLX_AGENT);
-            }
-        }
-        deposit_column<K>(a, a.col_from + col, acc, r, lds, nfilled, lane);
-        if (++nfilled == C) {
-            finish_slots<K>(a, lds, C, lane);
-            nfilled = 0;
-        }
-    }
-    if (nfilled > 0) finish_slots<K>(a, lds, nfilled, threadIdx.x);
-}
 
 // geometry of the one-column-per-wave factorisation (finish_single): S lanes per row
 template <int K>
@@ -802,40 +707,8 @@ struct Geo1 {
 // draw and the coalesced 8K-byte store follow.
 // ---------------------------------------------------------------------------
 // `assemble(sA, sb, LD, lane)` writes the full symmetric G (K x LD, row-major) and the rhs sums
-// into LDS: from 16x16x4 accumulator tiles (assemble16) or from the 4x4x4 blocks (assemble44).
-template <int K>
-__device__ __forceinline__ void assemble16(const d4 (&acc)[Geo<K>::NTRI], const double (&r)[Geo<K>::NT], double *sA, double *sb,
-                                           int LD, int lane)
-{
-    constexpr int NT = Geo<K>::NT;
-    const int kq = lane >> 4, li = lane & 15;
-    int tri = 0;
-#pragma unroll
-    for (int I = 0; I < NT; ++I)
-#pragma unroll
-        for (int J = I; J < NT; ++J, ++tri)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int gi = I * 16 + kq + 4 * reg, gj = J * 16 + li;
-                if (gi < K && gj < K) {
-                    if constexpr (Geo1<K>::PACKED) {                 // lower triangle only: G(gi, gj) -> row max, column min
-                        if (gi <= gj) sA[Geo1<K>::roff_c(0) + ((gj & 1) ? ((gj + 1) * (gj + 1)) / 2 : (gj * (gj + 2)) / 2) + gi] = acc[tri][reg];
-                    } else {
-                        sA[gi * LD + gj] = acc[tri][reg];
-                        if (I != J) sA[gj * LD + gi] = acc[tri][reg];
-                    }
-                }
-            }
-    if (kq == 0) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-            if (t * 16 + li < K) sb[t * 16 + li] = r[t];
-    }
-}
-
-// WT: the sample is stored write-through (relaxed device-scope atomic store): another workgroup of the SAME launch reads it
-// (k_sample1p: the partner side's items wait in-kernel for this side's columns)
-template <int K, bool WT = false, typename Assemble>
+// into LDS from the 4x4x4 blocks (assemble44).
+template <int K, typename Assemble>
 __device__ __forceinline__ void finish_single(const SampleArgs &a, int col_local, double *lds, int lane_in, bool have_z,
                                               Assemble &&assemble)
 {
@@ -991,8 +864,7 @@ __device__ __forceinline__ void finish_single(const SampleArgs &a, int col_local
     }
     const double xi = bi * my_dinv;
 
-    if constexpr (WT) { if (lane < K) __hip_atomic_store(&a.items[(size_t)idx * K + lane], xi, BPMF_RLX_AGENT); }
-    else if (lane < K) a.items[(size_t)idx * K + lane] = xi;       // items().col(idx) = rr (:324)
+    if (lane < K) a.items[(size_t)idx * K + lane] = xi;            // items().col(idx) = rr (:324)
     // a non-positive (or NaN) pivot makes its 1/sqrt NaN or inf, which reaches every later entry
     // and the sample itself: Eigen LLT's info() != Success -> THROWERROR("Cholesky failed") (:308)
     const bool bad = !(fabs(xi) <= 1.79769313486231570815e+308);
@@ -1028,114 +900,6 @@ __device__ __forceinline__ void gate_stage_body(int block, int nblocks, const un
                                                 double *__restrict__ dst, int n, unsigned *dflag, unsigned dval,
                                                 unsigned long long *tmo, unsigned long long wait_ticks);
 
-// ---- pair launch (k_sample1p): both half-iterations of a Gibbs iteration in ONE grid ---------------------------
-// The second side's items sit behind the first side's in the same grid.  They request their index blocks and draw their
-// normals while the first side's last items still run, then wait (wait_partner) until every column of the first side has
-// been written: the tail of one launch and the ramp of the next overlap, and one of the two kernel boundaries per iteration
-// is gone.  Why this is safe: (a) the workgroups of a grid are handed out in order (per XCD: workgroup i -> XCD i mod 8), so
-// when a workgroup of the second side spins, every workgroup of the first side is resident or finished -- no deadlock (two
-// kernels on two queues do NOT have that property); (b) no cache can hold a stale line of the columns waited for: they are
-// stored write-through (finish_single<.., WT>) into the copy of the factor matrix that was last READ two launches ago (the
-// samplers write the copy that is not current), and every launch starts with invalidated caches.  Completion count: one
-// hot word takes ~88 RMW / us and a launch retires ~130 items / us, so the columns count into 16 shards (col & 15), each on
-// a line of its own; the last arriver of the last shard writes the launch's generation into 64 copies of the flag the
-// waiters poll (one copy per workgroup id mod 64).
-enum { BPMF_TMO_PARTNER = 4 };
-
-__device__ __forceinline__ void pair_signal(const PairArgs &p, int col, int lane)
-{
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the column's write-through stores have landed
-    if (lane == 0) {
-        const int sh = col & 15;
-        const unsigned expect = (unsigned)((p.nloc - sh + 15) >> 4);  // columns with col % 16 == sh
-        const unsigned nshard = (unsigned)(p.nloc < 16 ? p.nloc : 16); // shards that have columns at all
-        const unsigned t = __hip_atomic_fetch_add(&p.words[sh * PAIR_STRIDE], 1u, BPMF_RLX_AGENT);
-        if (t + 1u == expect) {
-            __hip_atomic_store(&p.words[sh * PAIR_STRIDE], 0u, BPMF_RLX_AGENT);      // re-arm for the next pair launch
-            const unsigned d = __hip_atomic_fetch_add(&p.words[16 * PAIR_STRIDE], 1u, BPMF_RLX_AGENT);
-            if (d + 1u == nshard) {                                   // every column of the first side is written
-                __hip_atomic_store(&p.words[16 * PAIR_STRIDE], 0u, BPMF_RLX_AGENT);
-                for (int j = 0; j < PAIR_NFLAG; ++j) __hip_atomic_store(&p.words[(17 + j) * PAIR_STRIDE], p.gen, BPMF_RLX_AGENT);
-            }
-        }
-    }
-}
-
-__device__ __forceinline__ void wait_partner(const PairArgs &p, unsigned long long *tmo, unsigned long long wait_ticks)
-{
-    const unsigned long long t0 = wall_clock64();
-    const unsigned *flag = &p.words[(17 + (blockIdx.x & (PAIR_NFLAG - 1))) * PAIR_STRIDE];    // (one of 64 copies: the pollers spread over 64 lines)
-    // (signed distance: the generation is monotonic and may wrap)
-    while ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - p.gen) < 0) {
-        __builtin_amdgcn_s_sleep(16);
-        if (wait_ticks && wall_clock64() - t0 > wait_ticks) {
-            if (threadIdx.x == 0) flag_timeout(tmo, BPMF_TMO_PARTNER);
-            break;
-        }
-    }
-    asm volatile("" ::: "memory");
-}
-
-// one work item of a pair launch, K <= 32 (the item body of k_sample1: index blocks, normals, Gram on the 4x4x4 MFMA shape, chunk
-// hand-over, factorisation).  ROLE 1 / 2: first / second side (1 signals its columns, 2 waits for the first side's before its
-// first gather).
-template <int K, int ROLE>
-__device__ __forceinline__ void sample1_item44(const SampleArgs &a, int w, double *lds, int lane, const PairArgs &p)
-{
-    const int col = a.wi_col[w];
-    const int64_t p0 = a.wi_p0[w];
-    const int len = a.wi_len[w];
-    const int mc = a.wi_mc[w];
-    const int glen = (a.ablate & 2u) ? 0 : len;
-    const IdxBlock ib0 = load_idx_block(a.rowidx + p0, a.vals + p0, 0, lane, glen, a.zero_row);
-    const IdxBlock ib1 = load_idx_block(a.rowidx + p0, a.vals + p0, 64, lane, glen, a.zero_row);
-    if (mc < 0 && !(a.ablate & 1u))
-        draw_normals<K>(sample_counter(a.col_from + col, a.ktrue, a.iter_plus_1), a.ktrue, lds + Geo1<K>::AWORDS + K, lane, K);
-    if constexpr (ROLE == 2) wait_partner(p, a.tmo, a.wait_ticks);    // the rows gathered below are the first side's fresh columns
-    using G4 = Geo44<K>;
-    constexpr int NB = G4::NB, NG = G4::NG, PART = G4::PART;
-    double acc[NB], rr[NG];
-#pragma unroll
-    for (int t = 0; t < NB; ++t) acc[t] = 0.0;
-#pragma unroll
-    for (int t = 0; t < NG; ++t) rr[t] = 0.0;
-    gram_chunk44<K>(a.rowidx + p0, a.vals + p0, glen, a.other_items, a.zero_row, a.mean_rating, a.alpha, ib0, ib1, acc, rr, lane,
-                    (a.ablate & 4u) ? 63 : -1);
-    if (mc >= 0) {
-        const int nch = a.mc_nchunks[mc];
-        double *pbase = a.partials + (size_t)a.mc_slot0[mc] * PART;
-        double *pp = pbase + (size_t)a.wi_chunk[w] * PART;
-#pragma unroll
-        for (int t = 0; t < NB; ++t) __hip_atomic_store(&pp[t * 64 + lane], acc[t], BPMF_RLX_AGENT);
-#pragma unroll
-        for (int t = 0; t < NG; ++t) __hip_atomic_store(&pp[(NB + t) * 64 + lane], rr[t], BPMF_RLX_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned t = 0;
-        if (lane == 0) t = __hip_atomic_fetch_add(&a.mc_count[mc], 1u, BPMF_RLX_AGENT);
-        t = __builtin_amdgcn_readfirstlane(t);
-        if ((int)t != nch - 1) return;
-        if (lane == 0) __hip_atomic_store(&a.mc_count[mc], 0u, BPMF_RLX_AGENT);
-#pragma unroll
-        for (int t2 = 0; t2 < NB; ++t2) acc[t2] = 0.0;
-#pragma unroll
-        for (int t2 = 0; t2 < NG; ++t2) rr[t2] = 0.0;
-        for (int ch = 0; ch < nch; ++ch) {
-            const double *pc = pbase + (size_t)ch * PART;
-            double tmp[NB + NG];
-#pragma unroll
-            for (int t2 = 0; t2 < NB + NG; ++t2) tmp[t2] = __hip_atomic_load(&pc[t2 * 64 + lane], BPMF_RLX_AGENT);
-#pragma unroll
-            for (int t2 = 0; t2 < NB; ++t2) acc[t2] += tmp[t2];
-#pragma unroll
-            for (int t2 = 0; t2 < NG; ++t2) rr[t2] += tmp[NB + t2];
-        }
-    }
-    wait_params(a);
-    finish_single<K, true>(a, col, lds, lane, mc < 0,
-                           [&](double *sA, double *sb, int LD, int ln) { assemble44<K>(acc, rr, sA, sb, LD, ln); });
-    if constexpr (ROLE == 1) pair_signal(p, col, lane);
-}
-
 template <int K>
 __global__ __launch_bounds__(64, Geo1<K>::WPS) void k_sample1(SampleArgs a, FusedArgs f)
 {
@@ -1167,7 +931,8 @@ __global__ __launch_bounds__(64, Geo1<K>::WPS) void k_sample1(SampleArgs a, Fuse
     if (mc < 0 && !(a.ablate & 1u))
         draw_normals<K>(sample_counter(a.col_from + col, a.ktrue, a.iter_plus_1), a.ktrue, lds + Geo1<K>::AWORDS + K, lane, K);
 
-    if constexpr (K <= 32) {
+    static_assert(K <= 32, "k_sample1: K <= 32 (K = 64 runs the slab form, K = 128 the workgroup form)");
+    {
         // Gram on the 4x4x4 MFMA shape: NB block accumulators + NG rhs sums per lane
         using G4 = Geo44<K>;
         constexpr int NB = G4::NB, NG = G4::NG, PART = G4::PART;
@@ -1218,97 +983,7 @@ __global__ __launch_bounds__(64, Geo1<K>::WPS) void k_sample1(SampleArgs a, Fuse
         wait_params(a);
         finish_single<K>(a, col, lds, lane, mc < 0,
                          [&](double *sA, double *sb, int LD, int ln) { assemble44<K>(acc, rr, sA, sb, LD, ln); });
-    } else {
-        constexpr int NT = Geo<K>::NT, NTRI = Geo<K>::NTRI, PART = Geo<K>::PART;
-        d4 acc[NTRI];
-        double r[NT];
-#pragma unroll
-        for (int t = 0; t < NTRI; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int t = 0; t < NT; ++t) r[t] = 0.0;
-        gram_chunk<K>(a.rowidx + p0, a.vals + p0, (a.ablate & 2u) ? 0 : len, a.other_items, a.zero_row, a.mean_rating, a.alpha, acc, r, lane, (a.ablate & 4u) ? 63 : -1);
-
-        if (a.ablate & 1u) {
-            double v = r[0];
-#pragma unroll
-            for (int t = 0; t < NTRI; ++t) v += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
-            if (mc < 0 && lane < K) a.items[(size_t)(a.col_from + col) * K + lane] = v;
-            return;
-        }
-        if (mc >= 0) {
-            const int nch = a.mc_nchunks[mc];
-            double *pbase = a.partials + (size_t)a.mc_slot0[mc] * PART;
-            double *p = pbase + (size_t)a.wi_chunk[w] * PART;
-#pragma unroll
-            for (int t = 0; t < NTRI; ++t)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) __hip_atomic_store(&p[(t * 4 + reg) * 64 + lane], acc[t][reg], BPMF_RLX_AGENT);
-            if (lane < 16) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) __hip_atomic_store(&p[NTRI * 256 + t * 16 + lane], r[t], BPMF_RLX_AGENT);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            unsigned t = 0;
-            if (lane == 0) t = __hip_atomic_fetch_add(&a.mc_count[mc], 1u, BPMF_RLX_AGENT);
-            t = __builtin_amdgcn_readfirstlane(t);
-            if ((int)t != nch - 1) return;
-            if (lane == 0) __hip_atomic_store(&a.mc_count[mc], 0u, BPMF_RLX_AGENT);
-#pragma unroll
-            for (int t2 = 0; t2 < NTRI; ++t2) acc[t2] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int t2 = 0; t2 < NT; ++t2) r[t2] = 0.0;
-            for (int ch = 0; ch < nch; ++ch) {
-                const double *pc = pbase + (size_t)ch * PART;
-#pragma unroll
-                for (int t2 = 0; t2 < NTRI; ++t2)
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) acc[t2][reg] += __hip_atomic_load(&pc[(t2 * 4 + reg) * 64 + lane], BPMF_RLX_AGENT);
-#pragma unroll
-                for (int t2 = 0; t2 < NT; ++t2) r[t2] += __hip_atomic_load(&pc[NTRI * 256 + t2 * 16 + (lane & 15)], BPMF_RLX_AGENT);
-            }
-        }
-        wait_params(a);
-        finish_single<K>(a, col, lds, lane, mc < 0,
-                         [&](double *sA, double *sb, int LD, int ln) { assemble16<K>(acc, r, sA, sb, LD, ln); });
     }
-}
-
-// Pair launch: grid = [gate A][statistics riders of the side sampled before A][items of A] [gate B][statistics riders of A][items of B].
-// fa / fb: what each half carries besides its items (as k_sample1's FusedArgs); the riders of the second half read A's fresh
-// columns and wait for them like B's items do.
-template <int K>
-__global__ __launch_bounds__(64, Geo1<K>::WPS) void k_sample1p(SampleArgs a, FusedArgs fa, SampleArgs b, FusedArgs fb, PairArgs p)
-{
-    static_assert(K <= 32, "the pair launch exists for the one-item-per-wave form, K <= 32");
-    __shared__ __attribute__((aligned(16))) double lds[Geo1<K>::LDS_WORDS];
-    const int lane = threadIdx.x;
-    int bid = blockIdx.x;
-    const int n1 = (fa.gate_host ? 1 : 0) + fa.nstat + a.nwork;
-    if (bid < n1) {
-        if (fa.gate_host) {
-            if (bid == 0) { gate_stage_body(0, 1, fa.gate_host, fa.gate_want, fa.src_host, fa.dst, fa.n, fa.dflag, fa.dval, a.tmo, a.wait_ticks); return; }
-            --bid;
-        }
-        if (bid < fa.nstat) {
-            colstats_body<K>(bid, fa.st_items, fa.st_c0, fa.st_c1, fa.nstat, fa.st_partials, fa.st_fail, fa.st_out, fa.st_ticket, fa.st_flag, fa.st_seq,
-                             fa.st_tmo, a.wait_ticks);
-            return;
-        }
-        sample1_item44<K, 1>(a, bid - fa.nstat, lds, lane, p);
-        return;
-    }
-    bid -= n1;
-    if (fb.gate_host) {
-        if (bid == 0) { gate_stage_body(0, 1, fb.gate_host, fb.gate_want, fb.src_host, fb.dst, fb.n, fb.dflag, fb.dval, b.tmo, b.wait_ticks); return; }
-        --bid;
-    }
-    if (bid < fb.nstat) {
-        wait_partner(p, fb.st_tmo, b.wait_ticks);                     // A's columns are what these riders sum
-        colstats_body<K>(bid, fb.st_items, fb.st_c0, fb.st_c1, fb.nstat, fb.st_partials, fb.st_fail, fb.st_out, fb.st_ticket, fb.st_flag, fb.st_seq,
-                         fb.st_tmo, b.wait_ticks);
-        return;
-    }
-    sample1_item44<K, 2>(b, bid - fb.nstat, lds, lane, p);
 }
 
 // ---------------------------------------------------------------------------

@@ -1,20 +1,11 @@
-// fp32 large-K form of the hot path (K = 128): BASELINE config "MovieLens-1M, K=128, fp32".
+// fp32 large-K form of the hot path (K = 128): BASELINE config "MovieLens-1M, K=128, fp32" -- the pieces around the
+// sampler (kernels_wg2.h): tile geometry and MFMA traits, column statistics, prediction.
 //
 // The reference computes in fp64 throughout (c++/bpmf.h:55-58); this path keeps the factors,
 // the Gram, the factorisation and the solves in fp32 and everything that leaves the column loop
 // (hyper-parameters, column statistics, prediction sums, the normal draws) in fp64.  It is the
 // "mixed-precision tolerance study" of the north star: tests/test_gpu_f32.py states what the
 // fp32 arithmetic costs against the fp64 restatement of the reference.
-//
-// One workgroup of four waves per column (c++/sample.cpp:263-336 for one idx):
-//   * Gram: v_mfma_f32_16x16x4_f32 on the 36 upper 16x16 tiles of the 128x128 Gram, nine tiles
-//     per wave; every wave walks all ratings of the column (operands come straight from the
-//     gathered registers: lane (kq, li) loads U[row_kq][16 t + li], 64 contiguous bytes per 16
-//     lanes), so no cross-wave reduction is needed.
-//   * Lambda* = LambdaF + alpha G is formed in the MFMA accumulator tiles and stays there: the
-//     blocked right-looking Cholesky (Lambda* = R^T R, 16-wide block rows) updates the register
-//     tiles with MFMAs whose operands are the finished block rows of R, parked in LDS (41 KB).
-//   * forward solve, + z, backward solve by wave 0 (two rows per lane, no barriers), coalesced store.
 // Operand / result layout of v_mfma_f32_16x16x4_f32 (tools/probes/layout16f32_probe.hip):
 //   A lane 16 k + i, B lane 16 k + j (one float each);  D[i = 4 (lane / 16) + reg][j = lane % 16].
 #pragma once
@@ -59,298 +50,6 @@ struct GeoF {
     __host__ __device__ static constexpr int tile_i(int t) { int I = 0; while (t >= NT - I) { t -= NT - I; ++I; } return I; }
     __host__ __device__ static constexpr int tile_j(int t) { int I = 0; while (t >= NT - I) { t -= NT - I; ++I; } return I + t; }
 };
-
-// ---------------------------------------------------------------------------
-// Per-wave part of one column: Gram of the wave's tiles, Lambda* in registers, blocked
-// right-looking Cholesky  Lambda* = R^T R  on the register tiles.  Block step s:
-//   A  the owners of the tiles (s, J >= s) park them in block row s of the LDS copy of R;
-//   B  wave 0 factors the 16x16 diagonal block (lane c < 16 holds column c; pivots and row
-//      entries travel through v_readlane) and stores R_ss and 1 / R_kk;
-//   C  one thread per remaining column of the block row solves R_ss^T x = a (16 steps);
-//   D  every wave applies  A_IJ -= R_sI^T R_sJ  to its own tiles (I, J), s < I <= J, with four
-//      v_mfma_f32_16x16x4_f32 per tile whose operands are read from block row s.
-// Three workgroup barriers per block step.
-// ---------------------------------------------------------------------------
-template <int K, typename T, int NW, int W>
-__device__ __forceinline__ bool wg_column(const SampleArgsW<T> &a, int col_local, int64_t p0, int len, T *R, T *dinv, T *bv, int tid)
-{
-    using G = GeoF<K>;
-    using X = WgTraits<T>;
-    typedef typename X::acc_t acc_t;
-    constexpr int NT = G::NT, TPW = (G::NTRI + NW - 1) / NW;
-    const int lane = tid & 63;
-    const int kq = lane >> 4, li = lane & 15;
-    acc_t acc[TPW];
-    T r[NT];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[t] = acc_t{0, 0, 0, 0};
-#pragma unroll
-    for (int t = 0; t < NT; ++t) r[t] = 0;
-    const int32_t *rowidx = a.rowidx + p0;
-    const double *vals = a.vals + p0;
-    // 64 ratings per coalesced index block = 4 groups of 4 k-steps (16 ratings); the operands of the
-    // next group (32 registers) are in flight while the 36 MFMAs of the current one issue
-    int ri_n = (lane < len) ? rowidx[lane] : -1;
-    T wv_n = (lane < len) ? (T)((vals[lane] - a.mean_rating) * a.alpha) : (T)0;               // c++/sample.cpp:256
-    for (int b0 = 0; b0 < len; b0 += 64) {
-        const int ri = ri_n;
-        const T wv = wv_n;
-        if (b0 + 64 < len) {                                                     // workgroup-uniform
-            const int q = b0 + 64 + lane;
-            ri_n = (q < len) ? rowidx[q] : -1;
-            wv_n = (q < len) ? (T)((vals[q] - a.mean_rating) * a.alpha) : (T)0;
-        }
-        const int ngroups = (len - b0 >= 64) ? 4 : (len - b0 + 15) >> 4;
-        T y[4][NT], yn[4][NT], ww[4], wn[4];
-        auto gather = [&](int gg, T (&yy)[4][NT], T (&w1)[4]) {
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const int src = (gg * 4 + st) * 4 + kq;
-                const int row = __shfl(ri, src);
-                w1[st] = __shfl(wv, src);
-                const T *u = a.other_items + (size_t)(row >= 0 ? row : 0) * K + li;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) yy[st][t] = (row >= 0) ? u[16 * t] : (T)0;
-            }
-        };
-        gather(0, y, ww);
-#pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-            if (gg >= ngroups) break;                                            // workgroup-uniform
-            const bool more = gg + 1 < ngroups;
-            if (gg < 3 && more) gather(gg + 1, yn, wn);
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                if (W == 0) {
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) r[t] = fma(y[st][t], ww[st], r[t]);
-                }
-#pragma unroll
-                for (int I = 0; I < NT; ++I)
-#pragma unroll
-                    for (int J = I; J < NT; ++J)
-                        if ((G::tri(I, J) % NW) == W)
-                            acc[G::tri(I, J) / NW] = X::mfma(y[st][I], y[st][J], acc[G::tri(I, J) / NW]);
-            }
-            if (gg < 3 && more) {
-#pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    ww[st] = wn[st];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) y[st][t] = yn[st][t];
-                }
-            }
-        }
-    }
-    // Lambda* = LambdaF + alpha G in the register tiles (:297-298); b = LambdaF mu + rr (:285,:256)
-    const double *LF = a.prop_lambda ? a.prop_lambda + (size_t)col_local * K * K : a.LambdaF;
-#pragma unroll
-    for (int I = 0; I < NT; ++I)
-#pragma unroll
-        for (int J = I; J < NT; ++J)
-            if ((G::tri(I, J) % NW) == W) {
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int gi = 16 * I + X::drow(kq, reg), gj = 16 * J + li;
-                    acc[G::tri(I, J) / NW][reg] = (a.diag_only && gi != gj) ? (T)0 : (T)fma(a.alpha, (double)acc[G::tri(I, J) / NW][reg], LF[gi + (size_t)gj * K]);
-                }
-            }
-    if (W == 0) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            T v = r[t];
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            if (kq == 0) {
-                double lm = a.Lmu[16 * t + li];
-                if (a.prop_lambda) {                                 // rr = Lambda_i * hp.mu (:285)
-                    lm = 0.0;
-                    for (int j = 0; j < K; ++j) lm = fma(LF[16 * t + li + (size_t)j * K], a.mu[j], lm);
-                }
-                bv[16 * t + li] = (T)(lm + (double)v);
-            }
-        }
-    }
-
-    bool bad = false;
-#pragma unroll
-    for (int s = 0; s < NT; ++s) {
-        T *Rs = R + G::roff(s);
-        const int LDs = G::ld(s), Ws = G::width(s);
-        // A: park the tiles of block row s
-#pragma unroll
-        for (int J = s; J < NT; ++J)
-            if ((G::tri(s, J) % NW) == W) {
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) Rs[X::drow(kq, reg) * LDs + 16 * (J - s) + li] = acc[G::tri(s, J) / NW][reg];
-            }
-        __syncthreads();
-        // B: diagonal block, upper Cholesky, by the first 16 lanes of wave 0 (column c in registers)
-        if (W == 0) {
-            const int c = lane & 15;
-            T col[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) col[k] = Rs[k * LDs + c];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const T d = X::bcast(col[k], k);
-                bad |= !(d > (T)0);
-                const T rinv = X::rsqrt_acc(d);
-                col[k] *= rinv;                                       // R(k, c), c >= k (entries left of the diagonal are not used)
-                if (lane == k) dinv[16 * s + k] = rinv;
-#pragma unroll
-                for (int m = k + 1; m < 16; ++m) {
-                    const T rkm = X::bcast(col[k], m);
-                    col[m] = fma(-rkm, col[k], col[m]);               // A(m, c) -= R(k, m) R(k, c)
-                }
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) Rs[k * LDs + c] = col[k];
-            }
-        }
-        __syncthreads();
-        // C: the other columns of the block row: R_ss^T x = a, one thread per column
-        for (int cc = tid; cc < Ws - 16; cc += 64 * NW) {
-            T *cp = Rs + 16 + cc;
-            T x[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) x[k] = cp[k * LDs];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                x[k] *= dinv[16 * s + k];
-#pragma unroll
-                for (int m = k + 1; m < 16; ++m) x[m] = fma(-Rs[k * LDs + m], x[k], x[m]);
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) cp[k * LDs] = x[k];
-        }
-        __syncthreads();
-        // D: trailing update of this wave's tiles
-        if (s + 1 < NT) {
-#pragma unroll
-            for (int I = s + 1; I < NT; ++I) {
-                bool any = false;
-#pragma unroll
-                for (int J = I; J < NT; ++J) any |= (G::tri(I, J) % NW) == W;
-                if (!any) continue;                                  // compile-time
-                T opI[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) opI[q] = -Rs[(4 * q + kq) * LDs + 16 * (I - s) + li];
-#pragma unroll
-                for (int J = I; J < NT; ++J)
-                    if ((G::tri(I, J) % NW) == W) {
-                        T opJ[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) opJ[q] = Rs[(4 * q + kq) * LDs + 16 * (J - s) + li];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            acc[G::tri(I, J) / NW] = X::mfma(opI[q], opJ[q], acc[G::tri(I, J) / NW]);
-                    }
-            }
-        }
-    }
-    return bad;
-}
-
-template <int K, typename T, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void k_sample_wg(SampleArgsW<T> a)
-{
-    using G = GeoF<K>;
-    using X = WgTraits<T>;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[G::template lds_bytes<T>()];
-    double *zs = reinterpret_cast<double *>(smem);                   // K normals (fp64 draw, as the reference)
-    T *R = reinterpret_cast<T *>(zs + K);                            // R by block rows
-    T *bv = R + G::RWORDS;                                           // rhs
-    T *dinv = bv + K;                                                // 1 / R(k,k)
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int w = blockIdx.x;
-    const int col = a.wi_col[w];
-    const int64_t p0 = a.wi_p0[w];
-    const int len = a.wi_len[w];
-    const int64_t idx = a.col_from + col;
-
-    // z ~ N(0, I): stream (idx+1)*K*(iter+1) mod 2^32 (c++/sample.cpp:266); the last wave has the fewest tiles
-    if (wave == NW - 1) draw_normals<K>(sample_counter(idx, a.ktrue, a.iter_plus_1), a.ktrue, zs, lane, K);
-    bool bad;
-    if constexpr (NW == 1) {
-        bad = wg_column<K, T, 1, 0>(a, col, p0, len, R, dinv, bv, tid);
-    } else if constexpr (NW == 2) {
-        if (wave == 0) bad = wg_column<K, T, 2, 0>(a, col, p0, len, R, dinv, bv, tid);
-        else bad = wg_column<K, T, 2, 1>(a, col, p0, len, R, dinv, bv, tid);
-    } else {
-        switch (wave) {
-        case 0: bad = wg_column<K, T, 4, 0>(a, col, p0, len, R, dinv, bv, tid); break;
-        case 1: bad = wg_column<K, T, 4, 1>(a, col, p0, len, R, dinv, bv, tid); break;
-        case 2: bad = wg_column<K, T, 4, 2>(a, col, p0, len, R, dinv, bv, tid); break;
-        default: bad = wg_column<K, T, 4, 3>(a, col, p0, len, R, dinv, bv, tid); break;
-        }
-    }
-    __syncthreads();
-
-    // ---- R^T y = b (:321), y += z (:322), R x = y (:323): wave 0, rows (lane, lane + 64).
-    // Sixteen steps (one block row of R) at a time: their R entries and 1/R(k,k) are loaded into
-    // registers first, so that the dependency chain of a step is readlane -> multiply -> fma only.
-    if (wave == 0) {
-        T y0 = bv[lane], y1 = (K > 64) ? bv[lane + 64] : (T)0;
-        // forward: after y_k is known, b_j -= R(k, j) y_k for j > k (row k of R: contiguous)
-        for (int s = 0; s < G::NT; ++s) {
-            const T *Rs = R + G::roff(s) - 16 * s;                   // Rs[r * ld + j] = R(16 s + r, j)
-            const int LDs = G::ld(s);
-            T r0[16], r1[16], di[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = 16 * s + r;
-                di[r] = dinv[k];
-                r0[r] = (lane > k) ? Rs[r * LDs + lane] : (T)0;
-                r1[r] = (K > 64 && lane + 64 > k) ? Rs[r * LDs + lane + 64] : (T)0;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = 16 * s + r;
-                const T own = (k < 64) ? y0 : y1;
-                const T yk = X::bcast(own, k & 63) * di[r];
-                if (lane == (k & 63)) { if (k < 64) y0 = yk; else y1 = yk; }
-                y0 = fma(-r0[r], yk, y0);
-                if (K > 64) y1 = fma(-r1[r], yk, y1);
-            }
-        }
-        y0 += (T)zs[lane];
-        if (K > 64) y1 += (T)zs[lane + 64];
-        // backward: x_k = y_k / R(k,k); y_i -= R(i, k) x_k for i < k (column k of R: per-lane row bases)
-        int base0, base1;
-        {
-            const int s0 = lane >> 4, s1 = (lane + 64) >> 4;
-            base0 = G::roff(s0) + (lane & 15) * G::ld(s0) - 16 * s0;
-            base1 = G::roff(s1) + (lane & 15) * G::ld(s1) - 16 * s1;
-        }
-        for (int s = G::NT - 1; s >= 0; --s) {
-            T c0[16], c1[16], di[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = 16 * s + r;
-                di[r] = dinv[k];
-                c0[r] = (lane < k) ? R[base0 + k] : (T)0;            // R(lane, k)
-                c1[r] = (K > 64 && lane + 64 < k) ? R[base1 + k] : (T)0;
-            }
-#pragma unroll
-            for (int r = 15; r >= 0; --r) {
-                const int k = 16 * s + r;
-                const T own = (k < 64) ? y0 : y1;
-                const T xk = X::bcast(own, k & 63) * di[r];
-                if (lane == (k & 63)) { if (k < 64) y0 = xk; else y1 = xk; }
-                y0 = fma(-c0[r], xk, y0);
-                if (K > 64) y1 = fma(-c1[r], xk, y1);
-            }
-        }
-        T *dst = a.items + (size_t)idx * K;                                     // items().col(idx) = rr (:324)
-        dst[lane] = y0;
-        if (K > 64) dst[lane + 64] = y1;
-        // non-positive pivot or a non-finite sample: "Cholesky failed" (:308)
-        const bool nf = !(fabs((double)y0) <= 1.7e308) || !(fabs((double)y1) <= 1.7e308);
-        if (__any(nf || bad) && lane == 0) atomicMin(a.fail, (unsigned long long)idx);
-    }
-}
 
 // ---------------------------------------------------------------------------
 // sum x, sum x x^T (fp64 accumulation of the fp32 columns): workgroup w takes a contiguous slice
@@ -462,24 +161,6 @@ __device__ __forceinline__ void colstats_f32_rider(const StatRiders &r, int rb, 
     constexpr int NT = K / 16, NTRI = NT * (NT + 1) / 2, PARTW = NTRI * 256 + K, NOUT = K * K + K, NTH = 64 * NW;
     __shared__ unsigned stk;
     const int wave = tid >> 6, lane = tid & 63, kq = lane >> 4, li = lane & 15;
-    if (r.tail) {
-        // tail riders: the columns are this launch's own.  Workgroups are dispatched in grid order, so every work item is
-        // resident or finished when a rider starts (no deadlock); their samples were stored write-through ahead of their
-        // count and are read with device-scope loads below.
-        if (tid == 0) {
-            const unsigned long long t0 = wall_clock64();
-            // (polled: a word of its own that the LAST item sets to this launch's sequence number -- hundreds of riders polling
-            //  the counter itself kept its cache line so busy that the items' increments queued behind the polls: launches
-            //  90-110 us longer)
-            while (__hip_atomic_load(r.done + 16, BPMF_RLX_AGENT) != r.seq) {
-                __builtin_amdgcn_s_sleep(32);
-                if (r.wait_ticks && wall_clock64() - t0 > r.wait_ticks) { flag_timeout(r.tmo, BPMF_TMO_STATS); break; }
-            }
-        }
-        __syncthreads();
-        // (no acquire fence here: a `buffer_inv sc1` per rider wave -- 1 152 cache invalidates behind one another -- made the
-        //  launches ~100 us longer; the columns are read with device-scope loads instead, which cannot hit a stale line)
-    }
     const int job = rb * NW + wave;
     if (job < r.nsl * NTRI) {                                         // wave-uniform
         const int tri = job % NTRI, sl = job / NTRI;
@@ -498,8 +179,7 @@ __device__ __forceinline__ void colstats_f32_rider(const StatRiders &r, int rb, 
             for (int u = 0; u < 4; ++u) {
                 const int64_t cc = c + 4 * u + kq;
                 const size_t at = (size_t)((cc < e) ? cc : b) * K;
-                if (r.tail) { a4[u] = __hip_atomic_load(&xi[at], BPMF_RLX_AGENT); b4[u] = __hip_atomic_load(&xj[at], BPMF_RLX_AGENT); }
-                else { a4[u] = xi[at]; b4[u] = xj[at]; }
+                a4[u] = xi[at]; b4[u] = xj[at];
             }
         };
         if (b < e) fetch(b, fa, fb);
@@ -565,7 +245,7 @@ __device__ __forceinline__ void colstats_f32_rider(const StatRiders &r, int rb, 
         __hip_atomic_store(&r.out[NOUT], (fw == ~0ull) ? 0.0 : (double)(fw + 1ull), BPMF_RLX_SYSTEM);
         __hip_atomic_store(&reinterpret_cast<unsigned long long *>(r.out)[NOUT + 1], fw, BPMF_RLX_SYSTEM);
     }
-    publish_when_last(r.ticket + 1, (unsigned)nfin, r.flag, r.seq, r.ticket, r.tail ? r.done : nullptr);
+    publish_when_last(r.ticket + 1, (unsigned)nfin, r.flag, r.seq, r.ticket);
 }
 
 // ---------------------------------------------------------------------------

@@ -1,20 +1,11 @@
-// k_sample_lr<K, NB>: the column update for columns with only a few ratings, K = 64.
+// Product form of the column update for columns with only a few ratings, K = 64 (k_pf_prepare + k_sample_pf).
 //
 // A column with n ratings has  Lambda* = LambdaF + alpha sum_r u_r u_r^T  (c++/sample.cpp:248-258,297-298):
-// a rank-n update of a matrix that is the SAME for every column of the half-iteration.  The
-// host ships R0 = chol(LambdaF).matrixU() with the parameters; the wave applies the update to it in
-// sweeps over NB <= 4 ratings (lr_update_block: one Householder reflector per row; R stays upper
-// triangular with a positive diagonal, i.e. THE Cholesky factor the reference computes at :306, up
-// to rounding), then solves as the reference does: x = R'^-1 (R'^-T b + z) (:321-323).  O(n K^2)
-// instead of K^3 / 3: on a ChEMBL-shaped side (483 500 compounds, ~2 activities each) the full
-// factorisation is >95 % of the work.
-//
-// One wave per column, lane j owns COLUMN j of R in registers (r[i] = R[i][j], zero below the
-// diagonal).  Update step k broadcasts R[k][k] and the x_m[k] (v_readlane), forms the reflector once
-// per wave, and every lane updates its (R[k][j], x_m[j]).  The forward solve R^T y = b is lane-local
-// (lane k needs column k); the backward solve R x = w needs ROWS: the columns pass through LDS 16
-// at a time (a K x 17 tile, conflict-free both ways).  Columns without ratings skip all of that:
-// x = R0^-1 (y0 + z) with R0^-1 and y0 = R0^-T LambdaF mu from the host.
+// a rank-n update of a matrix that is the SAME for every column of the half-iteration.  The host ships
+// R0 = chol(LambdaF).matrixU(), R0^-1 and y0 = R0^-T LambdaF mu with the parameters.  O(n K) scans + one K x K
+// matrix-vector product instead of K^3 / 3: on a ChEMBL-shaped side (483 500 compounds, ~2 activities each) the full
+// factorisation is >95 % of the work.  (Round 2's Householder sweeps over R0 -- k_sample_lr -- lost to this form on
+// every column it covered and left the library in round 5: docs/FINDINGS.md.)
 #pragma once
 #include "kernels.h"
 
@@ -28,155 +19,8 @@ __device__ __forceinline__ double readlane_d(double v, int lane)
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
-__device__ __forceinline__ double rcp_nr(double d)
-{
-    double y = __builtin_amdgcn_rcp(d);
-    double e = fma(-d, y, 1.0);
-    y = fma(y, e, y);
-    e = fma(-d, y, 1.0);
-    return fma(y, e, y);
-}
-
-// R^T R += sum_{m < NB} x_m x_m^T for NB ratings at once: step k annihilates x_0[k] .. x_{NB-1}[k] against
-// R[k][k] with ONE Householder reflector (v = a + |a| e_1 for a = (R[k][k], x_0[k], ...), row k negated
-// afterwards so that its diagonal stays positive: no cancellation, same R as NB Givens sweeps up to
-// rounding).  With sigma = |a|, v1 = R[k][k] + sigma, beta = 1 / (sigma v1), t_j = v1 R[k][j] + sum_m x_m[k] x_m[j]:
-//     R'[k][j] = t_j / sigma - R[k][j],     x_m'[j] = x_m[j] - (x_m[k] beta) t_j.
-// Per step 2 NB + 2 instructions per lane and 4 NB + 17 wave-uniform ones (one 1/sqrt, one reciprocal)
-// instead of NB x (4 + 18) for NB separate rotations.
-template <int K, int NB>
-__device__ __forceinline__ void lr_update_block(double (&r)[K], double &b, const LrArgs &a, int64_t p, int navail, int lane)
-{
-    double x[NB];
-#pragma unroll
-    for (int m = 0; m < NB; ++m) {                                     // (slots past the column's last rating: a zero vector)
-        const bool ok = m < navail;                                   // wave-uniform
-        const int row = ok ? a.rowidx[p + m] : 0;
-        const double u = ok ? a.other_items[(size_t)row * K + lane] : 0.0;
-        const double wv = ok ? (a.vals[p + m] - a.mean_rating) * a.alpha : 0.0;  // c++/sample.cpp:256
-        b = fma(u, wv, b);
-        x[m] = u * a.sqrt_alpha;
-    }
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const double Rkk = readlane_d(r[k], k);
-        double xk[NB];
-        double s2 = Rkk * Rkk;
-#pragma unroll
-        for (int m = 0; m < NB; ++m) { xk[m] = readlane_d(x[m], k); s2 = fma(xk[m], xk[m], s2); }
-        const double inv = rsqrt_nr(s2);                              // 1 / sigma
-        const double v1 = fma(s2, inv, Rkk);                          // R[k][k] + sigma
-        const double beta = inv * rcp_nr(v1);
-        const double rk = r[k];
-        double t = v1 * rk;
-#pragma unroll
-        for (int m = 0; m < NB; ++m) t = fma(xk[m], x[m], t);
-        r[k] = fma(inv, t, -rk);
-#pragma unroll
-        for (int m = 0; m < NB; ++m) x[m] = fma(-(xk[m] * beta), t, x[m]);
-        // (lane k's x_m is now ~1e-17 |x_m[k]| instead of 0 and leaks that much into the LOWER triangle of the
-        //  later rows; nothing reads it: the solves below touch R[i][j] with i <= j only.  Zeroing it
-        //  with a `lane == k` select would keep 64 loop-invariant compare masks -- 128 SGPRs -- alive.)
-    }
-}
-
-// NB = ratings per sweep: one instantiation per class of columns (the host sorts the light columns by
-// their number of ratings: 1 | 2 | 3, 5, 6, 9 | 4, 7, 8, 10, 11, 12; a switch between sweep widths inside
-// one kernel makes the register allocator spill ~400 registers)
-template <int K, int NB>
-__global__ __launch_bounds__(64, 3) void k_sample_lr(LrArgs a)
-{
-    static_assert(K == 64, "one lane per column of R");
-    constexpr int TLD = 17;
-    __shared__ double sz[K];
-    __shared__ double tile[K * TLD];
-    const int lane = threadIdx.x;
-    const int w = blockIdx.x;
-    const int col = a.col[w];
-    const int64_t p0 = a.p0[w];
-    const int len = a.len[w];
-
-    // (the normal draw first: its Philox / log / sqrt temporaries are dead before R occupies 128 registers)
-    draw_normals<K>(sample_counter(a.col_from + col, a.ktrue, a.iter_plus_1), a.ktrue, sz, lane, K);
-    __builtin_amdgcn_sched_barrier(0);
-
-    if (len == 0) {
-        // no ratings (a third of a ChEMBL-shaped side): Lambda* = LambdaF, so the factor, its inverse and the
-        // forward solve are the same for all of them and come from the host: x = R0^-1 (y0 + z), one
-        // triangular matrix-vector product (lane i = row i of R0^-1, w_j broadcast)
-        __syncthreads();
-        const double wv = a.y0[lane] + sz[lane];
-        double x0 = 0.0, x1 = 0.0;
-#pragma unroll
-        for (int j = 0; j < K; j += 2) {
-            x0 = fma(a.S0t[(size_t)j * K + lane], readlane_d(wv, j), x0);
-            x1 = fma(a.S0t[(size_t)(j + 1) * K + lane], readlane_d(wv, j + 1), x1);
-        }
-        const double xs0 = x0 + x1;
-        a.items[(size_t)(a.col_from + col) * K + lane] = xs0;
-        const bool bad0 = !(fabs(xs0) <= 1.79769313486231570815e+308);
-        if (__any(bad0)) { if (lane == 0) atomicMin(a.fail, (unsigned long long)(a.col_from + col)); }
-        return;
-    }
-
-    double r[K];
-#pragma unroll
-    for (int i = 0; i < K; ++i) r[i] = a.R0[(size_t)i * K + lane];
-    double b = a.Lmu[lane];                                            // rr = LambdaF mu (:285)
-
-    // ---- rank-n update of R (R^T R += alpha sum u u^T) and of the rhs (:251-256), NB ratings per sweep
-    for (int t = 0; t < len; t += NB) lr_update_block<K, NB>(r, b, a, p0 + t, len - t, lane);
-
-    // ---- my diagonal entry and its reciprocal
-    double dg = 0.0;
-#pragma unroll
-    for (int i = 0; i < K; ++i) dg = (lane == i) ? r[i] : dg;
-    const double rs = rsqrt_nr(dg);
-    const double invd = rs * rs;                                      // 1 / R[lane][lane]; NaN for a non-positive pivot
-
-    // ---- forward solve R^T y = b (:321): lane k accumulates sum_{i<k} R[i][k] y_i from its own column
-    // (lane k stops accumulating at step k: (b - acc) * invd is then its y for good -- no per-step capture,
-    //  which the compiler turns into 64 live candidates)
-    double acc = 0.0;
-#pragma unroll
-    for (int i = 0; i < K; ++i) {
-        const double yi = readlane_d((b - acc) * invd, i);            // y_i: final in lane i at step i
-        acc = (i < lane) ? fma(r[i], yi, acc) : acc;
-    }
-    const double y = (b - acc) * invd;
-    __syncthreads();                                                  // the normals are in LDS
-    double wk = y + sz[lane];                                         // :322
-
-    // ---- backward solve R x = w (:323): rows of R through LDS, 16 columns at a time
-#pragma unroll
-    for (int jb = K / 16 - 1; jb >= 0; --jb) {
-        __syncthreads();
-        if ((lane >> 4) == jb) {
-            const int jj = lane & 15;
-#pragma unroll
-            for (int i = 0; i < K; ++i)
-                if (i < 16 * (jb + 1)) tile[i * TLD + jj] = r[i];     // column `lane`, rows 0 .. 16 jb + 15
-        }
-        __syncthreads();
-#pragma unroll
-        for (int jj = 15; jj >= 0; --jj) {
-            const int j = 16 * jb + jj;
-            const double xj = readlane_d(wk * invd, j);               // x_j: lane j's w no longer changes from here on
-            const double Rkj = tile[lane * TLD + jj];                 // R[lane][j] (rows >= 16 (jb + 1): not written, not used)
-            wk = (lane < j) ? fma(-Rkj, xj, wk) : wk;
-        }
-    }
-    const double xs = wk * invd;
-
-    // ---- items().col(idx) = rr (:324); a failed factorisation (:308) shows as a non-finite sample
-    a.items[(size_t)(a.col_from + col) * K + lane] = xs;
-    const bool bad = !(fabs(xs) <= 1.79769313486231570815e+308);
-    if (__any(bad)) { if (lane == 0) atomicMin(a.fail, (unsigned long long)(a.col_from + col)); }
-}
-
-
 // ---------------------------------------------------------------------------
-// k_sample_pf<K, NCAP>: the same update in PRODUCT FORM, for columns with at most NCAP <= 16 ratings.
+// k_sample_pf<K, NCAP>: the column update in PRODUCT FORM, for columns with at most NCAP <= 16 ratings.
 //
 // With x_1 = sqrt(alpha) u_1 and p_1 = R0^-T x_1:  Lambda* = R0^T (I + p_1 p_1^T) R0, and the Cholesky
 // factor of a rank-one update of the identity is known in closed form: I + p p^T = C^T C with
@@ -582,45 +426,6 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
     const int npass = (a.nitems + NB - 1) / NB;
     for (int p = (int)blockIdx.x * NW + wave; p < npass; p += (int)gridDim.x * NW)
         pf_pass<K, NCAP>(a, (npass - 1 - p) * NB, a.nitems, S0, sr[wave], sv[wave], y0, lane);
-}
-
-// The three classes of product-form columns (<= 3 | 4..6 | 7..16 ratings: pf_c[0..3], the item list is sorted by the
-// number of ratings) in ONE launch.  As three launches each class ended on its own tail -- with 512 resident workgroups
-// of eight waves a launch is a whole number of rounds of 16 384 columns: the 20 876 columns with 7..12 ratings (the third class then) of the
-// ChEMBL-shaped side took two rounds for 1.27 rounds of work.  Here the passes (four columns of one class) of all three
-// form one list, the most expensive first (classes in descending order, inside a class from its end: the item list is
-// ascending in the number of ratings), and wave w of the N resident ones takes the passes w, w + N, w + 2 N, ...: every
-// round of N passes is of (nearly) one cost, so the waves' totals differ by less than the cost of one pass of the most
-// expensive kind and the launch ends on passes of the cheapest.  (A ticket counter handing out the passes one at a time
-// was built first and measured 2.4 x SLOWER -- 1 603 against 677 us for the compounds side of the ChEMBL shape: 120 000
-// read-modify-writes of one hot word at ~88 per microsecond are 1.4 ms.)  The three bodies are the three instantiations
-// of pf_pass; all of them fit the 128 registers the LDS-bound occupancy (2 workgroups per CU) leaves a wave.
-template <int K>
-__global__ __launch_bounds__(512, 4) void k_sample_pf_all(LrArgs a)
-{
-    static_assert(K == 64, "one lane per latent index");
-    constexpr int NW = 8, NB = 4;
-    __shared__ __attribute__((aligned(16))) double S0[pf_s0_words<K>()];
-    __shared__ double sr[NW][2][K];
-    __shared__ __attribute__((aligned(16))) double sv[NW][NB][pf_svld<K>()];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    pf_fill_s0<K>(S0, a.S0t, tid, 64 * NW);
-    const double y0 = a.y0[lane];
-    __syncthreads();
-    const int np2 = (a.pf_c[3] - a.pf_c[2] + NB - 1) / NB, np1 = (a.pf_c[2] - a.pf_c[1] + NB - 1) / NB, np0 = (a.pf_c[1] - a.pf_c[0] + NB - 1) / NB;
-    const int npass = np2 + np1 + np0;
-    for (int p = (int)blockIdx.x * NW + wave; p < npass; p += (int)gridDim.x * NW) {
-        if (p < np2) {
-            const int q = np2 - 1 - p;
-            pf_pass<K, 16>(a, a.pf_c[2] + q * NB, a.pf_c[3], S0, sr[wave], sv[wave], y0, lane);
-        } else if (p < np2 + np1) {
-            const int q = np1 - 1 - (p - np2);
-            pf_pass<K, 6>(a, a.pf_c[1] + q * NB, a.pf_c[2], S0, sr[wave], sv[wave], y0, lane);
-        } else {
-            const int q = np0 - 1 - (p - np2 - np1);
-            pf_pass<K, 3>(a, a.pf_c[0] + q * NB, a.pf_c[1], S0, sr[wave], sv[wave], y0, lane);
-        }
-    }
 }
 
 }  // namespace bpmf

@@ -418,8 +418,7 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
         bool nf = false;
         for (int i = lane; i < K; i += 64) {
             const T v = xs[i];
-            if (a.wt_store) __hip_atomic_store(&dst[i], v, BPMF_RLX_AGENT);       // (tail riders of this launch read it)
-            else dst[i] = v;
+            dst[i] = v;
             nf |= F32 ? !(fabsf((float)v) <= 3.0e38f) : !(fabs((double)v) <= 1.7e308);
         }
         // a non-positive pivot turns into NaN / inf and reaches the sample: "Cholesky failed" (:308)
@@ -433,16 +432,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sample_wg2(SampleArgs a, StatRid
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[GeoW2<K>::template lds_bytes<T>()];
     const int tid = threadIdx.x, wave = tid >> 6;
-    // column statistics as rider workgroups (colstats_f32_rider): the previous launch's side at the head of the grid, or this
-    // launch's own side at its tail
-    int w;
-    if (r.tail) {
-        if ((int)blockIdx.x >= a.nwork) { colstats_f32_rider<K, NW, T>(r, (int)blockIdx.x - a.nwork, tid); return; }
-        w = (int)blockIdx.x;
-    } else {
-        if ((int)blockIdx.x < r.nblocks) { colstats_f32_rider<K, NW, T>(r, (int)blockIdx.x, tid); return; }
-        w = (int)blockIdx.x - r.nblocks;
-    }
+    // column statistics as rider workgroups (colstats_f32_rider): the previous launch's side at the head of the grid
+    if ((int)blockIdx.x < r.nblocks) { colstats_f32_rider<K, NW, T>(r, (int)blockIdx.x, tid); return; }
+    const int w = (int)blockIdx.x - r.nblocks;
     const unsigned long long t_begin = a.stamps ? wall_clock64() : 0ull;
     if constexpr (NW == 2) {
         if (wave == 0) wg2_column<K, 2, 0, T>(a, w, smem, tid);
@@ -454,12 +446,6 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sample_wg2(SampleArgs a, StatRid
         case 2: wg2_column<K, 4, 2, T>(a, w, smem, tid); break;
         default: wg2_column<K, 4, 3, T>(a, w, smem, tid); break;
         }
-    }
-    if (r.tail) {                                                     // this item is done: its sample (if it produced one) is in memory
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0 && __hip_atomic_fetch_add(r.done, 1u, BPMF_RLX_AGENT) == (unsigned)r.nitems - 1u)
-            __hip_atomic_store(r.done + 16, r.seq, BPMF_RLX_AGENT);   // the last item: the tail riders may start (r.done + 16: a cache line of its own)
     }
     if (a.stamps && tid == 0) {                                        // profiling: sum of the items' lifetimes (wave 0), their number, first start / last end
         atomicAdd(&a.stamps[128 + 0], wall_clock64() - t_begin);

@@ -5,10 +5,12 @@
 #include "state.h"
 
 // one kernel launch of a sampler sequence: events ride on the dispatch packet when given, the pending launch flags are consumed
+// (EVERY kernel of a sampler sequence must be launched through this macro: bpmf_hip_side_kernel_resources runs the dispatch
+//  logic over live factor pointers with a probe installed, and only this macro knows not to launch then)
 #define BPMF_LAUNCH(kernel, grid, block, st, e0, e1, ...)                                                         \
     do {                                                                                                          \
-        const unsigned fl_ = bpmf_launch::take_flags();                                                           \
         if (bpmf_launch::probe()) { bpmf_launch::probe()->record(reinterpret_cast<const void *>(kernel), #kernel, block); break; }   \
+        const unsigned fl_ = bpmf_launch::take_flags();                                                           \
         hipEvent_t e0_ = (e0), e1_ = (e1);                                                                        \
         if (e0_ || e1_ || fl_) hipExtLaunchKernelGGL(kernel, grid, block, 0, st, e0_, e1_, fl_, __VA_ARGS__);    \
         else hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                                         \
@@ -49,13 +51,6 @@ inline unsigned take_flags() { unsigned &f = next_flags(); const unsigned v = f;
 template <int K, bool F32>
 int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *other, int iter, double alpha, double *d_in, hipStream_t st,
                  hipEvent_t ev_start, hipEvent_t ev_stop);
-// Pair launch (K <= 32, one item per wave, fused stateful path): the half-iteration of `A` and the following one of `B` in ONE
-// grid (k_sample1p).  outA / outB: the factor copies they write; B gathers from outA.  fa / fb: gate + statistics riders of the
-// two halves.  Returns BPMF_HIP_EINVAL for K > 32.
-template <int K, bool F32>
-int sampler_pair(bpmf_hip_side *A, double *outA, int iterA, double *d_inA, const bpmf::FusedArgs &fa,
-                 bpmf_hip_side *B, double *outB, int iterB, double *d_inB, const bpmf::FusedArgs &fb,
-                 unsigned gate_wantA, unsigned gate_wantB, double alpha, const bpmf::PairArgs &p, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop);
 // multi-GPU: every rank's fresh columns travel to the others, in place in the replicated factor matrix.
 // sub < 0: the whole range of every rank; sub >= 0: sub-range `sub` of every rank (bpmf_hip_side_set_overlap:
 // the exchange of one part of a side's columns runs on a stream of its own beside the sampling of the next part)
@@ -65,29 +60,21 @@ int exchange(bpmf_hip_side *self, hipStream_t st, int sub);
 template <int K, bool F32>
 int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_host_dev, unsigned *flag, unsigned seq, unsigned *ticket,
           hipEvent_t ev_done = nullptr);     // ev_done: rides on the dispatch packet of the pass's last kernel (single GPU; no marker packet behind it)
-// group A of a split statistics pass (see bpmf_hip_side::d_stat_list): partials only, behind the side's ev_stat_a
-template <int K, bool F32>
-int stats_a(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_host_dev, unsigned *ticket);
 template <int K, bool F32>
 void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items, const void *other_items, int n, hipStream_t ps, bool beside);
 
-// K = 64: every kernel family but k_sample1 sits in a unit of its own (k64_*.hip) -- the instantiations
+// K = 64: every kernel family sits in a unit of its own (k64_*.hip) -- the instantiations
 // of this size take minutes to compile.  e0 / e1: events riding on the dispatch packet, or NULL.
-void k64_persistent(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a);
-void k64_wg(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgsW<double> &a);
-void k64_lr(int width, int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::LrArgs &a);     // sweep width 1..4
 void k64_pf(int cls, int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::LrArgs &a);       // class 0..2: <= 3 | 6 | 16 ratings
-void k64_pf_all(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::LrArgs &a);                // all three classes in one launch (k_sample_pf_all)
 void k64_pf_prepare(int grid, hipStream_t st, hipEvent_t e0, const double *S0t, const double *other_items, int64_t nrows, double *Q);
 
-// slab form (kernels_slab.h): K = 64 fp64 and K = 128 fp32 factors, one wave per work item
+// slab form (kernels_slab.h): K = 64 fp64, one wave per work item
 void k64_slab(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a);
-void k128_slab(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a);
-// K = 128 fp32: workgroup of 2 / 4 waves per item, second form (kernels_wg2.h)
+// K = 128 fp32: workgroup of two waves per item (kernels_wg2.h)
 // (r: column statistics of another side as rider workgroups at the head of the grid, or r.nblocks == 0)
-void k128_wg2(int grid, int nwaves, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a, const bpmf::StatRiders &r);
-// K = 128 fp64 (num_latent 65 .. 128 in the reference's arithmetic): the same form with fp64 factors (k128_f64.hip)
-void k128_wg2_f64(int grid, int nwaves, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a, const bpmf::StatRiders &r);
+void k128_wg2(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a, const bpmf::StatRiders &r);
+// K = 128 fp64 (num_latent 65 .. 128 in the reference's arithmetic): the same form with fp64 factors, four waves per item (k128_f64.hip)
+void k128_wg2_f64(int grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const bpmf::SampleArgs &a, const bpmf::StatRiders &r);
 
 // BPMF_REDUCE formulation (kernels_reduce.h, kreduce.hip): fp64, K = 8 .. 64
 int reduce_part_words(int K);                  // doubles per column of a side's `prec` array (0: K not supported)

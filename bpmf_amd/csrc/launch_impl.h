@@ -6,8 +6,6 @@
 #include "kernels_f32.h"
 #include "kernels_q4.h"
 #include "kernels_slab.h"
-#include "kernels_q1.h"
-#include "kernels_x4.h"
 
 namespace bpmf_launch {
 
@@ -27,41 +25,6 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
 {
     using namespace bpmf;
     bpmf_hip_ctx *c = self->ctx;
-    auto launch = [&](auto kernel, dim3 grid, dim3 block, auto args) {
-        BPMF_LAUNCH(kernel, grid, block, st, ev_start, ev_stop, args);
-    };
-    // one workgroup per column (k_sample_wg): the fp32 large-K path, and K = 64 in fp64
-    auto launch_wg = [&](auto zero) {
-        typedef decltype(zero) T;
-        SampleArgsW<T> f;
-        f.rowidx = self->d_rowidx; f.vals = self->d_vals;
-        const int fw0 = self->item_n >= 0 ? self->item_off : 0;
-        f.wi_col = self->d_wi_col + fw0; f.wi_p0 = self->d_wi_p0 + fw0; f.wi_len = self->d_wi_len + fw0;
-        f.other_items = reinterpret_cast<const T *>(other->d_items); f.items = reinterpret_cast<T *>(out_items);
-        f.col_from = self->from;
-        f.LambdaF = d_in; f.Lmu = d_in + (size_t)K * K;
-        f.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
-        f.mu = d_in + (size_t)K * K + K + 2; f.prop_lambda = self->d_prop; f.diag_only = c->diag_only;
-        f.mean_rating = self->mean_rating; f.alpha = alpha; f.iter_plus_1 = (uint32_t)(iter + 1); f.ktrue = c->Kt;
-        // four waves per column at K = 128; one wave owning all tiles at K = 64 (no idle waves in the
-        // serial phases of the factorisation: the column-dominated shapes are what K = 64 is run on)
-        const int fnw = self->item_n >= 0 ? self->item_n : self->nwork;
-        if (fnw > 0) {
-            if constexpr (F32) {
-                // two waves per column (18 tiles each) by default: three columns in flight per CU instead of two,
-                // and one idle wave instead of three through the serial phases (0.66 -> 0.58 ms per launch)
-                if (env_int("BPMF_HIP_WG_WAVES", 2) == 4) launch(k_sample_wg<K, T, 4>, dim3(fnw), dim3(256), f);
-                else launch(k_sample_wg<K, T, 2>, dim3(fnw), dim3(128), f);
-            }
-            else if constexpr (K == 64) k64_wg(fnw, st, ev_start, ev_stop, f);
-        }
-    };
-    if constexpr (F32) {
-        if (self->mode == 2) { launch_wg(0.0f); return 0; }
-    }
-    if constexpr (K == 64) {
-        if (self->mode == 2) { launch_wg(0.0); return 0; }
-    }
     SampleArgs a;
     a.rowidx = self->d_rowidx; a.vals = self->d_vals;
     // (item window: the whole list, or the items of one part of the columns -- bpmf_hip_side_set_overlap)
@@ -74,45 +37,32 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
     a.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
     a.mu = d_in + (size_t)K * K + K + 2; a.prop_lambda = self->d_prop; a.diag_only = c->diag_only;
     a.mean_rating = self->mean_rating; a.alpha = alpha; a.iter_plus_1 = (uint32_t)(iter + 1); a.ktrue = c->Kt;
-    a.ablate = c->ablate; a.stamps = c->d_stamps; a.wt_store = 0u;
+    a.ablate = c->ablate; a.stamps = c->d_stamps;
     a.gate_flag = self->cur_gate_flag; a.gate_want = self->cur_gate_want;
     a.tmo = self->cur_gate_flag ? tmo_word(self->a_h_out_dev, K) : nullptr; a.wait_ticks = wait_ticks();
     a.zero_row = c->d_zero;
     a.lf32 = (lf32_words(c) && !self->d_prop) ? reinterpret_cast<const float *>(d_in + c->in_words) : nullptr;
-    a.q_col_slot = self->d_q_col_slot; a.q_grp_cols = self->d_q_grp_cols; a.q_count = self->d_q_count; a.q_scratch = self->d_q_scratch;
-    bpmf::StatRiders rr = self->cur_riders;                          // (K = 128 only)
-    if (rr.tail) { rr.items = out_items; rr.nitems = nwork; a.wt_store = 1u; }   // this launch's own columns: the copy it writes
-    if constexpr (F32) {                                             // fp32 factors (items / other_items are float arrays)
-        if (nwork > 0) {
-            if (self->mode == 4) k128_slab(nwork, st, ev_start, ev_stop, a);
-            else k128_wg2(nwork, env_int("BPMF_HIP_WG_WAVES", 2) == 4 ? 4 : 2, st, ev_start, ev_stop, a, rr);
-        }
+    const bpmf::StatRiders &rr = self->cur_riders;                   // (K = 128 fp32 only)
+    if constexpr (F32) {                                             // fp32 factors (items / other_items are float arrays): kernels_wg2.h, T = float
+        if (nwork > 0) k128_wg2(nwork, st, ev_start, ev_stop, a, rr);
         return 0;
     } else if constexpr (K == 128) {                                 // fp64 factors, workgroup of four waves per item (kernels_wg2.h, T = double)
-        if (nwork > 0) k128_wg2_f64(nwork, env_int("BPMF_HIP_WG_WAVES_F64", 4) == 2 ? 2 : 4, st, ev_start, ev_stop, a, rr);
+        if (nwork > 0) k128_wg2_f64(nwork, st, ev_start, ev_stop, a, rr);
         return 0;
     } else {
     if constexpr (K <= 32) {
         if (nwork > 0 && self->mode == 3) {                          // four columns per wave (k_sample4)
-            launch(k_sample4<K>, dim3((nwork + 3) / 4), dim3(64), a);
+            BPMF_LAUNCH(k_sample4<K>, dim3((nwork + 3) / 4), dim3(64), st, ev_start, ev_stop, a);
             return 0;
         }
     }
     if constexpr (K == 64) {
         if (self->lr_n > 0 && !self->d_prop && !c->diag_only && !(c->ablate & 3u)) {
-            // light columns: rank-n update of the shared factor of LambdaF (k_sample_lr); the others as usual
+            // light columns (<= 16 ratings): product form over the shared factor of LambdaF (k_sample_pf); the others in the slab form
             if (self->hv_nwork > 0) {
                 a.wi_col = self->d_hv_col; a.wi_p0 = self->d_hv_p0; a.wi_len = self->d_hv_len; a.wi_mc = self->d_hv_mc;
                 a.wi_chunk = self->d_hv_chunk; a.nwork = self->hv_nwork;
-                if (self->mode == 4) {
-                    k64_slab(self->hv_nwork, st, ev_start, nullptr, a);
-                } else if (self->mode == 1) {
-                    const FusedArgs f0{};
-                    BPMF_LAUNCH(k_sample1<K>, dim3(self->hv_nwork), dim3(64), st, ev_start, (hipEvent_t) nullptr, a, f0);
-                } else {
-                    const int grid = std::min(self->hv_nwork, env_int("BPMF_HIP_GRID", c->num_cu * 4 * Geo<K>::WPS));
-                    k64_persistent(grid, st, ev_start, nullptr, a);
-                }
+                k64_slab(self->hv_nwork, st, ev_start, nullptr, a);
             }
             LrArgs l;
             l.rowidx = self->d_rowidx; l.vals = self->d_vals; l.col = self->d_lr_col; l.p0 = self->d_lr_p0; l.len = self->d_lr_len;
@@ -120,12 +70,9 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
             l.R0 = d_in + (size_t)K * K + K + 2 + K; l.S0t = l.R0 + (size_t)K * K; l.y0 = l.S0t + (size_t)K * K;
             l.Lmu = a.Lmu; l.fail = a.fail;
             l.mean_rating = self->mean_rating; l.alpha = alpha; l.sqrt_alpha = std::sqrt(alpha); l.iter_plus_1 = (uint32_t)(iter + 1); l.ktrue = c->Kt;
-            // product form for the columns with <= 6 ratings: two instantiations (<= 2, <= 6), persistent workgroups
-            // of eight waves with R0^-1 in LDS; then one launch per sweep width for the rest (the events ride on
-            // the first / last launch of the side)
+            // three instantiations (<= 3, <= 6, <= 16 ratings), persistent workgroups of eight waves with R0^-1 in LDS
+            // (the events ride on the first / last launch of the side)
             l.Q = self->d_pf_q;
-            int first = 0, last = 0;
-            for (int cls = 1; cls <= 4; ++cls) if (self->lr_class[cls] > self->lr_class[cls - 1]) { if (!first) first = cls; last = cls; }
             bool started = self->hv_nwork > 0;
             if (self->pf_class[3] > self->pf_class[0] && self->d_pf_q) {
                 // Q = U_other R0^-1 once per half-iteration (k_pf_prepare), ahead of the product-form launches
@@ -133,49 +80,21 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
                 k64_pf_prepare(grid, st, started ? nullptr : ev_start, l.S0t, other->d_items, self->nrows, self->d_pf_q);
                 started = true;
             }
-            int last_pf = -1, npf = 0;
-            for (int pc = 0; pc < 3; ++pc) if (self->pf_class[pc + 1] > self->pf_class[pc]) { last_pf = pc; ++npf; }
-            const int pf_merge = env_int("BPMF_HIP_PF_MERGE", 0);     // (read per launch: the tests flip it)
-            if (npf > 1 && pf_merge && !self->d_stat_list) {
-                // the three classes in one launch of persistent workgroups, passes dealt round-robin, most expensive first (k_sample_pf_all)
-                LrArgs lc = l;
-                for (int q = 0; q < 4; ++q) lc.pf_c[q] = self->pf_class[q];
-                lc.nitems = self->pf_class[3];
-                const bool is_last = last == 0;
-                int npass = 0;
-                for (int pc = 0; pc < 3; ++pc) npass += (self->pf_class[pc + 1] - self->pf_class[pc] + 3) / 4;
-                const int grid = std::max(1, std::min((npass + 7) / 8, c->num_cu * 2));       // two workgroups per CU are resident (58 KB of LDS each)
-                k64_pf_all(grid, st, started ? nullptr : ev_start, is_last ? ev_stop : nullptr, lc);
-                started = true;
-            } else
+            int last_pf = -1;
+            for (int pc = 0; pc < 3; ++pc) if (self->pf_class[pc + 1] > self->pf_class[pc]) last_pf = pc;
             for (int pc = 0; pc < 3; ++pc) {
                 const int n0 = self->pf_class[pc], n1 = self->pf_class[pc + 1];
                 if (n1 <= n0) continue;
                 LrArgs lc = l;
                 lc.col = l.col + n0; lc.p0 = l.p0 + n0; lc.len = l.len + n0; lc.nitems = n1 - n0;
-                const bool is_last = last == 0 && pc == last_pf;
-                hipEvent_t e0 = started ? nullptr : ev_start, e1 = is_last ? ev_stop : nullptr;
-                if (pc == 0 && !is_last && self->d_stat_list && self->ev_stat_a && self->stat_nA > 0 && self->item_n < 0 && !(c->comm != nullptr && !self->bounds.empty())) {
-                    e1 = self->ev_stat_a;                                 // group A of the statistics may start behind this launch
-                    self->stat_a_ready = true;
-                }
+                hipEvent_t e0 = started ? nullptr : ev_start, e1 = pc == last_pf ? ev_stop : nullptr;
                 started = true;
                 const int grid = std::max(1, std::min((n1 - n0 + 31) / 32, c->num_cu * 4));     // eight waves x four columns per pass
                 k64_pf(pc, grid, st, e0, e1, lc);
             }
-            for (int cls = 1; cls <= 4; ++cls) {
-                const int n0 = self->lr_class[cls - 1], n1 = self->lr_class[cls];
-                if (n1 <= n0) continue;
-                LrArgs lc = l;
-                lc.col = l.col + n0; lc.p0 = l.p0 + n0; lc.len = l.len + n0; lc.nitems = n1 - n0;
-                hipEvent_t e0 = (cls == first && !started) ? ev_start : nullptr, e1 = (cls == last) ? ev_stop : nullptr;
-                k64_lr(cls, n1 - n0, st, e0, e1, lc);
-            }
             return 0;
         }
-    }
-    if constexpr (K == 64) {
-        if (nwork > 0 && self->mode == 4) {
+        if (nwork > 0) {
             const FusedArgs &f = self->cur_fused;                    // (all zero outside the fused stateful path)
             if (f.gate_host || f.nstat) {                            // gate workgroup + statistics riders + items in one launch
                 const dim3 grid((unsigned)(nwork + (f.gate_host ? 1 : 0) + f.nstat));
@@ -183,90 +102,16 @@ int sampler_into(bpmf_hip_side *self, double *out_items, const bpmf_hip_side *ot
             } else {
                 k64_slab(nwork, st, ev_start, ev_stop, a);
             }
-            return 0;
         }
-    }
-    if constexpr (K <= 32) {
-        if (nwork > 0 && self->mode == 6) {                          // Gram one column per wave, factorisation four columns per wave
-            const FusedArgs &f = self->cur_fused;
-            const dim3 grid((unsigned)(nwork + (f.gate_host ? 1 : 0) + f.nstat));
-            BPMF_LAUNCH(k_sample1q<K>, grid, dim3(64), st, ev_start, ev_stop, a, f);
-            return 0;
-        }
-        if (nwork > 0 && self->mode == 8) {                          // the same in two launches: Grams, then every group's factorisation side by side
-            const FusedArgs &f = self->cur_fused;
-            const dim3 grid((unsigned)(nwork + (f.gate_host ? 1 : 0) + f.nstat));
-            BPMF_LAUNCH((k_sample1q<K, true>), grid, dim3(64), st, ev_start, (hipEvent_t) nullptr, a, f);
-            BPMF_LAUNCH(k_finish_groups<K>, dim3((unsigned)self->q_ngroups), dim3(64), st, (hipEvent_t) nullptr, ev_stop, a, self->q_ngroups);
-            return 0;
-        }
-    }
-    if constexpr (K <= 32) {
-        if (nwork > 0 && self->mode == 7) {                          // up to four items per wave one after the other, factorised in lockstep
-            const FusedArgs &f = self->cur_fused;
-            // as many waves as the chip holds at this kernel's occupancy (every wave then walks nwork / nwaves items of
-            // about the same total length), more only when that would be more than four items per wave
-            static const int waves_env = env_int("BPMF_HIP_X4_WAVES", 0);
-            const int slots = waves_env > 0 ? waves_env : c->num_cu * 4 * GeoX<K>::WPS;
-            const int nwaves = std::max(std::min(nwork, slots), (nwork + GeoX<K>::NITEM - 1) / GeoX<K>::NITEM);
-            const dim3 grid((unsigned)(nwaves + (f.gate_host ? 1 : 0) + f.nstat));
-            BPMF_LAUNCH(k_sample1x<K>, grid, dim3(64), st, ev_start, ev_stop, a, f, nwaves);
-            return 0;
-        }
-    }
-    if (nwork > 0 && self->mode == 1) {
+        return 0;
+    } else {
+    if (nwork > 0) {                                                 // K <= 32: one work item per single-wave workgroup (k_sample1)
         const FusedArgs &f = self->cur_fused;                        // (all zero outside the fused stateful path)
         const dim3 grid((unsigned)(nwork + (f.gate_host ? 1 : 0) + f.nstat));
-        if constexpr (K == 32 || K == 16) {
-            // the slab form of the item body (kernels_slab.h) behind the same launch format: BPMF_HIP_SLAB32
-            static const int slab = env_int("BPMF_HIP_SLAB32", 0);
-            if (slab) {
-                BPMF_LAUNCH(k_sample1s<K>, grid, dim3(64), st, ev_start, ev_stop, a, f);
-                return 0;
-            }
-        }
         BPMF_LAUNCH(k_sample1<K>, grid, dim3(64), st, ev_start, ev_stop, a, f);
-    } else if (nwork > 0) {
-        // persistent waves: as many single-wave workgroups as the chip holds at this kernel's occupancy
-        const int resident = c->num_cu * 4 * Geo<K>::WPS;
-        const int grid = std::min(nwork, env_int("BPMF_HIP_GRID", resident));
-        if constexpr (K == 64) k64_persistent(grid, st, ev_start, ev_stop, a);
-        else launch(k_sample<K>, dim3(grid), dim3(64), a);
     }
     return 0;
     }
-}
-
-template <int K, bool F32>
-int sampler_pair(bpmf_hip_side *A, double *outA, int iterA, double *d_inA, const bpmf::FusedArgs &fa,
-                 bpmf_hip_side *B, double *outB, int iterB, double *d_inB, const bpmf::FusedArgs &fb,
-                 unsigned gate_wantA, unsigned gate_wantB, double alpha, const bpmf::PairArgs &p, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop)
-{
-    using namespace bpmf;
-    if constexpr (K > 32 || F32) return fail(BPMF_HIP_EINVAL, "pair launch: K <= 32 in fp64 only");
-    else {
-    bpmf_hip_ctx *c = A->ctx;
-    auto fill = [&](SampleArgs &a, bpmf_hip_side *self, double *out_items, const double *other_items, int iter, double *d_in, unsigned gate_want) {
-        a = SampleArgs{};
-        a.rowidx = self->d_rowidx; a.vals = self->d_vals;
-        a.wi_col = self->d_wi_col; a.wi_p0 = self->d_wi_p0; a.wi_len = self->d_wi_len; a.wi_mc = self->d_wi_mc; a.wi_chunk = self->d_wi_chunk;
-        a.mc_slot0 = self->d_mc_slot0; a.mc_nchunks = self->d_mc_nch; a.mc_count = self->d_mc_count;
-        a.partials = self->d_partials; a.nwork = self->nwork;
-        a.other_items = other_items; a.items = out_items; a.col_from = self->from;
-        a.LambdaF = d_in; a.Lmu = d_in + (size_t)K * K;
-        a.fail = (unsigned long long *)(d_in + (size_t)K * K + K);
-        a.mu = d_in + (size_t)K * K + K + 2; a.prop_lambda = self->d_prop; a.diag_only = c->diag_only;
-        a.mean_rating = self->mean_rating; a.alpha = alpha; a.iter_plus_1 = (uint32_t)(iter + 1); a.ktrue = c->Kt;
-        a.gate_flag = self->a_dflag; a.gate_want = gate_want;
-        a.tmo = tmo_word(self->a_h_out_dev, K); a.wait_ticks = wait_ticks();
-        a.zero_row = c->d_zero;
-    };
-    SampleArgs a, b;
-    fill(a, A, outA, B->d_items, iterA, d_inA, gate_wantA);            // A gathers from B's CURRENT copy
-    fill(b, B, outB, outA, iterB, d_inB, gate_wantB);                 // B gathers from the copy A writes in this launch
-    const unsigned grid = (unsigned)((fa.gate_host ? 1 : 0) + fa.nstat + a.nwork + (fb.gate_host ? 1 : 0) + fb.nstat + b.nwork);
-    BPMF_LAUNCH(k_sample1p<K>, dim3(grid), dim3(64), st, ev_start, ev_stop, a, fa, b, fb, p);
-    return 0;
     }
 }
 
@@ -376,13 +221,7 @@ int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_h
         return 0;
     } else {
     if (!(c->comm != nullptr && !self->bounds.empty())) {
-        if (self->nstat_wg > 0 && self->stat_a_done) {                // group B + the sum over both groups' partials
-            self->stat_a_done = false;
-            hipLaunchKernelGGL(k_colstats_wg<K>, dim3(self->stat_wgB), dim3(256), 0, st,
-                               (const double *)self->d_items + (size_t)self->from * K, self->stat_nA, self->stat_n, self->stat_wgB, self->d_stat_partials,
-                               failp, out_host_dev, ticket, flag, seq, tmo_word(out_host_dev, K), wait_ticks(),
-                               (const int32_t *)self->d_stat_list, self->stat_wgA, self->stat_wgA + self->stat_wgB, 1);
-        } else if (self->nstat_wg > 0) {
+        if (self->nstat_wg > 0) {
             if (ev_done)
                 hipExtLaunchKernelGGL(k_colstats_wg<K>, dim3(self->nstat_wg), dim3(256), 0, st, nullptr, ev_done, 0,
                                       (const double *)self->d_items, self->from, self->to, self->nstat_wg, self->d_stat_partials,
@@ -427,27 +266,6 @@ int stats(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_h
     }
 }
 
-template <int K, bool F32>
-int stats_a(bpmf_hip_side *self, hipStream_t st, const double *d_in, double *out_host_dev, unsigned *ticket)
-{
-    using namespace bpmf;
-    if constexpr (K == 128) return 0;
-    else {
-    if (!(self->nstat_wg > 0 && self->d_stat_list && self->stat_a_ready)) return 0;
-    self->stat_a_ready = false;
-    const unsigned long long *failp = (const unsigned long long *)(d_in + (size_t)K * K + K);
-    hipLaunchKernelGGL(k_colstats_wg<K>, dim3(self->stat_wgA), dim3(256), 0, st,
-                       (const double *)self->d_items + (size_t)self->from * K, (int64_t)0, self->stat_nA, self->stat_wgA, self->d_stat_partials,
-                       failp, out_host_dev, ticket, (unsigned *)nullptr, 0u, tmo_word(out_host_dev, K), wait_ticks(),
-                       (const int32_t *)self->d_stat_list, 0, self->stat_wgA + self->stat_wgB, 0);
-    self->stat_a_done = true;
-    return 0;
-    }
-}
-
-// k_predict on stream `ps` over explicit factor pointers.  in_order: on the main stream behind the
-// samplers.  Otherwise (`beside`): behind ev_in (everything that was on the main stream when the
-// evaluation was requested), with ev_done recorded after it for launch_sampler's hazard check.
 template <int K, bool F32>
 void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items, const void *other_items, int n,
                     hipStream_t ps, bool beside)
@@ -527,7 +345,4 @@ void predict(bpmf_hip_test *t, const bpmf_hip_side *self, const void *self_items
                                                hipEvent_t, hipEvent_t);                                                          \
     template int bpmf_launch::exchange<KK, FF>(bpmf_hip_side *, hipStream_t, int);                                                        \
     template int bpmf_launch::stats<KK, FF>(bpmf_hip_side *, hipStream_t, const double *, double *, unsigned *, unsigned, unsigned *, hipEvent_t); \
-    template int bpmf_launch::stats_a<KK, FF>(bpmf_hip_side *, hipStream_t, const double *, double *, unsigned *);                       \
-    template void bpmf_launch::predict<KK, FF>(bpmf_hip_test *, const bpmf_hip_side *, const void *, const void *, int, hipStream_t, bool);   \
-    template int bpmf_launch::sampler_pair<KK, FF>(bpmf_hip_side *, double *, int, double *, const bpmf::FusedArgs &, bpmf_hip_side *, double *, int, double *, \
-                                                   const bpmf::FusedArgs &, unsigned, unsigned, double, const bpmf::PairArgs &, hipStream_t, hipEvent_t, hipEvent_t);
+    template void bpmf_launch::predict<KK, FF>(bpmf_hip_test *, const bpmf_hip_side *, const void *, const void *, int, hipStream_t, bool);

@@ -147,7 +147,6 @@ struct bpmf_hip_ctx {
     struct bpmf_hip_side *pending_stats = nullptr; unsigned pending_seq = 0; int pending_evset = 0;
     // ... or, unfused sides with a stand-alone statistics pass (big sides, the fp32 path): the pass goes onto S0 itself just
     // ahead of the NEXT sampler launch, which is then launched "any order" (no barrier bit): see bpmf_hip_sys_sample
-    bool pending_inorder = false;
     // ... or, fp32 path: as rider workgroups at the head of the next k_sample_wg2 launch (StatRiders, args.h)
     bool pending_riders = false;
     std::vector<bpmf_hip_side *> sides;  // stateful sides with a statistics stream of their own (for ctx_sync)
@@ -202,18 +201,12 @@ struct bpmf_hip_side {
     double *d_prop = nullptr;            // propagated posterior (-m / -l): K x K prior precision per local column, or NULL
     // schedule
     int nwork = 0, nmulti = 0, nslots = 0, mode = 0;
-    // mode 6 (k_sample1q): groups of four columns factorised in lockstep by the last wave to deliver its Gram
-    int32_t *d_q_col_slot = nullptr, *d_q_grp_cols = nullptr;
-    unsigned *d_q_count = nullptr;
-    double *d_q_scratch = nullptr;
-    int q_ngroups = 0;
-    // K = 64: columns with a handful of ratings take the low-rank form (k_sample_lr), the rest the regular
-    // one -- lr_n light items + hv_nwork others (the full list above stays for per-column priors etc.)
+    // K = 64: columns with <= 16 ratings take the product form (k_sample_pf), the rest the slab form --
+    // lr_n light items + hv_nwork others (the full list above stays for per-column priors etc.)
     int lr_n = 0, hv_nwork = 0;
-    int lr_class[5] = {0, 0, 0, 0, 0};     // light items sorted by sweep width: class c (1..4 ratings per sweep) is [lr_class[c-1], lr_class[c])
     int64_t pf_ratings2 = 0;
     int64_t pf_ratings = 0;                // ratings of the product-form columns (bpmf_hip_side_schedule_info)
-    int pf_class[4] = {0, 0, 0, 0};        // ahead of them: product-form items (k_sample_pf): <= 3 ratings, 4..6, 7..16 -- class c is [pf_class[c], pf_class[c+1])
+    int pf_class[4] = {0, 0, 0, 0};        // the light items by class: <= 3 ratings, 4..6, 7..16 -- class c is [pf_class[c], pf_class[c+1])
     double *d_pf_q = nullptr;              // product form: R0^-T u_row for every row of the other side (nrows x K), per half-iteration
     int32_t *d_lr_col = nullptr, *d_lr_len = nullptr; int64_t *d_lr_p0 = nullptr;
     int32_t *d_hv_col = nullptr, *d_hv_len = nullptr, *d_hv_mc = nullptr, *d_hv_chunk = nullptr; int64_t *d_hv_p0 = nullptr;
@@ -224,11 +217,6 @@ struct bpmf_hip_side {
     double *d_partials = nullptr;
     int nstat_waves = 0;
     int nstat_wg = 0;                    // > 0: the side's stand-alone statistics pass runs as this many four-wave workgroups (k_colstats_wg: big sides)
-    // big side with several sampler launches per half-iteration (K = 64 low-rank classes): the statistics of the columns
-    // of the FIRST launches (heavy + <= 2 ratings: group A, the first stat_nA entries of d_stat_list) run beside the later
-    // launches, only the rest waits for the end of the side's samplers
-    int32_t *d_stat_list = nullptr; int64_t stat_nA = 0, stat_n = 0; int stat_wgA = 0, stat_wgB = 0;
-    hipEvent_t ev_stat_a = nullptr; bool stat_a_ready = false, stat_a_done = false;
     hipEvent_t ev_stat_go = nullptr;     // big side: S0 continues only once S1 has reached the statistics kernel (head start for its workgroups)
     double *d_stat_partials = nullptr;
     std::vector<int64_t> bounds;         // multi-GPU: column range of every rank (nranks + 1 entries)
@@ -279,21 +267,7 @@ struct bpmf_hip_side {
     hipStream_t saux = nullptr;          // this side's statistics stream (high priority: its few blocks must not queue behind the other side's sampler)
     // host worker of this side: collects its sums when they land, forms cov, draws its next
     // hyper-parameters and releases the gate of its next sampler, all while the GPU samples the other side
-    struct Job { int iter; unsigned seq; int evset; bool timed; hipEvent_t prev_stop; bool paired = false; struct bpmf_hip_side *partner = nullptr; };
-    // Pair launch (k_sample1p): this side's NEXT half-iteration was enqueued inside its partner's launch -- the bookkeeping of
-    // Sys::sample (iter++, the copies swap, the collector's job) waits for the caller's bpmf_hip_sys_sample of this side
-    // (accept_prelaunch in capi.hip); anything that invalidates it (other alpha, other partner, factors replaced) discards it.
-    struct Prelaunch {
-        int iter = -1;                   // the half-iteration that is in flight (-1: none)
-        unsigned seq = 0; int evset = 0;
-        double alpha = 0.0;
-        struct bpmf_hip_side *partner = nullptr;
-        hipEvent_t ev_stop = nullptr;    // completes with the pair launch (the partner's event)
-    } pre;
-    unsigned *d_pair = nullptr;          // 16 shard counters + the word the partner's items poll (PairArgs); as first side of a pair
-    bool pair_seen = false;              // a half-iteration of this side ran inside a pair launch (reports name k_sample1p)
-    unsigned pair_launches = 0;          // pair launches with this side first (the poll word stands at 16 * pair_launches)
-    std::atomic<double> pair_credit_ms{0.0};   // this side's half of a timed pair launch, measured by the partner's collector
+    struct Job { int iter; unsigned seq; int evset; bool timed; hipEvent_t prev_stop; };
     hipEvent_t last_stop = nullptr;      // stop event of this side's newest sampler (diagnostic: boundary to the next launch)
     double tot_gap_ms = 0.0; int64_t n_gap = 0;
     std::thread worker;

@@ -32,6 +32,10 @@ def double_mode(request, monkeypatch):
     an NCCL kernel does, a helper thread per communicator completes the operations after random, rank-dependent delays --
     so that the two communicators and the exchange stream of a rank interleave differently from its peers' (VERDICT r3:
     what the synchronous double serialises away).  Same assertions in both modes."""
+    # the tests that go through a whole `bench.py` / `bpmf` process (tens of seconds each: preflight children, watchdogs) run in
+    # the asynchronous mode only -- the library-level tests below them keep both
+    if request.param == "sync" and request.node.name.startswith(("test_bench_", "test_bpmf_g2")):
+        pytest.skip("process-level test: asynchronous mode only")
     if request.param == "async":
         monkeypatch.setenv("BPMF_RCCL_DOUBLE_ASYNC", "1")
         # The double's helper threads move the data with HIP copies on streams of their own, and HIP maps the streams of a

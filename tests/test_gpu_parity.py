@@ -15,16 +15,14 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-9
 
 
-@pytest.fixture(params=[None, 0, 1, 2, 3, 6, 7, 8], ids=["auto", "persistent", "per-item", "workgroup", "four-columns", "gram1-finish4", "four-in-a-row", "gram1-then-finish4"])
+@pytest.fixture(params=[None, 1, 3], ids=["auto", "per-item", "four-columns"])
 def sampler_mode(request):
-    """The forms of the sampler (BPMF_HIP_MODE, read when a side is created): 0 = persistent
-    waves with C = 64/K columns factorised side by side, 1 = one work item per single-wave
-    workgroup, 2 = one four-wave workgroup per column (K = 64 only; other K fall back to auto),
-    3 = four columns per wave, factorisation on the 4x4x4 MFMA shape (K <= 32), 6 = the Gram of a column by one wave, the
-    factorisation of four columns by the last wave of their group to deliver (k_sample1q, K <= 32; other K: auto),
-    7 = a wave forms the Grams of up to four work items one after the other and factorises their columns in lockstep
-    (k_sample1x, K <= 32; other K: auto), 8 = form 6 in two launches: the Grams, then one wave per group of four columns
-    (k_sample1q<K, split> + k_finish_groups, K <= 32; other K: auto)."""
+    """The two shipped forms of the K <= 32 sampler (BPMF_HIP_MODE, read when a side is created): 1 = one work item per
+    single-wave workgroup (k_sample1: what a side with < 20 000 columns runs), 3 = four columns per wave with the factorisation
+    on the 4x4x4 MFMA shape (k_sample4: what a bigger side runs).  `auto` picks by size, so the small matrices of these tests
+    reach k_sample4 only when it is forced.  K = 64 (slab form + product form) and K = 128 (workgroup form) have one form each:
+    the switch does nothing there and the tests skip the forced runs.  (Rounds 1-4 kept seven more forms behind this switch:
+    docs/FINDINGS.md.)"""
     import os
     old = os.environ.get("BPMF_HIP_MODE")
     if request.param is None:
@@ -40,6 +38,11 @@ def sampler_mode(request):
 
 def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def _one_form_only(K, mode):
+    if K > 32 and mode is not None:
+        pytest.skip("K = %d has one form: BPMF_HIP_MODE does nothing" % K)
 
 
 def half_iteration_pair(oracle, eng, K, M, nrows, other_items, it, alpha=2.0, cov=None, chunk_note=""):
@@ -80,6 +83,7 @@ def test_device_normal_stream(oracle, hip_engine_factory, counter):
 
 @pytest.mark.parametrize("K", [8, 16, 32, 64])
 def test_tiny_first_half_iterations(oracle, hip_engine_factory, K, sampler_mode):
+    _one_form_only(K, sampler_mode)
     M, Mt, T, Tt, nu, nm = util.tiny()
     eng = hip_engine_factory(K)
     rng = np.random.default_rng(K)
@@ -91,40 +95,18 @@ def test_tiny_first_half_iterations(oracle, hip_engine_factory, K, sampler_mode)
 
 
 def test_low_rank_columns(oracle, hip_engine_factory, monkeypatch):
-    """K = 64, a ChEMBL-shaped side (thousands of columns with 0..12 ratings, a few heavy ones): the
-    light columns update the shared factor of LambdaF by reflector sweeps over 1..4 ratings (k_sample_lr)
-    instead of factorising Lambda*; same Cholesky factor, hence the reference's sample for the same
-    normals.  Checked against the oracle, and against the regular path (BPMF_HIP_LOWRANK_MAX=0)."""
-    K = 64
-    rng = np.random.default_rng(64)
-    ncols, nrows = 3000, 150
-    # (every count up to 12 -- the sweeps take 1..4 ratings at a time, the last one padded -- and some heavy columns)
-    counts = rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 40], size=ncols,
-                        p=[0.06, 0.2, 0.2, 0.1, 0.08, 0.05, 0.05, 0.04, 0.04, 0.03, 0.03, 0.03, 0.03, 0.03, 0.03])
-    colptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-    rowidx = np.concatenate([np.sort(rng.choice(nrows, size=c, replace=False)) for c in counts]).astype(np.int32)
-    vals = rng.normal(6.0, 1.3, size=len(rowidx))
-    M = (colptr, rowidx, vals)
-    U = 0.4 * rng.standard_normal((nrows, K))
-    A = rng.standard_normal((K, 3 * K)); cov = A @ A.T / (3 * K)
-    eng = hip_engine_factory(K)
-    hip, ref = half_iteration_pair(oracle, eng, K, M, nrows, U, 4, cov=cov)
-    check_half_iteration(hip, ref)
-    monkeypatch.setenv("BPMF_HIP_LOWRANK_MAX", "0")
-    reg, _ = half_iteration_pair(oracle, eng, K, M, nrows, U, 4, cov=cov)
-    assert rel_err(hip[0], reg[0]) < RTOL
-
-
-def test_product_form_classes_in_one_launch(oracle, hip_engine_factory, monkeypatch):
-    """k_sample_pf_all: the three classes of product-form columns (<= 3 | 4..6 | 7..16 ratings) as ONE launch whose waves
-    take passes of four columns round-robin from one list, most expensive first.  Several launches on the same side, class
-    sizes that are not multiples of four (ragged last pass of every class), against the oracle and bit for bit against the
-    three separate launches (BPMF_HIP_PF_MERGE=0)."""
+    """K = 64, a ChEMBL-shaped side (thousands of columns with 0..16 ratings, a few heavy ones): the light columns take the
+    product form over the shared factor of LambdaF (k_pf_prepare + k_sample_pf<64, 3 | 6 | 16>: same Cholesky factor, hence
+    the reference's sample for the same normals) instead of factorising Lambda*.  Class sizes that are not multiples of four
+    (ragged last pass of every class), several launches on the same side; against the oracle every time, and against the
+    regular path (BPMF_HIP_PF=0: every column in the slab form)."""
     K = 64
     rng = np.random.default_rng(641)
-    nrows = 120
-    counts = np.concatenate([np.full(301, 0), np.full(203, 1), np.full(97, 2), rng.integers(3, 7, 1001), rng.integers(7, 17, 333),
-                             np.full(9, 30)])
+    nrows = 400
+    counts = np.concatenate([np.full(301, 0), np.full(203, 1), np.full(97, 2), np.full(250, 3),                  # 851 = 3 mod 4
+                             np.full(333, 4), np.full(334, 5), np.full(335, 6)] +                               # 1 002 = 2 mod 4
+                            [np.full(33, n) for n in range(7, 17)] +                                            # 330 = 2 mod 4
+                            [np.full(9, 30), np.full(3, 300)])          # (300 ratings: a chunked column of the slab form)
     rng.shuffle(counts)
     ncols = len(counts)
     colptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
@@ -135,38 +117,42 @@ def test_product_form_classes_in_one_launch(oracle, hip_engine_factory, monkeypa
     eng = hip_engine_factory(K)
     A = rng.standard_normal((K, 3 * K)); cov = A @ A.T / (3 * K)
 
-    def run(merge):
-        monkeypatch.setenv("BPMF_HIP_PF_MERGE", merge)
+    def run(pf):
+        if pf is None:
+            monkeypatch.delenv("BPMF_HIP_PF", raising=False)
+        else:
+            monkeypatch.setenv("BPMF_HIP_PF", pf)
         me = eng.side_create(ncols, nrows, *M, mean)
         ot = eng.side_create(nrows, ncols, np.zeros(nrows + 1, np.int64), np.zeros(0, np.int32), np.zeros(0), 0.0)
         name = eng.kernel_name(me)
+        info = eng.schedule_info(me)
         out = []
         r = np.random.default_rng(7)
-        for it in range(4):
+        for it in range(3):
             U = (0.3 + 0.05 * it) * r.standard_normal((nrows, K))
             mu, LU, LF = oracle.hyper_sample(K, ncols, cov * (1.0 + it), it)
             eng.set_items(ot, U)
             s, p, n = eng.sample_side(me, ot, it, 2.0, mu, LF)
             out.append((eng.get_items(me).copy(), s, p, n, U, mu, LF))
         eng.side_destroy(me); eng.side_destroy(ot)
-        return out, name
+        return out, name, info
 
-    merged, name = run("1")
-    if name:
-        assert "k_sample_pf_all<64>" in name
-    for it, (items, s, p, n, U, mu, LF) in enumerate(merged):
+    pf, name, info = run(None)
+    assert name == "k_sample_pf<64,3> + k_sample_pf<64,6> + k_sample_pf<64,16> + k_sample_slab<64>", name
+    assert (info["pf_le3"], info["pf_4to6"], info["pf_7to16"], info["lr_columns"]) == (851, 1002, 330, 0)
+    for it, (items, s, p, n, U, mu, LF) in enumerate(pf):
         ref = np.zeros((ncols, K))
         s_ref, p_ref, n_ref = oracle.sample_side(K, M, mean, 2.0, U, ref, it, mu, LF)
         check_half_iteration((items, s, p, n), (ref, s_ref, p_ref, n_ref))
-    separate, name0 = run("0")
-    if name0:
-        assert "k_sample_pf<64,3>" in name0
-    for a, b in zip(merged, separate):
-        assert np.array_equal(a[0], b[0])
+    regular, name0, info0 = run("0")
+    assert "k_sample_pf" not in name0 and info0["pf_le3"] == 0
+    for a, b in zip(pf, regular):
+        assert rel_err(a[0], b[0]) < RTOL
 
 
 @pytest.mark.parametrize("K", [16, 32, 64])
 def test_ml100k_half_iterations(oracle, hip_engine_factory, K, sampler_mode):
+    _one_form_only(K, sampler_mode)
     M, Mt, T, Tt, nu, nm = util.ml100k()
     eng = hip_engine_factory(K)
     rng = np.random.default_rng(100 + K)
@@ -503,58 +489,6 @@ def test_posterior_moments_of_one_column(hip_engine_factory):
     eng.side_destroy(me); eng.side_destroy(ot)
 
 
-@pytest.mark.parametrize("K", [8, 16, 32])
-def test_pair_launch_is_the_same_chain(oracle, hip_engine_factory, monkeypatch, K):
-    """Both half-iterations of a Gibbs iteration in ONE grid (k_sample1p, BPMF_HIP_PAIR=1; VERDICT r3 item 3 / docs/FINDINGS.md 8.6: the
-    second side's items wait in-kernel for the first side's columns; the caller's sys_sample of the second side only does the
-    bookkeeping) against the two launches: same hyper-parameters, samples, norms and RMSE sums bit for bit -- in the plain
-    loop, and in the odd call orders that must DISCARD a half-iteration enqueued ahead of its call: state read straight after
-    a sample, a side sampled twice in a row, a stateless launch that replaces the factors the prelaunched half was drawn
-    from, factors set from the host, a raw-pointer request.  And the plain loop against the oracle."""
-    from bpmf_amd.sys import Sys
-    M, Mt, T, Tt, nu, nm = util.ml100k()
-    eng = hip_engine_factory(K)
-
-    def run(pair, odd):
-        monkeypatch.setenv("BPMF_HIP_PAIR", pair)
-        Sys.nsims, Sys.burnin, Sys.alpha = 9, 2, 2.0
-        movies = Sys("movs", eng, M, nm, nu, T=T)
-        users = Sys("users", eng, Mt, nu, nm)
-        out = []
-        for i in range(9):
-            movies.sample(users)
-            if odd and i == 2:
-                out.append(eng.sys_state(movies.side)[1])
-            if odd and i == 4:
-                movies.sample(users)
-            users.sample(movies)
-            if odd and i == 5:
-                eng.sample_side(users.side, movies.side, 99, 2.0, np.zeros(K), np.eye(K))
-            if odd and i == 6:
-                eng.set_items(users.side, 0.5 * eng.get_items(users.side))
-            if odd and i == 7:
-                assert eng.items_dev_ptr(movies.side)
-            movies.predict(users)
-            out += [movies.rmse, movies.rmse_avg]
-        name = eng.kernel_name(users.side)
-        st_m, st_u = eng.sys_state(movies.side), eng.sys_state(users.side)
-        out += [st_m[1], st_u[1]]
-        U, V = users.items().copy(), movies.items().copy()
-        eng.side_destroy(movies.side); eng.side_destroy(users.side)
-        return np.asarray(out), U, V, name
-
-    for odd in (False, True):
-        a, b = run("0", odd), run("1", odd)
-        assert "k_sample1<" in a[3] and "k_sample1p<" in b[3], (a[3], b[3])
-        for x, y in zip(a[:3], b[:3]):
-            assert np.array_equal(x, y), "odd call order" if odd else "plain loop"
-    monkeypatch.setenv("BPMF_HIP_PAIR", "1")
-    import bpmf_amd
-    res = bpmf_amd.gibbs(eng, M, Mt, T, nu, nm, nsims=12, burnin=4)
-    ref = oracle.gibbs(K, M, Mt, T, Tt, nsims=12, burnin=4)
-    assert np.allclose(res["rmse"], ref["rmse"], atol=1e-6) and rel_err(res["U"], ref["U"]) < 1e-6 and rel_err(res["V"], ref["V"]) < 1e-6
-
-
 def test_cholesky_failure_is_reported(hip_engine_factory):
     """THROWERROR("Cholesky failed") (c++/sample.cpp:308) -> BPMF_HIP_ECHOL + column id."""
     import bpmf_amd
@@ -694,6 +628,7 @@ def test_sharded_parts_single_rank(K):
 
 @pytest.mark.parametrize("K", [16, 32, 64])
 def test_propagated_posterior_priors(oracle, hip_engine_factory, K, sampler_mode):
+    _one_form_only(K, sampler_mode)
     """-m / -l of the reference (c++/sample.cpp:157-174,272-277): every column has its own prior
     precision Lambda_i (from a previous run's *-Lambda.ddm); rr = Lambda_i * hp.mu keeps the
     global mu (the loaded per-column mu is never used: SURVEY Q2)."""
@@ -752,6 +687,7 @@ def test_blocking_fallback_paths_give_the_same_chain():
 
 @pytest.mark.parametrize("K", [16, 32, 64])
 def test_no_covariance_variant(oracle, hip_engine_factory, K, sampler_mode):
+    _one_form_only(K, sampler_mode)
     """BPMF_NO_COVARIANCE (c++/sample.cpp:300-304) as a run-time switch: only the diagonal of
     Lambda* is factorised."""
     M, Mt, T, Tt, nu, nm = util.ml100k()
