@@ -13,6 +13,7 @@
 // reference's fp64 arithmetic.  --fp32 (or BPMF_HIP_F32=1; K > 64 only) opts into the library's mixed-precision large-K path
 // and says so on stdout: never chosen silently.
 #include <getopt.h>
+#include <fcntl.h>
 #include <unistd.h>
 
 #include <chrono>
@@ -82,17 +83,23 @@ void usage()
 // (c++/mpi_common.h:28-31): the message, then the process ends at once.
 std::atomic<bool> g_rank_threads{false};
 std::mutex g_die_mutex;
-std::vector<std::ostream *> g_rank_streams;                          // bpmf_<rank>.out of every rank (-g N / -r): flushed before the process ends
+std::vector<std::string> g_rank_files;                               // bpmf_<rank>.out of every rank (-g N / -r): the failure message is appended to each
 
 [[noreturn]] void die(const std::string &msg)
 {
     if (g_rank_threads.load()) {
-        {   // _Exit runs no destructors: the rank logs' buffered lines (the diagnostics of the failing run) go out here.  A rank
-            // that is writing its log right now may interleave with this flush; losing the lines would be worse.
+        {   // _Exit runs no destructors.  Every line a rank writes ends in std::endl, so its log file is current up to the line it
+            // is formatting right now; the failure message goes into every rank's log through a descriptor of its own (O_APPEND +
+            // write): the other ranks' std::ofstream objects are NOT touched from this thread -- they may be inside operator<<
+            // (inserting into / flushing them from here was a data race on iostream state that could lose the very
+            // diagnostic it was meant to save).
             std::lock_guard<std::mutex> lk(g_die_mutex);
             std::cerr << "bpmf: " << msg << std::endl;
-            for (std::ostream *o : g_rank_streams) if (o) { *o << "bpmf: " << msg << std::endl; o->flush(); }
-            fflush(nullptr);
+            const std::string line = "bpmf: " + msg + "\n";
+            for (const std::string &f : g_rank_files) {
+                const int fd = ::open(f.c_str(), O_WRONLY | O_APPEND);
+                if (fd >= 0) { ssize_t w = ::write(fd, line.data(), line.size()); (void)w; ::close(fd); }
+            }
         }
         std::_Exit(1);
     }
@@ -549,7 +556,7 @@ int main(int argc, char *argv[])
     };
     if (to_files) for (int r = 0; r < J.nranks; ++r) {
         files.emplace_back(new std::ofstream("bpmf_" + std::to_string(r) + ".out"));
-        g_rank_streams.push_back(files.back().get());
+        g_rank_files.push_back("bpmf_" + std::to_string(r) + ".out");
     }
 
     if (J.nranks == 1) {

@@ -411,7 +411,7 @@ static int ctx_create_impl(int device, int Ktrue, int dtype, void *stream, bpmf_
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     c->in_words = (size_t)K * K + K + 2 + K;                           // LambdaF | Lmu | fail | pad | mu (even: staged as 16-byte words)
-    if (K == 64 && dtype == BPMF_HIP_F64) c->in_words += 2 * (size_t)K * K + K;   // | R0 = chol(LambdaF).matrixU() row-major | (R0^-1)^T | R0^-T LambdaF mu (k_sample_lr)
+    if (K == 64 && dtype == BPMF_HIP_F64) c->in_words += 2 * (size_t)K * K + K;   // | R0 = chol(LambdaF).matrixU() row-major | (R0^-1)^T | R0^-T LambdaF mu (k_sample_pf)
     c->out_words = (size_t)K * K + K + 1 + 1 + 2 + 1;
     HIP_TRY(hipHostMalloc((void **)&c->h_in, c->in_words * sizeof(double), hipHostMallocMapped));
     HIP_TRY(hipHostMalloc((void **)&c->h_out, c->out_words * sizeof(double), hipHostMallocMapped));
@@ -940,8 +940,8 @@ void fill_blob(int K, const double *mu, const double *LambdaF, double *h_in, boo
     h_in[(size_t)K * K + K + 1] = 0.0;
     memcpy(&h_in[(size_t)K * K + K + 2], mu, sizeof(double) * K);       // hp.mu itself: the propagated-posterior columns need it
     if (with_factor) {
-        // R0 = chol(LambdaF).matrixU(), row-major with zeros below the diagonal: the factor every
-        // light column updates (k_sample_lr).  Not positive definite: NaN, which reaches the samples
+        // R0 = chol(LambdaF).matrixU(), row-major with zeros below the diagonal: the factor shared by every
+        // light column (k_sample_pf).  Not positive definite: NaN, which reaches the samples
         // and is reported as "Cholesky failed" like the reference's own LLT (c++/sample.cpp:306-308).
         double *R = h_in + (size_t)K * K + K + 2 + K;
         bool ok = true;
@@ -977,6 +977,14 @@ void fill_blob(int K, const double *mu, const double *LambdaF, double *h_in, boo
                 }
                 for (int r = 0; r <= c; ++r) S0t[(size_t)c * K + r] = x[r];
             }
+            // Invariant k_sample_pf's final GEMM relies on (kernels_lr.h: the 24 of 64 tile products that lie below the diagonal
+            // are not issued): S = R0^-1 has an EXACTLY zero strict lower triangle -- also for a padded num_latent, whose extra
+            // dimensions are an identity block.  True by construction (zero fill above, only r <= c written); checked because a
+            // later edit of this loop would otherwise fail silently.
+            for (int c = 0; c < K && ok; ++c)
+                for (int r = c + 1; r < K; ++r)
+                    if (S0t[(size_t)c * K + r] != 0.0) { ok = false; break; }
+            if (!ok) { for (size_t q = 0; q < 2 * (size_t)K * K + K; ++q) R[q] = std::numeric_limits<double>::quiet_NaN(); return; }
             const double *Lmu = h_in + (size_t)K * K;
             for (int k = 0; k < K; ++k) {                  // R0^T y = Lmu
                 double v = Lmu[k];
@@ -2200,7 +2208,6 @@ extern "C" int bpmf_hip_test_set_twin(bpmf_hip_test *t, bpmf_hip_test *twin)
     twin->owner = t;
     // Same entries, transposed?  Then one kernel serves both copies: entry q of `t` is entry perm[q] of the twin.
     // (Otherwise -- shards of different column ranges -- the twin keeps a kernel of its own.)
-    bpmf_hip_ctx *c = t->side->ctx;
     const bool whole = t->side->to - t->side->from == t->side->ncols && twin->side->to - twin->side->from == twin->side->ncols;
     if (whole && t->nnz == twin->nnz && t->nnz > 0 && t->nnz < ((int64_t)1 << 31)) {
         const int64_t n = t->nnz, ncm = t->side->ncols;

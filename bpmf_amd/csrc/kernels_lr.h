@@ -338,7 +338,8 @@ __device__ __forceinline__ void pf_group_stream(const LrArgs &a, int w0, int g, 
 }
 
 // One pass of a wave: the items [w0, wend) (at most NB = 4 columns of at most NCAP ratings each) -- normals, the product-form
-// solves, x = R0^-1 v of the four as one MFMA GEMM, stores.  S0 = (R0^-1) in LDS (K x (K + 1)), sr / sv this wave's slots.
+// solves, x = R0^-1 v of the four as one MFMA GEMM, stores.  S0 = R0^-1 in LDS in the GEMM's A-operand order (pf_fill_s0: lane
+// stride PF_SLD = 18 doubles), sr / sv this wave's slots (the four columns of a pass K + 8 doubles apart).
 template <int K, int NCAP>
 __device__ __forceinline__ void pf_pass(const LrArgs &a, int w0, int wend, const double *S0, double (*sr)[K], double (*sv)[pf_svld<K>()], double y0, int lane)
 {
@@ -411,9 +412,9 @@ __global__ __launch_bounds__(512, 4) void k_sample_pf(LrArgs a)
 {
     static_assert(K == 64, "one lane per latent index");
     constexpr int NW = 8, NB = 4;                                     // NB columns per wave and pass: their final products x = R0^-1 v run as ONE MFMA GEMM
-    // (round 4, measured: LD = K + 4 / v slots K + 8 -- which a bank model of the GEMM's operand reads says are conflict-free where
-    // K + 1 / K put up to 4 lanes on a bank pair -- made the compounds side of the ChEMBL shape SLOWER, 770 against 733 us,
-    // interleaved A/B of the two builds: the 25 % of r03_pmc_chembl.txt are not these reads; K + 1 / K stay)
+    // (LDS layout: see PF_SLD / pf_svld above.  Round 5, per-kernel counters of the final kernels, profiles/r05_pmc_by_kernel_chembl.txt:
+    // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 32 % in k_sample_pf<64, 3>, 26 % / 24 % in <64, 6> / <64, 16> -- with the LDS
+    // array 28 % busy in the <64, 3> launch and its VALU 68 %: the conflicts are not what bounds these kernels)
     __shared__ __attribute__((aligned(16))) double S0[pf_s0_words<K>()];   // R0^-1 in operand order (pf_fill_s0)
     __shared__ double sr[NW][2][K];                                   // r2 of the accepted polar attempts of a pair of columns (draw_normals_pair)
     __shared__ __attribute__((aligned(16))) double sv[NW][NB][pf_svld<K>()];   // per column of a pass: its normals z, then v, then x

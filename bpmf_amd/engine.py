@@ -27,8 +27,9 @@ class HipEngine:
     name = "hip"
 
     def __init__(self, K, device=0, stream=None, dtype="f64"):
-        """dtype "f64" (the reference's arithmetic; K = 8, 16, 32, 64) or "f32" (large-K mixed
-        precision path, K = 128: fp32 factors / Gram / factorisation, fp64 everything else)."""
+        """dtype "f64": the reference's arithmetic, any num_latent 1 .. 128 (8, 16, 32, 64, 128 have kernels of their own, any other
+        K runs on the next of those sizes with zero rows in the extra dimensions: ld()); "f32": the opt-in large-K mixed
+        precision path, num_latent 65 .. 128 (fp32 factors / Gram / factorisation, fp64 everything else)."""
         self.lib = _lib.load_library()
         self.K = int(K)
         self.dtype = dtype
