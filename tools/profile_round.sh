@@ -9,7 +9,7 @@ O=gpurun_out/profiles; mkdir -p $O; rm -f $O/${R}_pmc_$W.txt
 echo "# kernel-source-sha: $(python -c 'import bench; print(bench.kernel_source_sha())')" > $O/${R}_pmc_$W.txt
 echo "# rocprofv3 --pmc <one group per pass> --kernel-trace -- python bench.py --workload $W --steps 10 --warmup 2 --repeats 1 --prewarm-ms 0 --no-cpu-baseline --no-strong   (per-launch averages of the sampler kernels)" >> $O/${R}_pmc_$W.txt
 CMD="python bench.py --workload $W --no-cpu-baseline --no-strong --no-bpmf-exe"
-PCMD="python bench.py --workload $W --steps 10 --warmup 2 --repeats 1 --prewarm-ms 0 --no-cpu-baseline --no-strong --no-bpmf-exe"
+PCMD="python bench.py --workload $W --steps 10 --warmup 2 --repeats 1 --prewarm-ms 0 --no-cpu-baseline --no-strong --no-bpmf-exe --no-parity"
 PAT="%k_sample%"
 PENV=""
 if [ "$W" = "ml1m_k128" ]; then
