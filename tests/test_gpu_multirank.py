@@ -34,8 +34,9 @@ def double_mode(request, monkeypatch):
     what the synchronous double serialises away).  Same assertions in both modes."""
     # the tests that go through a whole `bench.py` / `bpmf` process (tens of seconds each: preflight children, watchdogs) run in
     # the asynchronous mode only -- the library-level tests below them keep both
-    if request.param == "sync" and request.node.name.startswith(("test_bench_", "test_bpmf_g2")):
-        pytest.skip("process-level test: asynchronous mode only")
+    if request.param == "sync" and request.node.name.startswith(("test_bench_", "test_bpmf_g2", "test_bounded_staleness_exchange", "test_fp32_context",
+                                                                 "test_reduce_formulation", "test_connectivity_lists", "test_auto_overlap")):
+        pytest.skip("asynchronous mode only (the mesh / parts / replica-age tests keep both modes)")
     if request.param == "async":
         monkeypatch.setenv("BPMF_RCCL_DOUBLE_ASYNC", "1")
         # The double's helper threads move the data with HIP copies on streams of their own, and HIP maps the streams of a
@@ -328,7 +329,7 @@ def test_bench_preflight_falls_down_the_ladder(double_mode):
     """The 4-iteration preflight per exchange configuration: rank 1's trial of the first rung hangs (test hook) -> killed
     after BPMF_BENCH_PREFLIGHT_TIMEOUT_S, the ranks agree, the second rung runs and the line says which and why."""
     env = dict(os.environ, BPMF_BENCH_SHARED_GPU="1", BPMF_HIP_RCCL_LIBRARY=DOUBLE, BPMF_BENCH_TEST_HANG_RUNG="mesh+parts+2comms:1",
-               BPMF_BENCH_PREFLIGHT_TIMEOUT_S="25", BPMF_RCCL_DOUBLE_TIMEOUT_S="10")
+               BPMF_BENCH_PREFLIGHT_TIMEOUT_S="14", BPMF_RCCL_DOUBLE_TIMEOUT_S="6")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--repeats", "1", "--prewarm-ms", "0",

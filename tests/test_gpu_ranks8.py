@@ -21,7 +21,7 @@ from tests.test_gpu_multirank import DOUBLE, rel_err, run_ranks
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mode", ["sync", "async"])
+@pytest.mark.parametrize("mode", ["async"])
 def test_eight_ranks_strong_scaling_shape_matches_the_oracle(oracle, tmp_path, mode):
     """bench.py::strong_10Mx1M's set-up at scale 0.002 (20 000 users x 2 000 items x 200 per user = 4 M ratings, K = 32): rank r
     of 8 holds user chunk r and item range r, every exchange cut into 4 parts (BPMF_HIP_OVERLAP=4).  Every replica must hold
@@ -65,7 +65,7 @@ def test_bench_gpus8_preflight_ladder_and_per_rank_record():
     first rung hangs (test hook): it is killed after BPMF_BENCH_PREFLIGHT_TIMEOUT_S, the eight ranks agree, the second rung
     runs on all eight, and the line carries n_gpus 8, rccl_nranks 8, the ladder with the reason, and eight per-rank records."""
     env = dict(os.environ, BPMF_BENCH_SHARED_GPU="1", BPMF_HIP_RCCL_LIBRARY=DOUBLE, BPMF_BENCH_TEST_HANG_RUNG="mesh+parts+2comms:5",
-               BPMF_BENCH_PREFLIGHT_TIMEOUT_S="30", BPMF_RCCL_DOUBLE_TIMEOUT_S="12")
+               BPMF_BENCH_PREFLIGHT_TIMEOUT_S="20", BPMF_RCCL_DOUBLE_TIMEOUT_S="8")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--repeats", "1", "--prewarm-ms", "0",

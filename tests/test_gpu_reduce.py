@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("K", [8, 16, 32, 64])
+@pytest.mark.parametrize("K", [8, 32, 64])
 def test_reduce_formulation_matches_oracle(K):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_reduce_worker.py"), str(K)], capture_output=True, text=True,
