@@ -34,7 +34,12 @@ def double_mode(request, monkeypatch):
     what the synchronous double serialises away).  Same assertions in both modes."""
     # the tests that go through a whole `bench.py` / `bpmf` process (tens of seconds each: preflight children, watchdogs) run in
     # the asynchronous mode only -- the library-level tests below them keep both
-    if request.param == "sync" and request.node.name.startswith(("test_bench_", "test_bpmf_g2", "test_bounded_staleness_exchange", "test_fp32_context",
+    # (the stalled-rank test: synchronous mode only -- 14 s against 34 s in the asynchronous mode, whose helper threads the abort
+    #  has to wait out; what it checks -- a bounded wait turns a stalled peer into an error record -- does not depend on the mode)
+    if request.node.name.startswith("test_bench_stalled_rank"):
+        if request.param == "async":
+            pytest.skip("synchronous mode only")
+    elif request.param == "sync" and request.node.name.startswith(("test_bench_", "test_bpmf_g2", "test_bounded_staleness_exchange", "test_fp32_context",
                                                                  "test_reduce_formulation", "test_connectivity_lists", "test_auto_overlap")):
         pytest.skip("asynchronous mode only (the mesh / parts / replica-age tests keep both modes)")
     if request.param == "async":
