@@ -1181,7 +1181,7 @@ int ensure_state(bpmf_hip_side *s)
     memset(s->a_h_out, 0, c->out_words * sizeof(double));
     memset(s->a_gate, 0, 64);
     HIP_TRY(hipMalloc((void **)&s->a_d_in, (c->in_words + lf32_words(c)) * sizeof(double)));
-    HIP_TRY(hipMalloc((void **)&s->a_ticket, 256));                 // [0], [1] statistics tickets; [8] tail riders' item count; [24] their go word
+    HIP_TRY(hipMalloc((void **)&s->a_ticket, 256));                 // [0], [1] statistics tickets (+ spare words)
     HIP_TRY(hipMemset(s->a_ticket, 0, 256));
     HIP_TRY(hipMalloc((void **)&s->a_dflag, 64));
     HIP_TRY(hipMemset(s->a_dflag, 0, 64));
@@ -1730,7 +1730,7 @@ extern "C" int bpmf_hip_side_kernel_resources(bpmf_hip_side *s, int64_t *out, in
 // The static schedule of a side in numbers (build_schedule), for reports: out[0..15] =
 //   0 sampler form (mode)   1 work items   2 chunks of heavy columns (partial slots)   3 heavy columns cut into chunks
 //   4 light columns in the low-rank / product forms   5 work items of the others   6..8 product-form columns with <= 3 | 4..6 | 7..16 ratings
-//   9 columns in k_sample_lr   10 parts (bpmf_hip_side_set_overlap)   11 local columns   12 local ratings
+//   9 (was: columns in k_sample_lr; 0 since round 5)   10 parts (bpmf_hip_side_set_overlap)   11 local columns   12 local ratings
 //   13, 14 sum over the product-form columns of their number of ratings n, of n^2   15 reserved (0)
 extern "C" int bpmf_hip_side_schedule_info(const bpmf_hip_side *s, int64_t *out, int n)
 {

@@ -1187,7 +1187,7 @@ __device__ __forceinline__ void colstats_body(int w, const double *__restrict__ 
     if (f == 0 && lane == 0) {
         // failed column: as the u64 word of the blob, and as a double (0 = none, id + 1 otherwise)
         // that survives a SUM all-reduce of the blob over the ranks
-        // (device-scope load: in a pair launch the word may have been lowered by an item of this very launch on another XCD)
+        // (device-scope load: as riders of a fused launch the pass runs beside items that may lower the word on another XCD)
         const unsigned long long fw = __hip_atomic_load(fail_in, BPMF_RLX_AGENT);
         __hip_atomic_store(&out[K * K + K], (fw == ~0ull) ? 0.0 : (double)(fw + 1ull), BPMF_RLX_SYSTEM);
         __hip_atomic_store(&reinterpret_cast<unsigned long long *>(out)[K * K + K + 1], fw, BPMF_RLX_SYSTEM);
@@ -1343,8 +1343,7 @@ __global__ __launch_bounds__(256) void k_colstats_wg(const double *__restrict__ 
 }
 
 // NT: threads per workgroup.  256 by default; 64 (single-wave workgroups) for small test sets: beside a sampler launch that
-// keeps refilling every wave slot with single-wave workgroups a four-wave workgroup only gets in when the launch drains --
-// with ONE launch per iteration (k_sample1p) the evaluation then landed a whole launch late and the host loop waited for it.
+// keeps refilling every wave slot with single-wave workgroups a four-wave workgroup only gets in when the launch drains.
 template <int K, int NT = 256, typename T = double>
 __global__ __launch_bounds__(NT) void k_predict(const int32_t *__restrict__ tcol, const int32_t *__restrict__ trow,
                                                  const double *__restrict__ tval, int64_t nnz,

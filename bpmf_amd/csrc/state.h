@@ -79,7 +79,7 @@ inline unsigned long long wait_ticks()
 static const char *const kTimeoutWhat[5] = {"", "the gate of the hyper-parameters never opened (host worker stalled?)",
                                      "the staged parameters never arrived (gate workgroup not scheduled?)",
                                      "the column statistics never completed (waves not scheduled?)",
-                                     "pair launch: the first side's columns never completed (workgroups of a grid not dispatched in order?)"};
+                                     "(unused)"};
 
 // RCCL entry points, resolved at run time: single-GPU users never load the library, and inside a
 // torch process the already-loaded librccl.so.1 is reused (one communicator runtime per process).
