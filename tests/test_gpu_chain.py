@@ -11,6 +11,7 @@ reference's start (zero factors, iter = -1) and must stay on the oracle's chain:
   * configs[2]  ChEMBL shape, K = 64 fp64, -i 6 -b 2           same
   * ML-1M shape, K = 128 fp64 (what -d 128 means), -i 6 -b 2   same
   * configs[4]  ML-1M shape, K = 128 fp32 opt-in, -i 6 -b 2    RMSE traces 1e-3 (the north star's bar), factors 2e-3 max|U|
+  * the form of configs[3]'s ranks: 110 000 x 24 000 x 5 M ratings, K = 32, -i 6 -b 2 (k_sample4, unfused launches)
 
 No sampler-mode override anywhere in this file: what runs is what `bpmf` and bench.py run.
 """
@@ -27,11 +28,20 @@ NT = max(1, min(os.cpu_count() or 1, 32))
 _ref_cache = {}
 
 
+_data_cache = {}
+
+
 def _data(shape):
     from bpmf_amd import synth
-    if shape == "ml1m":
-        return synth.ml1m_shaped(seed=42)                       # the matrix bench.py times
-    return synth.ratings(483500, 5775, 1_023_952, seed=42, real_valued=True)
+    if shape not in _data_cache:
+        _data_cache.clear()                                      # (one matrix at a time: the ChEMBL shape is 250 MB of factors per copy)
+        if shape == "ml1m":
+            _data_cache[shape] = synth.ml1m_shaped(seed=42)      # the matrix bench.py times
+        elif shape == "large":
+            _data_cache[shape] = synth.ratings(110_000, 24_000, 5_000_000, seed=5)
+        else:
+            _data_cache[shape] = synth.ratings(483500, 5775, 1_023_952, seed=42, real_valued=True)
+    return _data_cache[shape]
 
 
 def _oracle_chain(oracle, shape, K, nsims, burnin):
@@ -77,6 +87,14 @@ def test_chain_chembl_k64(oracle):
     """BASELINE configs[2]: the compounds side in the product form (three classes + k_pf_prepare per half-iteration + the slab
     form for the heavier columns), the targets side in k_sample1s, chained through the hyper-parameter draws."""
     _chain(oracle, "chembl", 64, 6, 2)
+
+
+def test_chain_large_sides_k32(oracle):
+    """Sides of >= 20 000 columns (the form BASELINE configs[3] runs on every rank): k_sample4 -- four columns per wave, the
+    factorisation on the MFMA in lockstep -- behind the UNFUSED stateful launches (gate kernel on the side's stream, sampler,
+    stand-alone statistics pass: k_colstats_wg for the 110 000-column side), 5 M ratings, chained through the hyper-parameter
+    draws for six iterations."""
+    _chain(oracle, "large", 32, 6, 2)
 
 
 def test_chain_ml1m_k128_fp64(oracle):
