@@ -150,6 +150,72 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
     for (int t = 0; t < TPW; ++t) acc[t] = acc_t{0, 0, 0, 0};
 #pragma unroll
     for (int t = 0; t < NT; ++t) r[t] = 0;
+    // Lambda* = LambdaF + alpha G in the register tiles (:297-298).  A whole column (round 5) starts its accumulators at
+    // LambdaF / alpha -- the loads of the prior, 2.7 us of L2 round trips per item when they came after the Gram, are in flight
+    // beside the first gathers -- and multiplies by alpha at the end; the last chunk of a heavy column, which sums partials,
+    // adds the prior as before.  (alpha = 2, the reference's default: LambdaF / alpha and the product are exact.)
+    const double *LF = a.prop_lambda ? a.prop_lambda + (size_t)col * K * K : a.LambdaF;
+    bool lf_tiles = false;
+    if constexpr (F32) lf_tiles = a.lf32 != nullptr;
+    const double inv_alpha = 1.0 / a.alpha;
+    auto prior = [&](auto firstc) {
+        constexpr bool first = decltype(firstc)::value;
+    if constexpr (F32) if (lf_tiles) {                                // (workgroup-uniform) the prior as fp32 tiles: one 16-byte load per tile
+        const f4 *lt = reinterpret_cast<const f4 *>(a.lf32);
+        const T alpha_f = (T)a.alpha, inv_alpha_f = (T)(1.0 / a.alpha);
+        f4 lf[TPW];
+#pragma unroll
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int J = I; J < NT; ++J)
+                if ((G::tri(I, J) % NW) == W) lf[G::tri(I, J) / NW] = lt[G::tri(I, J) * 64 + lane];
+#pragma unroll
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int J = I; J < NT; ++J)
+                if ((G::tri(I, J) % NW) == W) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const T v = first ? lf[G::tri(I, J) / NW][reg] * inv_alpha_f : fmaf(alpha_f, acc[G::tri(I, J) / NW][reg], lf[G::tri(I, J) / NW][reg]);
+                        acc[G::tri(I, J) / NW][reg] = (!first && a.diag_only && (16 * I + 4 * kq + reg) != (16 * J + li)) ? (T)0 : v;
+                    }
+                }
+    }
+    if (!lf_tiles) {
+        // LambdaF(gj, gi): the lower triangle, which is what LLT reads (:306); 16 lanes = one 128-byte line.  The loads of
+        // a batch of tiles are issued together and without control flow around them (with the diag_only select wrapped
+        // around each load they were 72 serialised L2 round trips: 14.6 of the ~50 us a mid-size column lived)
+        constexpr int BATCH = first ? TPW : 6;                       // (before the Gram the registers are free: every load in one batch)
+#pragma unroll
+        for (int t0 = 0; t0 < TPW; t0 += BATCH) {
+            double lf[BATCH][4];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int tri = (t0 + u) * NW + W;
+                if (t0 + u < TPW && tri < G::NTRI) {
+                    const int I = G::tile_i(tri), J = G::tile_j(tri);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) lf[u][reg] = LF[(16 * J + li) + (size_t)(16 * I + X::drow(kq, reg)) * K];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int tri = (t0 + u) * NW + W;
+                if (t0 + u < TPW && tri < G::NTRI) {
+                    const int I = G::tile_i(tri), J = G::tile_j(tri);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const T v = first ? (T)(lf[u][reg] * inv_alpha) : (T)fma(a.alpha, (double)acc[t0 + u][reg], lf[u][reg]);
+                        acc[t0 + u][reg] = (!first && a.diag_only && (16 * I + X::drow(kq, reg)) != (16 * J + li)) ? (T)0 : v;
+                    }
+                }
+            }
+        }
+    }
+    };
+    // (not where the prior comes as fp32 tiles, one 16-byte load per tile and lane: that is a single round trip, and starting
+    // from it measured no gain -- 289 / 352 against 291 / 354 us per launch)
+    const bool whole = mc < 0 && a.alpha != 0.0 && !lf_tiles;     // (workgroup-uniform)
     {
         const int32_t *rowidx = a.rowidx + p0;
         const double *vals = a.vals + p0;
@@ -220,7 +286,9 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
                         acc[G::tri(I, J) / NW] = X::mfma(yy[I], yy[J], acc[G::tri(I, J) / NW]);
         };
         const int ngr = (len + 15) >> 4;                               // groups of 16 ratings (the same in every wave)
-        if (ngr > 0) { fetch(0); stage(0); }
+        if (ngr > 0) fetch(0);
+        if (whole) prior(std::true_type{});                            // (its loads fly with the first gathers')
+        if (ngr > 0) stage(0);
         __syncthreads();
         for (int g = 0; g < ngr; ++g) {
             const int gl = g & 3;
@@ -310,19 +378,8 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
         if (lane < 16) reinterpret_cast<T *>(a.items)[(size_t)idx * K + 16 * W + lane] = v;
         return;
     }
-    // Lambda* = LambdaF + alpha G in the register tiles (:297-298); b = LambdaF mu + rr (:285,:256)
-    const double *LF = a.prop_lambda ? a.prop_lambda + (size_t)col * K * K : a.LambdaF;
-    bool lf_tiles = false;
-    if constexpr (F32) lf_tiles = a.lf32 != nullptr;
-    if constexpr (F32) if (lf_tiles) {                                // (workgroup-uniform) the prior as fp32 tiles: one 16-byte load per tile
-        const f4 *lt = reinterpret_cast<const f4 *>(a.lf32);
-        const T alpha_f = (T)a.alpha;
-        f4 lf[TPW];
-#pragma unroll
-        for (int I = 0; I < NT; ++I)
-#pragma unroll
-            for (int J = I; J < NT; ++J)
-                if ((G::tri(I, J) % NW) == W) lf[G::tri(I, J) / NW] = lt[G::tri(I, J) * 64 + lane];
+    // b = LambdaF mu + rr (:285,:256) below; Lambda* = LambdaF + alpha G (:297-298)
+    if (whole) {
 #pragma unroll
         for (int I = 0; I < NT; ++I)
 #pragma unroll
@@ -330,41 +387,12 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
                 if ((G::tri(I, J) % NW) == W) {
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
-                        const T v = fmaf(alpha_f, acc[G::tri(I, J) / NW][reg], lf[G::tri(I, J) / NW][reg]);
-                        acc[G::tri(I, J) / NW][reg] = (a.diag_only && (16 * I + 4 * kq + reg) != (16 * J + li)) ? (T)0 : v;
+                        const T v = (T)a.alpha * acc[G::tri(I, J) / NW][reg];
+                        acc[G::tri(I, J) / NW][reg] = (a.diag_only && (16 * I + X::drow(kq, reg)) != (16 * J + li)) ? (T)0 : v;
                     }
                 }
-    }
-    if (!lf_tiles) {
-        // LambdaF(gj, gi): the lower triangle, which is what LLT reads (:306); 16 lanes = one 128-byte line.  The loads of
-        // a batch of tiles are issued together and without control flow around them (with the diag_only select wrapped
-        // around each load they were 72 serialised L2 round trips: 14.6 of the ~50 us a mid-size column lived)
-        constexpr int BATCH = 6;
-#pragma unroll
-        for (int t0 = 0; t0 < TPW; t0 += BATCH) {
-            double lf[BATCH][4];
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int tri = (t0 + u) * NW + W;
-                if (t0 + u < TPW && tri < G::NTRI) {
-                    const int I = G::tile_i(tri), J = G::tile_j(tri);
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) lf[u][reg] = LF[(16 * J + li) + (size_t)(16 * I + X::drow(kq, reg)) * K];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                const int tri = (t0 + u) * NW + W;
-                if (t0 + u < TPW && tri < G::NTRI) {
-                    const int I = G::tile_i(tri), J = G::tile_j(tri);
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const T v = (T)fma(a.alpha, (double)acc[t0 + u][reg], lf[u][reg]);
-                        acc[t0 + u][reg] = (a.diag_only && (16 * I + X::drow(kq, reg)) != (16 * J + li)) ? (T)0 : v;
-                    }
-                }
-            }
-        }
+    } else {
+        prior(std::false_type{});
     }
     stamp(a, w, 42);
     if (W == 0 && kq == 0) {
