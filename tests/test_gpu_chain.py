@@ -104,3 +104,22 @@ def test_chain_ml1m_k128_fp64(oracle):
 def test_chain_ml1m_k128_fp32(oracle):
     """BASELINE configs[4] (mixed-precision tolerance study): fp32 factors / Gram / factorisation against the fp64 chain."""
     _chain(oracle, "ml1m", 128, 6, 2, dtype="f32", rmse_tol=1e-3, item_tol=2e-3, norm_tol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_k128_chains_are_bit_reproducible(dtype):
+    """The K = 128 workgroups hand operands and tiles over through LDS (staged gathers, the look-ahead factorisation's three
+    barriers per step, one of them inside wave 0's diagonal block): a missing barrier shows as bits that differ from run to
+    run.  The same `-i 4 -b 1` chain in six fresh engines must give identical factors."""
+    import hashlib
+    import bpmf_amd
+    M, Mt, T, Tt, nu, nm = _data("ml1m")
+    seen = set()
+    for _ in range(6):
+        eng = bpmf_amd.HipEngine(128, dtype=dtype)
+        try:
+            res = bpmf_amd.gibbs(eng, M, Mt, T, nu, nm, nsims=4, burnin=1, Tt=Tt, pipelined=True)
+        finally:
+            eng.close()
+        seen.add(hashlib.sha1(np.ascontiguousarray(res["U"]).tobytes() + np.ascontiguousarray(res["V"]).tobytes()).hexdigest())
+    assert len(seen) == 1, seen
