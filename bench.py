@@ -167,7 +167,7 @@ def parity_record(gpu, ref, dtype, nsims, burnin, chain_info):
     return out
 
 
-def cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies, budget_s=12.0, parity=None):
+def cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies, budget_s=12.0, parity=None, parity_only=False):
     """oracle/cpu_baseline.py in a process of its own (placement: one thread per physical core, spread).
     parity = (nsims, burnin): the child also runs the oracle's chain of that length and this function returns its
     traces + factors under the key "parity_ref" (popped by the caller)."""
@@ -191,6 +191,8 @@ def cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies, budget_s=12.0, parity=None):
                "--budget", str(budget_s), "--usable", str(usable)]
         if parity:
             cmd += ["--parity-nsims", str(parity[0]), "--parity-burnin", str(parity[1]), "--parity-out", ppath]
+        if parity_only:
+            cmd += ["--parity-only"]
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not line:
@@ -209,8 +211,11 @@ def cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies, budget_s=12.0, parity=None):
                 pass
 
 
-def timed_blocks(step_block, fence, steps, dist_max, min_blocks=5, max_blocks=25, budget_s=8.0):
-    """R blocks of exactly `steps` steps; returns the block times (max over ranks each)."""
+def timed_blocks(step_block, fence, steps, dist_max, min_blocks=5, max_blocks=4000, budget_s=20.0, window_s=2.5):
+    """R blocks of exactly `steps` steps; returns the block times (max over ranks each).  Blocks are repeated until the
+    TIMED time (the sum of the blocks, fences excluded) reaches `window_s`: at 0.1 ms per step a handful of 20-step blocks is
+    50 ms of GPU work in a 20 s command, which an outside observer sampling the device's busy counter cannot see (VERDICT
+    r5 "weak" 7); 2.5 s of back-to-back iterations can be seen.  Bounded by `max_blocks` and by `budget_s` of wall time."""
     times = []
     t_all = time.perf_counter()
     while True:
@@ -219,7 +224,8 @@ def timed_blocks(step_block, fence, steps, dist_max, min_blocks=5, max_blocks=25
         step_block(steps)
         fence()
         times.append(dist_max(time.perf_counter() - t0))
-        done = len(times) >= max_blocks or (len(times) >= min_blocks and time.perf_counter() - t_all > budget_s)
+        done = (len(times) >= max_blocks or
+                (len(times) >= min_blocks and (sum(times) >= window_s or time.perf_counter() - t_all > budget_s)))
         if dist_max(1.0 if done else 0.0) > 0.5:          # (every rank takes the same decision)
             return times
 
@@ -615,6 +621,56 @@ def bpmf_exe_record(M, T, nusers, nmovies, K, nsims=25, burnin=5):
         shutil.rmtree(d, ignore_errors=True)
 
 
+# The other single-GPU configurations BASELINE.json names, in the order they are run after the headline (configs[2], configs[4],
+# then the two the same kernels' fp64 / K = 64 forms give for free).  Each is THIS script, run as a child with the workload
+# named, the same --steps / --warmup, its own >= 2 s timed window and the parity chain against the oracle (no CPU timing
+# sweep, no strong-scaling record): a leg that fails or outlives its limit becomes {"value": null, "error": ...} and the
+# headline survives.
+CONFIG_LEGS = [("chembl", "BASELINE configs[2]: ChEMBL-20 shape, K = 64 fp64"),
+               ("ml1m_k128", "BASELINE configs[4]: ML-1M shape, K = 128, fp32 factors (opt-in)"),
+               ("ml1m_k64", "ML-1M shape, K = 64 fp64"),
+               ("ml1m_k128_f64", "ML-1M shape, K = 128 in the reference's fp64 (`bpmf -d 128`)")]
+
+
+def config_leg(name, what, steps, warmup, limit_s):
+    """One entry of the line's `configs` object: ms_per_step / value / dtype / kernels / per-side launch times / roofline /
+    parity of workload `name`, measured by a child run of this script through the same `step_block` and `timed_blocks`."""
+    t0 = time.perf_counter()
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", str(steps), "--warmup", str(warmup),
+           "--no-strong", "--no-bpmf-exe", "--no-configs", "--cpu-parity-only", "--window-s", "2.0"]
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        return {"what": what, "value": None, "error": "no line within %.0f s (killed)" % limit_s, "wall_s": time.perf_counter() - t0}
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    if not lines:
+        tail = " | ".join([l for l in (r.stderr or r.stdout).strip().splitlines() if l.strip()][-3:])
+        return {"what": what, "value": None, "error": "exit code %d, no line: %s" % (r.returncode, tail[-400:]), "wall_s": time.perf_counter() - t0}
+    c = json.loads(lines[-1])
+    if c.get("value") is None:
+        return {"what": what, "value": None, "error": c.get("error", "the child reported no value"), "wall_s": time.perf_counter() - t0}
+    rf, par = c.get("roofline", {}), c.get("parity", {})
+    out = {"what": what, "command": "bench.py " + " ".join(cmd[2:]),
+           "ms_per_step": c["ms_per_step"], "value": c["value"], "unit": c["unit"], "dtype": c["dtype"], "steps": c["steps"],
+           "repeats": c.get("repeats"), "timed_window_s": c.get("timed_window_s"),
+           "ms_per_step_min": c.get("ms_per_step_min"), "ms_per_step_max": c.get("ms_per_step_max"),
+           "kernel_per_side": rf.get("kernel_per_side"),
+           "launch_us_per_side": {k: v * 1e3 for k, v in (rf.get("launch_ms_per_side") or {}).items()},
+           "roofline": {k: rf.get(k) for k in ("bound", "frac", "achieved", "peak", "unit", "traffic", "hbm_frac", "hbm_frac_per_side",
+                                               "executed_flops_per_launch", "algorithmic_bytes_per_launch", "issue_bound") if k in rf},
+           "rmse": c.get("rmse"), "workload": c.get("config", {}).get("workload"),
+           "wall_s": time.perf_counter() - t0}
+    if par.get("ok") is not None:
+        out["parity"] = {k: par.get(k) for k in ("ok", "iterations", "burnin", "d_rmse_max", "d_final_avg_rmse", "d_items_rel", "d_norm_rel",
+                                                 "rmse_gpu", "rmse_cpu", "tolerance", "oracle_pinned")}
+    else:
+        out["parity"] = {"ok": None, "reason": par.get("reason")}
+    return out
+
+
 def strong_model(NU, NI, K, world, ranks, ms_per_step):
     """The predicted 1 -> 8 curve of the strong-scaling record, so that the first measured SCALE record can be read against
     it.  Ingredients: the sampler time of the whole matrix (sum over the ranks of their two launches -- at N = 1 the measured
@@ -708,7 +764,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--K", type=int, default=None, help="shorthand: ML-1M shape with this K (32, 64, 128)")
-    ap.add_argument("--repeats", type=int, default=0, help="timed blocks of --steps steps (0 = auto: 5..25 within ~8 s)")
+    ap.add_argument("--repeats", type=int, default=0, help="timed blocks of --steps steps (0 = auto: as many as fill --window-s of timed time, at least 5)")
+    ap.add_argument("--window-s", type=float, default=2.5, help="timed time the blocks must add up to when --repeats is 0 (the median block is reported)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (the other single-GPU BASELINE configurations, one child run each)")
+    ap.add_argument("--cpu-parity-only", action="store_true", help="the CPU leg runs the oracle's parity chain only (no timing sweep): what the `configs` children use")
     ap.add_argument("--prewarm-ms", type=float, default=50.0, help="untimed steps until this much time has passed (0: the W warm-up steps only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the `parity` object (the -i N -b B chain through the timed pipeline against the oracle's chain)")
@@ -871,7 +930,7 @@ def run(args, wl, R, wd):
     if args.repeats > 0:
         times = timed_blocks(step_block, fence, args.steps, dist_max, min_blocks=args.repeats, max_blocks=args.repeats)
     else:
-        times = timed_blocks(step_block, fence, args.steps, dist_max)
+        times = timed_blocks(step_block, fence, args.steps, dist_max, window_s=args.window_s)
     fence()
     dt = float(np.median(times))
 
@@ -982,7 +1041,7 @@ def run(args, wl, R, wd):
                    "parallelism": "columns of U and V sharded over %d GPU(s)" % world},
         "exchange_config": exchange_config,
         "rccl_nranks": rccl_nranks, "launcher": "self" if os.environ.get("BPMF_BENCH_SELF_LAUNCHED") else ("external" if "WORLD_SIZE" in os.environ else "none"),
-        "repeats": len(times), "prewarm_ms": prewarm_ms, "prewarm_extra_steps": extra,
+        "repeats": len(times), "timed_window_s": float(sum(times)), "prewarm_ms": prewarm_ms, "prewarm_extra_steps": extra,
         "ms_per_step_median": dt / args.steps * 1e3, "ms_per_step_min": min(times) / args.steps * 1e3,
         "ms_per_step_max": max(times) / args.steps * 1e3, "ms_per_step_first_block": times[0] / args.steps * 1e3,
         "roofline": roofline,
@@ -1050,11 +1109,22 @@ def run(args, wl, R, wd):
         out["bpmf_exe"] = bpmf_exe_record(M, T, nusers, nmovies, K, nsims=400)      # (0.1 ms per iteration: a 25-iteration run is all start-up)
         if out["bpmf_exe"].get("steady_items_per_s"):
             out["bpmf_exe"]["over_python_host"] = out["bpmf_exe"]["steady_items_per_s"] / out["value"]
+    if rank == 0 and world == 1 and wl == "ml1m" and not args.no_configs and args.ablate is None:
+        # every other single-GPU configuration of BASELINE.json in the SAME line: driver-timed, not builder-run
+        out["configs"] = {}
+        leg_limit = float(os.environ.get("BPMF_BENCH_CONFIG_LEG_TIMEOUT_S", "150"))
+        for name, what in CONFIG_LEGS:
+            wd.stage("configs leg '%s'" % name, leg_limit + 30)
+            try:
+                out["configs"][name] = config_leg(name, what, args.steps, args.warmup, leg_limit)
+            except Exception as e:
+                out["configs"][name] = {"what": what, "value": None, "error": repr(e)[:400]}
     if rank == 0:
         wd.stage("cpu baseline", 700)
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies, parity=parity_cfg if gpu_chain else None)
+                out["cpu_baseline"] = cpu_baseline(M, Mt, T, Tt, K, nusers, nmovies, parity=parity_cfg if gpu_chain else None,
+                                                   parity_only=args.cpu_parity_only)
             except Exception as e:  # the GPU number must still be reported
                 out["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": "failed: %r" % (e,)}

@@ -153,7 +153,7 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
     // Lambda* = LambdaF + alpha G in the register tiles (:297-298).  A whole column (round 5) starts its accumulators at
     // LambdaF / alpha -- the loads of the prior, 2.7 us of L2 round trips per item when they came after the Gram, are in flight
     // beside the first gathers -- and multiplies by alpha at the end; the last chunk of a heavy column, which sums partials,
-    // adds the prior as before.  (alpha = 2, the reference's default: LambdaF / alpha and the product are exact.)
+    // adds the prior as before.  (alpha = 2, the reference's default: LambdaF / alpha and the product are exact; see `whole`.)
     const double *LF = a.prop_lambda ? a.prop_lambda + (size_t)col * K * K : a.LambdaF;
     bool lf_tiles = false;
     if constexpr (F32) lf_tiles = a.lf32 != nullptr;
@@ -215,7 +215,13 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
     };
     // (not where the prior comes as fp32 tiles, one 16-byte load per tile and lane: that is a single round trip, and starting
     // from it measured no gain -- 289 / 352 against 291 / 354 us per launch)
-    const bool whole = mc < 0 && a.alpha != 0.0 && !lf_tiles;     // (workgroup-uniform)
+    // Only where it is EXACT: alpha a positive power of two (mantissa bits all zero; the reference's default 2), so that
+    // LambdaF / alpha and alpha * (LambdaF / alpha + G) round as LambdaF + alpha G does.  Any other -a F (1.5, 3, 10 ...) would put
+    // two more roundings on every entry, and a different result by whether a column was chunked: those take the prior after the
+    // Gram, fma(alpha, G, LambdaF), like a chunked column and like every other kernel (tests/test_gpu_alpha.py).
+    const bool alpha_pow2 = a.alpha > 0.0 && (__double_as_longlong(a.alpha) & 0x000FFFFFFFFFFFFFll) == 0 &&
+                            a.alpha >= 0x1p-500 && a.alpha <= 0x1p500;
+    const bool whole = mc < 0 && alpha_pow2 && !lf_tiles;           // (workgroup-uniform)
     {
         const int32_t *rowidx = a.rowidx + p0;
         const double *vals = a.vals + p0;

@@ -83,6 +83,7 @@ def main():
                     "on the same matrix and write its traces + factors to --parity-out: what bench.py's `parity` object is compared with")
     ap.add_argument("--parity-burnin", type=int, default=5)
     ap.add_argument("--parity-out", default=None)
+    ap.add_argument("--parity-only", action="store_true", help="the parity chain only, no timing (bench.py's `configs` legs: their CPU figure is not asked for)")
     args = ap.parse_args()
 
     from oracle import oracle as orc
@@ -114,6 +115,11 @@ def main():
                  final=np.array([r["final_rmse_avg"], float(r["num_predict"])]), U=r["U"], V=r["V"])
         parity = {"iterations": args.parity_nsims, "burnin": args.parity_burnin, "threads": limit, "seconds": time.time() - t0,
                   "build": "oracle/libbpmf_oracle.so (gcc -O2 -ffp-contract=off -fopenmp)"}
+
+    if args.parity_only:
+        print(json.dumps({"parity_chain": parity, "value": None, "unit": "samples/s", "cores": limit, "kind": "port",
+                          "sample": "not timed (--parity-only): the oracle's chain for the `parity` object only"}))
+        return
 
     def per_iter(nt, n):
         o.gibbs(K, M, Mt, T, Tt, nsims=1, burnin=0, nthreads=nt)               # first touch + warm-up

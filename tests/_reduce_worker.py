@@ -20,17 +20,18 @@ def main():
     from bpmf_amd.sys import Sys
     from oracle import oracle as orc
     K = int(sys.argv[1])
+    alpha = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0        # (-a F, c++/bpmf.cpp:91: tests/test_gpu_alpha.py)
     nsims = 4
     # one heavy movie (650 ratings), empty columns on both sides
     M, Mt, T, Tt, nu, nm = synth.ratings(700, 500, 30000, seed=3, heavy=(7, 650))
     mean = float(np.sum(M[2])) / len(M[2])
-    ref = orc.Oracle().gibbs_reduce(K, M, Mt, T, alpha=2.0, nsims=nsims, burnin=1)
+    ref = orc.Oracle().gibbs_reduce(K, M, Mt, T, alpha=alpha, nsims=nsims, burnin=1)
 
     def run(comm, reduce, nocov=False):
         eng = bpmf_amd.HipEngine(K)
         if comm:
             eng.comm_init(1, 0, eng.comm_unique_id())
-        Sys.nsims, Sys.burnin, Sys.alpha = nsims, 1, 2.0
+        Sys.nsims, Sys.burnin, Sys.alpha = nsims, 1, alpha
         movies = Sys("movs", eng, M, nm, nu, T=T, mean_rating=mean)
         users = Sys("users", eng, Mt, nu, nm, mean_rating=mean)
         if comm:
@@ -62,7 +63,7 @@ def main():
     shard = run(True, True)
     for a, b in zip(got, shard):
         assert np.array_equal(a, b), "BPMF_REDUCE over a one-rank communicator differs from the plain one"
-    print("REDUCE-OK K=%d factors %.1e / %.1e rmse %.1e" % (K, eu, ev, er))
+    print("REDUCE-OK K=%d alpha=%g factors %.1e / %.1e rmse %.1e" % (K, alpha, eu, ev, er))
 
 
 if __name__ == "__main__":
