@@ -136,6 +136,45 @@ def profiled(workload):
     return traffic, conflict, os.path.basename(files[-1]), sha
 
 
+# cycles one SIMD is busy per MFMA of the shape that dominates a workload's sampler (tools/probes/mfma_probe.hip, mfma44_probe.hip,
+# profiles/r05_mfma_shapes_probe.txt): v_mfma_f64_4x4x4_4b 18, v_mfma_f64_16x16x4 104, v_mfma_f32_16x16x4 38
+MFMA_CYCLES = {"ml1m": 18.0, "ml1m_k64": 18.0, "chembl": 18.0, "ml1m_k128": 38.0, "ml1m_k128_f64": 104.0, "ml1m_k100": 104.0}
+VALU_CYCLES = 4.2          # measured issue cost of a wave64 VALU instruction with >= 2 waves per SIMD (profiles/r04_valu_rate_probe.txt: 4.2 - 5)
+CLOCK_GHZ = 2.4            # MI355X_MICROARCH.md: max engine clock (the sustained clock under load is lower: the bound is a floor)
+
+
+def issue_bound(workload, launch_s, num_cu=256):
+    """Why the sampler is where it is against the flop peak, carried with the number: the time its instruction
+    stream needs to ISSUE -- (VALU instructions x measured cycles + MFMA instructions x the shape's cycles) / SIMDs / clock --
+    from the per-launch counters of the committed PMC pass, over the measured launch time.  SQ_INSTS_VALU counts the MFMAs too
+    (checked against the static ISA of the Gram loop: 86 VALU + 144 MFMA per 64 ratings), so they are taken out of it; f64
+    MFMA and VALU issue add on a SIMD.  Counters of a profile of OTHER kernel sources are history: null."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.txt" % workload)))
+    if not files:
+        return None
+    vals, sha = {}, None
+    for line in open(files[-1]):
+        if line.startswith("# kernel-source-sha:"):
+            sha = line.split(":", 1)[1].strip()
+        f = line.replace("avg=", "avg= ").split()
+        if len(f) >= 4 and f[2] == "avg=":
+            try:
+                vals[f[1]] = float(f[3])
+            except ValueError:
+                pass
+    if "SQ_INSTS_VALU" not in vals or "SQ_INSTS_MFMA" not in vals or launch_s <= 0:
+        return None
+    mfma = vals["SQ_INSTS_MFMA"]; valu = max(0.0, vals["SQ_INSTS_VALU"] - mfma)
+    cyc = valu * VALU_CYCLES + mfma * MFMA_CYCLES.get(workload, 18.0)
+    issue_s = cyc / (num_cu * 4) / (CLOCK_GHZ * 1e9)
+    return {"valu_insts_per_launch": valu, "mfma_insts_per_launch": mfma, "cycles_per_valu": VALU_CYCLES,
+            "cycles_per_mfma": MFMA_CYCLES.get(workload, 18.0), "simds": num_cu * 4, "clock_ghz": CLOCK_GHZ,
+            "issue_us": issue_s * 1e6, "launch_us": launch_s * 1e6, "frac_of_launch": issue_s / launch_s,
+            "source": os.path.basename(files[-1]), "current": bool(sha == kernel_source_sha()),
+            "note": "instruction-issue time of the sampler's own stream at the max clock / measured launch time: the part of the launch that is "
+                    "not waiting; the rest is latency, tails and the clock below 2.4 GHz.  What lifts roofline.frac is fewer instructions per column"}
+
+
 PARITY_TOL = {"f64": {"rmse": 1e-6, "items_rel": 1e-6, "norm_rel": 1e-7}, "f32": {"rmse": 1e-3, "items_rel": 2e-3, "norm_rel": 1e-3}}
 
 
@@ -792,6 +831,12 @@ def main():
     env_ablate = os.environ.get("BPMF_HIP_ABLATE", "0") or "0"
     if args.ablate is not None:
         os.environ["BPMF_HIP_ABLATE"] = str(args.ablate)
+        # the phase switches exist only in the profiling build of the library (bpmf_amd/csrc/Makefile: `make prof`)
+        prof = os.path.join(ROOT, "bpmf_amd", "libbpmf_hip_prof.so")
+        if "BPMF_HIP_LIBRARY" not in os.environ:
+            if not os.path.exists(prof):
+                raise SystemExit("bench.py --ablate needs the profiling build: make -C bpmf_amd/csrc prof")
+            os.environ["BPMF_HIP_LIBRARY"] = prof
     elif env_ablate not in ("0", ""):
         raise SystemExit("bench.py: BPMF_HIP_ABLATE=%s is set (the sampler would skip work and return wrong samples); "
                          "unset it, or ask for it with --ablate N" % env_ablate)
@@ -986,6 +1031,8 @@ def run(args, wl, R, wd):
                 "profiled": {"source": pmc_file, "kernel_source_sha": pmc_sha, "current": bool(pmc_current),
                              "traffic": p_traffic, "bank_conflict_rate": p_conflict},
                 "kernel_source_sha": src_sha}
+    if world == 1:
+        roofline["issue_bound"] = issue_bound(wl, launch_s, getattr(eng, "num_cu", 256))
     if abs(flops_launch - flops_alg) > 1e-6 * flops_alg:
         # Columns in the product form (ChEMBL shape) are never factorised, so neither flop count is a SURVEY 8(d) quantity of
         # what runs: the roofline of this workload is stated in 8(d) BYTES (the compounds side streams Q rows, ratings and

@@ -407,7 +407,16 @@ static int ctx_create_impl(int device, int Ktrue, int dtype, void *stream, bpmf_
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+#if defined(BPMF_PROFILING) && BPMF_PROFILING
     c->ablate = (unsigned)env_int("BPMF_HIP_ABLATE", 0);
+#else
+    // the product build has no profiling hooks in its kernels (kernels.h: kProfiling): asking for them must not pass silently
+    if (env_int("BPMF_HIP_ABLATE", 0) || env_int("BPMF_HIP_STAMPS", 0)) {
+        delete c;
+        return fail(BPMF_HIP_EINVAL, "BPMF_HIP_ABLATE / BPMF_HIP_STAMPS need the profiling build of the library "
+                                     "(make -C bpmf_amd/csrc prof; BPMF_HIP_LIBRARY=<repo>/bpmf_amd/libbpmf_hip_prof.so)");
+    }
+#endif
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else { HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     c->in_words = (size_t)K * K + K + 2 + K;                           // LambdaF | Lmu | fail | pad | mu (even: staged as 16-byte words)
@@ -424,7 +433,9 @@ static int ctx_create_impl(int device, int Ktrue, int dtype, void *stream, bpmf_
     HIP_TRY(hipMemset(c->d_ticket, 0, 64));
     HIP_TRY(hipMalloc((void **)&c->d_zero, 1024));
     HIP_TRY(hipMemset(c->d_zero, 0, 1024));
+#if defined(BPMF_PROFILING) && BPMF_PROFILING
     if (env_int("BPMF_HIP_STAMPS", 0)) { HIP_TRY(hipMalloc((void **)&c->d_stamps, 4096)); HIP_TRY(hipMemset(c->d_stamps, 0, 4096)); }
+#endif
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
     *out = c;
     return BPMF_HIP_OK;

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64, Geo4<K>::WPS) void k_sample4(SampleArgs a)
     const int64_t p0 = valid ? a.wi_p0[w] : 0;
     const int len = valid ? a.wi_len[w] : 0;
     const int mc = valid ? a.wi_mc[w] : -1;
-    const int glen = (a.ablate & 2u) ? 0 : len;
+    const int glen = (ablate_bits(a) & 2u) ? 0 : len;
     const int32_t *rowidx = a.rowidx + p0;
     const double *vals = a.vals + p0;
 
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64, Geo4<K>::WPS) void k_sample4(SampleArgs a)
         const int al = __builtin_amdgcn_readfirstlane(__shfl((int)alive, 4 * sb));
         if (c >= 0 && m >= 0 && al) draw_normals<K>(sample_counter(a.col_from + c, a.ktrue, a.iter_plus_1), a.ktrue, sz[sb], lane, K);
     }
-    if (a.ablate & 1u) {
+    if (ablate_bits(a) & 1u) {
         double v = rr[0];
 #pragma unroll
         for (int t = 0; t < NB; ++t) v += acc[t];

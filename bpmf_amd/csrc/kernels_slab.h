@@ -1,5 +1,6 @@
-// kernels_slab.h -- k_sample_slab<K, T>: the column update for K = 64 (fp64 factors) and K = 128
-// (fp32 factors), one wave per work item, the whole factorisation on v_mfma_f64_4x4x4_4b_f64.
+// kernels_slab.h -- k_sample_slab<64, double> / k_sample1s<64>: the column update for K = 64 (fp64), one wave per work
+// item, Gram and the whole factorisation on v_mfma_f64_4x4x4_4b_f64.  (K = 128 ran here in fp32 until round 5: it is
+// k_sample_wg2's now, kernels_wg2.h; factor_block44 and quad_splat below are shared with it.)
 //
 // Reference: Sys::sample(long idx, Sys&) + computeMuLambda, c++/sample.cpp:248-336.
 //
@@ -26,8 +27,6 @@
 //     are added with two DPP row rotates.
 // Natural 4-index blocks: R is THE Cholesky factor of the reference's Lambda* in the reference's
 // order, so x = R^-1 (R^-T b + z) is the reference's sample for the same z.
-// K = 128 keeps factors and Gram in fp32 (v_mfma_f32_16x16x4_f32) as the "fp32 large-K path" is defined
-// (BASELINE configs[4]); the 36 tiles are widened into fp64 slabs once per column and factorised in fp64.
 // Heavy columns are cut into chunks like everywhere else (partials in tile layout, last arriver adds).
 #pragma once
 #include "kernels.h"
@@ -49,7 +48,15 @@ struct GeoS {
     static constexpr int LDS_WORDS = 2 * K + 4 * LDR + 16 * NG + (K == 128 ? 16 * 17 / 2 + 8 : 0);
     // doubles in the partial of one chunk of a heavy column (tile layout)
     static constexpr int PART = K == 128 ? (NTRI * 256 + NT * 16) / 2 : NREG * 64 + NT * 16;
-    static constexpr int WPS = K == 128 ? 1 : (K == 64 ? 2 : 4);    // waves per SIMD the kernels are compiled for
+#ifndef BPMF_SLAB_WPS
+#define BPMF_SLAB_WPS 2
+#endif
+    static constexpr int WPS = K == 128 ? 1 : (K == 64 ? BPMF_SLAB_WPS : 4);    // waves per SIMD the kernels are compiled for
+    // operand sets of the Gram loop (the gathers run DEPTH - 1 groups of 4 ratings ahead of the MFMAs)
+#ifndef BPMF_SLAB_DEPTH
+#define BPMF_SLAB_DEPTH 4
+#endif
+    static constexpr int DEPTH = BPMF_SLAB_DEPTH;
 };
 
 // W = R_ss^-1 of a 4x4 SPD block given by its 10 upper entries (wave-uniform values): returns the
@@ -107,13 +114,17 @@ __device__ __forceinline__ void gram_slab(const int32_t *__restrict__ rowidx, co
     constexpr int NT = K / 16, NG = G::NG;
     const int kq = lane >> 4, li = lane & 15;
     if (len <= 0) return;
+    // byte addresses (4 x source lane) of the two operand permutations of the shared instruction of a diagonal tile
+    const int bq = (lane >> 2) & 3, xi = lane & 3;
+    const int pz_a = 4 * (16 * kq + 4 * (bq == 1 ? 3 : 2) + xi);      // A: row block [2, 3, 2, 2] by slot
+    const int pz_b = 4 * (16 * kq + 4 * (bq == 0 ? 0 : (bq == 2 ? 2 : 3)) + xi);   // B: column block [0, 3, 2, 3] by slot
     // index blocks of 64 ratings (lane l holds rating b0 + l): the current one and the next one
     int ri = (lane < len) ? rowidx[lane] : -1;
     double wv = (lane < len) ? (vals[lane] - mean) * alpha : 0.0;                // c++/sample.cpp:256
     int ri_n = (64 + lane < len) ? rowidx[64 + lane] : -1;
     double wv_n = (64 + lane < len) ? (vals[64 + lane] - mean) * alpha : 0.0;
-    // Group st of the block (4 ratings, k = lane >> 4 picks one); st = 16..18 are the first groups of the NEXT
-    // block: the gathers run THREE groups ahead of the MFMAs, across block boundaries too (one group of
+    // Group st of the block (4 ratings, k = lane >> 4 picks one); st >= 16 are the first groups of the NEXT
+    // block: the gathers run DEPTH - 1 groups ahead of the MFMAs, across block boundaries too (one group of
     // 40 MFMAs is ~700 cycles, an L2 hit under load about as much: one group ahead left 57 % of the wave
     // cycles waiting).  No control flow around the loads -- the compiler's s_waitcnt counts stay exact --
     // and slots beyond the end of the chunk gather a row of zeros.
@@ -126,39 +137,58 @@ __device__ __forceinline__ void gram_slab(const int32_t *__restrict__ rowidx, co
 #pragma unroll
         for (int t = 0; t < NT; ++t) yy[t] = u[16 * t];
     };
+    // The 16 x 16 diagonal tile TI needs 10 of its 16 blocks (c >= r).  Rows r = 0 and 1 keep their slabs (blocks (0, *) and
+    // (1, *): one wasted block); rows 2 and 3 SHARE one instruction -- the four blocks of v_mfma_f64_4x4x4_4b are independent
+    // products, so slot b of "Z" computes (2,0) | (3,3) | (2,2) | (2,3): A operand = row block [2, 3, 2, 2], B operand = column
+    // block [0, 3, 2, 3] of the gathered register, both ONE ds_bpermute of it (lane addresses pz_a / pz_b, built once).  36
+    // MFMAs per group of four ratings instead of 40; the splats of rows 2 and 3 of the LAST tile are not needed any more.
+    // unpack_diag() puts (3,3) where the factorisation expects it, once per column.
+    auto permute = [&](double v, int addr) -> double {
+        const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
+        const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+        return __hiloint2double(hi, lo);
+    };
     auto contract = [&](const double (&yy)[NT], double ww) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) r[t] = fma(yy[t], ww, r[t]);
 #pragma unroll
         for (int I = 0; I < NG; ++I) {
-            double aI;
-            switch (I & 3) {
-            case 0: aI = quad_splat<0>(yy[I >> 2]); break;
-            case 1: aI = quad_splat<1>(yy[I >> 2]); break;
-            case 2: aI = quad_splat<2>(yy[I >> 2]); break;
-            default: aI = quad_splat<3>(yy[I >> 2]); break;
+            const int TI = I >> 2, m = I & 3;
+            if (TI == NT - 1 && m >= 2) {                             // last tile: rows 2 and 3 have no slab to the right
+                if (m == 3) A[G::reg(4 * TI + 2, TI)] = mfma44(permute(yy[TI], pz_a), permute(yy[TI], pz_b), A[G::reg(4 * TI + 2, TI)]);
+                continue;
             }
+            double aI;
+            switch (m) {
+            case 0: aI = quad_splat<0>(yy[TI]); break;
+            case 1: aI = quad_splat<1>(yy[TI]); break;
+            case 2: aI = quad_splat<2>(yy[TI]); break;
+            default: aI = quad_splat<3>(yy[TI]); break;
+            }
+            if (m < 2) A[G::reg(I, TI)] = mfma44(aI, yy[TI], A[G::reg(I, TI)]);
+            else if (m == 3) A[G::reg(4 * TI + 2, TI)] = mfma44(permute(yy[TI], pz_a), permute(yy[TI], pz_b), A[G::reg(4 * TI + 2, TI)]);
 #pragma unroll
-            for (int q = I >> 2; q < NT; ++q) A[G::reg(I, q)] = mfma44(aI, yy[q], A[G::reg(I, q)]);
+            for (int q = TI + 1; q < NT; ++q) A[G::reg(I, q)] = mfma44(aI, yy[q], A[G::reg(I, q)]);
         }
     };
-    double y0[NT], y1[NT], y2[NT], y3[NT], w0, w1, w2, w3;
-    gather(0, y0, w0);
-    gather(1, y1, w1);
-    gather(2, y2, w2);
+    // D operand sets: the gathers run D - 1 groups ahead of the MFMAs (GeoS<K>::DEPTH).  A group whose four ratings all lie
+    // beyond the end of the chunk is gathered (a row of zeros: the loads stay unconditional) but NOT contracted: the
+    // guard is wave-uniform, one scalar branch per group, and skipping a product with zeros changes no sum.
+    constexpr int D = G::DEPTH;
+    static_assert(D >= 2 && 16 % D == 0, "the operand sets must rotate evenly through the 16 groups of an index block");
+    double y[D][NT], w[D];
+#pragma unroll
+    for (int u = 0; u < D - 1; ++u) gather(u, y[u], w[u]);
     for (int b0 = 0; b0 < len; b0 += 64) {
-        const int nsteps = (len - b0 >= 64) ? 16 : ((len - b0 + 15) >> 4) * 4;   // groups of this block, rounded up to 4
-        for (int st = 0; st < nsteps; st += 4) {
-            gather(st + 3, y3, w3);
-            contract(y0, w0);
-            gather(st + 4, y0, w0);
-            contract(y1, w1);
-            gather(st + 5, y1, w1);
-            contract(y2, w2);
-            gather(st + 6, y2, w2);
-            contract(y3, w3);
+        const int ngroups = (len - b0 >= 64) ? 16 : (len - b0 + 3) >> 2;         // groups of 4 ratings in this block
+        for (int st = 0; st < ngroups; st += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                gather(st + u + D - 1, y[(u + D - 1) % D], w[(u + D - 1) % D]);
+                if (st + u < ngroups) contract(y[u], w[u]);
+            }
         }
-        // next block: its first three groups are in flight already
+        // next block: its first D - 1 groups are in flight already
         ri = ri_n; wv = wv_n;
         const int q = b0 + 128 + lane;
         ri_n = (q < len) ? rowidx[q] : -1;
@@ -168,6 +198,24 @@ __device__ __forceinline__ void gram_slab(const int32_t *__restrict__ rowidx, co
     for (int t = 0; t < NT; ++t) {
         r[t] += __shfl_xor(r[t], 16);
         r[t] += __shfl_xor(r[t], 32);
+    }
+}
+
+// gram_slab() leaves rows 2 and 3 of every diagonal tile in ONE register (slot b: (2,0) | (3,3) | (2,2) | (2,3)), in the place
+// of slab (4 TI + 2, TI), and slab (4 TI + 3, TI) untouched (zero).  Row 2's blocks (2,2), (2,3) are where a slab holds them
+// already; row 3's block (3,3) moves from slot 1 to slot 3 (a rotate by 8 lanes inside each row of 16: one DPP move per half).
+// The blocks below the diagonal of a diagonal tile are never read (slab_cholesky_solve masks them: b <= b0).  Linear, so a
+// chunked column unpacks once, after its partials were added.
+template <int K>
+__device__ __forceinline__ void unpack_diag(double (&A)[GeoS<K>::NREG])
+{
+    using G = GeoS<K>;
+#pragma unroll
+    for (int TI = 0; TI < G::NT; ++TI) {
+        const long long v = __builtin_bit_cast(long long, A[G::reg(4 * TI + 2, TI)]);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);          // row_ror:8
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), 0x128, 0xF, 0xF, true);
+        A[G::reg(4 * TI + 3, TI)] = __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
     }
 }
 
@@ -206,20 +254,24 @@ __device__ __forceinline__ void slab_cholesky_solve(double (&A)[GeoS<K>::NREG], 
 #pragma unroll
         for (int q = q0; q < NQ; ++q) A[G::reg(s, q)] = mfma44(WA, A[G::reg(s, q)], 0.0);
         if (s + 1 < NG) {
-            // rhs: b_J -= R_sJ^T y_s for J > s -- the slab of block row s IS the A operand (four J per instruction)
+            // rhs: b_J -= R_sJ^T y_s for J > s -- the slab of block row s IS the A operand (four J per instruction).
+            // -R_sJ is formed ONCE per slab: it is this operand and what gets published (the trailing update reads its A
+            // operand back negated already: one sign flip per slab instead of one per row block I > s).
+            double nA[NQ];
 #pragma unroll
             for (int q = q0; q < NQ; ++q) {
+                nA[q] = -A[G::reg(s, q)];
                 if (q == q0 && b0 == 3) continue;
-                const double nR = (q == q0 && b <= b0) ? 0.0 : -A[G::reg(s, q)];
+                const double nR = (q == q0 && b <= b0) ? 0.0 : nA[q];
                 bv[q] = mfma44(nR, ys, bv[q]);
             }
-            // publish block row s; the A operand of row block I: lane (k, b, i) <- R[4 s + k][4 I + i]
+            // publish block row s (negated); the A operand of row block I: lane (k, b, i) <- -R[4 s + k][4 I + i]
 #pragma unroll
-            for (int q = q0; q < NQ; ++q) srow[kq * LDR + 16 * q + c16] = A[G::reg(s, q)];
+            for (int q = q0; q < NQ; ++q) srow[kq * LDR + 16 * q + c16] = nA[q];
             __syncthreads();
 #pragma unroll
             for (int I = s + 1; I < NG; ++I) {
-                const double nI = -srow[kq * LDR + 4 * I + x];
+                const double nI = srow[kq * LDR + 4 * I + x];
 #pragma unroll
                 for (int q = I >> 2; q < NQ; ++q) A[G::reg(I, q)] = mfma44(nI, A[G::reg(s, q)], A[G::reg(I, q)]);   // A_IJ -= R_sI^T R_sJ
             }
@@ -257,13 +309,13 @@ template <int K, typename T>
 __device__ __forceinline__ void slab_item(const SampleArgs &a, int w, double *lds, int lane)
 {
     using G = GeoS<K>;
-    constexpr int NG = G::NG, NQ = G::NQ, NT = G::NT, NTRI = G::NTRI, NREG = G::NREG;
+    constexpr int NG = G::NG, NQ = G::NQ, NT = G::NT, NREG = G::NREG;
     constexpr bool F32 = sizeof(T) == 4;
     double *sz = lds, *sb = lds + K, *srow = lds + 2 * K, *sw = srow + 4 * G::LDR;
     const int kq = lane >> 4, li = lane & 15, x = lane & 3;
     const int col = a.wi_col[w];
     const int64_t p0 = a.wi_p0[w];
-    const int len = (a.ablate & 2u) ? 0 : a.wi_len[w];             // (profiling switch: no Gram)
+    const int len = (ablate_bits(a) & 2u) ? 0 : a.wi_len[w];             // (profiling switch: no Gram)
     const int mc = a.wi_mc[w];
     const int64_t idx = a.col_from + col;
     const T *other = reinterpret_cast<const T *>(a.other_items);
@@ -275,7 +327,8 @@ __device__ __forceinline__ void slab_item(const SampleArgs &a, int w, double *ld
     stamp(a, w, 1);
     double A[NREG];
     double rsum[NT];                                                  // rr[16 t + li] (all kq)
-    if constexpr (!F32) {
+    {
+        static_assert(!F32 && K == 64, "the slab form is the K = 64 fp64 sampler (K = 128 runs k_sample_wg2)");
 #pragma unroll
         for (int t = 0; t < NREG; ++t) A[t] = 0.0;
 #pragma unroll
@@ -315,127 +368,11 @@ __device__ __forceinline__ void slab_item(const SampleArgs &a, int w, double *ld
             }
             draw_normals_deferred<K>(sample_counter(idx, a.ktrue, a.iter_plus_1), a.ktrue, sz, srow, lane, K);
         }
-    } else {
-        // fp32 Gram on v_mfma_f32_16x16x4_f32: D[i = 4 (lane / 16) + reg][j = lane % 16]
-        f4 acc[NTRI];
-        float r[NT];
-#pragma unroll
-        for (int t = 0; t < NTRI; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < NT; ++t) r[t] = 0.f;
-        {
-            const int32_t *rowidx = a.rowidx + p0;
-            const double *vals = a.vals + p0;
-            int ri_n = (lane < len) ? rowidx[lane] : -1;
-            float wv_n = (lane < len) ? (float)((vals[lane] - a.mean_rating) * a.alpha) : 0.f;      // c++/sample.cpp:256
-            for (int b0 = 0; b0 < len; b0 += 64) {
-                const int ri = ri_n;
-                const float wv = wv_n;
-                if (b0 + 64 < len) {                                  // wave-uniform
-                    const int q = b0 + 64 + lane;
-                    ri_n = (q < len) ? rowidx[q] : -1;
-                    wv_n = (q < len) ? (float)((vals[q] - a.mean_rating) * a.alpha) : 0.f;
-                }
-                const int ngroups = (len - b0 >= 64) ? 4 : (len - b0 + 15) >> 4;
-                float y[4][NT], yn[4][NT], ww[4], wn[4];
-                auto gather = [&](int gg, float (&yy)[4][NT], float (&w1)[4]) {
-#pragma unroll
-                    for (int st = 0; st < 4; ++st) {
-                        const int src = (gg * 4 + st) * 4 + kq;
-                        const int row = __shfl(ri, src);
-                        w1[st] = __shfl(wv, src);
-                        const float *u = other + (size_t)(row >= 0 ? row : 0) * K + li;
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) yy[st][t] = (row >= 0) ? u[16 * t] : 0.f;
-                    }
-                };
-                gather(0, y, ww);
-#pragma unroll
-                for (int gg = 0; gg < 4; ++gg) {
-                    if (gg >= ngroups) break;                         // wave-uniform
-                    const bool more = gg + 1 < ngroups;
-                    if (gg < 3 && more) gather(gg + 1, yn, wn);
-#pragma unroll
-                    for (int st = 0; st < 4; ++st) {
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) r[t] = fmaf(y[st][t], ww[st], r[t]);
-                        int tri = 0;
-#pragma unroll
-                        for (int I = 0; I < NT; ++I)
-#pragma unroll
-                            for (int J = I; J < NT; ++J, ++tri)
-                                acc[tri] = __builtin_amdgcn_mfma_f32_16x16x4f32(y[st][I], y[st][J], acc[tri], 0, 0, 0);
-                    }
-                    if (gg < 3 && more) {
-#pragma unroll
-                        for (int st = 0; st < 4; ++st) {
-                            ww[st] = wn[st];
-#pragma unroll
-                            for (int t = 0; t < NT; ++t) y[st][t] = yn[st][t];
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                r[t] += __shfl_xor(r[t], 16);
-                r[t] += __shfl_xor(r[t], 32);
-            }
-        }
-        if (mc >= 0) {
-            constexpr int PART = G::PART;                             // in doubles; the partial itself is floats
-            const int nch = a.mc_nchunks[mc];
-            float *pbase = reinterpret_cast<float *>(a.partials + (size_t)a.mc_slot0[mc] * PART);
-            float *p = pbase + (size_t)a.wi_chunk[w] * (2 * PART);
-#pragma unroll
-            for (int t = 0; t < NTRI; ++t)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) __hip_atomic_store(&p[(t * 4 + reg) * 64 + lane], acc[t][reg], BPMF_RLX_AGENT);
-            if (lane < 16) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) __hip_atomic_store(&p[NTRI * 256 + t * 16 + lane], r[t], BPMF_RLX_AGENT);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            unsigned tk = 0;
-            if (lane == 0) tk = __hip_atomic_fetch_add(&a.mc_count[mc], 1u, BPMF_RLX_AGENT);
-            tk = __builtin_amdgcn_readfirstlane(tk);
-            if ((int)tk != nch - 1) return;
-            if (lane == 0) __hip_atomic_store(&a.mc_count[mc], 0u, BPMF_RLX_AGENT);
-#pragma unroll
-            for (int t = 0; t < NTRI; ++t) acc[t] = f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < NT; ++t) r[t] = 0.f;
-            for (int ch = 0; ch < nch; ++ch) {
-                const float *pc = pbase + (size_t)ch * (2 * PART);
-#pragma unroll
-                for (int t = 0; t < NTRI; ++t)
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) acc[t][reg] += __hip_atomic_load(&pc[(t * 4 + reg) * 64 + lane], BPMF_RLX_AGENT);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) r[t] += __hip_atomic_load(&pc[NTRI * 256 + t * 16 + li], BPMF_RLX_AGENT);
-            }
-            draw_normals_deferred<K>(sample_counter(idx, a.ktrue, a.iter_plus_1), a.ktrue, sz, srow, lane, K);
-        }
-        // widen: tile element (4 kq + reg, li) -> slab m lane (kq', li) = tile element (4 m + kq', li), through a 16 x 17 LDS tile
-        float *stile = reinterpret_cast<float *>(sw + 16 * NG);
-        int tri = 0;
-#pragma unroll
-        for (int TI = 0; TI < NT; ++TI)
-#pragma unroll
-            for (int TJ = TI; TJ < NT; ++TJ, ++tri) {
-                __syncthreads();
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) stile[(4 * kq + reg) * 17 + li] = acc[tri][reg];
-                __syncthreads();
-#pragma unroll
-                for (int m = 0; m < 4; ++m) A[G::reg(4 * TI + m, TJ)] = (double)stile[(4 * m + kq) * 17 + li];
-            }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) rsum[t] = (double)r[t];
     }
+    unpack_diag<K>(A);
 
     stamp(a, w, 2);
-    if (a.ablate & 1u) {                                              // (profiling switch: Gram only -- keep it live)
+    if (ablate_bits(a) & 1u) {                                              // (profiling switch: Gram only -- keep it live)
         double v = rsum[0];
 #pragma unroll
         for (int t = 0; t < NREG; ++t) v += A[t];

@@ -137,7 +137,7 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
     const int kq = lane >> 4, li = lane & 15;
     const int col = a.wi_col[w];
     const int64_t p0 = a.wi_p0[w];
-    const int len = (a.ablate & 2u) ? 0 : a.wi_len[w];             // (profiling switch: no Gram)
+    const int len = (ablate_bits(a) & 2u) ? 0 : a.wi_len[w];             // (profiling switch: no Gram)
     const int mc = a.wi_mc[w];
     const int64_t idx = a.col_from + col;
     const T *other = reinterpret_cast<const T *>(a.other_items);
@@ -238,8 +238,8 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
         T wv = (lane < len) ? (T)((vals[lane] - a.mean_rating) * a.alpha) : (T)0;                 // c++/sample.cpp:256
         int ri_n = (64 + lane < len) ? rowidx[64 + lane] : -1;
         T wv_n = (64 + lane < len) ? (T)((vals[64 + lane] - a.mean_rating) * a.alpha) : (T)0;
-        const int rowmask = (a.ablate & 4u) ? 63 : -1;                 // (profiling switch: gather from 64 hot rows only)
-        const bool no_mfma = (a.ablate & 8u) != 0;                     // (profiling switch: operands are loaded and summed, no MFMA)
+        const int rowmask = (ablate_bits(a) & 4u) ? 63 : -1;                 // (profiling switch: gather from 64 hot rows only)
+        const bool no_mfma = (ablate_bits(a) & 8u) != 0;                     // (profiling switch: operands are loaded and summed, no MFMA)
         constexpr int SPW = 4 / NW;                                    // k-steps of a group gathered by one wave
         constexpr int EPV = 16 / (int)sizeof(T), VPR = NT / EPV;       // elements per 16-byte piece, pieces per lane and k-step
         typedef T tvec __attribute__((ext_vector_type(EPV)));
@@ -329,7 +329,7 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
     // arbitration over the co-resident workgroups' Gram loops (throughput-bound, they only lose slots they can spare)
     __builtin_amdgcn_s_setprio(3);
     stamp(a, w, 1);
-    if (W == 1 && a.stamps && lane == 0 && (w == 0 || w == a.nwork / 2)) a.stamps[(w == 0 ? 0 : 64) + 48] = wall_clock64();   // (wave 1's Gram ends)
+    if (kProfiling && W == 1 && a.stamps && lane == 0 && (w == 0 || w == a.nwork / 2)) a.stamps[(w == 0 ? 0 : 64) + 48] = wall_clock64();   // (wave 1's Gram ends)
     if (mc >= 0) {
         // chunk of a heavy column: every wave parks its tiles (tile `tri` at [tri * 256 + reg * 64 + lane]), wave 0 the rhs;
         // the workgroup that draws the last ticket adds the partials in chunk order
@@ -377,7 +377,7 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
         }
     }
 
-    if (a.ablate & 1u) {                                              // (profiling switch: Gram only -- keep it live)
+    if (ablate_bits(a) & 1u) {                                              // (profiling switch: Gram only -- keep it live)
         T v = r[0];
 #pragma unroll
         for (int t = 0; t < TPW; ++t) v += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sample_wg2(SampleArgs a, StatRid
     // column statistics as rider workgroups (colstats_f32_rider): the previous launch's side at the head of the grid
     if ((int)blockIdx.x < r.nblocks) { colstats_f32_rider<K, NW, T>(r, (int)blockIdx.x, tid); return; }
     const int w = (int)blockIdx.x - r.nblocks;
-    const unsigned long long t_begin = a.stamps ? wall_clock64() : 0ull;
+    const unsigned long long t_begin = (kProfiling && a.stamps) ? wall_clock64() : 0ull;
     if constexpr (NW == 2) {
         if (wave == 0) wg2_column<K, 2, 0, T>(a, w, smem, tid);
         else wg2_column<K, 2, 1, T>(a, w, smem, tid);
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_sample_wg2(SampleArgs a, StatRid
         default: wg2_column<K, 4, 3, T>(a, w, smem, tid); break;
         }
     }
-    if (a.stamps && tid == 0) {                                        // profiling: sum of the items' lifetimes (wave 0), their number, first start / last end
+    if (kProfiling && a.stamps && tid == 0) {                                        // profiling: sum of the items' lifetimes (wave 0), their number, first start / last end
         atomicAdd(&a.stamps[128 + 0], wall_clock64() - t_begin);
         atomicAdd(&a.stamps[128 + 1], 1ull);
         atomicMin(&a.stamps[128 + 2], t_begin);

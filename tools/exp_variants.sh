@@ -7,7 +7,7 @@ for r in $(seq $ROUNDS); do
   for wl in $WLS; do
     for lib in "$@"; do
       E=""; [ $lib != tree ] && E="BPMF_HIP_LIBRARY=$PWD/bpmf_amd/csrc/variants/$lib.so"
-      env $E timeout 300 python bench.py --workload $wl --no-cpu-baseline --no-strong --no-bpmf-exe --no-parity --steps 60 --warmup 10 2>/dev/null | line "$wl $lib"
+      env $E timeout 300 python bench.py --workload $wl --no-cpu-baseline --no-strong --no-bpmf-exe --no-parity --no-configs --window-s ${WINDOW_S:-0.6} --steps 60 --warmup 10 2>/dev/null | line "$wl $lib"
     done
   done
 done
