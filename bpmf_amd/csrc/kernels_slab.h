@@ -43,6 +43,20 @@ struct GeoS {
     __host__ __device__ static constexpr int roff(int I) { int n = 0; for (int t = 0; t < I; ++t) n += NQ - (t >> 2); return n; }
     static constexpr int NREG = roff(NG);                 // slabs kept: q >= I / 4
     __host__ __device__ static constexpr int reg(int I, int q) { return roff(I) + q - (I >> 2); }
+    // Gram accumulators (gram_slab): tile (TI, TJ), TI <= TJ, keeps one register per quad rotation d of the B operand --
+    // d = 0 .. 3 off the diagonal, d = 0 .. 2 on it (the blocks d = 3 would give are transposes of d = 1's)
+    __host__ __device__ static constexpr int nrot(int TI, int TJ) { return TI == TJ ? 3 : 4; }
+    __host__ __device__ static constexpr int aoff(int TI, int TJ)
+    {
+        int n = 0;
+        for (int a = 0; a < NT; ++a)
+            for (int b = a; b < NT; ++b) {
+                if (a == TI && b == TJ) return n;
+                n += nrot(a, b);
+            }
+        return n;
+    }
+    static constexpr int NACC = aoff(NT - 1, NT - 1) + 3;  // 36 at K = 64 (the slab form itself needs NREG = 40)
     static constexpr int LDR = K + 2;                     // row stride of the published block row (doubles)
     // LDS: z [K] | rhs [K] | block row [4][LDR] | inverted diagonal blocks [NG][16] | (fp32 path) one 16 x 17 tile
     static constexpr int LDS_WORDS = 2 * K + 4 * LDR + 16 * NG + (K == 128 ? 16 * 17 / 2 + 8 : 0);
@@ -100,33 +114,48 @@ __device__ __forceinline__ double quad_splat(double v)
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
-// Gram of one chunk straight into the slabs, on the 4x4x4 shape (fp64, K = 64): per group of 4 ratings
-// (k = lane >> 4 picks the rating) the B operand of slab column q is the gathered register itself --
-// lane (k, c) holds u_k[16 q + c] -- and the A operand of row block I is quad I & 3 of register I >> 2
-// splatted over the four quads (u_k[4 I + i] for every b).  40 instructions of ~18 cycles per 4 ratings
-// instead of 10 of ~105-130 (v_mfma_f64_16x16x4_f64 at two waves per SIMD).
+// x rotated by 4 * D lanes inside each row of 16 lanes (quad b reads quad (b + D) % 4): one DPP move per half, no LDS
+template <int D>
+__device__ __forceinline__ double quad_rot(double x)
+{
+    constexpr int CTRL = 0x120 + (16 - 4 * D);                       // row_ror:(16 - 4 D): lane l reads lane (l + 4 D) % 16 of its row
+    const long long v = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Gram of one chunk on the 4x4x4 shape (fp64, K = 64).  A group is 4 ratings (k = lane >> 4 picks one); the gathered
+// register t holds u_k[16 t + c] in lane (k, c), c = 4 b + j.  The four blocks b of v_mfma_f64_4x4x4_4b are independent
+// 4 x 4 x 4 products, so with A = register TI as it is (block b = latent rows 16 TI + 4 b ..) and B = register TJ ROTATED by d
+// quads (block b = latent columns 16 TJ + 4 ((b + d) % 4) ..) one instruction accumulates the four blocks
+// (4 TI + b, 4 TJ + (b + d) % 4) of tile (TI, TJ): d = 0 .. 3 cover an off-diagonal tile; on the diagonal d = 0, 1, 2 do --
+// the blocks below the diagonal that d = 1, 2 produce are the transposes of (0,3), (0,2), (1,3).  36 MFMAs per group and
+// 22 DPP moves (11 rotated registers x two halves); NO cross-lane operation through the LDS pipe.
+// Rounds 1-5 made the A operand of row block I by splatting quad I & 3 of register I >> 2 over its row (two ds_swizzle per
+// operand, 32 per group, 40 MFMAs per group).  Round 6 measured what that costs: on a SIMD the issue of an LDS-pipe
+// instruction ADDS to the MFMA time like a VALU instruction does (tools/probes/cbsz_probe.hip: 28.2 cycles per MFMA with two
+// swizzles each against 19.0 without; the Gram loop ran ~1000 cycles per group against 720 of MFMAs) -- fewer MFMAs bought
+// with more swizzles / bpermutes gained nothing (-1 %), deeper gathers nothing, the splats one group ahead nothing; what
+// counts is the NUMBER of instructions of any kind.  (The MFMA's own A-broadcast controls, cbsz / abid, are accepted by the
+// assembler for this shape and ignored by the hardware: tools/probes/cbsz_map_probe.hip.)
+// The accumulators are NOT in slab layout: slabs_from_acc() converts once per column.
 template <int K>
 __device__ __forceinline__ void gram_slab(const int32_t *__restrict__ rowidx, const double *__restrict__ vals, int len,
                                           const double *__restrict__ other, const double *__restrict__ zero_row, double mean, double alpha,
-                                          double (&A)[GeoS<K>::NREG], double (&r)[K / 16], int lane)
+                                          double (&C)[GeoS<K>::NACC], double (&r)[K / 16], int lane)
 {
     using G = GeoS<K>;
-    constexpr int NT = K / 16, NG = G::NG;
+    constexpr int NT = K / 16;
     const int kq = lane >> 4, li = lane & 15;
     if (len <= 0) return;
-    // byte addresses (4 x source lane) of the two operand permutations of the shared instruction of a diagonal tile
-    const int bq = (lane >> 2) & 3, xi = lane & 3;
-    const int pz_a = 4 * (16 * kq + 4 * (bq == 1 ? 3 : 2) + xi);      // A: row block [2, 3, 2, 2] by slot
-    const int pz_b = 4 * (16 * kq + 4 * (bq == 0 ? 0 : (bq == 2 ? 2 : 3)) + xi);   // B: column block [0, 3, 2, 3] by slot
     // index blocks of 64 ratings (lane l holds rating b0 + l): the current one and the next one
     int ri = (lane < len) ? rowidx[lane] : -1;
     double wv = (lane < len) ? (vals[lane] - mean) * alpha : 0.0;                // c++/sample.cpp:256
     int ri_n = (64 + lane < len) ? rowidx[64 + lane] : -1;
     double wv_n = (64 + lane < len) ? (vals[64 + lane] - mean) * alpha : 0.0;
-    // Group st of the block (4 ratings, k = lane >> 4 picks one); st >= 16 are the first groups of the NEXT
-    // block: the gathers run DEPTH - 1 groups ahead of the MFMAs, across block boundaries too (one group of
-    // 40 MFMAs is ~700 cycles, an L2 hit under load about as much: one group ahead left 57 % of the wave
-    // cycles waiting).  No control flow around the loads -- the compiler's s_waitcnt counts stay exact --
+    // Group st of the block; st >= 16 are the first groups of the NEXT block: the gathers run DEPTH - 1 groups ahead of the
+    // MFMAs, across block boundaries too.  No control flow around the loads -- the compiler's s_waitcnt counts stay exact --
     // and slots beyond the end of the chunk gather a row of zeros.
     auto gather = [&](int st, double (&yy)[NT], double &ww) {
         const bool nx = st >= 16;
@@ -137,39 +166,24 @@ __device__ __forceinline__ void gram_slab(const int32_t *__restrict__ rowidx, co
 #pragma unroll
         for (int t = 0; t < NT; ++t) yy[t] = u[16 * t];
     };
-    // The 16 x 16 diagonal tile TI needs 10 of its 16 blocks (c >= r).  Rows r = 0 and 1 keep their slabs (blocks (0, *) and
-    // (1, *): one wasted block); rows 2 and 3 SHARE one instruction -- the four blocks of v_mfma_f64_4x4x4_4b are independent
-    // products, so slot b of "Z" computes (2,0) | (3,3) | (2,2) | (2,3): A operand = row block [2, 3, 2, 2], B operand = column
-    // block [0, 3, 2, 3] of the gathered register, both ONE ds_bpermute of it (lane addresses pz_a / pz_b, built once).  36
-    // MFMAs per group of four ratings instead of 40; the splats of rows 2 and 3 of the LAST tile are not needed any more.
-    // unpack_diag() puts (3,3) where the factorisation expects it, once per column.
-    auto permute = [&](double v, int addr) -> double {
-        const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v));
-        const int hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
-        return __hiloint2double(hi, lo);
-    };
     auto contract = [&](const double (&yy)[NT], double ww) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) r[t] = fma(yy[t], ww, r[t]);
+        double rot[NT][4];
 #pragma unroll
-        for (int I = 0; I < NG; ++I) {
-            const int TI = I >> 2, m = I & 3;
-            if (TI == NT - 1 && m >= 2) {                             // last tile: rows 2 and 3 have no slab to the right
-                if (m == 3) A[G::reg(4 * TI + 2, TI)] = mfma44(permute(yy[TI], pz_a), permute(yy[TI], pz_b), A[G::reg(4 * TI + 2, TI)]);
-                continue;
-            }
-            double aI;
-            switch (m) {
-            case 0: aI = quad_splat<0>(yy[TI]); break;
-            case 1: aI = quad_splat<1>(yy[TI]); break;
-            case 2: aI = quad_splat<2>(yy[TI]); break;
-            default: aI = quad_splat<3>(yy[TI]); break;
-            }
-            if (m < 2) A[G::reg(I, TI)] = mfma44(aI, yy[TI], A[G::reg(I, TI)]);
-            else if (m == 3) A[G::reg(4 * TI + 2, TI)] = mfma44(permute(yy[TI], pz_a), permute(yy[TI], pz_b), A[G::reg(4 * TI + 2, TI)]);
-#pragma unroll
-            for (int q = TI + 1; q < NT; ++q) A[G::reg(I, q)] = mfma44(aI, yy[q], A[G::reg(I, q)]);
+        for (int t = 0; t < NT; ++t) {
+            rot[t][0] = yy[t];
+            rot[t][1] = quad_rot<1>(yy[t]);
+            rot[t][2] = quad_rot<2>(yy[t]);
+            if (t > 0) rot[t][3] = quad_rot<3>(yy[t]);               // (register 0 is a B operand of its diagonal tile only)
         }
+#pragma unroll
+        for (int TI = 0; TI < NT; ++TI)
+#pragma unroll
+            for (int TJ = TI; TJ < NT; ++TJ)
+#pragma unroll
+                for (int d = 0; d < G::nrot(TI, TJ); ++d)
+                    C[G::aoff(TI, TJ) + d] = mfma44(yy[TI], rot[TJ][d], C[G::aoff(TI, TJ) + d]);
     };
     // D operand sets: the gathers run D - 1 groups ahead of the MFMAs (GeoS<K>::DEPTH).  A group whose four ratings all lie
     // beyond the end of the chunk is gathered (a row of zeros: the loads stay unconditional) but NOT contracted: the
@@ -201,22 +215,38 @@ __device__ __forceinline__ void gram_slab(const int32_t *__restrict__ rowidx, co
     }
 }
 
-// gram_slab() leaves rows 2 and 3 of every diagonal tile in ONE register (slot b: (2,0) | (3,3) | (2,2) | (2,3)), in the place
-// of slab (4 TI + 2, TI), and slab (4 TI + 3, TI) untouched (zero).  Row 2's blocks (2,2), (2,3) are where a slab holds them
-// already; row 3's block (3,3) moves from slot 1 to slot 3 (a rotate by 8 lanes inside each row of 16: one DPP move per half).
-// The blocks below the diagonal of a diagonal tile are never read (slab_cholesky_solve masks them: b <= b0).  Linear, so a
-// chunked column unpacks once, after its partials were added.
+// The accumulators of gram_slab() -> the slabs the factorisation works on, once per column (a chunked column: after its
+// partials were added; the map is a permutation, so it commutes with the sums).  Tile by tile through 2 KB of LDS (the
+// block-row buffer and the buffer of the inverted diagonal blocks, both idle until the factorisation, taken in turn): lane
+// (i, b, j) of rotation d holds G[16 TI + 4 b + i][16 TJ + 4 ((b + d) % 4) + j] and stores it at [4 b + i][4 ((b + d) % 4) + j]
+// of a 16 x 16 image; slab (4 TI + m, TJ) is rows 4 m .. 4 m + 3 of the image, lane (i, c) <- [4 m + i][c].  A diagonal tile
+// stores every element at its mirror position too, so that the image is the full symmetric tile (the blocks d = 3 would have
+// given are the mirrors of d = 1's; an element written twice is written with the same bits: same products, same order).
+// One wave per workgroup: LDS operations of a wave complete in order, the barriers only pin the compiler's order.
 template <int K>
-__device__ __forceinline__ void unpack_diag(double (&A)[GeoS<K>::NREG])
+__device__ __forceinline__ void slabs_from_acc(const double (&C)[GeoS<K>::NACC], double (&A)[GeoS<K>::NREG], double *buf0, double *buf1, int lane)
 {
     using G = GeoS<K>;
+    constexpr int NT = G::NT;
+    const int i = lane >> 4, b = (lane >> 2) & 3, j = lane & 3;
+    int tix = 0;
 #pragma unroll
-    for (int TI = 0; TI < G::NT; ++TI) {
-        const long long v = __builtin_bit_cast(long long, A[G::reg(4 * TI + 2, TI)]);
-        const int lo = __builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);          // row_ror:8
-        const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), 0x128, 0xF, 0xF, true);
-        A[G::reg(4 * TI + 3, TI)] = __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-    }
+    for (int TI = 0; TI < NT; ++TI)
+#pragma unroll
+        for (int TJ = TI; TJ < NT; ++TJ, ++tix) {
+            double *img = (tix & 1) ? buf1 : buf0;
+#pragma unroll
+            for (int d = 0; d < G::nrot(TI, TJ); ++d) {
+                const int row = 4 * b + i, col = 4 * ((b + d) & 3) + j;
+                const double v = C[G::aoff(TI, TJ) + d];
+                img[row * 16 + col] = v;
+                if (TI == TJ && d > 0) img[col * 16 + row] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 4; ++m) A[G::reg(4 * TI + m, TJ)] = img[(4 * m + i) * 16 + (lane & 15)];
+            __syncthreads();
+        }
 }
 
 // Lambda* (slabs A) and the rhs in, the sample out.  The rhs is PACKED like a slab column: bv[Q], lane
@@ -318,7 +348,6 @@ __device__ __forceinline__ void slab_item(const SampleArgs &a, int w, double *ld
     const int len = (ablate_bits(a) & 2u) ? 0 : a.wi_len[w];             // (profiling switch: no Gram)
     const int mc = a.wi_mc[w];
     const int64_t idx = a.col_from + col;
-    const T *other = reinterpret_cast<const T *>(a.other_items);
 
     stamp(a, w, 0);
     // whole column in one item: its normals do not depend on the Gram -- drawn first, in the shadow of the first loads
@@ -329,22 +358,25 @@ __device__ __forceinline__ void slab_item(const SampleArgs &a, int w, double *ld
     double rsum[NT];                                                  // rr[16 t + li] (all kq)
     {
         static_assert(!F32 && K == 64, "the slab form is the K = 64 fp64 sampler (K = 128 runs k_sample_wg2)");
+        constexpr int NACC = G::NACC;
+        double C[NACC];                                               // Gram accumulators, rotated-block layout (gram_slab)
 #pragma unroll
-        for (int t = 0; t < NREG; ++t) A[t] = 0.0;
+        for (int t = 0; t < NACC; ++t) C[t] = 0.0;
 #pragma unroll
         for (int t = 0; t < NT; ++t) rsum[t] = 0.0;
-        gram_slab<K>(a.rowidx + p0, a.vals + p0, len, a.other_items, a.zero_row, a.mean_rating, a.alpha, A, rsum, lane);
+        gram_slab<K>(a.rowidx + p0, a.vals + p0, len, a.other_items, a.zero_row, a.mean_rating, a.alpha, C, rsum, lane);
         if (mc >= 0) {
-            // chunk of a heavy column: park the slabs; whichever chunk arrives last adds them up (chunk order)
+            // chunk of a heavy column: park the accumulators; whichever chunk arrives last adds them up (chunk order)
             constexpr int PART = G::PART;
+            static_assert(NACC * 64 + NT * 16 <= PART, "partial slot");
             const int nch = a.mc_nchunks[mc];
             double *pbase = a.partials + (size_t)a.mc_slot0[mc] * PART;
             double *p = pbase + (size_t)a.wi_chunk[w] * PART;
 #pragma unroll
-            for (int t = 0; t < NREG; ++t) __hip_atomic_store(&p[t * 64 + lane], A[t], BPMF_RLX_AGENT);
+            for (int t = 0; t < NACC; ++t) __hip_atomic_store(&p[t * 64 + lane], C[t], BPMF_RLX_AGENT);
             if (lane < 16) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) __hip_atomic_store(&p[NREG * 64 + t * 16 + lane], rsum[t], BPMF_RLX_AGENT);
+                for (int t = 0; t < NT; ++t) __hip_atomic_store(&p[NACC * 64 + t * 16 + lane], rsum[t], BPMF_RLX_AGENT);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             unsigned tk = 0;
@@ -353,23 +385,24 @@ __device__ __forceinline__ void slab_item(const SampleArgs &a, int w, double *ld
             if ((int)tk != nch - 1) return;
             if (lane == 0) __hip_atomic_store(&a.mc_count[mc], 0u, BPMF_RLX_AGENT);
 #pragma unroll
-            for (int t = 0; t < NREG; ++t) A[t] = 0.0;
+            for (int t = 0; t < NACC; ++t) C[t] = 0.0;
 #pragma unroll
             for (int t = 0; t < NT; ++t) rsum[t] = 0.0;
             for (int ch = 0; ch < nch; ++ch) {                        // fixed chunk order: deterministic
                 const double *pc = pbase + (size_t)ch * PART;
-                double tmp[NREG];
+                double tmp[NACC];
 #pragma unroll
-                for (int t = 0; t < NREG; ++t) tmp[t] = __hip_atomic_load(&pc[t * 64 + lane], BPMF_RLX_AGENT);
+                for (int t = 0; t < NACC; ++t) tmp[t] = __hip_atomic_load(&pc[t * 64 + lane], BPMF_RLX_AGENT);
 #pragma unroll
-                for (int t = 0; t < NREG; ++t) A[t] += tmp[t];
+                for (int t = 0; t < NACC; ++t) C[t] += tmp[t];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) rsum[t] += __hip_atomic_load(&pc[NREG * 64 + t * 16 + li], BPMF_RLX_AGENT);
+                for (int t = 0; t < NT; ++t) rsum[t] += __hip_atomic_load(&pc[NACC * 64 + t * 16 + li], BPMF_RLX_AGENT);
             }
             draw_normals_deferred<K>(sample_counter(idx, a.ktrue, a.iter_plus_1), a.ktrue, sz, srow, lane, K);
+            __syncthreads();                                          // (the draw parks r2 in srow: done before the images go there)
         }
+        slabs_from_acc<K>(C, A, srow, sw, lane);
     }
-    unpack_diag<K>(A);
 
     stamp(a, w, 2);
     if (ablate_bits(a) & 1u) {                                              // (profiling switch: Gram only -- keep it live)
