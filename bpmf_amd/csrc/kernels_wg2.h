@@ -595,31 +595,66 @@ __device__ __forceinline__ void wg2_column(const SampleArgs &a, int w, unsigned 
     });
     stamp(a, w, 40);
 
-    // ---- y += z (:322); backward solve R x = y (:323) block by block, wave 0: lane (kq, li) = row li, column group kq
+    // ---- y += z (:322); backward solve R x = y (:323), wave 0, COLUMN-ORIENTED (round 6).
+    // Rounds 2-5 formed t_s = sum_{J > s} R_sJ x_J when block s was due: per block step a row of up to 112 products split
+    // over the four lane groups, two cross-lane reductions, t through LDS, then x_s = W_s t -- six dependent LDS round
+    // trips per step on ONE wave with nothing beside it, 9.1 us of a 52 us fp64 item while the workgroup's LDS and its
+    // other waves' slots stay taken.  Here every block keeps its own partial sum: as soon as x_s is known, lane group g
+    // adds R_Is x_s to the sums of its blocks I < s (I = g and I = 4 + g: one 16-term dot product of a row of tile (I, s)
+    // with x_s per lane, 128-bit LDS reads), so that when block s - 1 is due its t is complete in the registers of its
+    // group.  Per step: v_s = y_s + z_s - t_s -> LDS | x_s = W_s v_s (every group, redundantly) -> LDS | the updates: two
+    // LDS round trips and two 8-deep pairs of FMA chains.  The sums run in another order than before (block by block, J
+    // descending): same tolerance class, still one fixed order.
     if (W == 0) {
+        typedef T vec_t __attribute__((ext_vector_type(16 / sizeof(T))));      // 128 bits: 4 floats / 2 doubles
+        constexpr int VN = 16 / sizeof(T), NV = 16 / VN;
+        auto load16 = [&](const T *p, T (&out)[16]) {
 #pragma unroll
-        for (int s = NT - 1; s >= 0; --s) {
-            const T *Rs = R + G::roff(s);
-            const int LDs = G::ld(s), Ws = G::width(s);
-            // (unrolled with compile-time bounds: the LDS reads of a step are issued together; two partial sums halve the chain)
-            T t = 0, t2 = 0;                                          // (fp32 products and sums: half the issue slots of the widened form)
+            for (int q = 0; q < NV; ++q) {
+                const vec_t v = reinterpret_cast<const vec_t *>(p)[q];
 #pragma unroll
-            for (int j = 16; j < Ws; j += 8) {
-                t = fma(Rs[li * LDs + j + kq], xs[16 * s + j + kq], t);
-                if (j + 4 < Ws) t2 = fma(Rs[li * LDs + j + 4 + kq], xs[16 * s + j + 4 + kq], t2);
+                for (int e = 0; e < VN; ++e) out[q * VN + e] = v[e];
             }
-            t += t2;
-            t += __shfl_xor(t, 16);
-            t += __shfl_xor(t, 32);
-            const double tt = (double)bv[16 * s + li] + zs[16 * s + li] - (double)t;
-            if (kq == 0) ts[li] = (T)tt;
+        };
+        // row li of the tiles (I, .) of this lane group's blocks I = kq and I = 4 + kq, as pointers to column block 0
+        const T *row0 = R + G::roff(kq) + li * G::ld(kq) - 16 * kq;
+        const T *row1 = R + G::roff(4 + kq) + li * G::ld(4 + kq) - 16 * (4 + kq);
+        T acc0 = 0, acc1 = 0;
+#pragma unroll 1
+        for (int s = NT - 1; s >= 0; --s) {                           // (rolled: eight unrolled steps hoisted their loads into 256 registers + spills)
+            const T *Rs = R + G::roff(s);
+            const int LDs = G::ld(s);
+            if (kq == (s & 3)) ts[li] = (T)((double)bv[16 * s + li] + zs[16 * s + li] - (double)((s >> 2) ? acc1 : acc0));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            // x_s = W_s t: x_i = sum_k W_s[i][k] t_k = sum_k Wt_s[k][i] t_k
-            T xsum = 0;
+            // x_s = W_s v: x_i = sum_k W_s[i][k] v_k = sum_k Wt_s[k][i] v_k
+            T v[16];
+            load16(ts, v);
+            T xa = 0, xb = 0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) xsum = fma(Rs[k * LDs + li], ts[k], xsum);
+            for (int k = 0; k < 16; k += 2) {
+                xa = fma(Rs[k * LDs + li], v[k], xa);
+                xb = fma(Rs[(k + 1) * LDs + li], v[k + 1], xb);
+            }
+            const T xsum = xa + xb;
             if (kq == 0) xs[16 * s + li] = xsum;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (s > 0) {
+                T xk[16];
+                load16(xs + 16 * s, xk);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    if (4 * m >= s) continue;                         // (wave-uniform: no block of slot m lies above block s)
+                    const bool valid = 4 * m + kq < s;
+                    const T *row = valid ? (m ? row1 : row0) + 16 * s : xs + 16 * s;      // (lanes without a block read x_s itself: in range)
+                    T rr[16];
+                    load16(row, rr);
+                    T da = 0, db = 0;
+#pragma unroll
+                    for (int k = 0; k < 16; k += 2) { da = fma(rr[k], xk[k], da); db = fma(rr[k + 1], xk[k + 1], db); }
+                    const T dsum = valid ? da + db : (T)0;
+                    if (m) acc1 += dsum; else acc0 += dsum;
+                }
+            }
         }
         T *dst = reinterpret_cast<T *>(a.items) + (size_t)idx * K;                 // items().col(idx) = rr (:324)
         bool nf = false;
