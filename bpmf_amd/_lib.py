@@ -29,6 +29,7 @@ _SIGNATURES = {
     "bpmf_hip_comm_unique_id": (C.c_int, [C.c_void_p]),
     "bpmf_hip_ctx_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "bpmf_hip_ctx_comm_nranks": (C.c_int, [C.c_void_p]),
+    "bpmf_hip_ctx_comm_streams": (C.c_int, [C.c_void_p]),
     "bpmf_hip_side_set_ranges": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bpmf_hip_side_set_overlap": (C.c_int, [C.c_void_p, C.c_int]),
     "bpmf_hip_side_set_staleness": (C.c_int, [C.c_void_p, C.c_int]),

@@ -1523,7 +1523,7 @@ __global__ __launch_bounds__(256) void k_unpack_cols(const double *__restrict__ 
 // block copies the blob into device memory.  The poll gives up after `wait_ticks` of wall clock
 // (default 20 s; host gone or descheduled): it then sets the side's sticky time-out word, the sampler
 // behind it runs on whatever the blob holds, and the host side discards that half-iteration with
-// BPMF_HIP_ENODEV "device wait timed out" (collect() in capi.hip).
+// BPMF_HIP_ENODEV "device wait timed out" (collect() in capi_sample.hip).
 __device__ __forceinline__ void gate_stage_body(int block, int nblocks, const unsigned *gate_host, unsigned want, const double *src_host,
                                                 double *__restrict__ dst, int n, unsigned *dflag, unsigned dval,
                                                 unsigned long long *tmo, unsigned long long wait_ticks)

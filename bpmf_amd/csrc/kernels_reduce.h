@@ -11,7 +11,7 @@
 // accumulator layout of the 16x16x4 f64 MFMA followed by the rhs sums -- the very partial a chunk of a heavy column
 // writes in k_sample (kernels.h), so the sampler below is k_sample with "load the partial" in place of the Gram.
 //   k_precompute<K>:  one wave per column j of O, over the TRANSPOSE of this rank's block of S's ratings (built once
-//                     by the host: capi.hip set_reduce), longest columns first
+//                     by the host: capi_comm.hip set_reduce), longest columns first
 //   k_sample_prec<K>: persistent waves, C = 64 / K columns factorised side by side (deposit_column + finish_slots)
 #pragma once
 #include "kernels.h"

@@ -1,4 +1,4 @@
-// launch.h -- what capi.hip needs from the translation units that hold the kernels.  The templates
+// launch.h -- what the C ABI (capi_*.hip) needs from the translation units that hold the kernels.  The templates
 // are defined in launch_impl.h and explicitly instantiated one K per file (k8.hip ... k128.hip), so
 // that the five instantiations of the sampler compile side by side (make -j).
 #pragma once

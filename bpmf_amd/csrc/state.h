@@ -1,4 +1,4 @@
-// state.h -- host-side state behind the opaque handles of include/bpmf_hip.h, shared by capi.hip
+// state.h -- host-side state behind the opaque handles of include/bpmf_hip.h, shared by capi_*.hip
 // (the C ABI) and the per-K launch units (k8.hip ... k128.hip, kcommon.hip).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -99,13 +99,13 @@ struct Rccl {
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclReduce) Reduce = nullptr;             // optional (BPMF_REDUCE formulation: the parts of a side's Gram onto the owners)
     decltype(&ncclCommCount) CommCount = nullptr;       // optional (bpmf_hip_ctx_comm_nranks)
-    decltype(&ncclCommAbort) CommAbort = nullptr;       // optional (a collective that never completes: comm_abort in capi.hip)
+    decltype(&ncclCommAbort) CommAbort = nullptr;       // optional (a collective that never completes: comm_abort in capi_context.hip)
 };
 
-Rccl *rccl();      // capi.hip
+Rccl *rccl();      // capi_context.hip
 
 // Every path that would enqueue a collective asks first: after a timed-out collective the communicators were aborted
-// (capi.hip comm_abort) and their handles must not be used again -- the call fails with BPMF_HIP_ENODEV instead.
+// (capi_context.hip comm_abort) and their handles must not be used again -- the call fails with BPMF_HIP_ENODEV instead.
 #define COMM_ALIVE_OR_FAIL(ctx_, who_)                                                                         \
     do {                                                                                                       \
         if ((ctx_)->comm_dead.load(std::memory_order_acquire))                                                 \
@@ -169,7 +169,7 @@ struct bpmf_hip_ctx {
     // two collectives on ONE communicator could not do.  NULL: everything on the main stream.
     ncclComm_t comm2 = nullptr;
     // A collective whose peer never shows up would hold this rank for ever: every host-side wait on a stream that may carry
-    // one is bounded (BPMF_HIP_COMM_TIMEOUT_MS, default 60 s; bounded_stream_sync / bounded_event_sync in capi.hip); when it
+    // one is bounded (BPMF_HIP_COMM_TIMEOUT_MS, default 60 s; bounded_stream_sync / bounded_event_sync in capi_context.hip); when it
     // runs out both communicators are aborted (ncclCommAbort), the context is dead for collectives and every later call that
     // needs them fails with BPMF_HIP_ENODEV -- the reference's MPI_ERRORS_ARE_FATAL / SUCCESS_OR_DIE (c++/mpi_common.h:16,
     // c++/bpmf_gaspi.h:26-64) as an error code instead of a hang.

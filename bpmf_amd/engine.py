@@ -72,6 +72,10 @@ class HipEngine:
         _lib.check(self.lib.bpmf_hip_ctx_comm_init(self.ctx, int(nranks), int(rank), buf))
         self.nranks, self.rank = int(nranks), int(rank)
 
+    def comm_streams(self):
+        """0 = no communicator, 1 = one, 2 = a second one split off for the statistics / evaluation streams (ncclCommSplit)"""
+        return int(self.lib.bpmf_hip_ctx_comm_streams(self.ctx))
+
     def comm_nranks(self):
         """Ranks of the communicator as the communication library counts them (1 without one)."""
         return int(self.lib.bpmf_hip_ctx_comm_nranks(self.ctx))

@@ -111,6 +111,12 @@ BPMF_API int bpmf_hip_ctx_comm_init(bpmf_hip_ctx *ctx, int nranks, int rank, con
 /* ranks of the context's communicator as the communication library itself counts them (ncclCommCount); 1 without one.
  * What `nprocs` is to the reference (Sys::nprocs, c++/mpi_common.h:14-22): reports print it next to the numbers. */
 BPMF_API int bpmf_hip_ctx_comm_nranks(const bpmf_hip_ctx *ctx);
+/* communicators the context holds: 0 = none (single GPU), 1 = one (exchange and statistics on the main stream), 2 = a second one
+ * was split off with ncclCommSplit for the statistics / evaluation streams (the default where the library offers it;
+ * BPMF_HIP_COMM_STREAMS=1 keeps one).  The reference's back-ends have one MPI_COMM_WORLD (c++/mpi_common.h:44-50); what
+ * the second communicator stands for is their second thread of progress (c++/mpi_isendirecv.h:222-260).  A run reports it
+ * so that a silent fall-back to one communicator (ncclCommSplit refused) shows. */
+BPMF_API int bpmf_hip_ctx_comm_streams(const bpmf_hip_ctx *ctx);
 BPMF_API int bpmf_hip_side_set_ranges(bpmf_hip_side *side, const int64_t *bounds);
 /* Overlap of exchange and sampling, the job of the reference's MPI_ISEND back-end (chunks of 100 fresh items are sent
  * while the next ones are sampled, c++/mpi_isendirecv.h:13-14,222-260): every rank's column range is cut into `nparts`
@@ -312,7 +318,7 @@ BPMF_API int bpmf_hip_randn_stream(bpmf_hip_ctx *ctx, uint32_t counter, int n, d
 
 /* Reporting (the reference's counters.cpp / measure_perf hooks have no numeric equivalent; these serve bench.py):
  * the kernel(s) a sampler launch of this side consists of, by name, as a profile shows them; and the side's static
- * schedule in numbers (16 words, see capi.hip: form, work items, chunks, columns per product-form class ...). */
+ * schedule in numbers (16 words, see capi_side.hip: form, work items, chunks, columns per product-form class ...). */
 BPMF_API int bpmf_hip_side_kernel_name(const bpmf_hip_side *side, char *buf, int n);
 /* LDS / register budget and residency of the kernel(s) of one sampler launch of the side (what `LDS occupancy on the Cholesky`
  * of the north star is computed from): per kernel 4 words in `out` -- static LDS bytes per workgroup, threads per workgroup,

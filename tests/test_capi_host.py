@@ -114,11 +114,11 @@ def test_hyper_sample_rejects_bad_arguments():
 
 def test_rccl_double_exports_what_the_library_resolves():
     """tests/rccl_double/librccl_double.so (test infrastructure for ranks that share a GPU, built by build()) must offer
-    every nccl* entry point capi.hip's rccl() looks up; loading it needs no GPU."""
+    every nccl* entry point rccl() (capi_context.hip) looks up; loading it needs no GPU."""
     path = os.path.join(ROOT, "tests", "rccl_double", "librccl_double.so")
     assert os.path.exists(path), "run __graft_entry__.build()"
     lib = C.CDLL(path)
-    src = open(os.path.join(ROOT, "bpmf_amd", "csrc", "capi.hip")).read()
+    src = open(os.path.join(ROOT, "bpmf_amd", "csrc", "capi_context.hip")).read()
     wanted = set(re.findall(r"BPMF_SYM\((\w+)\)", src)) - {"f"}
     assert {"GetUniqueId", "CommInitRank", "Send", "Recv", "AllReduce", "Reduce", "CommSplit", "CommCount"} <= wanted
     for name in wanted:

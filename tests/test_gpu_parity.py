@@ -626,6 +626,24 @@ def test_sharded_parts_single_rank(K):
     assert r.returncode == 0 and "PARTS-OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
 
 
+@pytest.mark.parametrize("streams", [2, 1])
+def test_real_rccl_split_parts_and_packed_lists_single_rank(streams):
+    """The REAL librccl, one rank: second communicator from ncclCommSplit (reported by bpmf_hip_ctx_comm_streams), exchanges cut
+    into four parts AND routed through the packed connectivity lists at once, in the pipelined loop with the twin evaluation:
+    the NO_COMM chain bit for bit (tests/_rccl1_worker.py).  streams = 1: BPMF_HIP_COMM_STREAMS=1, one communicator."""
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("BPMF_HIP_RCCL_LIBRARY", None)                            # the real library, not the tests' double
+    if streams == 1:
+        env["BPMF_HIP_COMM_STREAMS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl1_worker.py"), "32"], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL1-OK streams=%d" % streams in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
 @pytest.mark.parametrize("K", [16, 32, 64])
 def test_propagated_posterior_priors(oracle, hip_engine_factory, K, sampler_mode):
     _one_form_only(K, sampler_mode)

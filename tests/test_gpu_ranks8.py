@@ -21,7 +21,7 @@ from tests.test_gpu_multirank import DOUBLE, rel_err, run_ranks
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mode", ["async"])
+@pytest.mark.parametrize("mode", ["sync", "async"])
 def test_eight_ranks_strong_scaling_shape_matches_the_oracle(oracle, tmp_path, mode):
     """bench.py::strong_10Mx1M's set-up at scale 0.002 (20 000 users x 2 000 items x 200 per user = 4 M ratings, K = 32): rank r
     of 8 holds user chunk r and item range r, every exchange cut into 4 parts (BPMF_HIP_OVERLAP=4).  Every replica must hold

@@ -49,7 +49,8 @@ if [ "$PMC" = "1" ]; then
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM"; do
   rm -rf /tmp/prof_pmc; rocprofv3 --pmc $c --kernel-trace -d /tmp/prof_pmc -o p -- $PENV $PCMD > /dev/null 2> /tmp/prof_pmc.err
   DB=$(find /tmp/prof_pmc -name "*.db" | head -1)
-  python tools/pmc_dump.py "$DB" pmc "$PAT" >> $O/${R}_pmc_$W.txt
+  BYG=""; [ "$W" = "strong_10Mx1M" ] && BYG="bygrid"
+  python tools/pmc_dump.py "$DB" pmc "$PAT" $BYG >> $O/${R}_pmc_$W.txt
 done
 cat $O/${R}_pmc_$W.txt
 fi
