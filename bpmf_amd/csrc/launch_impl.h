@@ -133,7 +133,11 @@ int exchange(bpmf_hip_side *self, hipStream_t st, int sub)
         // connectivity-aware form (c++/assign.cpp:204-241 conn_map + send_item, c++/sample.cpp:370): a column
         // only travels to the ranks whose ratings / test entries reference it.  Pack the columns of
         // every peer's list into one buffer, one grouped send / receive per peer, scatter what arrived.
-        if (sub > 0) return 0;                                      // (not cut into parts: everything goes with part 0)
+        // Not cut into parts: the lists name columns of the whole range, so everything travels behind the LAST part -- the
+        // exchange stream has then waited for every part's sampler.  (Rounds 3-5 sent it with part 0, i.e. while the parts
+        // 1 .. n - 1 were still being sampled: stale columns to the peers and, at one rank, the scatter racing the samplers.
+        // The combination parts + lists had no test; tests/_rccl1_worker.py is it, round 6.)
+        if (sub >= 0 && self->nsub > 1 && sub != self->nsub - 1) return 0;
         const int64_t ns = self->conn_send_ptr.back(), nr = self->conn_recv_ptr.back();
         constexpr int P = K / 2;                                   // 16-byte pieces per column
         if (ns > 0)
