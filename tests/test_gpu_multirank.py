@@ -131,10 +131,13 @@ def test_auto_overlap_decision_is_rank_invariant(oracle, tmp_path):
     check_against_oracle(oracle, res, "ml100k", 16, nsims, burnin)
 
 
-def test_connectivity_lists_between_ranks(oracle, tmp_path):
-    """k_pack_cols -> grouped send / recv per peer -> k_unpack_cols between DIFFERENT ranks (c++/assign.cpp:204-241)."""
+@pytest.mark.parametrize("parts", [1, 3])
+def test_connectivity_lists_between_ranks(oracle, tmp_path, parts):
+    """k_pack_cols -> grouped send / recv per peer -> k_unpack_cols between DIFFERENT ranks (c++/assign.cpp:204-241).
+    parts = 3 (round 6): the side is ALSO sampled in three parts -- the packed lists are not cut, they must travel behind the
+    last part (until round 6 they went with part 0: the peers received the previous iteration's columns of parts 1, 2)."""
     nsims, burnin = 4, 1
-    res = run_ranks(tmp_path, 2, "conn", "blocks", 32, nsims, burnin)
+    res = run_ranks(tmp_path, 2, "conn", "blocks", 32, nsims, burnin, {"BPMF_HIP_OVERLAP": str(parts)} if parts > 1 else None)
     for r in res:
         assert r["conn_used"].all()
     check_against_oracle(oracle, res, "blocks", 32, nsims, burnin, owned_only=True)
