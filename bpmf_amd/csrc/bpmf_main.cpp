@@ -555,8 +555,12 @@ int main(int argc, char *argv[])
         return *files[(size_t)r];
     };
     if (to_files) for (int r = 0; r < J.nranks; ++r) {
-        files.emplace_back(new std::ofstream("bpmf_" + std::to_string(r) + ".out"));
-        g_rank_files.push_back("bpmf_" + std::to_string(r) + ".out");
+        // emptied, then opened in APPEND mode: die() adds its line through a descriptor of its own (O_APPEND), and a rank thread
+        // that writes its next line afterwards must append behind it, not overwrite it at its own file offset
+        const std::string name = "bpmf_" + std::to_string(r) + ".out";
+        { std::ofstream empty(name, std::ios::out | std::ios::trunc); }
+        files.emplace_back(new std::ofstream(name, std::ios::out | std::ios::app));
+        g_rank_files.push_back(name);
     }
 
     if (J.nranks == 1) {

@@ -168,6 +168,12 @@ class HipEngine:
         self.bind_items(side, t.data_ptr(), keep=t, ld=ld, nbytes=t.numel() * 8)
         return t
 
+    def factors_view(self, t):
+        """The num_latent factor rows of a tensor items_tensor() returned: t[:, :K].  WRITE through this view, never through the
+        whole tensor: with a padded num_latent (20 on the K = 32 kernels) the rows K .. ld()-1 of every column must stay zero --
+        the kernels read them as factor entries (`U.copy_(randn(U.shape))` filled them)."""
+        return t[:, :self.K]
+
     def set_prop_posterior(self, side, Lambda):
         """Per-column prior precisions of the side's local columns: [ncols_local, K*K] (each row a
         column-major K x K matrix, as in *-Lambda.ddm), or None to remove them."""

@@ -54,8 +54,8 @@ def main():
     movies = eng.side_create_dev(big.NI, big.NU, mcp, mri.data_ptr(), mva.data_ptr(), big.mean_rating, col_from=i0, col_to=i1, keep=(mri, mva))
     U = eng.items_tensor(users, dev); V = eng.items_tensor(movies, dev)
     g = torch.Generator(device=dev); g.manual_seed(7)
-    U.copy_(0.3 * torch.randn(U.shape, generator=g, device=dev, dtype=torch.float64))
-    V.copy_(0.3 * torch.randn(V.shape, generator=g, device=dev, dtype=torch.float64))
+    eng.factors_view(U).copy_(0.3 * torch.randn((U.shape[0], K), generator=g, device=dev, dtype=torch.float64))      # (never the padding rows)
+    eng.factors_view(V).copy_(0.3 * torch.randn((V.shape[0], K), generator=g, device=dev, dtype=torch.float64))
     U0 = U[:u0].clone() if u0 > 0 else None
     rng = np.random.default_rng(3)
     A = rng.standard_normal((K, 3 * K)); cov = A @ A.T / (3 * K) * 0.5

@@ -4,6 +4,8 @@ flops / bytes per launch) and diffs it with the figure bench.py printed from its
 import importlib.util
 import os
 
+import pytest
+
 from tests.conftest import ROOT
 
 
@@ -34,3 +36,27 @@ def test_kernel_name_normalisation():
     assert m.norm("void bpmf::k_sample_pf<64, 3>(bpmf::LrArgs)") == "k_sample_pf<64,3>"
     assert m.norm("k_sample_wg2<128,4,double>") == "k_sample_wg2<128,4,double>"
     assert m.norm("void bpmf::k_sample_wg2<128, 2, float>(bpmf::SampleArgs, bpmf::StatRiders)") == "k_sample_wg2<128,2>"
+
+
+def test_experiment_patches_apply(tmp_path):
+    """tools/patches/*.patch (the kernel variants behind docs/FINDINGS.md 17-19) must apply to the revision each one names in its
+    `# base:` line -- what tools/patches/apply.py checks out before patching (two of the three had stopped applying
+    to HEAD and nothing noticed).  Needs the git history; skipped in an export without it."""
+    import glob
+    import re
+    import subprocess
+    patches = sorted(glob.glob(os.path.join(ROOT, "tools", "patches", "*.patch")))
+    assert patches
+    if subprocess.run(["git", "-C", ROOT, "rev-parse", "--git-dir"], capture_output=True).returncode != 0:
+        pytest.skip("no git history here")
+    for p in patches:
+        m = re.match(r"# base:\s*([0-9a-f]+)", open(p).readline())
+        assert m, "%s does not name its base revision" % p
+        if subprocess.run(["git", "-C", ROOT, "cat-file", "-e", m.group(1) + "^{commit}"], capture_output=True).returncode != 0:
+            pytest.skip("base revision %s is not in this clone" % m.group(1))
+        d = tmp_path / os.path.basename(p)
+        d.mkdir()
+        tar = subprocess.run(["git", "-C", ROOT, "archive", m.group(1), "bpmf_amd/csrc", "include"], capture_output=True, check=True).stdout
+        subprocess.run(["tar", "-x", "-C", str(d)], input=tar, check=True)
+        r = subprocess.run(["patch", "-p1", "--dry-run", "-d", str(d), "-i", p], capture_output=True, text=True)
+        assert r.returncode == 0, (p, r.stdout[-600:])

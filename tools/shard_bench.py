@@ -92,8 +92,8 @@ users = eng.side_create_dev(NU, NI, u_colptr, u_rowidx.data_ptr(), u_vals.data_p
 movies = eng.side_create_dev(NI, NU, m_colptr, m_rowidx.data_ptr(), m_vals.data_ptr(), mean, col_from=i0, col_to=i1, keep=(m_rowidx, m_vals))
 U = eng.items_tensor(users, dev); V = eng.items_tensor(movies, dev)
 g = torch.Generator(device=dev); g.manual_seed(7)
-U.copy_(0.3 * torch.randn(U.shape, generator=g, device=dev, dtype=torch.float64))
-V.copy_(0.3 * torch.randn(V.shape, generator=g, device=dev, dtype=torch.float64))
+eng.factors_view(U).copy_(0.3 * torch.randn((U.shape[0], K), generator=g, device=dev, dtype=torch.float64))      # (never the padding rows)
+eng.factors_view(V).copy_(0.3 * torch.randn((V.shape[0], K), generator=g, device=dev, dtype=torch.float64))
 torch.cuda.synchronize()
 print("sides created (schedules built) in %.1f s" % (time.time() - t1), flush=True)
 
