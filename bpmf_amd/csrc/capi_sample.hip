@@ -416,7 +416,7 @@ int ensure_state(bpmf_hip_side *s)
     HIP_TRY(hipMalloc((void **)&s->a_dflag, 64));
     HIP_TRY(hipMemset(s->a_dflag, 0, 64));
     HIP_TRY(hipMalloc((void **)&s->a_d_red, (c->out_words + 8) * sizeof(double)));
-    static const unsigned evflags = env_int("BPMF_HIP_EVENT_FENCE", 0) ? 0u : hipEventDisableSystemFence;
+    static const unsigned evflags = hipEventDisableSystemFence;
     for (auto &set : s->evs) for (hipEvent_t &e : set) HIP_TRY(hipEventCreateWithFlags(&e, evflags));
     int lo = 0, hi = 0;                                              // numerically lowest = most urgent
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -795,7 +795,7 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     // 4 n-th from then on.
     static const int every = env_int("BPMF_HIP_TIMING_EVERY", 8);
     const bool timed = every > 0 && seq % (unsigned)(seq <= 64u ? every : 4 * every) == 0;
-    const bool ride = s1 != s0 && self->nwork > 0 && env_int("BPMF_HIP_EXT_EVENTS", 1) != 0;   // events on the sampler's own packet
+    const bool ride = s1 != s0 && self->nwork > 0;   // events on the sampler's own packet
     if (timed && !ride) HIP_TRY(hipEventRecord(ev[0], s0));
     self->cur_fused = fz;
     self->cur_riders = riders;
@@ -809,7 +809,7 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
     if (rc) return rc;
     if (!ride) HIP_TRY(hipEventRecord(ev[1], s0));
     // an evaluation requested next waits for this: no marker of its own on S0
-    c->last_sampler_done = (env_int("BPMF_HIP_EVAL_MARKER", 0) == 0) ? ev[1] : nullptr;
+    c->last_sampler_done = ev[1];
     if (carry) {                                                      // P's statistics are inside this launch: complete behind ev[1]
         P->stats_ev[c->pending_evset].store(ev[1], std::memory_order_release);
         c->pending_stats = nullptr;
@@ -842,7 +842,7 @@ extern "C" int bpmf_hip_sys_sample(bpmf_hip_side *self, bpmf_hip_side *other, do
         // in the same queue as that sampler, wins by the ~6 us of the cross-queue hop.  S0 therefore waits for a marker
         // S1 passes just ahead of the statistics kernel: the pass (0.1 ms alone) starts a hop ahead of the sampler, keeps
         // its slots, and the side's host chain is done before the partner's sampler is.
-        static const int head_start = env_int("BPMF_HIP_STATS_HEADSTART", 1);
+        constexpr int head_start = 1;
         // (fp32 path: 1 152 single-wave tile workgroups, same reasoning: 0.84 -> 0.81 ms.  NOT the fp64 form of K = 128 -- round 4,
         //  interleaved: 1.383 / 1.392 ms without the head start against 1.404 / 1.408 with it: its 22-us pass finds room anyway)
         if (head_start && sst != s0 && !dist && (self->nstat_wg > 0 || (K == 128 && c->dtype == BPMF_HIP_F32))) {

@@ -58,7 +58,7 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     // whole columns overtook them and every launch ended on the heavy columns' last arrivers.  Round 3, ML-1M shape:
     // K = 64 0.3645 -> 0.3045 ms per iteration, K = 128 0.822 -> 0.752, K = 32 0.0993 -> 0.0985; ChEMBL shape
     // 1.065 -> 1.031.  Flat between 1 and ~K^2 / 16; chunks ahead of ALL whole columns measured the same.
-    const int64_t fin_cost = env_int("BPMF_HIP_FINCOST", 0) > 0 ? env_int("BPMF_HIP_FINCOST", 0) : 32;     // (BPMF_HIP_FINCOST: experiments)
+    const int64_t fin_cost = 32;
     int32_t slots = 0;
     for (int64_t c = 0; c < nloc; ++c) {
         const int64_t p0 = colptr[c], n = colptr[c + 1] - colptr[c];
@@ -173,10 +173,8 @@ int build_schedule(bpmf_hip_side *s, const int64_t *colptr)
     // rider -- every rider is a wave slot the launch's first items do not get (ML-1M shape: 24-40 riders 0.0996 ms per
     // iteration, 189 / 116 riders 0.1011, 16: 0.107)
     if (nloc < 20000) s->nstat_waves = (int)std::max<int64_t>(1, std::min<int64_t>(s->nstat_waves, std::max<int64_t>((nloc + 159) / 160, 24)));
-    // (experiments)
-    if (env_int("BPMF_HIP_NSTAT", 0) > 0) s->nstat_waves = (int)std::min<int64_t>(env_int("BPMF_HIP_NSTAT", 0), std::max<int64_t>(1, (nloc + 31) / 32));
     // big sides: four-wave workgroups with a finisher that reads the partials contiguously (k_colstats_wg)
-    s->nstat_wg = (nloc > 100000 && env_int("BPMF_HIP_STATS_WG", 1) != 0) ? (int)std::min<int64_t>((nloc + 127) / 128, (int64_t)s->ctx->num_cu * 2) : 0;
+    s->nstat_wg = (nloc > 100000) ? (int)std::min<int64_t>((nloc + 127) / 128, (int64_t)s->ctx->num_cu * 2) : 0;
     if ((rc = dev_upload<double>(&s->d_stat_partials, nullptr, (size_t)std::max(s->nstat_waves, 2 * s->nstat_wg) * pw))) return rc;
     return 0;
 }
