@@ -1189,7 +1189,8 @@ def run(args, wl, R, wd):
         out["bpmf_exe"] = bpmf_exe_record(M, T, nusers, nmovies, K, nsims=400)      # (0.1 ms per iteration: a 25-iteration run is all start-up)
         if out["bpmf_exe"].get("steady_items_per_s"):
             out["bpmf_exe"]["over_python_host"] = out["bpmf_exe"]["steady_items_per_s"] / out["value"]
-    if rank == 0 and world == 1 and wl == "ml1m" and not args.no_configs and args.ablate is None:
+    # (a run without the CPU leg is a development / test run: no configs legs either -- their parity objects need the oracle's chain)
+    if rank == 0 and world == 1 and wl == "ml1m" and not args.no_configs and not args.no_cpu_baseline and args.ablate is None:
         # every other single-GPU configuration of BASELINE.json in the SAME line: driver-timed, not builder-run
         out["configs"] = {}
         leg_limit = float(os.environ.get("BPMF_BENCH_CONFIG_LEG_TIMEOUT_S", "150"))

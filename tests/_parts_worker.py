@@ -49,7 +49,7 @@ def main():
 
     base = run(False, 1)
     assert np.all(np.isfinite(base[1])) and np.all(np.isfinite(base[2]))
-    for parts in (1, 2, 3, 4, 8):
+    for parts in (1, 3, 8):                                          # (2 and 4 parts: tests/_rccl1_worker.py, tests/test_gpu_multirank.py)
         got = run(True, parts)
         for a, b in zip(base, got):
             assert np.array_equal(np.asarray(a), np.asarray(b)), "sharded chain with %d part(s) differs from the plain one" % parts

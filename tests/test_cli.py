@@ -228,7 +228,7 @@ def test_cpp_host_keeps_up_with_the_python_host():
     17 % behind: a bpmf_hip_sys_state per iteration drained the pipeline; bpmf_hip_sys_norm does not)."""
     import json
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "200", "--warmup", "20", "--no-strong", "--no-cpu-baseline"], cwd=ROOT,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "200", "--warmup", "20", "--repeats", "5", "--no-strong", "--no-cpu-baseline"], cwd=ROOT,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
