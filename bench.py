@@ -149,6 +149,8 @@ def issue_bound(workload, launch_s, num_cu=256):
     from the per-launch counters of the committed PMC pass, over the measured launch time.  SQ_INSTS_VALU counts the MFMAs too
     (checked against the static ISA of the Gram loop: 86 VALU + 144 MFMA per 64 ratings), so they are taken out of it; f64
     MFMA and VALU issue add on a SIMD.  Counters of a profile of OTHER kernel sources are history: null."""
+    if workload == "chembl":
+        return None                       # (six sampler kernels per iteration: the per-launch averages of the PMC file mix them; profiles/r*_pmc_by_kernel_chembl.txt)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.txt" % workload)))
     if not files:
         return None
@@ -731,7 +733,7 @@ def config_leg(name, what, steps, warmup, limit_s):
            "kernel_per_side": rf.get("kernel_per_side"),
            "launch_us_per_side": {k: v * 1e3 for k, v in (rf.get("launch_ms_per_side") or {}).items()},
            "roofline": {k: rf.get(k) for k in ("bound", "frac", "achieved", "peak", "unit", "traffic", "hbm_frac", "hbm_frac_per_side",
-                                               "executed_flops_per_launch", "algorithmic_bytes_per_launch", "issue_bound") if k in rf},
+                                               "executed_flops_per_launch", "algorithmic_bytes_per_launch", "issue_bound", "mfma_shape") if k in rf},
            "rmse": c.get("rmse"), "workload": c.get("config", {}).get("workload"),
            "wall_s": time.perf_counter() - t0}
     if par.get("ok") is not None:
@@ -1066,6 +1068,13 @@ def run(args, wl, R, wd):
                 "kernel_source_sha": src_sha}
     if world == 1:
         roofline["issue_bound"] = issue_bound(wl, launch_s, getattr(eng, "num_cu", 256))
+    # The ceiling of the MFMA SHAPE the sampler's Gram is built from, measured chip-wide on this hardware
+    # (tools/probes/mfma_shapes_probe.hip -> profiles/r05_mfma_shapes_probe.txt): the data-sheet peak (78.6 / 157.3 TF) is what `frac`
+    # is quoted against, but v_mfma_f64_16x16x4 sustains 48.4 TF and v_mfma_f32_16x16x4 138.7 TF whatever feeds them
+    shape = {"ml1m": ("v_mfma_f64_4x4x4_4b_f64", 68.9), "ml1m_k64": ("v_mfma_f64_4x4x4_4b_f64", 68.9), "chembl": ("v_mfma_f64_4x4x4_4b_f64", 68.9),
+             "ml1m_k128": ("v_mfma_f32_16x16x4_f32", 138.7), "ml1m_k128_f64": ("v_mfma_f64_16x16x4_f64", 48.4), "ml1m_k100": ("v_mfma_f64_16x16x4_f64", 48.4)}[wl]
+    roofline["mfma_shape"] = {"instruction": shape[0], "measured_peak_tflops": shape[1], "frac_of_shape_peak": tflops / shape[1],
+                              "source": "profiles/r05_mfma_shapes_probe.txt"}
     if abs(flops_launch - flops_alg) > 1e-6 * flops_alg:
         # Columns in the product form (ChEMBL shape) are never factorised, so neither flop count is a SURVEY 8(d) quantity of
         # what runs: the roofline of this workload is stated in 8(d) BYTES (the compounds side streams Q rows, ratings and
