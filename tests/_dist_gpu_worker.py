@@ -25,6 +25,13 @@ def main():
     comm = TorchComm(torch.device("cuda", 0))
     eng = bpmf_amd.HipEngine(K, device=0)
     res = gibbs_sharded(eng, comm, M, Mt, T, nu, nm, nsims=nsims, burnin=burnin)
+    # the tensors TorchComm bound (HipEngine.items_tensor: [ncols, ld()]): with a padded num_latent (K = 20 on the K = 32 kernels) the
+    # rows K .. ld()-1 of every column must still be zero after the run -- samplers, exchanges and every writer that went through
+    # factors_view() leave them alone (writing randn(t.shape) into the whole tensor fed non-zero padding to the kernels)
+    for t, _, _ in comm._items.values():
+        assert tuple(t.shape)[1] == eng.ld() and tuple(eng.factors_view(t).shape)[1] == K
+        assert not bool(t[:, K:].any()), "padding rows of a bound factor tensor were written"
+        assert bool(eng.factors_view(t).any())
     np.savez(out + ".rank%d.npz" % comm.rank, U=res["U"], V=res["V"], rmse=res["rmse"], rmse_avg=res["rmse_avg"],
              norm_u=res["norm_u"], norm_m=res["norm_m"], final=res["final_rmse_avg"], conn_used=np.asarray(res["conn_used"]),
              dom_m=np.asarray(res["dom_m"]), dom_u=np.asarray(res["dom_u"]))

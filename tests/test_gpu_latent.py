@@ -194,35 +194,3 @@ def test_bind_items_refuses_storage_with_the_callers_leading_dimension():
         if dev.value:
             hip.hipFree(dev)
 
-
-def test_items_tensor_is_written_through_the_factors_view(oracle):
-    """HipEngine.items_tensor at a padded num_latent (20 on the K = 32 kernels): the tensor a caller gets is [ncols, 32] -- what
-    RCCL / torch collectives move --, the factors are factors_view(t) = t[:, :20] and that is where a caller writes.  Random
-    factors through the view: the padding rows stay zero and a half-iteration against them is the oracle's (writing
-    randn(t.shape) into the whole tensor fed 12 non-zero padding rows per column to kernels that read them as factor entries)."""
-    import torch
-    import bpmf_amd
-    K = 20
-    M, Mt, T, Tt, nu, nm = util.ml100k()
-    eng = bpmf_amd.HipEngine(K)
-    try:
-        dev = torch.device("cuda", 0)
-        mean = util.mean_rating(M)
-        movies = eng.side_create(nm, nu, *M, mean)
-        users = eng.side_create(nu, nm, np.zeros(nu + 1, np.int64), np.zeros(0, np.int32), np.zeros(0), 0.0)
-        Ut = eng.items_tensor(users, dev)
-        assert tuple(Ut.shape) == (nu, 32) and tuple(eng.factors_view(Ut).shape) == (nu, K)
-        g = torch.Generator(device=dev); g.manual_seed(3)
-        eng.factors_view(Ut).copy_(0.3 * torch.randn((nu, K), generator=g, device=dev, dtype=torch.float64))
-        torch.cuda.synchronize()
-        assert not bool(Ut[:, K:].any())
-        U = eng.factors_view(Ut).cpu().numpy()
-        assert np.array_equal(eng.get_items(users), U)
-        mu, LU, LF = oracle.hyper_sample(K, nm, _cov(K, 2), 4)
-        ref = np.zeros((nm, K))
-        sr = oracle.sample_side(K, M, mean, 2.0, U, ref, 4, mu, LF, nthreads=NT)
-        s = eng.sample_side(movies, users, 4, 2.0, mu, LF)
-        check_half_iteration((eng.get_items(movies),) + tuple(s), (ref,) + tuple(sr))
-        eng.side_destroy(movies); eng.side_destroy(users)
-    finally:
-        eng.close()

@@ -40,7 +40,7 @@ def double_mode(request, monkeypatch):
         if request.param == "async":
             pytest.skip("synchronous mode only")
     elif request.param == "sync" and request.node.name.startswith(("test_bench_", "test_bpmf_g2", "test_bounded_staleness_exchange", "test_fp32_context",
-                                                                 "test_reduce_formulation", "test_connectivity_lists", "test_auto_overlap")):
+                                                                 "test_reduce_formulation", "test_connectivity_lists", "test_auto_overlap", "test_bounded_staleness_replica_age")):
         pytest.skip("asynchronous mode only (the mesh / parts / replica-age tests keep both modes)")
     if request.param == "async":
         monkeypatch.setenv("BPMF_RCCL_DOUBLE_ASYNC", "1")
@@ -107,16 +107,20 @@ def check_against_oracle(oracle, res, dataset, K, nsims, burnin, tol=1e-7, owned
     (2, 32, {"BPMF_HIP_COMM_STREAMS": "1"}),              # one communicator: statistics all-reduce on the main stream
     (2, 64, {}),                                           # slab form, unfused (sharded) launch
 ])
-def test_mesh_exchange_between_two_ranks(oracle, tmp_path, nranks, K, env):
+def test_mesh_exchange_between_two_ranks(oracle, tmp_path, nranks, K, env, double_mode):
+    if double_mode == "sync" and (env or K == 64):
+        pytest.skip("asynchronous mode only (both modes: the default exchange with 2 and with 3 ranks)")
     nsims, burnin = 4, 1
     res = run_ranks(tmp_path, nranks, "mesh", "ml100k", K, nsims, burnin, env)
     check_against_oracle(oracle, res, "ml100k", K, nsims, burnin)
 
 
 @pytest.mark.parametrize("nranks,parts", [(2, 2), (2, 4), (3, 3)])
-def test_parts_overlap_between_ranks(oracle, tmp_path, nranks, parts):
+def test_parts_overlap_between_ranks(oracle, tmp_path, nranks, parts, double_mode):
     """bpmf_hip_side_set_overlap with a peer: the per-part sub-ranges of every rank are all-gathered once, part c travels
     on the exchange stream while part c + 1 is sampled; `heavy`: a 650-rating column that is cut into chunks."""
+    if double_mode == "sync" and (nranks, parts) != (2, 4):
+        pytest.skip("asynchronous mode only (both modes: two ranks, four parts)")
     nsims, burnin = 4, 1
     res = run_ranks(tmp_path, nranks, "parts", "heavy", 32, nsims, burnin, {"BPMF_HIP_OVERLAP": str(parts)})
     check_against_oracle(oracle, res, "heavy", 32, nsims, burnin)
