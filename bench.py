@@ -124,7 +124,7 @@ def profiled(workload):
         if line.startswith("# kernel-source-sha:"):
             sha = line.split(":", 1)[1].strip()
         f = line.replace("avg=", "avg= ").split()
-        if len(f) >= 4 and f[2] == "avg=":
+        if len(f) >= 4 and f[2] == "avg=" and "[" not in f[0]:         # (lines `pmc[grid=N] ...` are per launch shape: profiled_by_grid)
             try:
                 vals[f[1]] = float(f[3])
             except ValueError:
@@ -159,7 +159,7 @@ def issue_bound(workload, launch_s, num_cu=256):
         if line.startswith("# kernel-source-sha:"):
             sha = line.split(":", 1)[1].strip()
         f = line.replace("avg=", "avg= ").split()
-        if len(f) >= 4 and f[2] == "avg=":
+        if len(f) >= 4 and f[2] == "avg=" and "[" not in f[0]:
             try:
                 vals[f[1]] = float(f[3])
             except ValueError:
@@ -635,6 +635,10 @@ def strong_10Mx1M(R, steps, scale=1.0, check=True):
         # taken with these kernel sources; algorithmic bytes per launch = half an iteration's
         p_traffic, _, pmc_file, pmc_sha = profiled("strong_10Mx1M")
         cur = pmc_file is not None and pmc_sha == kernel_source_sha()
+        sides = profiled_by_grid("strong_10Mx1M")
+        if sides and all(v.get("l2_memory_side_bytes") for v in sides.values()):
+            # per launch = the mean of the two sides (the plain per-launch average of the file is over the kept dispatches, 2 + 1)
+            p_traffic = 0.5 * sum(v["l2_memory_side_bytes"] for v in sides.values())
         per_launch = mine["algorithmic_bytes_per_iteration_this_rank"] / 2.0
         launch_s = 0.5 * sum(mine["sampler_ms"].values()) * 1e-3
         mine.update({"traffic": p_traffic if cur else None,
@@ -643,7 +647,7 @@ def strong_10Mx1M(R, steps, scale=1.0, check=True):
                      # shape is exactly 256 MB and the users side walks ascending row ids: part of this traffic is served by the MALL, and a
                      # rate above the ~6.3 TB/s a DRAM copy sustains is no contradiction.  The kernel is at the fabric-side roofline.
                      "traffic_is": "L2 memory-side requests (2 x FETCH_SIZE + WRITE_SIZE) incl. Infinity-Cache hits; not DRAM bytes",
-                     "per_side_counters": profiled_by_grid("strong_10Mx1M") if cur else None,
+                     "per_side_counters": sides if cur else None,
                      "algorithmic_bytes_per_launch": per_launch,
                      "hbm_traffic_over_algorithmic": (p_traffic / per_launch) if (cur and p_traffic) else None,
                      # the same fraction from the counters instead of the algorithmic bytes: HBM-side bytes per launch / launch time / 8 TB/s
