@@ -60,3 +60,32 @@ def test_experiment_patches_apply(tmp_path):
         subprocess.run(["tar", "-x", "-C", str(d)], input=tar, check=True)
         r = subprocess.run(["patch", "-p1", "--dry-run", "-d", str(d), "-i", p], capture_output=True, text=True)
         assert r.returncode == 0, (p, r.stdout[-600:])
+
+
+def test_committed_line_carries_every_single_gpu_config():
+    """The newest committed driver-style line (profiles/rNN_bench_20steps.json: `python bench.py --gpus 1 --steps 20 --warmup 5`) must be
+    what DESIGN.md section 5 says it is: the headline + the four other single-GPU BASELINE configurations as `configs` legs, each with a
+    roofline object and a GREEN chain parity against the oracle, a timed window of >= 2 s, `issue_bound` / `mfma_shape` in the
+    roofline, and the strong-scaling record saying what its traffic counter is."""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_20steps.json")))
+    assert files
+    tag = os.path.basename(files[-1]).split("_")[0]
+    if tag < "r06":
+        pytest.skip("lines before round 6 have no `configs` object")
+    d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    assert d["steps"] == 20 and d["n_gpus"] == 1 and d["value"] > 5e7 and d["timed_window_s"] >= 2.0 and d["repeats"] >= 100
+    assert d["parity"]["ok"] and d["parity"]["d_rmse_max"] < 1e-6
+    rf = d["roofline"]
+    assert 0.5 < rf["issue_bound"]["frac_of_launch"] < 1.0 and rf["issue_bound"]["current"]
+    assert rf["mfma_shape"]["frac_of_shape_peak"] > rf["frac"]
+    assert set(d["configs"]) == {"chembl", "ml1m_k128", "ml1m_k64", "ml1m_k128_f64"}
+    for name, c in d["configs"].items():
+        assert c.get("value"), (name, c.get("error"))
+        assert c["steps"] == 20 and c["timed_window_s"] >= 2.0 and c["parity"]["ok"], name
+        assert 0.0 < c["roofline"]["frac"] < 1.0 and set(c["launch_us_per_side"]) == {"movs", "users"}, name
+    assert d["configs"]["ml1m_k128"]["dtype"] == "f32" and d["configs"]["ml1m_k128_f64"]["dtype"] == "f64"
+    s = d["strong_10Mx1M"]
+    assert "Infinity-Cache" in s["traffic_is"] and set(s["per_side_counters"]) == {"items_side", "users_side"}
+    assert 0.8 < s["hbm_frac"] < 1.0
