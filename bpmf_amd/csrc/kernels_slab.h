@@ -29,6 +29,7 @@
 // order, so x = R^-1 (R^-T b + z) is the reference's sample for the same z.
 // Heavy columns are cut into chunks like everywhere else (partials in tile layout, last arriver adds).
 #pragma once
+#include <type_traits>
 #include "kernels.h"
 #include "kernels_f32.h"
 
@@ -114,6 +115,27 @@ __device__ __forceinline__ double quad_splat(double v)
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
 }
 
+// value of lane G of every row of 16 lanes, in all 16 lanes of the row (ds_swizzle, bit mode: lane' = (lane & 0x10) | G per
+// group of 32 lanes; 2.4 cycles per instruction and CU against the 6.3 of a ds_bpermute: profiles/r05_mfma_shapes_probe.txt)
+template <int G>
+__device__ __forceinline__ int row_lane_i(int v) { return __builtin_amdgcn_ds_swizzle(v, 0x10 | (G << 5)); }
+template <int G>
+__device__ __forceinline__ double row_lane_d(double v)
+{
+    const long long w = __builtin_bit_cast(long long, v);
+    const int lo = row_lane_i<G>((int)w), hi = row_lane_i<G>((int)(w >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// f(integral_constant<int, B>) ... f(integral_constant<int, E - 1>): a loop whose index has to be a constant expression
+template <int B, int E, typename F>
+__device__ __forceinline__ void slab_static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        slab_static_for<B + 1, E>(f);
+    }
+}
+
 // x rotated by 4 * D lanes inside each row of 16 lanes (quad b reads quad (b + D) % 4): one DPP move per half, no LDS
 template <int D>
 __device__ __forceinline__ double quad_rot(double x)
@@ -131,7 +153,7 @@ __device__ __forceinline__ double quad_rot(double x)
 // quads (block b = latent columns 16 TJ + 4 ((b + d) % 4) ..) one instruction accumulates the four blocks
 // (4 TI + b, 4 TJ + (b + d) % 4) of tile (TI, TJ): d = 0 .. 3 cover an off-diagonal tile; on the diagonal d = 0, 1, 2 do --
 // the blocks below the diagonal that d = 1, 2 produce are the transposes of (0,3), (0,2), (1,3).  36 MFMAs per group and
-// 22 DPP moves (11 rotated registers x two halves); NO cross-lane operation through the LDS pipe.
+// 16 DPP moves (8 rotated registers x two halves: see contract()); NO cross-lane operation through the LDS pipe.
 // Rounds 1-5 made the A operand of row block I by splatting quad I & 3 of register I >> 2 over its row (two ds_swizzle per
 // operand, 32 per group, 40 MFMAs per group).  Round 6 measured what that costs: on a SIMD the issue of an LDS-pipe
 // instruction ADDS to the MFMA time like a VALU instruction does (tools/probes/cbsz_probe.hip: 28.2 cycles per MFMA with two
@@ -149,19 +171,25 @@ __device__ __forceinline__ void gram_slab(const int32_t *__restrict__ rowidx, co
     constexpr int NT = K / 16;
     const int kq = lane >> 4, li = lane & 15;
     if (len <= 0) return;
-    // index blocks of 64 ratings (lane l holds rating b0 + l): the current one and the next one
-    int ri = (lane < len) ? rowidx[lane] : -1;
-    double wv = (lane < len) ? (vals[lane] - mean) * alpha : 0.0;                // c++/sample.cpp:256
-    int ri_n = (64 + lane < len) ? rowidx[64 + lane] : -1;
-    double wv_n = (64 + lane < len) ? (vals[64 + lane] - mean) * alpha : 0.0;
-    // Group st of the block; st >= 16 are the first groups of the NEXT block: the gathers run DEPTH - 1 groups ahead of the
+    // Index blocks of 64 ratings, the current one and the next one.  Lane (kq, g) = 16 kq + g holds rating 4 g + kq of its block,
+    // i.e. the rating group g's lane row kq gathers: the row id and the weight then reach the 16 lanes of the row through a
+    // ds_swizzle row broadcast (a compile-time pattern, no address register) instead of a ds_bpermute -- 2.4 against 6.3 cycles
+    // per instruction and CU, three per group of four ratings.  The 64 loads of a block still cover 256 contiguous bytes.
+    // (The row as a 64-bit byte offset instead of an id -- one add per gather instead of a compare, two selects, a shift and two
+    //  adds, at the price of a second permute for the upper half -- measured 1 % slower: 0.2767 against 0.2743 ms, round 6.)
+    const int slot = 4 * li + kq;                                     // this lane's rating within an index block
+    int ri = (slot < len) ? rowidx[slot] : -1;
+    double wv = (slot < len) ? (vals[slot] - mean) * alpha : 0.0;                // c++/sample.cpp:256
+    int ri_n = (64 + slot < len) ? rowidx[64 + slot] : -1;
+    double wv_n = (64 + slot < len) ? (vals[64 + slot] - mean) * alpha : 0.0;
+    // Group ST of the block; ST >= 16 are the first groups of the NEXT block: the gathers run DEPTH - 1 groups ahead of the
     // MFMAs, across block boundaries too.  No control flow around the loads -- the compiler's s_waitcnt counts stay exact --
     // and slots beyond the end of the chunk gather a row of zeros.
-    auto gather = [&](int st, double (&yy)[NT], double &ww) {
-        const bool nx = st >= 16;
-        const int src = ((st & 15) * 4 + kq);
-        const int row = __shfl(nx ? ri_n : ri, src);
-        ww = __shfl(nx ? wv_n : wv, src);
+    auto gather = [&](auto stc, double (&yy)[NT], double &ww) {
+        constexpr int ST = decltype(stc)::value;
+        constexpr bool nx = ST >= 16;
+        const int row = row_lane_i<(ST & 15)>(nx ? ri_n : ri);
+        ww = row_lane_d<(ST & 15)>(nx ? wv_n : wv);
         const double *u = ((row >= 0) ? other + (size_t)row * K : zero_row) + li;
 #pragma unroll
         for (int t = 0; t < NT; ++t) yy[t] = u[16 * t];
@@ -169,21 +197,26 @@ __device__ __forceinline__ void gram_slab(const int32_t *__restrict__ rowidx, co
     auto contract = [&](const double (&yy)[NT], double ww) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) r[t] = fma(yy[t], ww, r[t]);
-        double rot[NT][4];
+        // rotations by one and by two quads of every register: what the diagonal tiles need.  The off-diagonal tiles' d = 3 takes
+        // the A operand rotated by ONE quad against the natural B operand instead -- block b of that product is
+        // (4 TI + (b + 1) % 4, 4 TJ + b), the same four blocks {(r, r + 3)} in other slots (slabs_from_acc knows) -- so that no
+        // rotation by three is made: 8 rotated registers (16 DPP moves) per group instead of 11
+        double rot[NT][3];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             rot[t][0] = yy[t];
             rot[t][1] = quad_rot<1>(yy[t]);
             rot[t][2] = quad_rot<2>(yy[t]);
-            if (t > 0) rot[t][3] = quad_rot<3>(yy[t]);               // (register 0 is a B operand of its diagonal tile only)
         }
 #pragma unroll
         for (int TI = 0; TI < NT; ++TI)
 #pragma unroll
             for (int TJ = TI; TJ < NT; ++TJ)
 #pragma unroll
-                for (int d = 0; d < G::nrot(TI, TJ); ++d)
-                    C[G::aoff(TI, TJ) + d] = mfma44(yy[TI], rot[TJ][d], C[G::aoff(TI, TJ) + d]);
+                for (int d = 0; d < G::nrot(TI, TJ); ++d) {
+                    if (d < 3) C[G::aoff(TI, TJ) + d] = mfma44(yy[TI], rot[TJ][d], C[G::aoff(TI, TJ) + d]);
+                    else C[G::aoff(TI, TJ) + d] = mfma44(rot[TI][1], yy[TJ], C[G::aoff(TI, TJ) + d]);
+                }
     };
     // D operand sets: the gathers run D - 1 groups ahead of the MFMAs (GeoS<K>::DEPTH).  A group whose four ratings all lie
     // beyond the end of the chunk is gathered (a row of zeros: the loads stay unconditional) but NOT contracted: the
@@ -191,20 +224,22 @@ __device__ __forceinline__ void gram_slab(const int32_t *__restrict__ rowidx, co
     constexpr int D = G::DEPTH;
     static_assert(D >= 2 && 16 % D == 0, "the operand sets must rotate evenly through the 16 groups of an index block");
     double y[D][NT], w[D];
-#pragma unroll
-    for (int u = 0; u < D - 1; ++u) gather(u, y[u], w[u]);
+    slab_static_for<0, D - 1>([&](auto uc) { gather(uc, y[decltype(uc)::value], w[decltype(uc)::value]); });
     for (int b0 = 0; b0 < len; b0 += 64) {
         const int ngroups = (len - b0 >= 64) ? 16 : (len - b0 + 3) >> 2;         // groups of 4 ratings in this block
-        for (int st = 0; st < ngroups; st += D) {
-#pragma unroll
-            for (int u = 0; u < D; ++u) {
-                gather(st + u + D - 1, y[(u + D - 1) % D], w[(u + D - 1) % D]);
-                if (st + u < ngroups) contract(y[u], w[u]);
+        // all 16 groups of the block unrolled: the group number is a compile-time constant, so that which index block a gather
+        // reads (this one / the next) and the lane of its row that holds its rating cost no instruction; groups beyond the
+        // block's last one are skipped (wave-uniform guards)
+        slab_static_for<0, 16>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if (g < ngroups) {
+                gather(std::integral_constant<int, g + D - 1>{}, y[(g + D - 1) % D], w[(g + D - 1) % D]);
+                contract(y[g % D], w[g % D]);
             }
-        }
+        });
         // next block: its first D - 1 groups are in flight already
         ri = ri_n; wv = wv_n;
-        const int q = b0 + 128 + lane;
+        const int q = b0 + 128 + slot;
         ri_n = (q < len) ? rowidx[q] : -1;
         wv_n = (q < len) ? (vals[q] - mean) * alpha : 0.0;
     }
@@ -237,7 +272,8 @@ __device__ __forceinline__ void slabs_from_acc(const double (&C)[GeoS<K>::NACC],
             double *img = (tix & 1) ? buf1 : buf0;
 #pragma unroll
             for (int d = 0; d < G::nrot(TI, TJ); ++d) {
-                const int row = 4 * b + i, col = 4 * ((b + d) & 3) + j;
+                // (d = 3, off the diagonal only: made with the A operand rotated by one quad -- slot b is block ((b + 1) % 4, b))
+                const int row = d < 3 ? 4 * b + i : 4 * ((b + 1) & 3) + i, col = d < 3 ? 4 * ((b + d) & 3) + j : 4 * b + j;
                 const double v = C[G::aoff(TI, TJ) + d];
                 img[row * 16 + col] = v;
                 if (TI == TJ && d > 0) img[col * 16 + row] = v;
