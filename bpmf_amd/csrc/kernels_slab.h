@@ -74,11 +74,26 @@ struct GeoS {
     static constexpr int DEPTH = BPMF_SLAB_DEPTH;
 };
 
-// W = R_ss^-1 of a 4x4 SPD block given by its 10 upper entries (wave-uniform values): returns the
-// operand registers of k_sample4's scheme -- WA: lane (k, b, i) holds W[k][i] (A operand "W^T"),
-// WB: lane (k, b, i) holds W[i][k] (A operand "W").
+// Which of the ten entries of the upper triangular W = R_ss^-1 a lane is given by factor_block44: lane (k, b, i) holds W[k][i] (the
+// A operand "W^T" of the 4x4x4 shape), zero below the diagonal.  As ten factors 1.0 / 0.0 per lane, made once per kernel: the
+// entry is then a sum of ten products with exactly one non-zero term -- ten FMAs, bit-identical to a selection -- instead of the
+// 34 v_cndmask per pivot block the selection compiled to (round 6: the pivot blocks are 16 per column at K = 64 and 32 per item at
+// K = 128, each of them on the critical chain).  A failed factorisation (inf / NaN entries) turns every lane's W into NaN: the
+// column is reported as "Cholesky failed" either way.
+struct W44Select {
+    double m[10];                                                     // i0, i1, i2, i3, W01, W02, W03, W12, W13, W23
+    __device__ __forceinline__ W44Select(int kq, int x)
+    {
+        constexpr int P[10] = {0, 1, 2, 3, 0, 0, 0, 1, 1, 2}, Q[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
+#pragma unroll
+        for (int c = 0; c < 10; ++c) m[c] = (kq == P[c] && x == Q[c]) ? 1.0 : 0.0;
+    }
+};
+
+// W = R_ss^-1 of a 4x4 SPD block given by its 10 upper entries (wave-uniform values): returns the operand register of
+// k_sample4's scheme -- WA: lane (k, b, i) holds W[k][i] (A operand "W^T").
 __device__ __forceinline__ void factor_block44(double d00, double d01, double d02, double d03, double d11, double d12, double d13,
-                                               double d22, double d23, double d33, int kq, int x, double &WA, double &WB)
+                                               double d22, double d23, double d33, const W44Select &sel, double &WA)
 {
     const double i0 = rsqrt_nr(d00);
     const double R01 = d01 * i0, R02 = d02 * i0, R03 = d03 * i0;
@@ -94,15 +109,11 @@ __device__ __forceinline__ void factor_block44(double d00, double d01, double d0
     const double W02 = -i0 * fma(R01, W12, R02 * i2);
     const double W13 = -i1 * fma(R12, W23, R13 * i3);
     const double W03 = -i0 * fma(R01, W13, fma(R02, W23, R03 * i3));
-    auto pick = [&](int p, int q) -> double {
-        double v = 0.0;
-        v = (p == 0 && q == 0) ? i0 : v; v = (p == 1 && q == 1) ? i1 : v; v = (p == 2 && q == 2) ? i2 : v; v = (p == 3 && q == 3) ? i3 : v;
-        v = (p == 0 && q == 1) ? W01 : v; v = (p == 0 && q == 2) ? W02 : v; v = (p == 0 && q == 3) ? W03 : v;
-        v = (p == 1 && q == 2) ? W12 : v; v = (p == 1 && q == 3) ? W13 : v; v = (p == 2 && q == 3) ? W23 : v;
-        return v;
-    };
-    WA = pick(kq, x);
-    WB = pick(x, kq);
+    double v = sel.m[0] * i0;
+    v = fma(sel.m[1], i1, v); v = fma(sel.m[2], i2, v); v = fma(sel.m[3], i3, v);
+    v = fma(sel.m[4], W01, v); v = fma(sel.m[5], W02, v); v = fma(sel.m[6], W03, v);
+    v = fma(sel.m[7], W12, v); v = fma(sel.m[8], W13, v); v = fma(sel.m[9], W23, v);
+    WA = v;
 }
 
 // value of quad b' of every row of 16 lanes, in all four quads of the row (ds_swizzle, bit mode: no LDS memory)
@@ -296,6 +307,7 @@ __device__ __forceinline__ void slab_cholesky_solve(double (&A)[GeoS<K>::NREG], 
     using G = GeoS<K>;
     constexpr int NG = G::NG, NQ = G::NQ, LDR = G::LDR;
     const int kq = lane >> 4, b = (lane >> 2) & 3, x = lane & 3, c16 = lane & 15;
+    const W44Select wsel(kq, x);
 #pragma unroll
     for (int s = 0; s < NG; ++s) {
         const int q0 = s >> 2, b0 = s & 3;
@@ -304,11 +316,10 @@ __device__ __forceinline__ void slab_cholesky_solve(double (&A)[GeoS<K>::NREG], 
         const double d00 = bcast(dblk, 4 * b0 + 0), d01 = bcast(dblk, 4 * b0 + 1), d02 = bcast(dblk, 4 * b0 + 2), d03 = bcast(dblk, 4 * b0 + 3),
                      d11 = bcast(dblk, 16 + 4 * b0 + 1), d12 = bcast(dblk, 16 + 4 * b0 + 2), d13 = bcast(dblk, 16 + 4 * b0 + 3),
                      d22 = bcast(dblk, 32 + 4 * b0 + 2), d23 = bcast(dblk, 32 + 4 * b0 + 3), d33 = bcast(dblk, 48 + 4 * b0 + 3);
-        double WA, WB;
-        factor_block44(d00, d01, d02, d03, d11, d12, d13, d22, d23, d33, kq, x, WA, WB);
+        double WA;
+        factor_block44(d00, d01, d02, d03, d11, d12, d13, d22, d23, d33, wsel, WA);
         // W_s as the A operand of the backward solve: entry [kq][x] of the tile has to hold W[x][kq] -- the lane writes
         // ITS W[kq][x] to [x][kq] instead of selecting the transposed entry from the ten candidates a second time
-        (void)WB;
         if (b == 0) sw[16 * s + 4 * x + kq] = WA;
         // forward solve of this block row: y_s = W^T b_s (block b0 of bv[q0]); y_s in every b as a B operand
         const double ys_all = mfma44(WA, bv[q0], 0.0);

@@ -94,6 +94,7 @@ template <int MIDBAR = -1>
 __device__ __forceinline__ void diag16_factor_invert(double (&A)[4], double (&E)[4], int lane)
 {
     const int kq = lane >> 4, x = lane & 3, c16 = lane & 15;
+    const W44Select wsel(kq, x);
 #pragma unroll
     for (int I = 0; I < 4; ++I) E[I] = (4 * I + kq == c16) ? 1.0 : 0.0;
 #pragma unroll
@@ -102,9 +103,8 @@ __device__ __forceinline__ void diag16_factor_invert(double (&A)[4], double (&E)
         const double d00 = bcast(dblk, 4 * s + 0), d01 = bcast(dblk, 4 * s + 1), d02 = bcast(dblk, 4 * s + 2), d03 = bcast(dblk, 4 * s + 3),
                      d11 = bcast(dblk, 16 + 4 * s + 1), d12 = bcast(dblk, 16 + 4 * s + 2), d13 = bcast(dblk, 16 + 4 * s + 3),
                      d22 = bcast(dblk, 32 + 4 * s + 2), d23 = bcast(dblk, 32 + 4 * s + 3), d33 = bcast(dblk, 48 + 4 * s + 3);
-        double WA, WB;
-        factor_block44(d00, d01, d02, d03, d11, d12, d13, d22, d23, d33, kq, x, WA, WB);
-        (void)WB;
+        double WA;
+        factor_block44(d00, d01, d02, d03, d11, d12, d13, d22, d23, d33, wsel, WA);
         A[s] = mfma44(WA, A[s], 0.0);                                 // R_sJ = W^T A_sJ for the four J of the slab
         E[s] = mfma44(WA, E[s], 0.0);
         if (s == MIDBAR) __syncthreads();
