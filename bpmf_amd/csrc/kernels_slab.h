@@ -74,19 +74,19 @@ struct GeoS {
     static constexpr int DEPTH = BPMF_SLAB_DEPTH;
 };
 
-// Which of the ten entries of the upper triangular W = R_ss^-1 a lane is given by factor_block44: lane (k, b, i) holds W[k][i] (the
-// A operand "W^T" of the 4x4x4 shape), zero below the diagonal.  As ten factors 1.0 / 0.0 per lane, made once per kernel: the
-// entry is then a sum of ten products with exactly one non-zero term -- ten FMAs, bit-identical to a selection -- instead of the
-// 34 v_cndmask per pivot block the selection compiled to (round 6: the pivot blocks are 16 per column at K = 64 and 32 per item at
-// K = 128, each of them on the critical chain).  A failed factorisation (inf / NaN entries) turns every lane's W into NaN: the
-// column is reported as "Cholesky failed" either way.
+// What a lane gets from factor_block44 is ONE entry of the upper triangular W = R_ss^-1: lane (k, b, i) holds W[k][i] (the A operand
+// "W^T" of the 4x4x4 shape), zero below the diagonal.  Rounds 2-5 computed all ten entries wave-uniformly (16 operations) and
+// selected (34 v_cndmask per pivot block as compiled).  Round 6: the lane solves R w = e_i for ITS column i by back substitution --
+// the right-hand side is the lane's unit vector as four factors 1.0 / 0.0 (cx), ten operations -- and takes entry k of it with
+// four more (rk): 14 instead of 27 + 34 instructions per pivot block, of which there are 16 per column at K = 64 and 32 per item at
+// K = 128, every one on the critical chain.  The eight factors are made once per kernel.  (A failed factorisation -- inf / NaN
+// pivots -- gives NaN in every lane: the column is reported as "Cholesky failed" either way.)
 struct W44Select {
-    double m[10];                                                     // i0, i1, i2, i3, W01, W02, W03, W12, W13, W23
+    double cx[4], rk[4];                                              // (i == j), (k == j), j = 0 .. 3
     __device__ __forceinline__ W44Select(int kq, int x)
     {
-        constexpr int P[10] = {0, 1, 2, 3, 0, 0, 0, 1, 1, 2}, Q[10] = {0, 1, 2, 3, 1, 2, 3, 2, 3, 3};
 #pragma unroll
-        for (int c = 0; c < 10; ++c) m[c] = (kq == P[c] && x == Q[c]) ? 1.0 : 0.0;
+        for (int j = 0; j < 4; ++j) { cx[j] = (x == j) ? 1.0 : 0.0; rk[j] = (kq == j) ? 1.0 : 0.0; }
     }
 };
 
@@ -105,15 +105,12 @@ __device__ __forceinline__ void factor_block44(double d00, double d01, double d0
     const double R23 = fma(-R12, R13, fma(-R02, R03, d23)) * i2;
     const double e33 = fma(-R23, R23, fma(-R13, R13, fma(-R03, R03, d33)));
     const double i3 = rsqrt_nr(e33);
-    const double W01 = -i0 * R01 * i1, W12 = -i1 * R12 * i2, W23 = -i2 * R23 * i3;
-    const double W02 = -i0 * fma(R01, W12, R02 * i2);
-    const double W13 = -i1 * fma(R12, W23, R13 * i3);
-    const double W03 = -i0 * fma(R01, W13, fma(R02, W23, R03 * i3));
-    double v = sel.m[0] * i0;
-    v = fma(sel.m[1], i1, v); v = fma(sel.m[2], i2, v); v = fma(sel.m[3], i3, v);
-    v = fma(sel.m[4], W01, v); v = fma(sel.m[5], W02, v); v = fma(sel.m[6], W03, v);
-    v = fma(sel.m[7], W12, v); v = fma(sel.m[8], W13, v); v = fma(sel.m[9], W23, v);
-    WA = v;
+    // column i of W: R w = e_i, from the bottom (w_j = 0 for j > i comes out of the zeros of e_i)
+    const double w3 = sel.cx[3] * i3;
+    const double w2 = fma(-R23, w3, sel.cx[2]) * i2;
+    const double w1 = fma(-R13, w3, fma(-R12, w2, sel.cx[1])) * i1;
+    const double w0 = fma(-R03, w3, fma(-R02, w2, fma(-R01, w1, sel.cx[0]))) * i0;
+    WA = fma(sel.rk[3], w3, fma(sel.rk[2], w2, fma(sel.rk[1], w1, sel.rk[0] * w0)));
 }
 
 // value of quad b' of every row of 16 lanes, in all four quads of the row (ds_swizzle, bit mode: no LDS memory)
