@@ -779,12 +779,26 @@ def strong_model(NU, NI, K, world, ranks, ms_per_step):
                                                                    "over_model": ms_per_step / per_n[str(world)]["ms_per_step"] if str(world) in per_n else None}}
 
 
+def visible_devices():
+    """HIP devices this process can see -- from the HIP runtime directly (the launcher has no other use for torch, whose import is
+    seconds), torch as the fall-back."""
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        n = ctypes.c_int(0)
+        if hip.hipGetDeviceCount(ctypes.byref(n)) == 0:
+            return int(n.value)
+        return 0
+    except OSError:
+        import torch
+        return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
 def self_launch(n):
     """`bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) and relay their exit code."""
     import socket
-    import torch
     shared = os.environ.get("BPMF_BENCH_SHARED_GPU") == "1"
-    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    have = visible_devices()
     if have < n and not shared:
         raise SystemExit("bench.py: --gpus %d asked for, %d HIP device(s) visible: refusing to report fewer ranks as %d GPUs "
                          "(one rank per GPU; a launcher may set WORLD_SIZE / RANK / LOCAL_RANK instead)" % (n, have, n))
