@@ -177,10 +177,11 @@ def test_g1_runs_the_sharded_path_and_equals_the_plain_run(tmp_path, K):
     predict with their all-reduces, per-rank bpmf_<rank>.out -- and must print the chain of the plain run.
     The ADVICE finding of round 1: nprocs was hard-wired to 1 and the sharded path unreachable from the CLI."""
     args = ["-i", "6", "-b", "2", "-d", str(K), "-n", os.path.join(G, "ml100k-train.mtx.gz"), "-p", os.path.join(G, "ml100k-test.mtx.gz")]
-    plain = run(args, tmp_path)
+    # (one run each, with -o: the stdout chain AND the output files of the same two runs are compared)
+    (tmp_path / "o_plain").mkdir(); (tmp_path / "o_g1").mkdir(); (tmp_path / "g").mkdir()
+    plain = run(args + ["-o", "o_plain/"], tmp_path)
     assert plain.returncode == 0, plain.stderr
-    (tmp_path / "g").mkdir()
-    sharded = run(args + ["-g", "1", "-r"], tmp_path / "g")
+    sharded = run(args + ["-g", "1", "-r", "-o", "../o_g1/"], tmp_path / "g")
     assert sharded.returncode == 0, sharded.stderr
     out = (tmp_path / "g" / "bpmf_0.out").read_text()
     assert "nprocs: 1" in out and "movs domain: [0, 1682)" in out
@@ -188,10 +189,6 @@ def test_g1_runs_the_sharded_path_and_equals_the_plain_run(tmp_path, K):
     assert len(pick(out)) == 6 and pick(out) == pick(plain.stdout)
     assert re.search(r"Final Avg RMSE: (\S+)", out).group(1) == re.search(r"Final Avg RMSE: (\S+)", plain.stdout).group(1)
     # with outputs: Pavg / U-mu of the sharded run equal the plain run's
-    for d, extra in (("o_plain", []), ("o_g1", ["-g", "1"])):
-        (tmp_path / d).mkdir()
-        r = run(args + ["-o", d + "/"] + extra, tmp_path)
-        assert r.returncode == 0, r.stderr
     a = bio.read_sparse(tmp_path / "o_plain" / "Pavg.sdm"); b = bio.read_sparse(tmp_path / "o_g1" / "Pavg.sdm")
     assert np.array_equal(a[2][2], b[2][2])
     assert np.array_equal(bio.read_dense(tmp_path / "o_plain" / "U-mu.ddm"), bio.read_dense(tmp_path / "o_g1" / "U-mu.ddm"))

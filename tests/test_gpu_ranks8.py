@@ -65,7 +65,7 @@ def test_bench_gpus8_preflight_ladder_and_per_rank_record():
     first rung hangs (test hook): it is killed after BPMF_BENCH_PREFLIGHT_TIMEOUT_S, the eight ranks agree, the second rung
     runs on all eight, and the line carries n_gpus 8, rccl_nranks 8, the ladder with the reason, and eight per-rank records."""
     env = dict(os.environ, BPMF_BENCH_SHARED_GPU="1", BPMF_HIP_RCCL_LIBRARY=DOUBLE, BPMF_BENCH_TEST_HANG_RUNG="mesh+parts+2comms:5",
-               BPMF_BENCH_PREFLIGHT_TIMEOUT_S="20", BPMF_RCCL_DOUBLE_TIMEOUT_S="8")
+               BPMF_BENCH_PREFLIGHT_TIMEOUT_S="16", BPMF_RCCL_DOUBLE_TIMEOUT_S="8")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--repeats", "1", "--prewarm-ms", "0",
