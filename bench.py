@@ -143,6 +143,54 @@ VALU_CYCLES = 4.2          # measured issue cost of a wave64 VALU instruction wi
 CLOCK_GHZ = 2.4            # MI355X_MICROARCH.md: max engine clock (the sustained clock under load is lower: the bound is a floor)
 
 
+def issue_bound_by_kernel(workload, num_cu=256):
+    """The ChEMBL shape runs six sampler kernels per iteration: the same issue-time estimate per KERNEL, from the committed per-kernel
+    counters (profiles/r*_pmc_by_kernel_<workload>.txt, tools/pmc_by_kernel.py) and the committed kernel trace's average durations
+    (profiles/r*_kernel_trace_summary_<workload>.txt).  Both files are the builder's (rocprofv3 on the GPU box); `current` says
+    whether they were taken with this build's kernel sources."""
+    import re
+    pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_by_kernel_%s.txt" % workload)))
+    tr = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_trace_summary_%s.txt" % workload)))
+    if not pm or not tr:
+        return None
+    sha, cur, counters = None, None, {}
+    for line in open(pm[-1]):
+        if line.startswith("# kernel-source-sha:"):
+            sha = line.split(":", 1)[1].strip()
+        elif line.startswith("    "):
+            f = line.replace("avg=", "avg= ").split()
+            if cur and len(f) >= 3 and f[1] == "avg=":
+                counters.setdefault(cur, {})[f[0]] = float(f[2])
+        elif not line.startswith("#"):
+            m = re.search(r"(k_\w+<[^>]*>|k_\w+)", line)
+            cur = m.group(1).replace(" ", "") if m else None
+    dur = {}
+    for line in open(tr[-1]):
+        m = re.search(r"(k_\w+<[^>]*>|k_\w+)", line)
+        f = line.split()
+        if m and len(f) >= 5:
+            try:
+                dur[m.group(1).replace(" ", "")] = float(f[-4]) * 1e-6          # avg_us column
+            except ValueError:
+                pass
+    out = {}
+    for k, v in counters.items():
+        if not k.startswith("k_sample") and not k.startswith("k_pf_prepare"):
+            continue
+        if "SQ_INSTS_VALU" not in v or "SQ_INSTS_MFMA" not in v or k not in dur:
+            continue
+        mfma = v["SQ_INSTS_MFMA"]; valu = max(0.0, v["SQ_INSTS_VALU"] - mfma)
+        issue_s = (valu * VALU_CYCLES + mfma * 18.0) / (num_cu * 4) / (CLOCK_GHZ * 1e9)
+        out[k] = {"valu_insts_per_launch": valu, "mfma_insts_per_launch": mfma, "issue_us": issue_s * 1e6, "launch_us": dur[k] * 1e6,
+                  "frac_of_launch": issue_s / dur[k]}
+    if not out:
+        return None
+    return {"per_kernel": out, "cycles_per_valu": VALU_CYCLES, "cycles_per_mfma": 18.0, "clock_ghz": CLOCK_GHZ, "simds": num_cu * 4,
+            "source": [os.path.basename(pm[-1]), os.path.basename(tr[-1])], "current": bool(sha == kernel_source_sha()),
+            "note": "per kernel: instruction-issue time of its own stream at the max clock / its average duration in the committed trace (the "
+                    "targets-side launch shares the chip with the compounds side's statistics pass and the evaluation: its duration is not its own)"}
+
+
 def issue_bound(workload, launch_s, num_cu=256):
     """Why the sampler is where it is against the flop peak, carried with the number: the time its instruction
     stream needs to ISSUE -- (VALU instructions x measured cycles + MFMA instructions x the shape's cycles) / SIMDs / clock --
@@ -150,7 +198,7 @@ def issue_bound(workload, launch_s, num_cu=256):
     (checked against the static ISA of the Gram loop: 86 VALU + 144 MFMA per 64 ratings), so they are taken out of it; f64
     MFMA and VALU issue add on a SIMD.  Counters of a profile of OTHER kernel sources are history: null."""
     if workload == "chembl":
-        return None                       # (six sampler kernels per iteration: the per-launch averages of the PMC file mix them; profiles/r*_pmc_by_kernel_chembl.txt)
+        return issue_bound_by_kernel(workload, num_cu)                # (six sampler kernels per iteration: one record per kernel)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.txt" % workload)))
     if not files:
         return None
