@@ -54,6 +54,105 @@ __device__ __forceinline__ double mfma44(double a, double b, double c)
     return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
+// ---------------------------------------------------------------------------
+// The Gram of four K-vectors on the 4x4x4 shape with ROTATED-BLOCK accumulators (K = 64): shared by the sampler's
+// gram_slab (kernels_slab.h, which documents the scheme) and the column statistics (colstats_accumulate below).
+// Operand register t holds x_k[16 t + c] in lane (k, c), c = 4 b + j -- the operand layout of the 16x16x4 shape too.
+// ---------------------------------------------------------------------------
+template <int K>
+struct Rot44 {
+    static constexpr int NT = K / 16;
+    // tile (TI, TJ), TI <= TJ, keeps one accumulator per quad rotation d of the B operand -- d = 0 .. 3 off the
+    // diagonal, d = 0 .. 2 on it (the blocks d = 3 would give are transposes of d = 1's)
+    __host__ __device__ static constexpr int nrot(int TI, int TJ) { return TI == TJ ? 3 : 4; }
+    __host__ __device__ static constexpr int aoff(int TI, int TJ)
+    {
+        int n = 0;
+        for (int a = 0; a < NT; ++a)
+            for (int b = a; b < NT; ++b) {
+                if (a == TI && b == TJ) return n;
+                n += nrot(a, b);
+            }
+        return n;
+    }
+    static constexpr int NACC = aoff(NT - 1, NT - 1) + 3;  // 36 at K = 64
+};
+
+// x rotated by 4 * D lanes inside each row of 16 lanes (quad b reads quad (b + D) % 4): one DPP move per half, no LDS
+template <int D>
+__device__ __forceinline__ double quad_rot(double x)
+{
+    constexpr int CTRL = 0x120 + (16 - 4 * D);                       // row_ror:(16 - 4 D): lane l reads lane (l + 4 D) % 16 of its row
+    const long long v = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// C += the Gram of the four vectors in yy.  A = register TI as it is (block b = rows 16 TI + 4 b ..), B = register TJ rotated by
+// d quads (block b = columns 16 TJ + 4 ((b + d) % 4) ..): one instruction accumulates the blocks (4 TI + b, 4 TJ + (b + d) % 4).
+// Rotations by one and by two quads of every register are what the diagonal tiles need; the off-diagonal tiles' d = 3 takes the
+// A operand rotated by ONE quad against the natural B operand instead -- block b of that product is (4 TI + (b + 1) % 4, 4 TJ + b),
+// the same four blocks {(r, r + 3)} in other slots (rot44_images knows) -- so that no rotation by three is made: 8 rotated
+// registers (16 DPP moves) and NT (NT + 1) / 2 * 4 - NT MFMAs per call
+template <int K>
+__device__ __forceinline__ void rot44_contract(const double (&yy)[K / 16], double (&C)[Rot44<K>::NACC])
+{
+    using G = Rot44<K>;
+    constexpr int NT = K / 16;
+    double rot[NT][3];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        rot[t][0] = yy[t];
+        rot[t][1] = quad_rot<1>(yy[t]);
+        rot[t][2] = quad_rot<2>(yy[t]);
+    }
+#pragma unroll
+    for (int TI = 0; TI < NT; ++TI)
+#pragma unroll
+        for (int TJ = TI; TJ < NT; ++TJ)
+#pragma unroll
+            for (int d = 0; d < G::nrot(TI, TJ); ++d) {
+                if (d < 3) C[G::aoff(TI, TJ) + d] = mfma44(yy[TI], rot[TJ][d], C[G::aoff(TI, TJ) + d]);
+                else C[G::aoff(TI, TJ) + d] = mfma44(rot[TI][1], yy[TJ], C[G::aoff(TI, TJ) + d]);
+            }
+}
+
+// The accumulators of rot44_contract() -> 16 x 16 tiles in the accumulator layout of the 16x16x4 shape (register m of tile
+// (TI, TJ), lane (i, c) = element [16 TI + 4 m + i][16 TJ + c]), handed to sink(tile index, TI, TJ, m, value).  The map is a
+// permutation, so it commutes with sums of accumulators.  Tile by tile through two 2 KB LDS images taken in turn: lane
+// (i, b, j) of rotation d holds G[16 TI + 4 b + i][16 TJ + 4 ((b + d) % 4) + j] and stores it at [4 b + i][4 ((b + d) % 4) + j]
+// of the image.  A diagonal tile stores every element at its mirror position too, so that the image is the full symmetric
+// tile (an element written twice is written with the same bits: same products, same order).  The images belong to ONE wave
+// (LDS operations of a wave complete in order); the barriers pin the compiler's order and every wave of the workgroup has to
+// come through here.
+template <int K, typename Sink>
+__device__ __forceinline__ void rot44_images(const double (&C)[Rot44<K>::NACC], double *buf0, double *buf1, int lane, Sink &&sink)
+{
+    using G = Rot44<K>;
+    constexpr int NT = G::NT;
+    const int i = lane >> 4, b = (lane >> 2) & 3, j = lane & 3;
+    int tix = 0;
+#pragma unroll
+    for (int TI = 0; TI < NT; ++TI)
+#pragma unroll
+        for (int TJ = TI; TJ < NT; ++TJ, ++tix) {
+            double *img = (tix & 1) ? buf1 : buf0;
+#pragma unroll
+            for (int d = 0; d < G::nrot(TI, TJ); ++d) {
+                // (d = 3, off the diagonal only: made with the A operand rotated by one quad -- slot b is block ((b + 1) % 4, b))
+                const int row = d < 3 ? 4 * b + i : 4 * ((b + 1) & 3) + i, col = d < 3 ? 4 * ((b + d) & 3) + j : 4 * b + j;
+                const double v = C[G::aoff(TI, TJ) + d];
+                img[row * 16 + col] = v;
+                if (TI == TJ && d > 0) img[col * 16 + row] = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < 4; ++m) sink(tix, TI, TJ, m, img[(4 * m + i) * 16 + (lane & 15)]);
+            __syncthreads();
+        }
+}
+
 // 1/sqrt(d) to ~1 ulp: v_rsq_f64 (2^-23 relative) + one third-order (Halley) correction,
 // y = y0 (1 + e/2 + 3e^2/8) with e = 1 - d y0^2, error ~ e^3: 6 dependent instructions
 // instead of the ~25 of sqrt followed by a divide.  d <= 0 or NaN gives NaN/inf, which
@@ -918,7 +1017,7 @@ template <int K>
 __device__ __forceinline__ void colstats_body(int w, const double *__restrict__ items, int64_t c0, int64_t c1, int nwaves,
                                               double *partials, const unsigned long long *__restrict__ fail_in,
                                               double *__restrict__ out, unsigned *ticket, unsigned *flag, unsigned seq,
-                                              unsigned long long *tmo, unsigned long long wait_ticks);
+                                              unsigned long long *tmo, unsigned long long wait_ticks, double *img);
 __device__ __forceinline__ void gate_stage_body(int block, int nblocks, const unsigned *gate_host, unsigned want, const double *src_host,
                                                 double *__restrict__ dst, int n, unsigned *dflag, unsigned dval,
                                                 unsigned long long *tmo, unsigned long long wait_ticks);
@@ -935,7 +1034,7 @@ __global__ __launch_bounds__(64, Geo1<K>::WPS) void k_sample1(SampleArgs a, Fuse
     }
     if (bid < f.nstat) {
         colstats_body<K>(bid, f.st_items, f.st_c0, f.st_c1, f.nstat, f.st_partials, f.st_fail, f.st_out, f.st_ticket, f.st_flag, f.st_seq,
-                         f.st_tmo, a.wait_ticks);
+                         f.st_tmo, a.wait_ticks, lds);
         return;
     }
     const int w = bid - f.nstat;
@@ -1048,13 +1147,23 @@ __device__ __forceinline__ void publish_when_last(unsigned *ticket, unsigned nbl
 // sum x x^T (upper 16 x 16 tiles, accumulator layout of the f64 16x16x4 MFMA) and sum x of the columns [b, e): one wave
 // (list != NULL: positions [b, e) of a list of LOCAL column ids, column = c0 + list[position]; the ids of a trip are
 //  requested two trips ahead, its columns one trip ahead)
+// K = 64 (kColstatsRot): the products run on the 4x4x4 shape in rotated-block accumulators (rot44_contract: 36 instructions of
+// ~18 cycles per four columns instead of 10 of ~104) and are brought into the tile layout once at the end, through `img`:
+// 512 doubles of LDS that belong to this wave (every wave of the workgroup has to make the call: rot44_images has barriers).
+template <int K>
+constexpr bool kColstatsRot = (K == 64);
+
 template <int K>
 __device__ __forceinline__ void colstats_accumulate(const double *__restrict__ items, int64_t b, int64_t e,
-                                                    d4 (&acc)[Geo<K>::NTRI], double (&r)[Geo<K>::NT], int lane,
+                                                    d4 (&acc)[Geo<K>::NTRI], double (&r)[Geo<K>::NT], int lane, double *img,
                                                     const int32_t *__restrict__ list = nullptr, int64_t c0 = 0)
 {
     constexpr int NT = Geo<K>::NT;
+    constexpr bool ROT = kColstatsRot<K>;
     const int kq = lane >> 4, li = lane & 15;
+    double C[ROT ? Rot44<K>::NACC : 1];
+#pragma unroll
+    for (int t = 0; t < (ROT ? Rot44<K>::NACC : 1); ++t) C[t] = 0.0;
 #pragma unroll
     for (int t = 0; t < Geo<K>::NTRI; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1100,13 +1209,18 @@ __device__ __forceinline__ void colstats_accumulate(const double *__restrict__ i
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) r[t] += y[s][t];
-            int tri = 0;
+            if constexpr (ROT) {
+                rot44_contract<K>(y[s], C);
+            } else {
+                int tri = 0;
 #pragma unroll
-            for (int I = 0; I < NT; ++I)
+                for (int I = 0; I < NT; ++I)
 #pragma unroll
-                for (int J = I; J < NT; ++J, ++tri) acc[tri] = mfma16(y[s][I], y[s][J], acc[tri]);
+                    for (int J = I; J < NT; ++J, ++tri) acc[tri] = mfma16(y[s][I], y[s][J], acc[tri]);
+            }
         }
     }
+    if constexpr (ROT) rot44_images<K>(C, img, img + 256, lane, [&](int tix, int, int, int m, double v) { acc[tix][m] = v; });
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         r[t] += __shfl_xor(r[t], 16);
@@ -1118,8 +1232,9 @@ template <int K>
 __device__ __forceinline__ void colstats_body(int w, const double *__restrict__ items, int64_t c0, int64_t c1, int nwaves,
                                               double *partials, const unsigned long long *__restrict__ fail_in,
                                               double *__restrict__ out, unsigned *ticket, unsigned *flag, unsigned seq,
-                                              unsigned long long *tmo, unsigned long long wait_ticks)
+                                              unsigned long long *tmo, unsigned long long wait_ticks, double *img)
 {
+    // img: kColstatsRot<K> ? 512 doubles of the (single-wave) workgroup's LDS : unused
     constexpr int NT = Geo<K>::NT, NTRI = Geo<K>::NTRI, PART = Geo<K>::PART;
     constexpr int NSLICE = (K * K + K + 15) / 16;
     const int lane = threadIdx.x;
@@ -1131,7 +1246,7 @@ __device__ __forceinline__ void colstats_body(int w, const double *__restrict__ 
     {
         d4 acc[NTRI];
         double r[NT];
-        colstats_accumulate<K>(items, b, e, acc, r, lane);
+        colstats_accumulate<K>(items, b, e, acc, r, lane, img);
         double *p = partials + (size_t)w * PART;
 #pragma unroll
         for (int t = 0; t < NTRI; ++t)
@@ -1224,7 +1339,8 @@ __global__ __launch_bounds__(64) void k_colstats(const double *__restrict__ item
                                                  double *__restrict__ out, unsigned *ticket, unsigned *flag, unsigned seq,
                                                  unsigned long long *tmo, unsigned long long wait_ticks)
 {
-    colstats_body<K>((int)blockIdx.x, items, c0, c1, nwaves, partials, fail_in, out, ticket, flag, seq, tmo, wait_ticks);
+    __shared__ double img[kColstatsRot<K> ? 512 : 1];
+    colstats_body<K>((int)blockIdx.x, items, c0, c1, nwaves, partials, fail_in, out, ticket, flag, seq, tmo, wait_ticks, img);
 }
 
 // ---------------------------------------------------------------------------
@@ -1264,7 +1380,9 @@ __global__ __launch_bounds__(256) void k_colstats_wg(const double *__restrict__ 
     {
         d4 acc[NTRI];
         double r[NT];
-        colstats_accumulate<K>(items, b, e, acc, r, lane, list, 0);   // (list mode: `items` points at local column 0)
+        static_assert(!kColstatsRot<K> || 4 * 512 <= PART, "the four waves' images fit the reduction buffer");
+        colstats_accumulate<K>(items, b, e, acc, r, lane, red + 512 * wave, list, 0);   // (list mode: `items` points at local column 0)
+        if (kColstatsRot<K>) __syncthreads();                         // (the images are read before `red` takes the sums)
         // waves 1, 2, 3 hand their sums to wave 0 through LDS, one after the other
         for (int src = 1; src < 4; ++src) {
             if (wave == src) {

@@ -44,20 +44,10 @@ struct GeoS {
     __host__ __device__ static constexpr int roff(int I) { int n = 0; for (int t = 0; t < I; ++t) n += NQ - (t >> 2); return n; }
     static constexpr int NREG = roff(NG);                 // slabs kept: q >= I / 4
     __host__ __device__ static constexpr int reg(int I, int q) { return roff(I) + q - (I >> 2); }
-    // Gram accumulators (gram_slab): tile (TI, TJ), TI <= TJ, keeps one register per quad rotation d of the B operand --
-    // d = 0 .. 3 off the diagonal, d = 0 .. 2 on it (the blocks d = 3 would give are transposes of d = 1's)
-    __host__ __device__ static constexpr int nrot(int TI, int TJ) { return TI == TJ ? 3 : 4; }
-    __host__ __device__ static constexpr int aoff(int TI, int TJ)
-    {
-        int n = 0;
-        for (int a = 0; a < NT; ++a)
-            for (int b = a; b < NT; ++b) {
-                if (a == TI && b == TJ) return n;
-                n += nrot(a, b);
-            }
-        return n;
-    }
-    static constexpr int NACC = aoff(NT - 1, NT - 1) + 3;  // 36 at K = 64 (the slab form itself needs NREG = 40)
+    // Gram accumulators (gram_slab): the rotated-block layout of rot44_contract (kernels.h)
+    __host__ __device__ static constexpr int nrot(int TI, int TJ) { return Rot44<K>::nrot(TI, TJ); }
+    __host__ __device__ static constexpr int aoff(int TI, int TJ) { return Rot44<K>::aoff(TI, TJ); }
+    static constexpr int NACC = Rot44<K>::NACC;           // 36 at K = 64 (the slab form itself needs NREG = 40)
     static constexpr int LDR = K + 2;                     // row stride of the published block row (doubles)
     // LDS: z [K] | rhs [K] | block row [4][LDR] | inverted diagonal blocks [NG][16] | (fp32 path) one 16 x 17 tile
     static constexpr int LDS_WORDS = 2 * K + 4 * LDR + 16 * NG + (K == 128 ? 16 * 17 / 2 + 8 : 0);
@@ -144,17 +134,6 @@ __device__ __forceinline__ void slab_static_for(F &&f)
     }
 }
 
-// x rotated by 4 * D lanes inside each row of 16 lanes (quad b reads quad (b + D) % 4): one DPP move per half, no LDS
-template <int D>
-__device__ __forceinline__ double quad_rot(double x)
-{
-    constexpr int CTRL = 0x120 + (16 - 4 * D);                       // row_ror:(16 - 4 D): lane l reads lane (l + 4 D) % 16 of its row
-    const long long v = __builtin_bit_cast(long long, x);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, 0xF, 0xF, true);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
-
 // Gram of one chunk on the 4x4x4 shape (fp64, K = 64).  A group is 4 ratings (k = lane >> 4 picks one); the gathered
 // register t holds u_k[16 t + c] in lane (k, c), c = 4 b + j.  The four blocks b of v_mfma_f64_4x4x4_4b are independent
 // 4 x 4 x 4 products, so with A = register TI as it is (block b = latent rows 16 TI + 4 b ..) and B = register TJ ROTATED by d
@@ -205,26 +184,7 @@ __device__ __forceinline__ void gram_slab(const int32_t *__restrict__ rowidx, co
     auto contract = [&](const double (&yy)[NT], double ww) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) r[t] = fma(yy[t], ww, r[t]);
-        // rotations by one and by two quads of every register: what the diagonal tiles need.  The off-diagonal tiles' d = 3 takes
-        // the A operand rotated by ONE quad against the natural B operand instead -- block b of that product is
-        // (4 TI + (b + 1) % 4, 4 TJ + b), the same four blocks {(r, r + 3)} in other slots (slabs_from_acc knows) -- so that no
-        // rotation by three is made: 8 rotated registers (16 DPP moves) per group instead of 11
-        double rot[NT][3];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            rot[t][0] = yy[t];
-            rot[t][1] = quad_rot<1>(yy[t]);
-            rot[t][2] = quad_rot<2>(yy[t]);
-        }
-#pragma unroll
-        for (int TI = 0; TI < NT; ++TI)
-#pragma unroll
-            for (int TJ = TI; TJ < NT; ++TJ)
-#pragma unroll
-                for (int d = 0; d < G::nrot(TI, TJ); ++d) {
-                    if (d < 3) C[G::aoff(TI, TJ) + d] = mfma44(yy[TI], rot[TJ][d], C[G::aoff(TI, TJ) + d]);
-                    else C[G::aoff(TI, TJ) + d] = mfma44(rot[TI][1], yy[TJ], C[G::aoff(TI, TJ) + d]);
-                }
+        rot44_contract<K>(yy, C);
     };
     // D operand sets: the gathers run D - 1 groups ahead of the MFMAs (GeoS<K>::DEPTH).  A group whose four ratings all lie
     // beyond the end of the chunk is gathered (a row of zeros: the loads stay unconditional) but NOT contracted: the
@@ -269,28 +229,8 @@ __device__ __forceinline__ void gram_slab(const int32_t *__restrict__ rowidx, co
 template <int K>
 __device__ __forceinline__ void slabs_from_acc(const double (&C)[GeoS<K>::NACC], double (&A)[GeoS<K>::NREG], double *buf0, double *buf1, int lane)
 {
-    using G = GeoS<K>;
-    constexpr int NT = G::NT;
-    const int i = lane >> 4, b = (lane >> 2) & 3, j = lane & 3;
-    int tix = 0;
-#pragma unroll
-    for (int TI = 0; TI < NT; ++TI)
-#pragma unroll
-        for (int TJ = TI; TJ < NT; ++TJ, ++tix) {
-            double *img = (tix & 1) ? buf1 : buf0;
-#pragma unroll
-            for (int d = 0; d < G::nrot(TI, TJ); ++d) {
-                // (d = 3, off the diagonal only: made with the A operand rotated by one quad -- slot b is block ((b + 1) % 4, b))
-                const int row = d < 3 ? 4 * b + i : 4 * ((b + 1) & 3) + i, col = d < 3 ? 4 * ((b + d) & 3) + j : 4 * b + j;
-                const double v = C[G::aoff(TI, TJ) + d];
-                img[row * 16 + col] = v;
-                if (TI == TJ && d > 0) img[col * 16 + row] = v;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int m = 0; m < 4; ++m) A[G::reg(4 * TI + m, TJ)] = img[(4 * m + i) * 16 + (lane & 15)];
-            __syncthreads();
-        }
+    // slab (4 TI + m, TJ) is rows 4 m .. 4 m + 3 of the image of tile (TI, TJ): register m of the tile
+    rot44_images<K>(C, buf0, buf1, lane, [&](int, int TI, int TJ, int m, double v) { A[GeoS<K>::reg(4 * TI + m, TJ)] = v; });
 }
 
 // Lambda* (slabs A) and the rhs in, the sample out.  The rhs is PACKED like a slab column: bv[Q], lane
@@ -526,8 +466,9 @@ __global__ __launch_bounds__(64, GeoS<K>::WPS) void k_sample1s(SampleArgs a, Fus
         --bid;
     }
     if (bid < f.nstat) {
+        static_assert(!kColstatsRot<K> || GeoS<K>::LDS_WORDS >= 512, "the riders' images");
         colstats_body<K>(bid, f.st_items, f.st_c0, f.st_c1, f.nstat, f.st_partials, f.st_fail, f.st_out, f.st_ticket, f.st_flag, f.st_seq,
-                         f.st_tmo, a.wait_ticks);
+                         f.st_tmo, a.wait_ticks, lds);
         return;
     }
     slab_item<K, double>(a, bid - f.nstat, lds, (int)threadIdx.x);
