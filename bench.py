@@ -1010,9 +1010,17 @@ def run(args, wl, R, wd):
         # BPMF_DIST=torch keeps the collectives in torch.distributed (same results, slower host path)
         comm = TorchComm(torch.device("cuda", local_rank)) if os.environ.get("BPMF_DIST") == "torch" else NativeComm(eng)
     Sys.nsims, Sys.burnin, Sys.alpha = 10 ** 6, 5, 2.0
+    handover_ms = None
     if comm is None:
+        # the boundary takes HOST buffers (bpmf_hip_side_create: the reference's SparseMatrixD in CSC form, c++/bpmf.h:130-137):
+        # the one-time hand-over -- both orientations of R and of the test set over PCIe, the static schedule, the initial
+        # factors -- is timed here and reported beside the steady-state value (`handover`), never inside it
+        torch.cuda.synchronize()
+        t_h = time.perf_counter()
         movies = Sys("movs", eng, M, nmovies, nusers, T=T, mean_rating=mean)
         users = Sys("users", eng, Mt, nusers, nmovies, T=Tt, mean_rating=mean)
+        eng.sync(); torch.cuda.synchronize()
+        handover_ms = (time.perf_counter() - t_h) * 1e3
         dom_m, dom_u = (0, nmovies), (0, nusers)
     else:
         from bpmf_amd.dist import build_sharded
@@ -1200,6 +1208,12 @@ def run(args, wl, R, wd):
         "ms_per_step_median": dt / args.steps * 1e3, "ms_per_step_min": min(times) / args.steps * 1e3,
         "ms_per_step_max": max(times) / args.steps * 1e3, "ms_per_step_first_block": times[0] / args.steps * 1e3,
         "roofline": roofline,
+        # PCIe-inclusive figure: the hand-over of the host matrices (once per run) + N iterations at the measured rate, for the
+        # reference's own default run length (`Sys::nsims = 20`, c++/bpmf.cpp:78) and for the 1 000 iterations a converged chain takes
+        "handover": None if handover_ms is None else {
+            "ms": handover_ms, "host_bytes": int(2 * (nnz * 12 + len(T[2]) * 12) + 8 * (nusers + nmovies + 2) * 2),
+            "what": "bpmf_hip_side_create x 2 + test sets from host CSC arrays: PCIe upload, static schedule, initial factors",
+            "value_incl_handover": {str(n): (nusers + nmovies) * n / (handover_ms * 1e-3 + n * dt / args.steps) for n in (20, 1000)}},
         "rmse": movies.rmse, "rmse_avg": movies.rmse_avg,
         # secondary figures of SURVEY 8(d): the reference's ratings/s (nnz / t_iter, bpmf.cpp:195) and
         # the sampling-only rate (columns of both sides / the two sampler launches of one iteration)
