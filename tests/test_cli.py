@@ -232,4 +232,6 @@ def test_cpp_host_keeps_up_with_the_python_host():
     x = j["bpmf_exe"]
     assert "error" not in x, x
     assert x["iterations"] == 400 and 0.5 < x["final_avg_rmse"] < 3.0          # (bpmf -i 400 whatever --steps says: a short run is all start-up)
+    h = j["handover"]                                                   # the host matrices' one-time hand-over, beside the value and never in it
+    assert 0.5 < h["ms"] < 500 and h["host_bytes"] > 2 * 12 * 1_000_000 and h["value_incl_handover"]["20"] < h["value_incl_handover"]["1000"] < j["value"]
     assert 0.85 <= x["over_python_host"] <= 1.25, x                     # (clean runs: 1.01 - 1.05, profiles/r05_bench*.json; inside a busy suite run 0.90 was seen)

@@ -77,6 +77,7 @@ def test_committed_line_carries_every_single_gpu_config():
     d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
     assert d["steps"] == 20 and d["n_gpus"] == 1 and d["value"] > 5e7 and d["timed_window_s"] >= 2.0 and d["repeats"] >= 100
     assert d["parity"]["ok"] and d["parity"]["d_rmse_max"] < 1e-6
+    assert d["handover"]["ms"] > 0 and d["handover"]["value_incl_handover"]["1000"] < d["value"]      # (PCIe-inclusive rate: DESIGN.md section 5)
     rf = d["roofline"]
     assert 0.5 < rf["issue_bound"]["frac_of_launch"] < 1.0 and rf["issue_bound"]["current"]
     assert rf["mfma_shape"]["frac_of_shape_peak"] > rf["frac"]
