@@ -1649,10 +1649,18 @@ __device__ __forceinline__ void gate_stage_body(int block, int nblocks, const un
     const int lane = threadIdx.x;
     if (lane == 0) {
         const unsigned long long t0 = wall_clock64();                 // 100 MHz
-        while (__hip_atomic_load(gate_host, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != want) {
-            __builtin_amdgcn_s_sleep(4);
+        // Relaxed polls, ONE acquire once the word is there; the first sixteen polls back to back (a gate that opens just after
+        // the launch started: the fused forms), then ~ 3.4 us apart (s_sleep 127).  A gate kernel polls beside the partner's
+        // sampler for hundreds of microseconds (K = 128: ~ 300 us per half-iteration, 16 waves): at one uncached system-scope read
+        // per ~ 0.3 us and wave those launches ran 1.2 % longer (FINDINGS section 25; the `buffer_inv sc0 sc1` an acquiring load
+        // drags along made no difference of its own).
+        int polls = 0;
+        while (__hip_atomic_load(gate_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != want) {
+            if (polls < 16) { __builtin_amdgcn_s_sleep(4); ++polls; }
+            else __builtin_amdgcn_s_sleep(127);
             if (wall_clock64() - t0 > wait_ticks) { flag_timeout(tmo, BPMF_TMO_GATE); break; }
         }
+        (void)__hip_atomic_load(gate_host, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
     // uncached host memory, read after the acquire: 16-byte PCIe reads, four in flight per lane
