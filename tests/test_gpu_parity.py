@@ -459,6 +459,38 @@ def test_users_predict_rides_with_movies_predict(hip_engine_factory, pipelined):
         eng.side_destroy(sd.side)
 
 
+def test_twin_matching_does_not_need_sorted_columns(hip_engine_factory):
+    """bpmf_hip_test_set_twin matches the entries of the two test copies with one cursor per user when both arrive in CSC order
+    with ascending rows (round 6: O(n)); anything else -- here the twin's rows DESCENDING inside every column -- takes the sorting
+    path.  Both give the fused evaluation the same sums, entry for entry."""
+    from bpmf_amd.sys import Sys
+    K = 16
+    M, Mt, T, Tt, nu, nm = util.ml100k()
+    cp, ri, va = Tt
+    ri2, va2 = ri.copy(), va.copy()
+    for c in range(len(cp) - 1):                                      # reverse every column of the users' copy
+        ri2[cp[c]:cp[c + 1]] = ri[cp[c]:cp[c + 1]][::-1]; va2[cp[c]:cp[c + 1]] = va[cp[c]:cp[c + 1]][::-1]
+    eng = hip_engine_factory(K)
+    Sys.nsims, Sys.burnin, Sys.alpha = 5, 1, 2.0
+    res = []
+    for tt in (Tt, (cp, ri2, va2)):
+        movies = Sys("movs", eng, M, nm, nu, T=T); users = Sys("users", eng, Mt, nu, nm, T=tt)
+        movies.set_twin(users)
+        tr = []
+        for i in range(5):
+            movies.sample(users); users.sample(movies); movies.predict(users); users.predict(movies)
+            tr.append((movies.rmse, movies.rmse_avg, users.rmse, users.rmse_avg))
+        pu, qu = eng.test_get(users.test)
+        res.append((np.asarray(tr), pu, qu))
+        for sd in (movies, users):
+            eng.side_destroy(sd.side)
+    (tr_a, pu_a, qu_a), (tr_b, pu_b, qu_b) = res
+    assert np.array_equal(tr_a[:, :2], tr_b[:, :2]) and np.allclose(tr_a[:, 2:], tr_b[:, 2:], rtol=1e-12)
+    assert np.allclose(tr_b[:, 0], tr_b[:, 2], rtol=1e-12) and np.allclose(tr_b[:, 1], tr_b[:, 3], rtol=1e-12)
+    for c in range(len(cp) - 1):                                      # the reversed copy holds the same running means, reversed
+        assert np.array_equal(pu_b[cp[c]:cp[c + 1]], pu_a[cp[c]:cp[c + 1]][::-1]) and np.array_equal(qu_b[cp[c]:cp[c + 1]], qu_a[cp[c]:cp[c + 1]][::-1])
+
+
 def test_posterior_moments_of_one_column(hip_engine_factory):
     """Statistical check that does not involve the oracle: many draws of the same column
     (different iter => different streams) have mean Lambda*^-1 b and covariance Lambda*^-1."""
